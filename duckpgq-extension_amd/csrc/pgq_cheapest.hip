@@ -1,0 +1,313 @@
+// pgq_cheapest.hip — cheapest_path_length on MI355X: batched, frontier-driven label-correcting SSSP.
+//
+// Replaces TemplatedBatchBellmanFord / TemplatedBellmanFord / CheapestPathLengthFunction
+// (src/core/functions/scalar/cheapest_path_length.cpp:52-89, :91-136, :138-163).
+//
+// The reference sweeps every vertex x every out-edge x every lane until nothing changes, relaxing with
+//     new = dist[v] + w;  if (new < dist[n]) dist[n] = new            (cheapest_path_length.cpp:29-36)
+// For non-negative weights that relaxation is monotone (IEEE + is monotone in its left operand for a fixed
+// non-negative right operand), so the fixpoint does not depend on the order of relaxations: the result is the
+// minimum over paths of the left-to-right fold of the weights, bit for bit, for int64 and for double.  We
+// therefore only relax out of vertices whose distance improved in the previous round (delta = "changed since
+// last round" frontier), with atomicMin on the 64-bit pattern (non-negative doubles order like their bits).
+// Negative weights are rejected (PGQ_ERR_UNSUPPORTED): the reference does not terminate on negative cycles
+// and its max/2 sentinel leaks for unreachable lanes.
+//
+// Layout: dist[V][LC] (vertex-major, LC = 64 lanes -> one 512-byte row per vertex, fully coalesced per wave),
+// dirty[parity][V] = 64-bit mask of lanes of v that improved in the previous round.  A lane is one distinct
+// source.  Rounds are kernel launches: improvements made in round r are consumed in round r+1, so no
+// intra-kernel visibility between XCDs is needed.
+#include <cstddef>
+#include <limits>
+#include <type_traits>
+
+#include "pgq_search.h"
+
+namespace pgq {
+
+static constexpr int LC = 64;
+
+template <typename T> struct Inf;
+template <> struct Inf<int64_t> {
+	static constexpr int64_t bits = std::numeric_limits<int64_t>::max() / 2; // cheapest_path_length.cpp:15
+};
+template <> struct Inf<double> {
+	// bit pattern of DBL_MAX / 2 = 0x7FDFFFFFFFFFFFFF
+	static constexpr int64_t bits = 0x7FDFFFFFFFFFFFFFll;
+};
+
+__global__ void k_fill64(int64_t *__restrict__ p, int64_t n, int64_t value) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) p[i] = value;
+}
+
+// sources of the batch: dist[src][lane] = 0, dirty, queued
+__global__ void k_cheapest_init(const int32_t *__restrict__ usrc, int64_t U, int64_t base, int64_t *__restrict__ dist,
+                                u64 *__restrict__ dirty, u32 *__restrict__ tflag, u32 tepoch,
+                                int32_t *__restrict__ touched, u32 *__restrict__ qcount, u32 *__restrict__ tcount,
+                                int32_t *__restrict__ q) {
+	int64_t g = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= U || g >= base + LC) return;
+	const int v = usrc[g];
+	const int l = (int)(g - base);
+	dist[(size_t)v * LC + l] = 0;
+	atomicOr(&dirty[v], 1ull << l);
+	q[atomicAdd(qcount, 1u)] = v; // distinct sources -> distinct vertices
+	tflag[v] = tepoch;
+	touched[atomicAdd(tcount, 1u)] = v;
+}
+
+// One wavefront per changed vertex v; lane l = search l.  Walks v's out-edges (wave-uniform loop, scalar
+// adjacency/weight loads), every lane relaxes its own distance: coalesced 512-byte rows of dist[n][*].
+template <typename T>
+__global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                               const T *__restrict__ w, int64_t *__restrict__ dist,
+                                               u64 *__restrict__ dirty_cur, u64 *__restrict__ dirty_nxt,
+                                               const int32_t *__restrict__ qcur, const u32 *__restrict__ nq_ptr,
+                                               int32_t *__restrict__ qnxt, u32 *__restrict__ nq_nxt,
+                                               u32 *__restrict__ qflag, u32 epoch, u32 *__restrict__ tflag,
+                                               u32 tepoch, int32_t *__restrict__ touched, u32 *__restrict__ tcount,
+                                               u64 *__restrict__ relaxed_edges) {
+	const int lane = threadIdx.x & 63;
+	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
+	const u32 nq = *nq_ptr;
+	u64 edges = 0;
+	for (u32 i = wave; i < nq; i += nwaves) {
+		const int v = qcur[i];
+		const u64 mask = dirty_cur[v];
+		if (lane == 0) dirty_cur[v] = 0; // consumed; nobody else touches dirty_cur this round
+		const bool mine = (mask >> lane) & 1ull;
+		const int64_t dvb = dist[(size_t)v * LC + lane];
+		const int64_t b = off[v], e = off[v + 1];
+		edges += (u64)(e - b);
+		for (int64_t k = b; k < e; k++) {
+			const int n = adj[k];
+			const T wt = w[k];
+			bool improved = false;
+			if (mine) {
+				int64_t cand;
+				if constexpr (sizeof(T) == 8 && std::is_same<T, double>::value) {
+					cand = __double_as_longlong(__longlong_as_double(dvb) + wt);
+				} else {
+					cand = dvb + (int64_t)wt;
+				}
+				int64_t *dp = &dist[(size_t)n * LC + lane];
+				if (cand < *dp) {
+					const int64_t old = atomicMin((long long *)dp, (long long)cand);
+					improved = cand < old;
+				}
+			}
+			const u64 imask = __ballot(improved);
+			if (imask && lane == 0) {
+				atomicOr(&dirty_nxt[n], imask);
+				if (qflag[n] != epoch && atomicExch(&qflag[n], epoch) != epoch) qnxt[atomicAdd(nq_nxt, 1u)] = n;
+				if (tflag[n] != tepoch && atomicExch(&tflag[n], tepoch) != tepoch) touched[atomicAdd(tcount, 1u)] = n;
+			}
+		}
+	}
+	if (lane == 0 && edges) atomicAdd(relaxed_edges, edges);
+}
+
+// results: out[row] = dist[dst][lane]; INF -> invalid.  Also trivial rows.
+__global__ void k_cheapest_results(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const u32 *__restrict__ sidx,
+                                   const int32_t *__restrict__ sdst, u32 base_lane, const int64_t *__restrict__ dist,
+                                   int64_t inf_bits, int64_t *__restrict__ out, uint8_t *__restrict__ ok) {
+	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= hi) return;
+	const u32 l = skey[i] - base_lane;
+	const int64_t d = dist[(size_t)sdst[i] * LC + l];
+	const u32 row = sidx[i];
+	if (d == inf_bits) {
+		ok[row] = 0;
+		out[row] = 0;
+	} else {
+		ok[row] = 1;
+		out[row] = d;
+	}
+}
+
+__global__ void k_cheapest_tails(int64_t lo_trivial, int64_t lo_null, int64_t n, const u32 *__restrict__ sidx,
+                                 int64_t *__restrict__ out, uint8_t *__restrict__ ok) {
+	int64_t i = lo_trivial + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u32 row = sidx[i];
+	out[row] = 0; // int64 0 and +0.0 share the bit pattern
+	ok[row] = i < lo_null ? 1 : 0;
+}
+
+__global__ void k_reset_touched(const int32_t *__restrict__ touched, const u32 *__restrict__ tcount,
+                                int64_t *__restrict__ dist, int64_t inf_bits) {
+	const u32 nt = *tcount;
+	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; t < (int64_t)nt * LC; t += stride) dist[(size_t)touched[t / LC] * LC + (t % LC)] = inf_bits;
+}
+
+struct RelaxCounters {
+	u32 nq[2];
+	u32 tcount;
+	u32 pad;
+	u64 relaxed_edges;
+};
+
+template <typename T>
+static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                           int64_t *d_out, uint8_t *d_ok) {
+	hipStream_t st = ws->stream;
+	const int64_t V = c->V;
+	const int64_t inf_bits = Inf<T>::bits;
+	pgq_stats_t &S = tstats().s;
+	S.pairs += n;
+	if (n == 0) return PGQ_OK;
+	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
+	u32 U = 0;
+	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U));
+	S.unique_sources += U;
+	const int nb = (int)(((int64_t)U + LC - 1) / LC);
+	PGQ_TRY(batch_bounds(ws, n, LC, nb));
+	const int64_t *bs = ws->h_bstart;
+	const size_t cells = (size_t)std::max<int64_t>(V, 1) * LC;
+	// distances start at INF; a full fill only when the array is new, afterwards only touched rows are reset
+	const int type_tag = std::is_same<T, double>::value ? 2 : 1; // the INF pattern differs between int64 and double
+	const bool fresh = ws->dist.cap < cells * 8 || ws->dist_V != V || ws->dist_lanes != type_tag;
+	ws->dist_V = -1; // stays invalid if we bail out half-way; restored at the end
+	PGQ_TRY(ws->dist.reserve(cells * 8));
+	for (int k = 0; k < 2; k++) PGQ_TRY(ws->dirty[k].reserve((size_t)std::max<int64_t>(V, 1) * 8));
+	PGQ_TRY(ws->qbuf[0].reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->qbuf[1].reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->touched.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->qflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->tflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	static_assert(sizeof(RelaxCounters) <= sizeof(Counters), "counter block too small");
+	RelaxCounters *d_rc = reinterpret_cast<RelaxCounters *>(ws->counters.p);
+	RelaxCounters *h_rc = reinterpret_cast<RelaxCounters *>(ws->h_cnt);
+	if (fresh) {
+		hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, ws->dist.as<int64_t>(), (int64_t)cells, inf_bits);
+	}
+	PGQ_HIP_TRY(hipMemsetAsync(ws->dirty[0].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
+	PGQ_HIP_TRY(hipMemsetAsync(ws->dirty[1].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
+	PGQ_HIP_TRY(hipMemsetAsync(ws->qflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
+	PGQ_HIP_TRY(hipMemsetAsync(ws->tflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
+	u32 epoch = 0, tepoch = 0;
+	const unsigned grid = 256 * 8;
+	for (int b = 0; b < nb; b++) {
+		const int64_t lo = bs[b], hi = bs[b + 1];
+		if (lo == hi) continue;
+		S.batches++;
+		const int64_t base = (int64_t)b * LC;
+		tepoch++;
+		PGQ_HIP_TRY(hipMemsetAsync(d_rc, 0, sizeof(RelaxCounters), st));
+		{
+			KernelTimer kt(st, K_PREP);
+			hipLaunchKernelGGL(k_cheapest_init, dim3(1), dim3(64), 0, st, ws->usrc.as<int32_t>(), (int64_t)U, base,
+			                   ws->dist.as<int64_t>(), ws->dirty[0].as<u64>(), ws->tflag.as<u32>(), tepoch,
+			                   ws->touched.as<int32_t>(), &d_rc->nq[0], &d_rc->tcount, ws->qbuf[0].as<int32_t>());
+			kt.stop();
+		}
+		int par = 0;
+		for (;;) {
+			epoch++;
+			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par ^ 1], 0, 4, st));
+			{
+				KernelTimer kt(st, K_RELAX);
+				hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, c->adj, (const T *)c->w,
+				                   ws->dist.as<int64_t>(), ws->dirty[par].as<u64>(), ws->dirty[par ^ 1].as<u64>(),
+				                   ws->qbuf[par].as<int32_t>(), &d_rc->nq[par], ws->qbuf[par ^ 1].as<int32_t>(),
+				                   &d_rc->nq[par ^ 1], ws->qflag.as<u32>(), epoch, ws->tflag.as<u32>(), tepoch,
+				                   ws->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges);
+				kt.stop();
+			}
+			PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			KernelTimer::flush();
+			S.levels++;
+			par ^= 1;
+			if (h_rc->nq[par] == 0) break;
+		}
+		S.edges_scanned += (int64_t)h_rc->relaxed_edges;
+		S.algo_bytes[K_RELAX] += (double)h_rc->relaxed_edges * (4.0 + 8.0 + 2.0 * 8.0 * LC);
+		hipLaunchKernelGGL(k_cheapest_results, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
+		                   ws->sidx.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, ws->dist.as<int64_t>(), inf_bits,
+		                   d_out, d_ok);
+		hipLaunchKernelGGL(k_reset_touched, dim3(256 * 4), dim3(256), 0, st, ws->touched.as<int32_t>(), &d_rc->tcount,
+		                   ws->dist.as<int64_t>(), inf_bits);
+	}
+	const int64_t lo_t = bs[nb + 1], lo_n = bs[nb + 2];
+	if (n > lo_t)
+		hipLaunchKernelGGL(k_cheapest_tails, dim3(blocks_for(n - lo_t)), dim3(256), 0, st, lo_t, lo_n, n,
+		                   ws->sidx.as<u32>(), d_out, d_ok);
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	ws->dist_V = V; // every touched row is back at INF
+	ws->dist_lanes = type_tag;
+	return PGQ_OK;
+}
+
+static int check_weighted(pgq_csr_t *csr) {
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (csr->w_type == PGQ_W_NONE || !csr->w)
+		return fail(PGQ_ERR_NOT_WEIGHTED, "Constraint Error: Need to initialize CSR before doing cheapest path");
+	if (csr->has_negative_weight)
+		return fail(PGQ_ERR_UNSUPPORTED, "cheapest_path_length: negative edge weights are not supported");
+	return PGQ_OK;
+}
+
+} // namespace pgq
+
+using namespace pgq;
+
+extern "C" {
+
+int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                         void *d_out, uint8_t *d_out_valid) {
+	PGQ_TRY(ensure_init());
+	PGQ_TRY(check_weighted(csr));
+	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out || !d_out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	if (csr->w_type == PGQ_W_INT64)
+		return cheapest_device<int64_t>(csr, lease.ws, n, d_src, d_dst, (int64_t *)d_out, d_out_valid);
+	return cheapest_device<double>(csr, lease.ws, n, d_src, d_dst, (int64_t *)d_out, d_out_valid);
+}
+
+int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, void *out,
+                             uint64_t *out_valid) {
+	PGQ_TRY(ensure_init());
+	PGQ_TRY(check_weighted(csr));
+	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");
+	if (n < 0 || (n > 0 && (!out || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
+	if (n == 0) return PGQ_OK;
+	FlatPairs fp;
+	PGQ_TRY(flatten_pairs(V, n, src, dst, fp, true));
+	for (int64_t i = 0; i < n; i++)
+		if (!fp.dst_valid[i]) fp.src[i] = -1; // NULL dst -> NULL (cheapest_path_length.cpp:74-76)
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	Workspace *ws = lease.ws;
+	PGQ_TRY(ws->in_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->in_dst.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_val.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_ok.reserve((size_t)n));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, fp.src.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, fp.dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	int rc;
+	if (csr->w_type == PGQ_W_INT64)
+		rc = cheapest_device<int64_t>(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
+		                              ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>());
+	else
+		rc = cheapest_device<double>(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
+		                             ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>());
+	PGQ_TRY(rc);
+	std::vector<uint8_t> ok(n);
+	PGQ_HIP_TRY(hipMemcpy(out, ws->out_val.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	PGQ_HIP_TRY(hipMemcpy(ok.data(), ws->out_ok.p, (size_t)n, hipMemcpyDeviceToHost));
+	mask_fill_valid(out_valid, n);
+	for (int64_t i = 0; i < n; i++)
+		if (!ok[i]) mask_set_invalid(out_valid, i);
+	return PGQ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,139 @@
+// pgq_internal.h — shared internals of libpgq_hip (not installed; the public boundary is include/pgq_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pgq_hip.h"
+
+namespace pgq {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define PGQ_HIP_TRY(expr)                                                                                          \
+	do {                                                                                                           \
+		hipError_t _e = (expr);                                                                                    \
+		if (_e != hipSuccess) {                                                                                    \
+			return ::pgq::fail(_e == hipErrorOutOfMemory ? PGQ_ERR_OOM : PGQ_ERR_HIP,                              \
+			                   std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+		}                                                                                                          \
+	} while (0)
+
+#define PGQ_TRY(expr)                                                                                              \
+	do {                                                                                                           \
+		int _rc = (expr);                                                                                          \
+		if (_rc != PGQ_OK) return _rc;                                                                             \
+	} while (0)
+
+int ensure_init();
+
+// ---- options --------------------------------------------------------------------------------------------
+struct Options {
+	int words = 0;          // lane-words per vertex per batch (0 = auto: 1,2,4,8,16 by unique sources)
+	int max_words = 16;     // upper bound for auto
+	double push_div = 12.0; // top-down while frontier out-degree sum * push_div < E
+	int profile = 0;        // per-kernel-class HIP event timing
+	int hub_chunk = 4096;   // adjacency entries per work item for high-degree vertices
+	int force_mode = 0;     // 0 adaptive, 1 always push, 2 always pull (tests)
+	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel
+	int cheapest_lanes = 64;
+	int trace = 0;          // per-level line on stderr
+};
+Options &options();
+
+// ---- kernel classes (stats) -----------------------------------------------------------------------------
+enum KClass {
+	K_PREP = 0,      // lane assignment, batch init
+	K_PUSH = 1,      // top-down expansion
+	K_PULL = 2,      // bottom-up expansion (+ fused sweep)
+	K_PULL_HUB = 3,  // bottom-up for split high-in-degree vertices
+	K_QUEUE = 4,     // frontier queue build / clear
+	K_DETECT = 5,    // per-pair destination test + active-lane mask
+	K_RECON = 6,     // path reconstruction
+	K_RELAX = 7,     // cheapest path relaxation
+	K_COUNT = 8
+};
+
+struct ThreadStats {
+	pgq_stats_t s;
+	ThreadStats();
+};
+ThreadStats &tstats();
+
+// ---- device CSR -----------------------------------------------------------------------------------------
+struct HubItem {
+	int32_t vertex;
+	int32_t pad;
+	int64_t begin, end; // slice of the (reverse) adjacency
+};
+
+} // namespace pgq
+
+struct pgq_csr {
+	int device = 0;
+	int64_t V = 0, E = 0;
+	int w_type = 0;
+	// forward CSR (slot order == host CSR slot order, never re-sorted)
+	int64_t *off = nullptr;      // V+1
+	int32_t *adj = nullptr;      // E
+	int64_t *edge_ids = nullptr; // E or null (slot index is the id)
+	void *w = nullptr;           // E x 8 B or null
+	// reverse CSR (in-neighbours), built on device at upload
+	int64_t *roff = nullptr; // V+1
+	int32_t *radj = nullptr; // E  source vertex of the in-edge
+	int64_t *rslot = nullptr; // E  forward slot of the in-edge (lazily built for shortestpath)
+	std::mutex lazy_lock;
+	// high in-degree vertices split into work items for the bottom-up kernel
+	pgq::HubItem *pull_hubs = nullptr; // device
+	int32_t *pull_hub_vertices = nullptr;
+	int64_t n_pull_hub_items = 0, n_pull_hub_vertices = 0;
+	int64_t hub_threshold = 0;
+	int64_t max_out_degree = 0, max_in_degree = 0;
+	int64_t bytes = 0;
+	bool has_negative_weight = false;
+};
+
+namespace pgq {
+
+// host mirror used by the chunk entry points: resolves UnifiedVectorFormat into flat arrays
+struct FlatPairs {
+	std::vector<int64_t> src, dst; // -1 src = NULL row
+	std::vector<uint8_t> dst_valid;
+};
+int flatten_pairs(int64_t V, int64_t n, const pgq_vec_t &src, const pgq_vec_t &dst, FlatPairs &out,
+                  bool check_dst_validity);
+
+inline void mask_fill_valid(uint64_t *mask, int64_t n) {
+	for (int64_t i = 0; i < (n + 63) / 64; i++) mask[i] = ~0ULL;
+}
+inline void mask_set_invalid(uint64_t *mask, int64_t row) { mask[row >> 6] &= ~(1ULL << (row & 63)); }
+
+// event timing of one kernel class; no-op unless options().profile
+struct KernelTimer {
+	hipStream_t stream;
+	int kclass;
+	hipEvent_t a = nullptr, b = nullptr;
+	KernelTimer(hipStream_t s, int k);
+	void stop(); // records the stop event
+	static void flush(); // resolves all pending pairs of this thread (call after a stream sync)
+};
+
+// scratch buffer that grows on demand, per workspace
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes);
+	void release();
+	template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+} // namespace pgq

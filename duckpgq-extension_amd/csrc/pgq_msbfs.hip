@@ -1,0 +1,1103 @@
+// pgq_msbfs.hip — multi-source batched BFS on MI355X: iterativelength and shortestpath.
+//
+// What it replaces (reference, file:line relative to cwida/duckpgq-extension):
+//   * the level kernel `IterativeLength`        src/core/functions/scalar/iterativelength.cpp:12-32
+//   * its batch driver IterativeLengthFunction  src/core/functions/scalar/iterativelength.cpp:34-143
+//   * the parent-tracking kernel + driver       src/core/functions/scalar/shortest_path.cpp:12-41, :43-207
+//
+// Design (DESIGN.md has the long form):
+//   * a batch holds L = 64*WD searches ("lanes"); a lane is one *distinct source vertex*, every (src,dst)
+//     pair with that source reads its answer from the lane (results are a pure function of (CSR,src,dst),
+//     SURVEY.md §8e).  State per vertex is WD contiguous 64-bit lane-words: seen[V][WD], frontier[V][WD].
+//   * a level is either TOP-DOWN (k_push: one wavefront per frontier vertex, one lane per out-neighbour,
+//     scalar loop over the non-empty lane-words; atomicOr into seen/next) or BOTTOM-UP (k_pull: one
+//     wavefront per vertex, WD adjacent lanes gather the WD contiguous lane-words of one in-neighbour, so a
+//     wave instruction fetches 64/WD full 8*WD-byte segments; no atomics, the `next &= ~seen; seen |= next`
+//     sweep of iterativelength.cpp:26-30 is fused in).  The host picks per level from the frontier's
+//     out-degree sum (direction-optimising BFS).
+//   * vertices whose (in-)degree exceeds `hub_chunk` are split into fixed-size work items.
+//   * shortestpath keeps every level's frontier bitmap instead of the reference's two 8 KiB/vertex parent
+//     arrays (shortest_path.cpp:82-83) and rebuilds each path backwards with the reference's tie-break:
+//     parent(x) = smallest frontier vertex of the previous level with an edge to x, edge = first CSR slot of
+//     that parent holding x (shortest_path.cpp:21-31) — i.e. the in-edge of x with the smallest forward slot
+//     whose source is in the previous frontier.
+//   * lengths are detected per pair each level from seen[dst] exactly like iterativelength.cpp:119-129.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstddef>
+#include <cstring>
+#include <memory>
+
+#include "pgq_search.h"
+
+namespace pgq {
+
+// ---- small device helpers -------------------------------------------------------------------------------------
+
+__device__ __forceinline__ u64 wave_or_slots(u64 x, int wd) {
+	for (int o = wd; o < 64; o <<= 1) x |= __shfl_xor(x, o);
+	return x;
+}
+
+// Appends ceil(deg/chunk) work items for vertex n (lanes with `take`), wave-aggregated.
+__device__ __forceinline__ void enqueue_items(bool take, int n, int64_t deg, int64_t chunk, u64 *__restrict__ q,
+                                              u32 qcap, u32 *__restrict__ qcount) {
+	const int lane = threadIdx.x & 63;
+	u32 c = 0;
+	if (take && deg > 0) c = (u32)((deg + chunk - 1) / chunk);
+	if (!__any(c != 0)) return;
+	u32 incl = c;
+	for (int o = 1; o < 64; o <<= 1) {
+		u32 t = __shfl_up(incl, o);
+		if (lane >= o) incl += t;
+	}
+	u32 total = __shfl(incl, 63);
+	u32 base = 0;
+	if (lane == 63) base = atomicAdd(qcount, total);
+	base = __shfl(base, 63);
+	u32 p = base + incl - c;
+	for (u32 k = 0; k < c; k++)
+		if (p + k < qcap) q[p + k] = (u64)(u32)n | ((u64)k << 32);
+}
+
+// ---- lane assignment -------------------------------------------------------------------------------------------
+
+__global__ void k_mark_sources(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                               u32 *__restrict__ flag, int64_t V, int *__restrict__ bad) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int64_t s = src[i], d = dst[i];
+	if (s < 0) return; // NULL row
+	if (s >= V || d < 0 || d >= V) {
+		*bad = 1;
+		return;
+	}
+	if (s != d) flag[s] = 1;
+}
+
+__global__ void k_compact_sources(int64_t V, const u32 *__restrict__ flag, const u32 *__restrict__ rank,
+                                  int32_t *__restrict__ usrc) {
+	int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < V && flag[v]) usrc[rank[v]] = (int32_t)v;
+}
+
+__global__ void k_pair_keys(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                            const u32 *__restrict__ rank, u32 *__restrict__ key, u32 *__restrict__ idx) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int64_t s = src[i];
+	u32 k = kNoLane;
+	if (s >= 0) k = (s == dst[i]) ? kTrivial : rank[s];
+	key[i] = k;
+	idx[i] = (u32)i;
+}
+
+// sorted-side copies: sdst, ssrc; sres = -1 (unresolved) / 0 (trivial)
+__global__ void k_gather_sorted(int64_t n, const u32 *__restrict__ skey, const u32 *__restrict__ sidx,
+                                const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                int32_t *__restrict__ ssrc, int32_t *__restrict__ sdst, int32_t *__restrict__ sres) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	u32 p = sidx[i];
+	u32 k = skey[i];
+	ssrc[i] = k == kNoLane ? -1 : (int32_t)src[p];
+	sdst[i] = k == kNoLane ? -1 : (int32_t)dst[p];
+	sres[i] = k == kTrivial ? 0 : -1;
+}
+
+// bstart[b] = first sorted position with key >= b*L, b = 0..nb; bstart[nb+1] = first kTrivial, [nb+2] = first kNoLane
+__global__ void k_batch_bounds(const u32 *__restrict__ skey, int64_t n, u32 L, int nb, int64_t *__restrict__ bstart) {
+	int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > nb + 2) return;
+	// laned keys are < U <= nb*L < 2^31, so b*L never collides with the two sentinels
+	u32 target = b <= nb ? (u32)b * L : (b == nb + 1 ? kTrivial : kNoLane);
+	int64_t lo = 0, hi = n;
+	while (lo < hi) {
+		int64_t mid = (lo + hi) >> 1;
+		if (skey[mid] < target) lo = mid + 1;
+		else hi = mid;
+	}
+	bstart[b] = lo;
+}
+
+__global__ void k_scatter_results(int64_t n, const u32 *__restrict__ sidx, const int32_t *__restrict__ sres,
+                                  const int64_t *__restrict__ soff, int64_t *__restrict__ out_len,
+                                  int64_t *__restrict__ out_off) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	u32 p = sidx[i];
+	out_len[p] = (int64_t)sres[i];
+	if (out_off) out_off[p] = soff[i];
+}
+
+// ---- batch init ------------------------------------------------------------------------------------------------
+
+template <int WD>
+__global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_t base, const int64_t *__restrict__ off,
+                             u64 *__restrict__ front0, u64 *__restrict__ seen, u64 *__restrict__ active,
+                             u64 *__restrict__ q, u32 qcap, int64_t chunk, Counters *__restrict__ cnt) {
+	int64_t g = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool ok = g < U && g < base + 64 * WD;
+	int v = 0;
+	int64_t deg = 0;
+	if (ok) {
+		v = usrc[g];
+		int l = (int)(g - base);
+		u64 bit = 1ull << (l & 63);
+		atomicOr(&front0[(size_t)v * WD + (l >> 6)], bit);
+		atomicOr(&seen[(size_t)v * WD + (l >> 6)], bit);
+		atomicOr(&active[l >> 6], bit);
+		deg = off[v + 1] - off[v];
+		atomicAdd(&cnt->front_edges, (u64)deg);
+		atomicAdd(&cnt->front_vertices, 1u);
+	}
+	enqueue_items(ok, v, deg, chunk, q, qcap, &cnt->q_count[0]);
+}
+
+// ---- top-down level ----------------------------------------------------------------------------------------------
+// One wavefront per work item (frontier vertex, or a hub_chunk slice of one); lane = out-neighbour.
+// For every non-empty lane-word of visit[v]: bits not yet in seen[n] are OR-ed into seen[n] and next[n]
+// (iterativelength.cpp:18-25 + :26-30 restricted to the touched vertices; same unseen-masking as
+// iterativelength2.cpp:24-26).  First toucher of n queues it for the next level.
+template <int WD>
+__global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                              const u64 *__restrict__ visit, u64 *__restrict__ seen,
+                                              u64 *__restrict__ next, const u64 *__restrict__ active,
+                                              const u64 *__restrict__ qcur, int par, u32 *__restrict__ qflag,
+                                              u32 epoch, u64 *__restrict__ qnext, u32 qcap, int64_t chunk,
+                                              Counters *__restrict__ cnt) {
+	const int lane = threadIdx.x & 63;
+	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
+	const u32 nq = min(cnt->q_count[par], qcap);
+	u64 scanned = 0, gathers = 0, mf = 0;
+	u32 nf = 0;
+	for (u32 i = wave; i < nq; i += nwaves) {
+		const u64 item = qcur[i];
+		const int v = (int)(u32)item;
+		const int64_t b = off[v] + (int64_t)(item >> 32) * chunk;
+		const int64_t e = min(off[v + 1], b + chunk);
+		u64 val[WD];
+#pragma unroll
+		for (int w = 0; w < WD; w++) val[w] = visit[(size_t)v * WD + w] & active[w];
+		for (int64_t base = b; base < e; base += 64) {
+			const int64_t idx = base + lane;
+			const bool has = idx < e;
+			const int n = has ? adj[idx] : 0;
+			bool enq = false;
+#pragma unroll
+			for (int w = 0; w < WD; w++) {
+				if (val[w] == 0) continue; // wave-uniform
+				if (has) {
+					u64 *sp = &seen[(size_t)n * WD + w];
+					u64 nb = val[w] & ~*sp;
+					if (nb) {
+						u64 old = atomicOr(sp, nb);
+						u64 fr = nb & ~old;
+						if (fr) {
+							atomicOr(&next[(size_t)n * WD + w], fr);
+							enq = true;
+						}
+					}
+				}
+				gathers += (u64)min((int64_t)64, e - base);
+			}
+			if (enq) enq = qflag[n] != epoch && atomicExch(&qflag[n], epoch) != epoch;
+			int64_t deg = 0;
+			if (enq) {
+				deg = off[n + 1] - off[n];
+				mf += (u64)deg;
+				nf++;
+			}
+			enqueue_items(enq, n, deg, chunk, qnext, qcap, &cnt->q_count[par ^ 1]);
+			scanned += (u64)min((int64_t)64, e - base);
+		}
+	}
+	// per-lane nf/mf, wave-uniform scanned/gathers
+	for (int o = 32; o > 0; o >>= 1) {
+		nf += __shfl_down(nf, o);
+		mf += __shfl_down(mf, o);
+	}
+	if (lane == 0) {
+		if (nf) atomicAdd(&cnt->front_vertices, nf);
+		if (mf) atomicAdd(&cnt->front_edges, mf);
+		if (scanned) atomicAdd(&cnt->edges_scanned, scanned);
+		if (gathers) atomicAdd(&cnt->word_gathers, gathers);
+	}
+}
+
+// zero the frontier words of the vertices just expanded (keeps the 2-buffer ring sparse-clean)
+template <int WD>
+__global__ void k_clear_items(const u64 *__restrict__ qcur, int par, u32 qcap, u64 *__restrict__ visit,
+                              const Counters *__restrict__ cnt) {
+	const u32 nq = min(cnt->q_count[par], qcap);
+	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; t < (int64_t)nq * WD; t += stride) {
+		u64 item = qcur[t / WD];
+		if ((item >> 32) == 0) visit[(size_t)(u32)item * WD + (t % WD)] = 0;
+	}
+}
+
+// frontier queue from a dense frontier (bottom-up level followed by a top-down level)
+template <int WD>
+__global__ void k_queue_from_dense(const u64 *__restrict__ front, int64_t V, const int64_t *__restrict__ off,
+                                   int64_t chunk, u64 *__restrict__ q, u32 qcap, int par, Counters *__restrict__ cnt) {
+	int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	const int64_t vmax = (V + 63) & ~63ll;
+	for (int64_t v = v0; v < vmax; v += stride) {
+		bool take = false;
+		int64_t deg = 0;
+		if (v < V) {
+			u64 any = 0;
+#pragma unroll
+			for (int w = 0; w < WD; w++) any |= front[(size_t)v * WD + w];
+			take = any != 0;
+			if (take) deg = off[v + 1] - off[v];
+		}
+		enqueue_items(take, (int)v, deg, chunk, q, qcap, &cnt->q_count[par]);
+	}
+}
+
+// ---- bottom-up level ----------------------------------------------------------------------------------------------
+// One wavefront per vertex n (persistent grid, interleaved assignment).  Lane = (slot, word): WD adjacent
+// lanes read the WD contiguous lane-words of one in-neighbour, 64/WD neighbours per gather instruction.
+//   next[n] = (OR over in-neighbours v of visit[v]) & active & ~seen[n];  seen[n] |= next[n]
+// which is iterativelength.cpp:18-30 evaluated per destination instead of per source.  A vertex whose
+// wanted lanes are already all seen is skipped; scanning stops early once every wanted lane is covered.
+template <int WD>
+__global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                              const int64_t *__restrict__ off, const u64 *__restrict__ visit,
+                                              u64 *__restrict__ seen, u64 *__restrict__ next,
+                                              const u64 *__restrict__ active, int V, int64_t hub_threshold,
+                                              Counters *__restrict__ cnt) {
+	constexpr int NS = 64 / WD;
+	__shared__ u64 red[4][4];
+	const int lane = threadIdx.x & 63;
+	const int word = lane & (WD - 1);
+	const int slot = lane / WD;
+	const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int nwaves = (gridDim.x * blockDim.x) >> 6;
+	const u64 act = active[word];
+	u64 nf = 0, mf = 0, scanned = 0;
+	for (int n = wave; n < V; n += nwaves) {
+		const int64_t b = roff[n], e = roff[n + 1];
+		if (e - b > hub_threshold) continue; // handled by k_pull_hub
+		const u64 s = seen[(size_t)n * WD + word];
+		const u64 want = act & ~s;
+		if (!__any(want != 0) || b == e) {
+			if (lane < WD) next[(size_t)n * WD + lane] = 0;
+			continue;
+		}
+		u64 acc = 0;
+		for (int64_t base = b; base < e; base += 64) {
+			const int c64 = (int)min((int64_t)64, e - base);
+			const int nb = lane < c64 ? radj[base + lane] : 0;
+#pragma unroll
+			for (int r = 0; r < WD; r++) {
+				const int j = r * NS + slot;
+				const int nbj = __shfl(nb, j);
+				if (j < c64) acc |= visit[(size_t)nbj * WD + word];
+			}
+			scanned += (u64)c64;
+			if (base + 64 < e) {
+				const u64 t = wave_or_slots(acc, WD);
+				if (__all((t & want) == want)) {
+					acc = t;
+					break;
+				}
+			}
+		}
+		acc = wave_or_slots(acc, WD);
+		const u64 fresh = acc & want;
+		if (lane < WD) {
+			next[(size_t)n * WD + lane] = fresh;
+			if (fresh) seen[(size_t)n * WD + lane] = s | fresh;
+		}
+		if (__any(fresh != 0)) {
+			nf += 1;
+			mf += (u64)(off[n + 1] - off[n]);
+		}
+	}
+	// block reduction of the wave-uniform counters, one atomic set per block
+	const int wib = threadIdx.x >> 6;
+	if (lane == 0) {
+		red[wib][0] = nf;
+		red[wib][1] = mf;
+		red[wib][2] = scanned;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u64 a = 0, bsum = 0, c = 0;
+		for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
+			a += red[k][0];
+			bsum += red[k][1];
+			c += red[k][2];
+		}
+		if (a) atomicAdd(&cnt->front_vertices, (u32)a);
+		if (bsum) atomicAdd(&cnt->front_edges, bsum);
+		if (c) {
+			atomicAdd(&cnt->edges_scanned, c);
+			atomicAdd(&cnt->word_gathers, c * WD);
+		}
+	}
+}
+
+// high in-degree vertices: zero next, OR partial results per slice, then fold into seen
+template <int WD>
+__global__ void k_pull_hub_zero(const int32_t *__restrict__ hubs, int64_t nh, u64 *__restrict__ next) {
+	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nh * WD) next[(size_t)hubs[t / WD] * WD + (t % WD)] = 0;
+}
+
+template <int WD>
+__global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ items, int64_t n_items,
+                                                  const int32_t *__restrict__ radj, const u64 *__restrict__ visit,
+                                                  const u64 *__restrict__ seen, u64 *__restrict__ next,
+                                                  const u64 *__restrict__ active, Counters *__restrict__ cnt) {
+	constexpr int NS = 64 / WD;
+	const int lane = threadIdx.x & 63;
+	const int word = lane & (WD - 1);
+	const int slot = lane / WD;
+	const int64_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	if (wave >= n_items) return;
+	const HubItem it = items[wave];
+	const int n = it.vertex;
+	const u64 want = active[word] & ~seen[(size_t)n * WD + word];
+	u64 have = next[(size_t)n * WD + word]; // other slices may already have covered it
+	if (__all(((have & want) == want))) return;
+	u64 acc = 0, scanned = 0;
+	for (int64_t base = it.begin; base < it.end; base += 64) {
+		const int c64 = (int)min((int64_t)64, it.end - base);
+		const int nb = lane < c64 ? radj[base + lane] : 0;
+#pragma unroll
+		for (int r = 0; r < WD; r++) {
+			const int j = r * NS + slot;
+			const int nbj = __shfl(nb, j);
+			if (j < c64) acc |= visit[(size_t)nbj * WD + word];
+		}
+		scanned += (u64)c64;
+		if (base + 64 < it.end) {
+			const u64 t = wave_or_slots(acc, WD);
+			if (__all((t & want) == want)) {
+				acc = t;
+				break;
+			}
+		}
+	}
+	acc = wave_or_slots(acc, WD);
+	const u64 fresh = acc & want;
+	if (lane < WD && fresh) atomicOr(&next[(size_t)n * WD + lane], fresh);
+	if (lane == 0) {
+		atomicAdd(&cnt->edges_scanned, scanned);
+		atomicAdd(&cnt->word_gathers, scanned * WD);
+	}
+}
+
+template <int WD>
+__global__ void k_pull_hub_fold(const int32_t *__restrict__ hubs, int64_t nh, const int64_t *__restrict__ off,
+                                u64 *__restrict__ seen, const u64 *__restrict__ next, Counters *__restrict__ cnt) {
+	int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (h >= nh) return;
+	const int n = hubs[h];
+	u64 any = 0;
+#pragma unroll
+	for (int w = 0; w < WD; w++) {
+		u64 f = next[(size_t)n * WD + w];
+		if (f) seen[(size_t)n * WD + w] |= f;
+		any |= f;
+	}
+	if (any) {
+		atomicAdd(&cnt->front_vertices, 1u);
+		atomicAdd(&cnt->front_edges, (u64)(off[n + 1] - off[n]));
+	}
+}
+
+// ---- per-pair detection (iterativelength.cpp:119-129) ------------------------------------------------------------
+template <int WD>
+__global__ void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const int32_t *__restrict__ sdst,
+                         int32_t *__restrict__ sres, u32 base_lane, const u64 *__restrict__ seen, int level,
+                         u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
+	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool open = false;
+	if (i < hi && sres[i] < 0) {
+		const u32 l = skey[i] - base_lane;
+		const u64 bit = 1ull << (l & 63);
+		if (seen[(size_t)sdst[i] * WD + (l >> 6)] & bit) {
+			sres[i] = level;
+		} else {
+			open = true;
+			atomicOr(&active_next[l >> 6], bit);
+		}
+	}
+	const u64 m = __ballot(open);
+	if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt->unresolved, (u32)__popcll(m));
+}
+
+// ---- traversed-edge accounting (measurement only; bench.py's MTEPS numerator) -----------------------------------
+// S[l] += out-degree of every vertex whose frontier has lane l set.  LDS-privatised per block.
+template <int WD>
+__global__ __launch_bounds__(256) void k_lane_degree_sums(const u64 *__restrict__ front, const int64_t *__restrict__ off,
+                                                          int64_t V, u64 *__restrict__ S) {
+	__shared__ u64 acc[64 * WD];
+	for (int i = threadIdx.x; i < 64 * WD; i += blockDim.x) acc[i] = 0;
+	__syncthreads();
+	int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; idx < V * WD; idx += stride) {
+		u64 word = front[idx];
+		if (!word) continue;
+		const int64_t v = idx / WD;
+		const int w = (int)(idx % WD);
+		const u64 deg = (u64)(off[v + 1] - off[v]);
+		while (word) {
+			const int b = __ffsll((long long)word) - 1;
+			atomicAdd(&acc[w * 64 + b], deg);
+			word &= word - 1;
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < 64 * WD; i += blockDim.x)
+		if (acc[i]) atomicAdd(&S[i], acc[i]);
+}
+
+// te[i] = sum over the levels this pair's own BFS expands (0..d-1, or all when unreachable)
+__global__ void k_pair_te(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const int32_t *__restrict__ sres,
+                          u32 base_lane, const u64 *__restrict__ S, int L, int nlevels, int64_t *__restrict__ ste) {
+	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= hi) return;
+	const u32 l = skey[i] - base_lane;
+	const int d = sres[i];
+	const int T = d < 0 ? nlevels : min(d, nlevels);
+	u64 te = 0;
+	for (int t = 0; t < T; t++) te += S[(size_t)t * L + l];
+	ste[i] = (int64_t)te;
+}
+
+__global__ void k_scatter_te(int64_t n, const u32 *__restrict__ sidx, const int64_t *__restrict__ ste,
+                             int64_t *__restrict__ out) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[sidx[i]] = ste[i];
+}
+
+// ---- path reconstruction (shortest_path.cpp:149-204 with the :21-31 tie-break) ---------------------------------
+// One wavefront per resolved pair.  Walks back from dst: among the in-edges of x whose source has the lane's
+// bit in the previous level's frontier, take the one with the smallest forward slot.
+template <int WD>
+__global__ __launch_bounds__(256) void k_reconstruct(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
+                                                     const int32_t *__restrict__ sdst,
+                                                     const int32_t *__restrict__ sres,
+                                                     const int64_t *__restrict__ soff, u32 base_lane,
+                                                     const u64 *const *__restrict__ levels,
+                                                     const int64_t *__restrict__ roff,
+                                                     const int32_t *__restrict__ radj,
+                                                     const int64_t *__restrict__ rslot,
+                                                     const int64_t *__restrict__ edge_ids,
+                                                     int64_t *__restrict__ child) {
+	const int lane = threadIdx.x & 63;
+	const int64_t i = lo + (int64_t)__builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	if (i >= hi) return;
+	const int k = sres[i];
+	if (k < 1) return;
+	const u32 l = skey[i] - base_lane;
+	const int w = (int)(l >> 6);
+	const u64 bit = 1ull << (l & 63);
+	int64_t *out = child + soff[i];
+	int x = sdst[i];
+	if (lane == 0) out[2 * k] = x;
+	for (int t = k - 1; t >= 0; t--) {
+		const u64 *F = levels[t];
+		u64 best = ~0ull;
+		int bv = -1;
+		for (int64_t j = roff[x] + lane; j < roff[x + 1]; j += 64) {
+			const int v = radj[j];
+			if (F[(size_t)v * WD + w] & bit) {
+				const u64 sl = (u64)rslot[j];
+				if (sl < best) {
+					best = sl;
+					bv = v;
+				}
+			}
+		}
+		u64 m = best;
+		for (int o = 32; o > 0; o >>= 1) {
+			u64 other = __shfl_xor(m, o);
+			m = other < m ? other : m;
+		}
+		const u64 who = __ballot(best == m);
+		const int src_lane = __ffsll((long long)who) - 1;
+		const int pv = __shfl(bv, src_lane);
+		if (lane == 0) {
+			out[2 * t + 1] = edge_ids ? edge_ids[m] : (int64_t)m;
+			out[2 * t] = pv;
+		}
+		x = pv;
+	}
+}
+
+__global__ void k_trivial_paths(int64_t lo, int64_t hi, const int32_t *__restrict__ ssrc, int64_t base_off,
+                                int64_t *__restrict__ soff, int64_t *__restrict__ child) {
+	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= hi) return;
+	soff[i] = base_off + (i - lo);
+	child[base_off + (i - lo)] = ssrc[i];
+}
+
+// ---- workspace ---------------------------------------------------------------------------------------------------
+
+Workspace::~Workspace() {
+	if (stream) (void)hipStreamDestroy(stream);
+	if (h_cnt) (void)hipHostFree(h_cnt);
+	if (h_bstart) (void)hipHostFree(h_bstart);
+	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &active, &flag, &rank, &usrc, &key, &idx, &skey,
+	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
+	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste })
+		b->release();
+	for (auto &l : levels) l->buf.release();
+}
+
+static std::mutex g_ws_lock;
+static std::vector<Workspace *> g_ws_free;
+
+int WorkspaceLease::acquire() {
+	{
+		std::lock_guard<std::mutex> g(g_ws_lock);
+		if (!g_ws_free.empty()) {
+			ws = g_ws_free.back();
+			g_ws_free.pop_back();
+		}
+	}
+	if (!ws) {
+		ws = new Workspace();
+		PGQ_HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+		PGQ_HIP_TRY(hipHostMalloc((void **)&ws->h_cnt, sizeof(Counters)));
+	}
+	return PGQ_OK;
+}
+WorkspaceLease::~WorkspaceLease() {
+	if (!ws) return;
+	std::lock_guard<std::mutex> g(g_ws_lock);
+	if (g_ws_free.size() < 8) g_ws_free.push_back(ws);
+	else delete ws;
+}
+
+// ---- lane assignment (host side) ------------------------------------------------------------------------------------
+int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out) {
+	hipStream_t st = ws->stream;
+	const int64_t V = c->V;
+	PGQ_TRY(ws->flag.reserve((size_t)(V + 1) * 4));
+	PGQ_TRY(ws->rank.reserve((size_t)(V + 1) * 4));
+	PGQ_TRY(ws->usrc.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	for (DevBuf *b : { &ws->key, &ws->idx, &ws->skey, &ws->sidx, &ws->ssrc, &ws->sdst, &ws->sres }) PGQ_TRY(b->reserve((size_t)n * 4));
+	PGQ_TRY(ws->soff.reserve((size_t)n * 8));
+	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	int *d_bad = reinterpret_cast<int *>(ws->counters.p); // reused before the batch loop resets it
+	PGQ_HIP_TRY(hipMemsetAsync(ws->flag.p, 0, (size_t)(V + 1) * 4, st));
+	PGQ_HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(Counters), st));
+	KernelTimer kt(st, K_PREP);
+	hipLaunchKernelGGL(k_mark_sources, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->flag.as<u32>(), V, d_bad);
+	size_t tmp = 0;
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ws->flag.as<u32>(), ws->rank.as<u32>(), (int)(V + 1), st));
+	PGQ_TRY(ws->scan_tmp.reserve(tmp + 16));
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp, ws->flag.as<u32>(), ws->rank.as<u32>(), (int)(V + 1), st));
+	if (V > 0)
+		hipLaunchKernelGGL(k_compact_sources, dim3(blocks_for(V)), dim3(256), 0, st, V, ws->flag.as<u32>(), ws->rank.as<u32>(), ws->usrc.as<int32_t>());
+	hipLaunchKernelGGL(k_pair_keys, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), ws->key.as<u32>(), ws->idx.as<u32>());
+	size_t stmp = 0;
+	PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, stmp, ws->key.as<u32>(), ws->skey.as<u32>(), ws->idx.as<u32>(), ws->sidx.as<u32>(), (int)n, 0, 32, st));
+	PGQ_TRY(ws->sort_tmp.reserve(stmp + 16));
+	PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ws->sort_tmp.p, stmp, ws->key.as<u32>(), ws->skey.as<u32>(), ws->idx.as<u32>(), ws->sidx.as<u32>(), (int)n, 0, 32, st));
+	hipLaunchKernelGGL(k_gather_sorted, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->skey.as<u32>(), ws->sidx.as<u32>(), d_src, d_dst, ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>());
+	kt.stop();
+	u32 U = 0;
+	int bad = 0;
+	PGQ_HIP_TRY(hipMemcpyAsync(&U, ws->rank.as<u32>() + V, 4, hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	if (bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+	*U_out = U;
+	return PGQ_OK;
+}
+
+int batch_bounds(Workspace *ws, int64_t n, int64_t L, int nb) {
+	hipStream_t st = ws->stream;
+	PGQ_TRY(ws->bstart.reserve((size_t)(nb + 3) * 8));
+	if (ws->h_bstart_cap < (size_t)(nb + 3)) {
+		if (ws->h_bstart) (void)hipHostFree(ws->h_bstart);
+		ws->h_bstart_cap = (size_t)(nb + 3) * 2;
+		PGQ_HIP_TRY(hipHostMalloc((void **)&ws->h_bstart, ws->h_bstart_cap * 8));
+	}
+	{
+		KernelTimer kt(st, K_PREP);
+		hipLaunchKernelGGL(k_batch_bounds, dim3(blocks_for(nb + 3)), dim3(256), 0, st, ws->skey.as<u32>(), n, (u32)L,
+		                   nb, ws->bstart.as<int64_t>());
+		kt.stop();
+	}
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_bstart, ws->bstart.p, (size_t)(nb + 3) * 8, hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	return PGQ_OK;
+}
+
+static int choose_words(int64_t unique_sources) {
+	const Options &o = options();
+	int wd = o.words;
+	if (wd <= 0) {
+		wd = 1;
+		while (wd < o.max_words && (int64_t)wd * 64 < unique_sources) wd <<= 1;
+	}
+	if (wd != 1 && wd != 2 && wd != 4 && wd != 8 && wd != 16) wd = wd > 16 ? 16 : (wd > 8 ? 8 : (wd > 4 ? 4 : (wd > 2 ? 2 : 1)));
+	return wd;
+}
+
+// ---- the batch driver ----------------------------------------------------------------------------------------------
+// Runs the searches for rows already resident in device memory (d_src/d_dst, -1 src = NULL row).
+// with_paths: also emit [src,e,v,...,dst] lists into ws->child and per-row offsets.
+struct SearchOutput {
+	int64_t child_used = 0;
+	bool want_te = false; // fill ws->ste with per-row traversed-edge counts
+};
+static constexpr int kMaxTeLevels = 1024;
+
+template <int WD>
+static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool with_paths, int64_t *d_child_ext,
+                       int64_t child_cap_ext, SearchOutput &outp) {
+	hipStream_t st = ws->stream;
+	const int64_t V = c->V, E = c->E;
+	const Options &opt = options();
+	const int64_t L = 64 * WD;
+	const int nb = (int)((U + L - 1) / L);
+	const int64_t chunk = c->hub_threshold;
+	const size_t words = (size_t)std::max<int64_t>(V, 1) * WD;
+	const u32 qcap = (u32)std::min<int64_t>(V + E / chunk + 128, 0xFFFFFF00ll);
+	pgq_stats_t &S = tstats().s;
+
+	PGQ_TRY(ws->seen.reserve(words * 8));
+	PGQ_TRY(ws->qbuf[0].reserve((size_t)qcap * 8));
+	PGQ_TRY(ws->qbuf[1].reserve((size_t)qcap * 8));
+	PGQ_TRY(ws->qflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	PGQ_TRY(ws->active.reserve(2 * 16 * 8));
+	if (outp.want_te) {
+		PGQ_TRY(ws->lane_sums.reserve((size_t)kMaxTeLevels * L * 8));
+		PGQ_TRY(ws->ste.reserve((size_t)n * 8));
+		PGQ_HIP_TRY(hipMemsetAsync(ws->ste.p, 0, (size_t)n * 8, st));
+	}
+	Counters *d_cnt = ws->counters.as<Counters>();
+	PGQ_TRY(batch_bounds(ws, n, L, nb));
+	PGQ_HIP_TRY(hipMemsetAsync(ws->qflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
+	ws->epoch = 0;
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	const int64_t *bs = ws->h_bstart;
+
+	int64_t child_base = 0;
+	int64_t *d_child = d_child_ext;
+	bool child_overflow = false;
+	std::vector<int32_t> h_res;
+	std::vector<int64_t> h_off;
+
+	const int ncu = 256;
+	const unsigned pull_grid = (unsigned)std::max(1, opt.blocks_per_cu) * ncu;
+	const unsigned push_grid = 8 * ncu;
+
+	for (int b = 0; b < nb; b++) {
+		const int64_t lo = bs[b], hi = bs[b + 1];
+		if (lo == hi) continue;
+		const u32 base_lane = (u32)((int64_t)b * L);
+		S.batches++;
+		// -- reset per-batch state
+		PGQ_HIP_TRY(hipMemsetAsync(ws->seen.p, 0, words * 8, st));
+		PGQ_HIP_TRY(hipMemsetAsync(ws->counters.p, 0, sizeof(Counters), st));
+		PGQ_HIP_TRY(hipMemsetAsync(ws->active.p, 0, 2 * 16 * 8, st));
+		auto level_buf = [&](int t) -> LevelBuf * {
+			size_t k = with_paths ? (size_t)t : (size_t)(t & 1);
+			while (ws->levels.size() <= k) ws->levels.emplace_back(new LevelBuf());
+			return ws->levels[k].get();
+		};
+		auto make_zero = [&](LevelBuf *lb) -> int {
+			PGQ_TRY(lb->buf.reserve(words * 8));
+			if (lb->dirty) {
+				PGQ_HIP_TRY(hipMemsetAsync(lb->buf.p, 0, words * 8, st));
+				lb->dirty = false;
+			}
+			return PGQ_OK;
+		};
+		for (auto &lb : ws->levels) lb->dirty = true; // previous batch / call left them in an unknown state
+		LevelBuf *cur = level_buf(0);
+		PGQ_TRY(make_zero(cur));
+		u64 *act_cur = ws->active.as<u64>();
+		u64 *act_nxt = ws->active.as<u64>() + 16;
+		{
+			KernelTimer kt(st, K_PREP);
+			hipLaunchKernelGGL(k_init_batch<WD>, dim3(blocks_for(L)), dim3(256), 0, st, ws->usrc.as<int32_t>(), U,
+			                   (int64_t)base_lane, c->off, cur->buf.as<u64>(), ws->seen.as<u64>(), act_cur,
+			                   ws->qbuf[0].as<u64>(), qcap, chunk, d_cnt);
+			kt.stop();
+		}
+		cur->dirty = true;
+		if (outp.want_te) {
+			PGQ_HIP_TRY(hipMemsetAsync(ws->lane_sums.p, 0, (size_t)kMaxTeLevels * L * 8, st));
+			hipLaunchKernelGGL(k_lane_degree_sums<WD>, dim3(4 * ncu), dim3(256), 0, st, cur->buf.as<u64>(), c->off, V,
+			                   ws->lane_sums.as<u64>());
+		}
+		PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		u64 front_edges = ws->h_cnt->front_edges;
+		u32 unresolved = (u32)(hi - lo);
+		bool queue_valid = true; // qbuf[par] describes `cur`
+		int par = 0;
+		int levels_run = 0;
+		bool prev_pull = false;
+		for (int t = 1; unresolved > 0 && front_edges > 0; t++) {
+			LevelBuf *nxt = level_buf(t);
+			bool push = opt.force_mode == 1 || (opt.force_mode == 0 && (double)front_edges * opt.push_div < (double)E);
+			if (opt.force_mode == 2) push = false;
+			// reset the per-level counters but keep the queue counts
+			PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->front_vertices, 0, sizeof(Counters) - offsetof(Counters, front_vertices), st));
+			if (push) {
+				if (!queue_valid) {
+					PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->q_count[par], 0, 4, st));
+					KernelTimer kt(st, K_QUEUE);
+					hipLaunchKernelGGL(k_queue_from_dense<WD>, dim3(std::min(blocks_for(V), 16u * ncu)), dim3(256), 0, st,
+					                   cur->buf.as<u64>(), V, c->off, chunk, ws->qbuf[par].as<u64>(), qcap, par, d_cnt);
+					kt.stop();
+				}
+				PGQ_TRY(make_zero(nxt));
+				PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->q_count[par ^ 1], 0, 4, st));
+				ws->epoch++;
+				{
+					KernelTimer kt(st, K_PUSH);
+					hipLaunchKernelGGL(k_push<WD>, dim3(push_grid), dim3(256), 0, st, c->off, c->adj, cur->buf.as<u64>(),
+					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, ws->qbuf[par].as<u64>(), par,
+					                   ws->qflag.as<u32>(), ws->epoch, ws->qbuf[par ^ 1].as<u64>(), qcap, chunk, d_cnt);
+					kt.stop();
+				}
+				nxt->dirty = true;
+				if (!with_paths) {
+					KernelTimer kt(st, K_QUEUE);
+					hipLaunchKernelGGL(k_clear_items<WD>, dim3(4 * ncu), dim3(256), 0, st, ws->qbuf[par].as<u64>(), par,
+					                   qcap, cur->buf.as<u64>(), d_cnt);
+					kt.stop();
+					cur->dirty = false;
+				}
+				par ^= 1;
+				queue_valid = true;
+				S.push_levels++;
+				prev_pull = false;
+			} else {
+				PGQ_TRY(nxt->buf.reserve(words * 8));
+				if (c->n_pull_hub_vertices > 0) {
+					KernelTimer kt(st, K_PULL_HUB);
+					hipLaunchKernelGGL(k_pull_hub_zero<WD>, dim3(blocks_for(c->n_pull_hub_vertices * WD)), dim3(256), 0,
+					                   st, c->pull_hub_vertices, c->n_pull_hub_vertices, nxt->buf.as<u64>());
+					hipLaunchKernelGGL(k_pull_hub<WD>, dim3(blocks_for(c->n_pull_hub_items * 64)), dim3(256), 0, st,
+					                   c->pull_hubs, c->n_pull_hub_items, c->radj, cur->buf.as<u64>(),
+					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, d_cnt);
+					hipLaunchKernelGGL(k_pull_hub_fold<WD>, dim3(blocks_for(c->n_pull_hub_vertices)), dim3(256), 0, st,
+					                   c->pull_hub_vertices, c->n_pull_hub_vertices, c->off, ws->seen.as<u64>(),
+					                   nxt->buf.as<u64>(), d_cnt);
+					kt.stop();
+				}
+				{
+					KernelTimer kt(st, K_PULL);
+					hipLaunchKernelGGL(k_pull<WD>, dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj, c->off,
+					                   cur->buf.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, (int)V,
+					                   chunk, d_cnt);
+					kt.stop();
+				}
+				nxt->dirty = true;
+				queue_valid = false;
+				S.pull_levels++;
+				prev_pull = true;
+			}
+			(void)prev_pull;
+			if (outp.want_te) {
+				if (t >= kMaxTeLevels) return fail(PGQ_ERR_UNSUPPORTED, "traversed-edge accounting supports at most 1023 levels");
+				hipLaunchKernelGGL(k_lane_degree_sums<WD>, dim3(4 * ncu), dim3(256), 0, st, nxt->buf.as<u64>(), c->off, V,
+				                   ws->lane_sums.as<u64>() + (size_t)t * L);
+			}
+			// -- detect finished pairs, rebuild the active-lane mask
+			PGQ_HIP_TRY(hipMemsetAsync(act_nxt, 0, 16 * 8, st));
+			{
+				KernelTimer kt(st, K_DETECT);
+				hipLaunchKernelGGL(k_detect<WD>, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
+				                   ws->sdst.as<int32_t>(), ws->sres.as<int32_t>(), base_lane, ws->seen.as<u64>(), t,
+				                   act_nxt, d_cnt);
+				kt.stop();
+			}
+			std::swap(act_cur, act_nxt);
+			PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			KernelTimer::flush();
+			const Counters &hc = *ws->h_cnt;
+			front_edges = hc.front_edges;
+			unresolved = hc.unresolved;
+			S.levels++;
+			S.edges_scanned += (int64_t)hc.edges_scanned;
+			S.word_gathers += (int64_t)hc.word_gathers;
+			S.frontier_vertices += (int64_t)hc.front_vertices;
+			// algorithmic bytes of this level's expansion kernel
+			if (push) {
+				S.algo_bytes[K_PUSH] += (double)hc.edges_scanned * 4.0 + (double)hc.word_gathers * 16.0;
+			} else {
+				S.algo_bytes[K_PULL] += (double)hc.edges_scanned * (4.0 + 8.0 * WD) + (double)V * (16.0 + 16.0 * WD);
+			}
+			if (opt.trace)
+				fprintf(stderr, "[pgq] batch %d level %d %s WD=%d front_v=%u front_e=%llu scanned=%llu gathers=%llu unresolved=%u push_ms=%.3f pull_ms=%.3f\n",
+				        b, t, push ? "push" : "pull", WD, hc.front_vertices, (unsigned long long)hc.front_edges,
+				        (unsigned long long)hc.edges_scanned, (unsigned long long)hc.word_gathers, hc.unresolved,
+				        S.kernel_ms[K_PUSH], S.kernel_ms[K_PULL] + S.kernel_ms[K_PULL_HUB]);
+			cur = nxt;
+			levels_run = t;
+		}
+		if (outp.want_te)
+			hipLaunchKernelGGL(k_pair_te, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
+			                   ws->sres.as<int32_t>(), base_lane, ws->lane_sums.as<u64>(), (int)L, levels_run + 1,
+			                   ws->ste.as<int64_t>());
+		// -- paths for this batch
+		if (with_paths) {
+			const int64_t cnt_pairs = hi - lo;
+			h_res.resize(cnt_pairs);
+			h_off.resize(cnt_pairs);
+			PGQ_HIP_TRY(hipMemcpyAsync(h_res.data(), ws->sres.as<int32_t>() + lo, (size_t)cnt_pairs * 4,
+			                           hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			int64_t need = child_base;
+			for (int64_t i = 0; i < cnt_pairs; i++) {
+				h_off[i] = need;
+				if (h_res[i] > 0) need += 2 * (int64_t)h_res[i] + 1;
+			}
+			PGQ_HIP_TRY(hipMemcpyAsync(ws->soff.as<int64_t>() + lo, h_off.data(), (size_t)cnt_pairs * 8,
+			                           hipMemcpyHostToDevice, st));
+			bool fits = true;
+			if (d_child_ext) {
+				fits = need <= child_cap_ext;
+			} else if ((size_t)need * 8 > ws->child.cap) {
+				// grow, preserving what earlier batches wrote
+				DevBuf bigger;
+				PGQ_TRY(bigger.reserve((size_t)need * 8 * 2));
+				if (child_base > 0)
+					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
+				PGQ_HIP_TRY(hipStreamSynchronize(st));
+				ws->child.release();
+				ws->child = bigger;
+				d_child = ws->child.as<int64_t>();
+			}
+			if (!d_child_ext) d_child = ws->child.as<int64_t>();
+			if (fits && need > child_base && levels_run > 0) {
+				std::vector<const u64 *> tab((size_t)levels_run + 1);
+				for (int t = 0; t <= levels_run; t++) tab[t] = ws->levels[t]->buf.as<u64>();
+				PGQ_TRY(ws->levels_tab.reserve(tab.size() * sizeof(u64 *)));
+				PGQ_HIP_TRY(hipMemcpyAsync(ws->levels_tab.p, tab.data(), tab.size() * sizeof(u64 *), hipMemcpyHostToDevice, st));
+				KernelTimer kt(st, K_RECON);
+				hipLaunchKernelGGL(k_reconstruct<WD>, dim3(blocks_for(cnt_pairs * 64)), dim3(256), 0, st, lo, hi,
+				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>(),
+				                   ws->soff.as<int64_t>(), base_lane, (const u64 *const *)ws->levels_tab.p, c->roff,
+				                   c->radj, c->rslot, c->edge_ids, d_child);
+				kt.stop();
+				PGQ_HIP_TRY(hipStreamSynchronize(st)); // tab is a stack vector
+				KernelTimer::flush();
+			}
+			if (!fits) child_overflow = true;
+			child_base = need;
+		}
+	}
+	if (with_paths) {
+		// src == dst rows: [src]
+		const int64_t lo = bs[nb + 1], hi = bs[nb + 2];
+		if (hi > lo) {
+			int64_t need = child_base + (hi - lo);
+			bool fits = true;
+			if (d_child_ext) fits = need <= child_cap_ext;
+			else if ((size_t)need * 8 > ws->child.cap) {
+				DevBuf bigger;
+				PGQ_TRY(bigger.reserve((size_t)need * 8));
+				if (child_base > 0)
+					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
+				PGQ_HIP_TRY(hipStreamSynchronize(st));
+				ws->child.release();
+				ws->child = bigger;
+			}
+			if (!d_child_ext) d_child = ws->child.as<int64_t>();
+			if (fits) {
+				hipLaunchKernelGGL(k_trivial_paths, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi,
+				                   ws->ssrc.as<int32_t>(), child_base, ws->soff.as<int64_t>(), d_child);
+			} else {
+				child_overflow = true;
+			}
+			child_base = need;
+		}
+		outp.child_used = child_base;
+		if (child_overflow) return fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(child_base) + " elements");
+	}
+	return PGQ_OK;
+}
+
+// Lane assignment + sorting of the rows, then the templated batch loop; results scattered back to row order.
+static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                         int64_t *d_out_len, bool with_paths, int64_t *d_out_off, int64_t *d_child_ext,
+                         int64_t child_cap_ext, SearchOutput &outp) {
+	hipStream_t st = ws->stream;
+	pgq_stats_t &S = tstats().s;
+	S.pairs += n;
+	if (n == 0) return PGQ_OK;
+	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
+	u32 U = 0;
+	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U));
+	S.unique_sources += U;
+	if (with_paths) PGQ_HIP_TRY(hipMemsetAsync(ws->soff.p, 0, (size_t)n * 8, st));
+	const int wd = choose_words(U);
+	int rc;
+	switch (wd) {
+	case 1: rc = run_batches<1>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
+	case 2: rc = run_batches<2>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
+	case 4: rc = run_batches<4>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
+	case 8: rc = run_batches<8>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
+	default: rc = run_batches<16>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
+	}
+	// results back to row order even when the child buffer overflowed (lengths are still right)
+	hipLaunchKernelGGL(k_scatter_results, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->sidx.as<u32>(), ws->sres.as<int32_t>(),
+	                   ws->soff.as<int64_t>(), d_out_len, with_paths ? d_out_off : nullptr);
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	return rc;
+}
+
+static int check_csr(pgq_csr_t *csr, int64_t V) {
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: Need to initialize CSR before doing shortest path");
+	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");
+	return PGQ_OK;
+}
+
+} // namespace pgq
+
+using namespace pgq;
+
+// per-thread arena for list payloads returned by the chunk API
+static thread_local std::vector<int64_t> t_child;
+
+extern "C" {
+
+void pgq_thread_release(void) {
+	t_child.clear();
+	t_child.shrink_to_fit();
+}
+
+int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                    int64_t *d_out_len) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out_len))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	SearchOutput so;
+	return search_device(csr, lease.ws, n, d_src, d_dst, d_out_len, false, nullptr, nullptr, 0, so);
+}
+
+int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                    int64_t *d_out_len, int64_t *d_out_te) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out_len || !d_out_te))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	SearchOutput so;
+	so.want_te = true;
+	PGQ_TRY(search_device(csr, lease.ws, n, d_src, d_dst, d_out_len, false, nullptr, nullptr, 0, so));
+	if (n > 0) {
+		hipLaunchKernelGGL(k_scatter_te, dim3(blocks_for(n)), dim3(256), 0, lease.ws->stream, n, lease.ws->sidx.as<u32>(),
+		                   lease.ws->ste.as<int64_t>(), d_out_te);
+		PGQ_HIP_TRY(hipStreamSynchronize(lease.ws->stream));
+	}
+	return PGQ_OK;
+}
+
+int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                 int64_t *d_out_len, int64_t *d_out_offset, int64_t *d_child, int64_t child_cap,
+                                 int64_t *child_used) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out_len || !d_out_offset || !d_child)))
+		return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	SearchOutput so;
+	int rc = search_device(csr, lease.ws, n, d_src, d_dst, d_out_len, true, d_out_offset, d_child, child_cap, so);
+	if (child_used) *child_used = so.child_used;
+	return rc;
+}
+
+int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
+                        uint64_t *out_valid) {
+	PGQ_TRY(ensure_init());
+	PGQ_TRY(check_csr(csr, V));
+	if (n < 0 || (n > 0 && (!out_len || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
+	if (n == 0) return PGQ_OK;
+	FlatPairs fp;
+	PGQ_TRY(flatten_pairs(V, n, src, dst, fp, false));
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	Workspace *ws = lease.ws;
+	PGQ_TRY(ws->in_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->in_dst.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_len.reserve((size_t)n * 8));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, fp.src.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, fp.dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	SearchOutput so;
+	PGQ_TRY(search_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
+	                      false, nullptr, nullptr, 0, so));
+	PGQ_HIP_TRY(hipMemcpy(out_len, ws->out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	mask_fill_valid(out_valid, n);
+	for (int64_t i = 0; i < n; i++)
+		if (out_len[i] < 0) mask_set_invalid(out_valid, i); // payload stays -1 like iterativelength.cpp:100,137
+	return PGQ_OK;
+}
+
+int pgq_shortestpath(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, uint64_t *out_offset,
+                     uint64_t *out_length, uint64_t *out_valid, const int64_t **out_child, uint64_t *out_child_len) {
+	PGQ_TRY(ensure_init());
+	PGQ_TRY(check_csr(csr, V));
+	if (n < 0 || (n > 0 && (!out_offset || !out_length || !out_valid)) || !out_child || !out_child_len)
+		return fail(PGQ_ERR_INVALID_ARG, "NULL output");
+	*out_child = nullptr;
+	*out_child_len = 0;
+	if (n == 0) return PGQ_OK;
+	FlatPairs fp;
+	PGQ_TRY(flatten_pairs(V, n, src, dst, fp, false));
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	Workspace *ws = lease.ws;
+	PGQ_TRY(ws->in_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->in_dst.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_len.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_off.reserve((size_t)n * 8));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, fp.src.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, fp.dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	SearchOutput so;
+	PGQ_TRY(search_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
+	                      true, ws->out_off.as<int64_t>(), nullptr, 0, so));
+	std::vector<int64_t> len(n), off(n);
+	PGQ_HIP_TRY(hipMemcpy(len.data(), ws->out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	PGQ_HIP_TRY(hipMemcpy(off.data(), ws->out_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	t_child.resize((size_t)so.child_used);
+	if (so.child_used > 0)
+		PGQ_HIP_TRY(hipMemcpy(t_child.data(), ws->child.p, (size_t)so.child_used * 8, hipMemcpyDeviceToHost));
+	mask_fill_valid(out_valid, n);
+	for (int64_t i = 0; i < n; i++) {
+		if (len[i] < 0) {
+			mask_set_invalid(out_valid, i);
+			out_offset[i] = 0;
+			out_length[i] = 0;
+		} else {
+			out_offset[i] = (uint64_t)off[i];
+			out_length[i] = (uint64_t)(2 * len[i] + 1);
+		}
+	}
+	*out_child = t_child.data();
+	*out_child_len = (uint64_t)so.child_used;
+	return PGQ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,504 @@
+// pgq_runtime.hip — process state, error/option/stat plumbing and the device CSR (upload, reverse CSR, hubs).
+//
+// Replaces, on the device side, the CSR object of the reference
+// (src/include/duckpgq/core/utils/compressed_sparse_row.hpp:25-47): the host CSR built by
+// create_csr_vertex/create_csr_edge (src/core/functions/scalar/csr_creation.cpp:86-198) is copied once to HBM,
+// the adjacency narrowed to int32, and an in-neighbour (reverse) CSR derived on the GPU for the bottom-up
+// kernel and for path reconstruction.  Slot order of the forward CSR is preserved bit for bit — it decides
+// which parallel edge shortestpath reports (shortest_path.cpp:23-30).
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+#include "pgq_internal.h"
+
+namespace pgq {
+
+static thread_local std::string t_err;
+void set_error(const std::string &msg) { t_err = msg; }
+int fail(int code, const std::string &msg) {
+	t_err = msg;
+	return code;
+}
+
+static std::mutex g_init_lock;
+static std::atomic<int> g_inited { 0 };
+static int g_device = 0;
+static Options g_opt;
+Options &options() { return g_opt; }
+
+ThreadStats::ThreadStats() { memset(&s, 0, sizeof(s)); }
+ThreadStats &tstats() {
+	static thread_local ThreadStats ts;
+	return ts;
+}
+
+static void env_int(const char *name, int &dst) {
+	const char *v = getenv(name);
+	if (v && *v) dst = atoi(v);
+}
+static void env_double(const char *name, double &dst) {
+	const char *v = getenv(name);
+	if (v && *v) dst = atof(v);
+}
+
+static int do_init(int device) {
+	std::lock_guard<std::mutex> g(g_init_lock);
+	if (g_inited.load()) return PGQ_OK;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		return fail(PGQ_ERR_NO_DEVICE, std::string("libpgq_hip needs a HIP device (gfx950); hipGetDeviceCount: ") +
+		                                   (e == hipSuccess ? "0 devices" : hipGetErrorString(e)));
+	}
+	if (device < 0) {
+		const char *v = getenv("PGQ_DEVICE");
+		if (!v || !*v) v = getenv("LOCAL_RANK");
+		device = (v && *v) ? atoi(v) : 0;
+		if (device >= count) device = device % count;
+	}
+	if (device >= count) return fail(PGQ_ERR_INVALID_ARG, "pgq_init: device index out of range");
+	e = hipSetDevice(device);
+	if (e != hipSuccess) return fail(PGQ_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+	g_device = device;
+	env_int("PGQ_WORDS", g_opt.words);
+	env_int("PGQ_MAX_WORDS", g_opt.max_words);
+	env_double("PGQ_PUSH_DIV", g_opt.push_div);
+	env_int("PGQ_PROFILE", g_opt.profile);
+	env_int("PGQ_HUB_CHUNK", g_opt.hub_chunk);
+	env_int("PGQ_FORCE_MODE", g_opt.force_mode);
+	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
+	env_int("PGQ_CHEAPEST_LANES", g_opt.cheapest_lanes);
+	env_int("PGQ_TRACE", g_opt.trace);
+	g_inited.store(1);
+	return PGQ_OK;
+}
+
+int ensure_init() {
+	if (!g_inited.load()) PGQ_TRY(do_init(-1));
+	// every host thread that calls in (DuckDB workers) must bind the device
+	hipError_t e = hipSetDevice(g_device);
+	if (e != hipSuccess) return fail(PGQ_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+	return PGQ_OK;
+}
+
+// ---- kernel timers ----------------------------------------------------------------------------------------
+struct PendingTimer {
+	hipEvent_t a, b;
+	int kclass;
+};
+static thread_local std::vector<PendingTimer> t_pending;
+static thread_local std::vector<hipEvent_t> t_event_pool;
+
+static hipEvent_t get_event() {
+	if (!t_event_pool.empty()) {
+		hipEvent_t e = t_event_pool.back();
+		t_event_pool.pop_back();
+		return e;
+	}
+	hipEvent_t e = nullptr;
+	(void)hipEventCreate(&e);
+	return e;
+}
+
+KernelTimer::KernelTimer(hipStream_t s, int k) : stream(s), kclass(k) {
+	tstats().s.launches[k]++;
+	if (!options().profile) return;
+	a = get_event();
+	b = get_event();
+	(void)hipEventRecord(a, stream);
+}
+void KernelTimer::stop() {
+	if (!a) return;
+	(void)hipEventRecord(b, stream);
+	t_pending.push_back({ a, b, kclass });
+	a = b = nullptr;
+}
+void KernelTimer::flush() {
+	for (auto &p : t_pending) {
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) tstats().s.kernel_ms[p.kclass] += ms;
+		t_event_pool.push_back(p.a);
+		t_event_pool.push_back(p.b);
+	}
+	t_pending.clear();
+}
+
+int DevBuf::reserve(size_t bytes) {
+	if (bytes <= cap) return PGQ_OK;
+	if (p) (void)hipFree(p);
+	p = nullptr;
+	cap = 0;
+	size_t want = bytes + bytes / 8 + 256;
+	hipError_t e = hipMalloc(&p, want);
+	if (e != hipSuccess) return fail(PGQ_ERR_OOM, std::string("hipMalloc(") + std::to_string(want) + "): " +
+	                                                  hipGetErrorString(e));
+	cap = want;
+	return PGQ_OK;
+}
+void DevBuf::release() {
+	if (p) (void)hipFree(p);
+	p = nullptr;
+	cap = 0;
+}
+
+// ---- UnifiedVectorFormat -> flat arrays --------------------------------------------------------------------
+int flatten_pairs(int64_t V, int64_t n, const pgq_vec_t &src, const pgq_vec_t &dst, FlatPairs &out,
+                  bool check_dst_validity) {
+	out.src.resize(n);
+	out.dst.resize(n);
+	out.dst_valid.assign(n, 1);
+	const int64_t *sd = static_cast<const int64_t *>(src.data);
+	const int64_t *dd = static_cast<const int64_t *>(dst.data);
+	if (n > 0 && (!sd || !dd)) return fail(PGQ_ERR_INVALID_ARG, "src/dst data pointer is NULL");
+	for (int64_t r = 0; r < n; r++) {
+		int64_t sp = src.sel ? (int64_t)src.sel[r] : r;
+		int64_t dp = dst.sel ? (int64_t)dst.sel[r] : r;
+		bool s_ok = !src.validity || ((src.validity[sp >> 6] >> (sp & 63)) & 1ULL);
+		bool d_ok = !dst.validity || ((dst.validity[dp >> 6] >> (dp & 63)) & 1ULL);
+		int64_t s = s_ok ? sd[sp] : -1;
+		int64_t d = dd[dp];
+		if (check_dst_validity && !d_ok) {
+			out.dst_valid[r] = 0;
+			d = 0; // never dereferenced as a vertex for an invalid row
+		}
+		if (s_ok && (s < 0 || s >= V)) return fail(PGQ_ERR_INVALID_ARG, "source rowid out of range [0,V)");
+		if (s_ok && out.dst_valid[r] && (d < 0 || d >= V)) {
+			// The reference never looks at dst validity (iterativelength.cpp:98,122); a NULL dst carries an
+			// arbitrary payload there.  Out-of-range payloads of *valid* sources are rejected here.
+			if (d_ok) return fail(PGQ_ERR_INVALID_ARG, "destination rowid out of range [0,V)");
+			s = -1; // NULL dst with garbage payload: report NULL instead of reading out of bounds
+		}
+		out.src[r] = s;
+		out.dst[r] = d;
+	}
+	return PGQ_OK;
+}
+
+// ---- CSR upload kernels --------------------------------------------------------------------------------------
+
+// adjacency int64 -> int32, in-degree histogram, range check
+__global__ void k_narrow_adj(const int64_t *__restrict__ adj64, int32_t *__restrict__ adj32, int *__restrict__ rcnt,
+                             int64_t E, int64_t V, int *__restrict__ bad) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < E; i += stride) {
+		int64_t d = adj64[i];
+		if (d < 0 || d >= V) {
+			*bad = 1;
+			d = 0;
+		}
+		adj32[i] = (int32_t)d;
+		atomicAdd(&rcnt[d], 1);
+	}
+}
+
+__global__ void k_widen(const int *__restrict__ in, int64_t *__restrict__ out, int64_t n_in, int64_t n_out) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_out) out[i] = i < n_in ? (int64_t)in[i] : 0;
+}
+
+// one thread per forward slot: find its source by binary search in the offsets, claim a reverse slot
+__global__ void k_scatter_reverse(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                  const int64_t *__restrict__ roff, int *__restrict__ fill,
+                                  int32_t *__restrict__ radj, int64_t *__restrict__ rslot, int64_t E, int64_t V) {
+	int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; e < E; e += stride) {
+		int64_t lo = 0, hi = V; // largest v with off[v] <= e
+		while (lo < hi) {
+			int64_t mid = (lo + hi + 1) >> 1;
+			if (off[mid] <= e) lo = mid;
+			else hi = mid - 1;
+		}
+		int32_t d = adj[e];
+		int64_t p = roff[d] + atomicAdd(&fill[d], 1);
+		radj[p] = (int32_t)lo;
+		rslot[p] = e;
+	}
+}
+
+__global__ void k_check_offsets(const int64_t *__restrict__ off, int64_t V, int *__restrict__ bad) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < V && off[i] > off[i + 1]) *bad = 1;
+	if (i == 0 && off[0] != 0) *bad = 1;
+}
+
+template <typename T> __global__ void k_any_negative(const T *__restrict__ w, int64_t E, int *__restrict__ flag) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < E; i += stride)
+		if (w[i] < (T)0) *flag = 1;
+}
+
+static int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
+	int64_t g = (n + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > cap) g = cap;
+	return (int)g;
+}
+
+// Builds everything derived from (off, adj64) that already sit in device memory.
+static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
+	const int64_t V = c->V, E = c->E;
+	int *d_flag = nullptr;
+	PGQ_HIP_TRY(hipMalloc(&d_flag, 2 * sizeof(int)));
+	PGQ_HIP_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+	if (V > 0) {
+		hipLaunchKernelGGL(k_check_offsets, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, c->off, V, d_flag);
+	}
+	int *d_cnt = nullptr;
+	PGQ_HIP_TRY(hipMalloc(&d_cnt, (size_t)(V + 1) * sizeof(int)));
+	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(V + 1) * sizeof(int), st));
+	PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
+	PGQ_HIP_TRY(hipMalloc(&c->radj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
+	PGQ_HIP_TRY(hipMalloc(&c->rslot, (size_t)std::max<int64_t>(E, 1) * sizeof(int64_t)));
+	PGQ_HIP_TRY(hipMalloc(&c->roff, (size_t)(V + 1) * sizeof(int64_t)));
+	if (E > 0) {
+		hipLaunchKernelGGL(k_narrow_adj, dim3(grid_for(E)), dim3(256), 0, st, d_adj64, c->adj, d_cnt, E, V, d_flag);
+	}
+	// in-degree -> roff by exclusive scan
+	int64_t *d_deg64 = nullptr;
+	PGQ_HIP_TRY(hipMalloc(&d_deg64, (size_t)(V + 1) * sizeof(int64_t)));
+	hipLaunchKernelGGL(k_widen, dim3((unsigned)((V + 1 + 255) / 256)), dim3(256), 0, st, d_cnt, d_deg64, V, V + 1);
+	void *d_tmp = nullptr;
+	size_t tmp_bytes = 0;
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_deg64, c->roff, (int)(V + 1), st));
+	PGQ_HIP_TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_deg64, c->roff, (int)(V + 1), st));
+	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(V + 1) * sizeof(int), st));
+	if (E > 0) {
+		hipLaunchKernelGGL(k_scatter_reverse, dim3(grid_for(E)), dim3(256), 0, st, c->off, c->adj, c->roff, d_cnt,
+		                   c->radj, c->rslot, E, V);
+	}
+	if (c->w && E > 0) {
+		if (c->w_type == PGQ_W_INT64)
+			hipLaunchKernelGGL(k_any_negative<int64_t>, dim3(grid_for(E)), dim3(256), 0, st, (const int64_t *)c->w, E,
+			                   d_flag + 1);
+		else
+			hipLaunchKernelGGL(k_any_negative<double>, dim3(grid_for(E)), dim3(256), 0, st, (const double *)c->w, E,
+			                   d_flag + 1);
+	}
+	// degrees back to the host for the hub work lists
+	std::vector<int64_t> h_roff((size_t)V + 1), h_off((size_t)V + 1);
+	int h_flag[2] = { 0, 0 };
+	PGQ_HIP_TRY(hipMemcpyAsync(h_roff.data(), c->roff, (size_t)(V + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipMemcpyAsync(h_off.data(), c->off, (size_t)(V + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipMemcpyAsync(h_flag, d_flag, sizeof(h_flag), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	(void)hipFree(d_flag);
+	(void)hipFree(d_cnt);
+	(void)hipFree(d_deg64);
+	(void)hipFree(d_tmp);
+	if (h_flag[0]) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: offsets not monotone or adjacency out of [0,V)");
+	c->has_negative_weight = h_flag[1] != 0;
+
+	const int64_t chunk = std::max(64, options().hub_chunk);
+	c->hub_threshold = chunk;
+	std::vector<HubItem> items;
+	std::vector<int32_t> hubs;
+	for (int64_t v = 0; v < V; v++) {
+		int64_t indeg = h_roff[v + 1] - h_roff[v];
+		int64_t outdeg = h_off[v + 1] - h_off[v];
+		c->max_in_degree = std::max(c->max_in_degree, indeg);
+		c->max_out_degree = std::max(c->max_out_degree, outdeg);
+		if (indeg > chunk) {
+			hubs.push_back((int32_t)v);
+			for (int64_t b = h_roff[v]; b < h_roff[v + 1]; b += chunk)
+				items.push_back({ (int32_t)v, 0, b, std::min(b + chunk, h_roff[v + 1]) });
+		}
+	}
+	c->n_pull_hub_items = (int64_t)items.size();
+	c->n_pull_hub_vertices = (int64_t)hubs.size();
+	if (!items.empty()) {
+		PGQ_HIP_TRY(hipMalloc(&c->pull_hubs, items.size() * sizeof(HubItem)));
+		PGQ_HIP_TRY(hipMemcpy(c->pull_hubs, items.data(), items.size() * sizeof(HubItem), hipMemcpyHostToDevice));
+		PGQ_HIP_TRY(hipMalloc(&c->pull_hub_vertices, hubs.size() * sizeof(int32_t)));
+		PGQ_HIP_TRY(hipMemcpy(c->pull_hub_vertices, hubs.data(), hubs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	}
+	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
+	           (int64_t)items.size() * (int64_t)sizeof(HubItem);
+	return PGQ_OK;
+}
+
+static void destroy_csr(pgq_csr *c) {
+	if (!c) return;
+	(void)hipFree(c->off);
+	(void)hipFree(c->adj);
+	(void)hipFree(c->edge_ids);
+	(void)hipFree(c->w);
+	(void)hipFree(c->roff);
+	(void)hipFree(c->radj);
+	(void)hipFree(c->rslot);
+	(void)hipFree(c->pull_hubs);
+	(void)hipFree(c->pull_hub_vertices);
+	delete c;
+}
+
+static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
+                       int w_type, bool on_device, pgq_csr_t **out) {
+	PGQ_TRY(ensure_init());
+	if (!out) return fail(PGQ_ERR_INVALID_ARG, "out handle pointer is NULL");
+	*out = nullptr;
+	if (V < 0 || V >= (1LL << 31) - 1) return fail(PGQ_ERR_INVALID_ARG, "V must be in [0, 2^31-1)");
+	if (!offsets) return fail(PGQ_ERR_INVALID_ARG, "offsets is NULL");
+	if (w_type < 0 || w_type > 2 || (w_type != 0 && !w)) return fail(PGQ_ERR_INVALID_ARG, "bad weight type / NULL weights");
+	const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+	int64_t E = 0;
+	if (on_device) PGQ_HIP_TRY(hipMemcpy(&E, offsets + V, sizeof(int64_t), hipMemcpyDeviceToHost));
+	else E = offsets[V]; // E_used = v[V], not e.size()
+	if (E < 0 || E >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "edge count must be in [0, 2^31)");
+	if (E > 0 && !adj) return fail(PGQ_ERR_INVALID_ARG, "adj is NULL");
+	pgq_csr *c = new pgq_csr();
+	(void)hipGetDevice(&c->device);
+	c->V = V;
+	c->E = E;
+	c->w_type = w_type;
+	hipStream_t st = nullptr;
+	int rc = PGQ_OK;
+	int64_t *d_adj64 = nullptr;
+	auto body = [&]() -> int {
+		PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		PGQ_HIP_TRY(hipMalloc(&c->off, (size_t)(V + 1) * sizeof(int64_t)));
+		PGQ_HIP_TRY(hipMemcpyAsync(c->off, offsets, (size_t)(V + 1) * sizeof(int64_t), kind, st));
+		if (E > 0) {
+			if (on_device) {
+				d_adj64 = const_cast<int64_t *>(adj);
+			} else {
+				PGQ_HIP_TRY(hipMalloc(&d_adj64, (size_t)E * sizeof(int64_t)));
+				PGQ_HIP_TRY(hipMemcpyAsync(d_adj64, adj, (size_t)E * sizeof(int64_t), kind, st));
+			}
+			if (edge_ids) {
+				PGQ_HIP_TRY(hipMalloc(&c->edge_ids, (size_t)E * sizeof(int64_t)));
+				PGQ_HIP_TRY(hipMemcpyAsync(c->edge_ids, edge_ids, (size_t)E * sizeof(int64_t), kind, st));
+			}
+			if (w_type != PGQ_W_NONE) {
+				PGQ_HIP_TRY(hipMalloc(&c->w, (size_t)E * 8));
+				PGQ_HIP_TRY(hipMemcpyAsync(c->w, w, (size_t)E * 8, kind, st));
+			}
+		}
+		return finish_upload(c, d_adj64, st);
+	};
+	rc = body();
+	if (st) {
+		(void)hipStreamSynchronize(st);
+		(void)hipStreamDestroy(st);
+	}
+	if (!on_device && d_adj64) (void)hipFree(d_adj64);
+	if (rc != PGQ_OK) {
+		destroy_csr(c);
+		return rc;
+	}
+	*out = c;
+	return PGQ_OK;
+}
+
+// simple float4 copy kernel for the measured HBM ceiling
+__global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, int64_t n) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) out[i] = in[i];
+}
+
+} // namespace pgq
+
+using namespace pgq;
+
+extern "C" {
+
+int pgq_init(int device) {
+	if (g_inited.load()) return ensure_init();
+	return do_init(device);
+}
+
+int pgq_device_count(void) {
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+	return count;
+}
+
+const char *pgq_last_error(void) { return t_err.c_str(); }
+const char *pgq_version(void) { return "pgq_hip 0.1 (gfx950)"; }
+
+int pgq_csr_upload(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
+                   int w_type, pgq_csr_t **out) {
+	return upload_impl(V, offsets, adj, edge_ids, w, w_type, false, out);
+}
+int pgq_csr_upload_device(int64_t V, const int64_t *d_offsets, const int64_t *d_adj, const int64_t *d_edge_ids,
+                          const void *d_w, int w_type, pgq_csr_t **out) {
+	return upload_impl(V, d_offsets, d_adj, d_edge_ids, d_w, w_type, true, out);
+}
+int pgq_csr_free(pgq_csr_t *csr) {
+	if (!csr) return PGQ_OK;
+	PGQ_TRY(ensure_init());
+	destroy_csr(csr);
+	return PGQ_OK;
+}
+int64_t pgq_csr_num_vertices(const pgq_csr_t *csr) { return csr ? csr->V : -1; }
+int64_t pgq_csr_num_edges(const pgq_csr_t *csr) { return csr ? csr->E : -1; }
+int pgq_csr_w_type(const pgq_csr_t *csr) { return csr ? csr->w_type : -1; }
+int64_t pgq_csr_device_bytes(const pgq_csr_t *csr) { return csr ? csr->bytes : -1; }
+
+int pgq_set_option(const char *key, const char *value) {
+	if (!key || !value) return fail(PGQ_ERR_INVALID_ARG, "NULL option");
+	std::string k(key);
+	Options &o = options();
+	if (k == "words") o.words = atoi(value);
+	else if (k == "max_words") o.max_words = atoi(value);
+	else if (k == "push_div") o.push_div = atof(value);
+	else if (k == "profile") o.profile = atoi(value);
+	else if (k == "hub_chunk") o.hub_chunk = atoi(value);
+	else if (k == "force_mode") o.force_mode = atoi(value);
+	else if (k == "blocks_per_cu") o.blocks_per_cu = atoi(value);
+	else if (k == "cheapest_lanes") o.cheapest_lanes = atoi(value);
+	else if (k == "trace") o.trace = atoi(value);
+	else return fail(PGQ_ERR_INVALID_ARG, "unknown option: " + k);
+	return PGQ_OK;
+}
+
+const char *pgq_kclass_name(int k) {
+	static const char *names[K_COUNT] = { "prep",   "push",   "pull",  "pull_hub",
+		                                  "queue",  "detect", "recon", "relax" };
+	return (k >= 0 && k < K_COUNT) ? names[k] : nullptr;
+}
+int pgq_get_stats(pgq_stats_t *out) {
+	if (!out) return fail(PGQ_ERR_INVALID_ARG, "NULL stats");
+	*out = tstats().s;
+	return PGQ_OK;
+}
+int pgq_reset_stats(void) {
+	memset(&tstats().s, 0, sizeof(pgq_stats_t));
+	return PGQ_OK;
+}
+
+int pgq_measure_copy_bandwidth(int64_t bytes, int iters, double *out_gbps) {
+	PGQ_TRY(ensure_init());
+	if (bytes < 1024 || iters < 1 || !out_gbps) return fail(PGQ_ERR_INVALID_ARG, "bad bandwidth probe arguments");
+	void *a = nullptr, *b = nullptr;
+	PGQ_HIP_TRY(hipMalloc(&a, (size_t)bytes));
+	PGQ_HIP_TRY(hipMalloc(&b, (size_t)bytes));
+	PGQ_HIP_TRY(hipMemset(a, 1, (size_t)bytes));
+	int64_t n = bytes / 16;
+	hipEvent_t e0, e1;
+	PGQ_HIP_TRY(hipEventCreate(&e0));
+	PGQ_HIP_TRY(hipEventCreate(&e1));
+	hipLaunchKernelGGL(k_copy16, dim3(256 * 16), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, n);
+	PGQ_HIP_TRY(hipEventRecord(e0, 0));
+	for (int i = 0; i < iters; i++)
+		hipLaunchKernelGGL(k_copy16, dim3(256 * 16), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, n);
+	PGQ_HIP_TRY(hipEventRecord(e1, 0));
+	PGQ_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0.f;
+	PGQ_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	*out_gbps = 2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9;
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	(void)hipFree(a);
+	(void)hipFree(b);
+	return PGQ_OK;
+}
+
+} // extern "C"

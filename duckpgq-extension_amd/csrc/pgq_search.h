@@ -1,0 +1,60 @@
+// pgq_search.h — per-call workspace and lane assignment shared by the BFS and cheapest-path drivers
+#pragma once
+#include <memory>
+
+#include "pgq_internal.h"
+
+namespace pgq {
+
+static constexpr u32 kNoLane = 0xFFFFFFFFu;   // NULL rows
+static constexpr u32 kTrivial = 0xFFFFFFFEu;  // src == dst rows (no search needed)
+
+struct Counters {
+	u32 q_count[2];      // work items in the frontier queues (by level parity)
+	u32 front_vertices;  // vertices that received fresh bits this level
+	u32 unresolved;      // pairs of the batch still without an answer
+	u64 front_edges;     // sum of their out-degrees
+	u64 edges_scanned;   // adjacency entries read this level
+	u64 word_gathers;    // 8-byte lane-words gathered or RMW'd this level
+};
+
+
+struct LevelBuf {
+	DevBuf buf;
+	bool dirty = true; // may hold non-zero words
+};
+
+struct Workspace {
+	hipStream_t stream = nullptr;
+	DevBuf seen, qbuf[2], qflag, counters, active, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
+	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
+	    tflag, out_val, out_ok, lane_sums, ste;
+	std::vector<std::unique_ptr<LevelBuf>> levels;
+	Counters *h_cnt = nullptr; // pinned
+	int64_t *h_bstart = nullptr;
+	size_t h_bstart_cap = 0;
+	u32 epoch = 0;
+	// cheapest path: which (V, lanes, type) the dist array is currently initialised for
+	int64_t dist_V = -1;
+	int dist_lanes = 0;
+	u32 touch_epoch = 0;
+	~Workspace();
+};
+
+struct WorkspaceLease {
+	Workspace *ws = nullptr;
+	int acquire();
+	~WorkspaceLease();
+};
+
+static inline unsigned blocks_for(int64_t n, int block = 256) {
+	return (unsigned)std::max<int64_t>(1, (n + block - 1) / block);
+}
+
+// Assigns one lane per distinct source: fills ws->usrc (lane -> vertex), the row arrays sorted by lane
+// (skey/sidx/ssrc/sdst/sres) and returns the number of distinct sources in *U.
+int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U);
+// bstart (pinned host) <- sorted-row boundaries of nb batches of L lanes (+ trivial / NULL tails)
+int batch_bounds(Workspace *ws, int64_t n, int64_t L, int nb);
+
+} // namespace pgq

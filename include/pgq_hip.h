@@ -1,0 +1,163 @@
+/* pgq_hip.h — C ABI of libpgq_hip.so: DuckPGQ's path-finding hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the bodies of the reference's search UDFs.  Each entry point replaces
+ * one reference function (file:line relative to the cwida/duckpgq-extension tree):
+ *
+ *   pgq_csr_upload            device mirror of `class CSR`                 src/include/duckpgq/core/utils/compressed_sparse_row.hpp:25-47
+ *                             (called lazily, under csr_lock, by the first search UDF that sees the CSR;
+ *                              built by create_csr_vertex/create_csr_edge  src/core/functions/scalar/csr_creation.cpp:86-198)
+ *   pgq_csr_free              ~CSR() / DuckPGQState::QueryEnd / delete_csr   src/duckpgq_state.cpp:162-170, src/core/functions/scalar/csr_deletion.cpp:10-20
+ *   pgq_iterativelength       IterativeLengthFunction                      src/core/functions/scalar/iterativelength.cpp:34-143
+ *                             (also serves iterativelength2                src/core/functions/scalar/iterativelength2.cpp:33-130 — same results)
+ *   pgq_shortestpath          ShortestPathFunction                         src/core/functions/scalar/shortest_path.cpp:43-207
+ *   pgq_cheapest_path_length  CheapestPathLengthFunction                   src/core/functions/scalar/cheapest_path_length.cpp:138-163
+ *   pgq_*_bulk_device         no reference counterpart: same semantics without the 2048-row chunk ceiling,
+ *                             inputs/outputs resident in HBM (used by bench.py)
+ *
+ * Conventions
+ *   - plain C, no exceptions, no C++ or torch types.  Every function returns PGQ_OK (0) or a negative
+ *     pgq_status; pgq_last_error() gives the thread-local message of the last failure on this thread.
+ *   - all entry points are thread-safe and re-entrant (DuckDB calls UDFs from many worker threads); a
+ *     pgq_csr_t is immutable after upload and shared read-only.
+ *   - pgq_vec_t is DuckDB's UnifiedVectorFormat as the UDFs consume it (iterativelength.cpp:57-64):
+ *     row r reads data[sel ? sel[r] : r]; validity (uint64 words, bit set = valid, NULL = all valid) is
+ *     indexed by that same selected position.
+ *   - result validity masks are written for rows [0,n): bit set = valid.  The caller provides
+ *     ceil(n/64) words.
+ *   - ids are DuckDB rowids: dense 0..V-1.  Out-of-range src/dst (undefined behaviour in the reference,
+ *     iterativelength.cpp:105,123) return PGQ_ERR_INVALID_ARG instead of corrupting memory.
+ *   - the HIP extension is mandatory: without a usable gfx950 device every call fails with
+ *     PGQ_ERR_NO_DEVICE.  There is no CPU fallback in this library.
+ */
+#ifndef PGQ_HIP_H
+#define PGQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pgq_status {
+	PGQ_OK = 0,
+	PGQ_ERR_NO_DEVICE = -1,    /* no HIP device / runtime failure at init */
+	PGQ_ERR_HIP = -2,          /* a HIP call failed; message has the hipError string */
+	PGQ_ERR_OOM = -3,          /* device or host allocation failed */
+	PGQ_ERR_INVALID_ARG = -4,  /* NULL handle, id out of range, bad weight type, ... */
+	PGQ_ERR_NOT_WEIGHTED = -5, /* cheapest path on a CSR without weights ("Need to initialize CSR before doing cheapest path") */
+	PGQ_ERR_UNSUPPORTED = -6   /* e.g. negative weights */
+} pgq_status;
+
+typedef struct pgq_csr pgq_csr_t; /* opaque: CSR resident in HBM */
+
+typedef struct pgq_vec {
+	const void *data;
+	const uint32_t *sel;      /* nullable */
+	const uint64_t *validity; /* nullable */
+} pgq_vec_t;
+
+/* weight types, same numbering as csr_get_w_type (src/core/functions/scalar/csr_get_w_type.cpp:16-36) */
+#define PGQ_W_NONE 0
+#define PGQ_W_INT64 1
+#define PGQ_W_DOUBLE 2
+
+/* ---- process ------------------------------------------------------------------------------------- */
+
+/* Idempotent. device < 0: use env PGQ_DEVICE, else LOCAL_RANK, else 0. */
+int pgq_init(int device);
+int pgq_device_count(void);
+const char *pgq_last_error(void);
+const char *pgq_version(void);
+
+/* ---- CSR ------------------------------------------------------------------------------------------ */
+
+/* Host arrays in the reference's layout: offsets = CSR::v (at least V+1 int64; the reference allocates
+ * V+2), adj = CSR::e, edge_ids = CSR::edge_ids (nullable: slot index is used), w = CSR::w (int64) or
+ * CSR::w_double (double) selected by w_type.  Only the first offsets[V] entries of adj/edge_ids/w are read
+ * (the undirected CTE over-allocates).  The device copy stores int32 adjacency. */
+int pgq_csr_upload(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
+                   int w_type, pgq_csr_t **out);
+/* Same, but the four arrays already live in device memory of the current device (they are copied). */
+int pgq_csr_upload_device(int64_t V, const int64_t *d_offsets, const int64_t *d_adj, const int64_t *d_edge_ids,
+                          const void *d_w, int w_type, pgq_csr_t **out);
+int pgq_csr_free(pgq_csr_t *csr);
+int64_t pgq_csr_num_vertices(const pgq_csr_t *csr);
+int64_t pgq_csr_num_edges(const pgq_csr_t *csr);
+int pgq_csr_w_type(const pgq_csr_t *csr);
+int64_t pgq_csr_device_bytes(const pgq_csr_t *csr);
+
+/* ---- searches, chunk form (host memory, UnifiedVectorFormat in, FLAT vector out) --------------------- */
+
+/* iterativelength(csr_id, V, src, dst) -> BIGINT.  NULL src -> NULL (payload -1); src == dst -> 0; reachable
+ * -> hop count; unreachable -> NULL (payload -1).  dst validity is ignored exactly like the reference. */
+int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
+                        uint64_t *out_valid);
+
+/* shortestpath(csr_id, V, src, dst) -> LIST(BIGINT) [src, e1, v1, ..., ek, dst].  list entries go to
+ * out_offset/out_length (list_entry_t fields), the child payload to *out_child (owned by the library, valid
+ * until the next pgq_shortestpath call on the same thread or pgq_thread_release).  NULL rows keep entry {0,0}. */
+int pgq_shortestpath(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, uint64_t *out_offset,
+                     uint64_t *out_length, uint64_t *out_valid, const int64_t **out_child, uint64_t *out_child_len);
+
+/* cheapest_path_length(csr_id, V, src, dst) -> BIGINT | DOUBLE (by the CSR's weight type; out is int64_t* or
+ * double*).  NULL src, NULL dst or unreachable -> NULL. */
+int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, void *out,
+                             uint64_t *out_valid);
+
+void pgq_thread_release(void); /* drop this thread's result arena */
+
+/* ---- searches, bulk form (device memory, no chunk ceiling) ---------------------------------------------- */
+
+/* d_src/d_dst/d_out_len: n int64 each in HBM.  d_out_len[i] = hop count, 0 for src==dst, -1 for NULL. */
+int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                    int64_t *d_out_len);
+/* Measurement helper: same search, additionally d_out_te[i] = edges traversed by pair i's own level-synchronous BFS
+ * up to the level that reaches dst (all levels if unreachable) — the numerator of bench.py's MTEPS. */
+int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                    int64_t *d_out_len, int64_t *d_out_te);
+/* d_out_len as above; paths are written packed into d_child (capacity child_cap int64), entry i at
+ * d_out_offset[i] with 2*len+1 elements (no entry for NULL rows).  *child_used returns the elements needed;
+ * PGQ_ERR_INVALID_ARG if child_cap was too small (nothing useful written then). */
+int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                 int64_t *d_out_len, int64_t *d_out_offset, int64_t *d_child, int64_t child_cap,
+                                 int64_t *child_used);
+/* out: int64 or double per weight type; NULL -> validity payload -1 (int64) / NaN is never used: d_out_valid
+ * (n bytes, 1 = valid) carries validity. */
+int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                         void *d_out, uint8_t *d_out_valid);
+
+/* ---- tuning & measurement --------------------------------------------------------------------------------- */
+
+/* Knobs (also readable from the environment at pgq_init: PGQ_WORDS, PGQ_PUSH_DIV, PGQ_PROFILE ...).
+ * key/value strings; returns PGQ_ERR_INVALID_ARG for unknown keys. */
+int pgq_set_option(const char *key, const char *value);
+
+/* Per-thread counters of the searches run since the last reset, and per-kernel-class HIP-event time
+ * (only accumulated while option "profile" = "1"). */
+#define PGQ_KCLASS_MAX 16
+typedef struct pgq_stats {
+	int64_t batches;          /* lane batches started */
+	int64_t levels;           /* BFS levels executed (all batches) */
+	int64_t push_levels;      /* of which top-down */
+	int64_t pull_levels;      /* of which bottom-up */
+	int64_t edges_scanned;    /* physical adjacency entries read by push+pull kernels */
+	int64_t word_gathers;     /* lane-words (8 B) gathered / RMW'd along those entries */
+	int64_t frontier_vertices;/* sum over levels of vertices with a non-empty frontier word */
+	int64_t unique_sources;   /* lanes used */
+	int64_t pairs;            /* rows handled */
+	double algo_bytes[PGQ_KCLASS_MAX]; /* algorithmic bytes per kernel class (DESIGN.md formulas) */
+	double kernel_ms[PGQ_KCLASS_MAX];  /* HIP-event time per kernel class (profile=1) */
+	int64_t launches[PGQ_KCLASS_MAX];
+} pgq_stats_t;
+const char *pgq_kclass_name(int kclass); /* NULL past the last class */
+int pgq_get_stats(pgq_stats_t *out);
+int pgq_reset_stats(void);
+
+/* Raw copy-bandwidth probe (bytes moved / second, read+write) used by bench.py for the measured HBM ceiling. */
+int pgq_measure_copy_bandwidth(int64_t bytes, int iters, double *out_gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGQ_HIP_H */

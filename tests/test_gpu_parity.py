@@ -1,0 +1,247 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+Bit-exact: hop counts, NULL masks, full [v,e,v,...] paths, int64 and double cheapest-path distances."""
+import numpy as np
+import pytest
+
+import duckpgq_extension_amd as pgq
+from duckpgq_extension_amd import graphgen
+from helpers import all_pairs, directed_rows, load_golden, undirected_rows
+from oracle.pgq_oracle import OracleCSR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _defaults():
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096)):
+        pgq.set_option(k, v)
+    yield
+
+
+def both(V, rows, w=None, csr_id=0):
+    s, d, e = rows
+    st = pgq.PgqState()
+    st.build_csr(csr_id, V, s, d, e, w)
+    return st, OracleCSR.from_edges(V, s, d, e, w)
+
+
+def lens(out, ok):
+    return [int(v) if k else None for v, k in zip(out, ok)]
+
+
+# ---- golden vectors of the reference's own tests, replayed on the GPU ------------------------------------------
+
+def test_golden_student_directed():
+    g = load_golden("student_directed.json")  # shortest_path.test:59-82
+    V = g["V"]
+    st, _ = both(V, directed_rows(g["edges"]))
+    s, d = all_pairs(V)
+    ln, ok = st.iterativelength(0, V, s, d)
+    paths = st.shortestpath(0, V, s, d)
+    got = {(int(a), int(b)): (int(l), p) for a, b, l, k, p in zip(s, d, ln, ok, paths) if k and 1 <= l <= 3}
+    assert got == {(p["src"], p["dst"]): (p["length"], p["path"]) for p in g["paths"]}
+
+
+def test_golden_student_undirected_and_edgeless():
+    g = load_golden("student_undirected.json")  # undirected_paths.test:91-123
+    V = g["V"]
+    st, _ = both(V, undirected_rows(g["edges"]))
+    s, d = all_pairs(V)
+    ln, ok = st.iterativelength(0, V, s, d)
+    assert [[int(a), int(b), int(l)] for a, b, l, k in zip(s, d, ln, ok) if k] == g["all_pairs"]
+    e = load_golden("edgeless.json")  # edgeless_graph.test:26-34
+    st, _ = both(e["V"], directed_rows(np.zeros((0, 2), dtype=np.int64)))
+    s, d = all_pairs(e["V"])
+    ln, ok = st.iterativelength(0, e["V"], s, d)
+    paths = st.shortestpath(0, e["V"], s, d)
+    assert [(int(a), p, int(l)) for a, b, l, k, p in zip(s, d, ln, ok, paths) if k] == \
+        [(r["src_id"] - 1, r["path"], r["length"]) for r in e["rows"]]
+    assert all(p is None for a, b, p in zip(s, d, paths) if a != b)
+
+
+def test_golden_snb003_paths():
+    g = load_golden("snb003_knows.json")  # complex_matching.test:329-360
+    V = g["V"]
+    st, ora = both(V, directed_rows(g["edges"]))
+    d = np.arange(V, dtype=np.int64)
+    s = np.full(V, 16, dtype=np.int64)
+    ln, ok = st.iterativelength(0, V, s, d)
+    paths = st.shortestpath(0, V, s, d)
+    got = sorted((int(b), p) for b, l, k, p in zip(d, ln, ok, paths) if k and 1 <= l <= 3)
+    assert got == sorted((p["dst"], p["path"]) for p in g["from16_1_3"])
+    s, d = all_pairs(V)  # all 2500 pairs against the oracle
+    ln, ok = st.iterativelength(0, V, s, d)
+    oln, ook = ora.iterativelength(V, s, d)
+    assert lens(ln, ok) == lens(oln, ook)
+    assert st.shortestpath(0, V, s, d) == ora.lean_shortestpath(V, s, d)
+    ic = g["ic13_directed"]  # snb.test:108-114
+    ln, ok = st.iterativelength(0, V, [ic["src"]], [ic["dst"]])
+    assert ok[0] and ln[0] == ic["length"]
+    st, _ = both(V, undirected_rows(g["edges"]))
+    ic = g["ic13_undirected"]
+    ln, ok = st.iterativelength(0, V, [ic["src"]], [ic["dst"]])
+    assert ok[0] and ln[0] == ic["length"]
+
+
+def test_null_selection_and_reachability():
+    g = load_golden("student_directed.json")
+    V = g["V"]
+    st, ora = both(V, directed_rows(g["edges"]))
+    src = np.array([0, 4, 2, 2, 1], dtype=np.int64)
+    dst = np.array([3, 0, 2, 0, 4], dtype=np.int64)
+    valid = np.array([True, False, True, True, True])
+    ln, ok = st.iterativelength(0, V, src, dst, src_valid=valid)
+    assert ln.tolist() == [1, -1, 0, 2, -1] and ok.tolist() == [True, False, True, True, False]
+    assert st.shortestpath(0, V, src, dst, src_valid=valid) == [[0, 2, 3], None, [2], [2, 6, 3, 3, 0], None]
+    sel = np.zeros(5, dtype=np.uint32)  # constant vector
+    ln, ok = st.iterativelength(0, V, np.array([4], dtype=np.int64), np.arange(5, dtype=np.int64), src_sel=sel)
+    assert lens(ln, ok) == [2, 3, 3, 1, 0]
+    r, rok = st.reachability(0, V, src, dst, src_valid=valid)
+    assert r.tolist() == [True, False, True, True, False] and rok.tolist() == [True, False, True, True, True]
+    ln2, ok2 = st.iterativelength(0, V, src, dst, src_valid=valid, variant=2)
+    assert (ln2 == ln_ref(ora, V, src, dst, valid)[0]).all()
+
+
+def ln_ref(ora, V, src, dst, valid):
+    return ora.iterativelength(V, src, dst, src_valid=valid)
+
+
+# ---- random graphs: every lane-word width, both directions, hubs -------------------------------------------------
+
+def random_graph(rng, V, E, skew=False):
+    if skew:
+        s = (rng.random(E) ** 3 * V).astype(np.int64)
+        d = (rng.random(E) ** 2 * V).astype(np.int64)
+    else:
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    return s, d, np.arange(E, dtype=np.int64)
+
+
+@pytest.mark.parametrize("words", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_random_graph_all_variants(words, mode):
+    rng = np.random.default_rng(100 * words + mode)
+    V, E = 3000, 14000
+    rows = random_graph(rng, V, E, skew=True)
+    st, ora = both(V, rows)
+    pgq.set_option("words", words)
+    pgq.set_option("force_mode", mode)
+    pgq.set_option("hub_chunk", 64)  # exercise the split-vertex (hub) paths on a small graph
+    n = 1500
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    valid = rng.random(n) > 0.05
+    ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
+    oln, ook = ora.lean_iterativelength(V, ps, pd)
+    want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)]
+    assert lens(ln, ok) == want
+    paths = st.shortestpath(0, V, ps[:700], pd[:700])
+    assert paths == ora.lean_shortestpath(V, ps[:700], pd[:700])
+
+
+def test_shared_sources_cross_product():
+    # the binder's shape: few sources x many destinations (match.cpp:467-495) -> lanes are per distinct source
+    rng = np.random.default_rng(5)
+    V, E = 5000, 40000
+    st, ora = both(V, random_graph(rng, V, E))
+    srcs = rng.integers(0, V, 7)
+    ps = np.repeat(srcs, V)
+    pd = np.tile(np.arange(V, dtype=np.int64), 7)
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+    assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
+    assert pgq.get_stats()["unique_sources"] >= 1
+
+
+def test_literal_reference_restatement_agrees():
+    # the literal 512-lane restatement (what cpu_baseline times) on a mid-size graph, > 512 pairs
+    rng = np.random.default_rng(9)
+    V, E = 20000, 120000
+    st, ora = both(V, random_graph(rng, V, E))
+    n = 1200
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    oln, ook = ora.iterativelength(V, ps, pd)
+    assert lens(ln, ok) == lens(oln, ook)
+    assert st.shortestpath(0, V, ps[:600], pd[:600]) == ora.shortestpath(V, ps[:600], pd[:600])
+
+
+def test_rmat18_and_snb_like_medium():
+    V, s, d = graphgen.rmat(18, seed=18)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    rng = np.random.default_rng(2)
+    n = 4096
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=8)
+    for words in (0, 4, 16):
+        pgq.set_option("words", words)
+        ln, ok = dev.iterativelength(ps, pd)
+        assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
+    paths = dev.shortestpath(ps[:1024], pd[:1024])
+    assert paths == ora.lean_shortestpath(V, ps[:1024], pd[:1024])
+    pgq.set_option("words", 0)
+    V2, s2, d2 = graphgen.snb_knows_like(V=20000, friendships=600_000, seed=3)
+    off2, adj2, eid2 = graphgen.csr_from_rows(V2, s2, d2)
+    ora2 = OracleCSR.adopt(V2, off2, adj2, eid2)
+    dev2 = pgq.DeviceCSR(V2, off2, adj2, eid2)
+    ps, pd = rng.integers(0, V2, n), rng.integers(0, V2, n)
+    ln, ok = dev2.iterativelength(ps, pd)
+    oln, ook = ora2.lean_iterativelength(V2, ps, pd, nthreads=8)
+    assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
+    # undirected graph: d(s,t) == d(t,s) (size-independent property)
+    ln_r, ok_r = dev2.iterativelength(pd, ps)
+    assert (ok_r == ok).all() and (ln_r == ln).all()
+    paths = dev2.shortestpath(ps[:1024], pd[:1024])
+    assert paths == ora2.lean_shortestpath(V2, ps[:1024], pd[:1024])
+
+
+# ---- cheapest path ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind", ["int64", "double"])
+def test_cheapest_path_bit_exact(kind):
+    rng = np.random.default_rng(13)
+    V, E = 4000, 30000
+    s, d, e = random_graph(rng, V, E, skew=True)
+    w = rng.integers(1, 1000, E) if kind == "int64" else rng.random(E) + 0.01
+    st, ora = both(V, (s, d, e), w=w)
+    for n in (1, 70, 300, 1500):
+        ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        out, ok = st.cheapest_path_length(0, V, ps, pd)
+        lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
+        assert (ok == lok).all()
+        assert (out[ok] == lout[ok]).all()  # bit-exact, doubles included
+        assert out.dtype == lout.dtype
+    # literal Bellman-Ford restatement (cheapest_path_length.cpp:52-136) on a batch that hits the 256-lane path
+    ps, pd = rng.integers(0, V, 300), rng.integers(0, V, 300)
+    out, ok = st.cheapest_path_length(0, V, ps, pd)
+    rout, rok = ora.cheapest_path_length(V, ps, pd)
+    assert (ok == rok).all() and (out[ok] == rout[ok]).all()
+    # NULL dst -> NULL (cheapest_path_length.cpp:74-76)
+    dv = np.ones(300, dtype=bool)
+    dv[::7] = False
+    out, ok = st.cheapest_path_length(0, V, ps, pd, dst_valid=dv)
+    assert (ok == (rok & dv)).all()
+
+
+def test_cheapest_forest_and_zero_weights():
+    rep = load_golden("snb003_replyof.json")
+    e = np.asarray(rep["edges"], dtype=np.int64)
+    rng = np.random.default_rng(3)
+    w = rng.integers(0, 50, len(e))  # zeros allowed
+    st, ora = both(rep["V"], (e[:, 0], e[:, 1], np.arange(len(e), dtype=np.int64)), w=w)
+    ps = rng.integers(0, rep["V"], 900)
+    pd = rng.integers(0, rep["V"], 900)
+    ps[:400], pd[:400] = e[:400, 0], e[:400, 1]
+    out, ok = st.cheapest_path_length(0, rep["V"], ps, pd)
+    lout, lok = ora.lean_cheapest_path_length(rep["V"], ps, pd)
+    assert (ok == lok).all() and (out[ok] == lout[ok]).all()
+
+
+def test_errors_from_the_device_layer():
+    g = load_golden("student_directed.json")
+    st, _ = both(g["V"], directed_rows(g["edges"]))
+    with pytest.raises(pgq.PgqError, match="out of range"):
+        st.iterativelength(0, g["V"], [0], [99])
+    with pytest.raises(pgq.PgqError, match="Need to initialize CSR before doing cheapest path"):
+        st.cheapest_path_length(0, g["V"], [0], [1])

@@ -1,0 +1,100 @@
+"""CPU-only checks of the product's host side: the C-ABI libraries load and export every declared symbol, the host
+mirror of create_csr_vertex/create_csr_edge reproduces the reference's CSR goldens, error texts match, and search
+calls fail loudly without a GPU (no CPU fallback exists)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import duckpgq_extension_amd as pgq
+from helpers import directed_rows, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgq_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.mark.parametrize("header,loader", [("pgq_hip.h", "load_hip"), ("pgq_udf.h", "load_udf")])
+def test_abi_exports_every_declared_symbol(header, loader):
+    lib = getattr(pgq, loader)()
+    syms = declared_symbols(header)
+    assert len(syms) >= 10
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert missing == []
+
+
+def test_host_csr_build_matches_getpgschema_golden():
+    g = load_golden("student_csr_layout.json")  # getpgschema.test:85-107
+    st = pgq.PgqState()
+    s, d, e = directed_rows(g["edges"])
+    assert st.build_csr(0, g["V"], s, d, e) == len(s)
+    assert st.get_csr_v(0).tolist() == g["csr_v"]  # V+2 entries
+    assert st.get_csr_e(0).tolist() == g["csr_e"]
+    assert st.csr_get_w_type(0) == 0
+    assert st.delete_csr(0) is True and st.delete_csr(0) is False  # delete_csr.test
+    with pytest.raises(pgq.PgqError, match="CSR not found with ID 0"):  # get_csr_ptr.test:62-65
+        st.get_csr_v(0)
+
+
+def test_host_csr_segfault_counts_and_chunking():
+    g = load_golden("csr_segfault.json")
+    V = g["V"]
+    ids = np.arange(V, dtype=np.int64)
+    st = pgq.PgqState()
+    st.build_csr(0, V, ids, ids, ids)  # 5000 rows -> three 2048-row chunks
+    assert len(st.get_csr_v(0)) == g["count_v"] and len(st.get_csr_e(0)) == g["count_e"]
+    assert (st.get_csr_e(0) == ids).all()
+
+
+def test_host_weight_types_and_errors():
+    g = load_golden("csr_w_type.json")
+    lay = load_golden("student_csr_layout.json")
+    s, d, e = directed_rows(lay["edges"])
+    st = pgq.PgqState()
+    st.build_csr(0, 5, s, d, e)
+    st.build_csr(1, 5, s, d, e, w=np.full(len(s), 12, dtype=np.int64))
+    st.build_csr(2, 5, s, d, e, w=np.full(len(s), 1.2))
+    want = [c["value"] for c in g["cases"]]
+    assert [st.csr_get_w_type(i) for i in range(3)] == want
+    with pytest.raises(pgq.PgqError, match="CSR not found with ID 3"):
+        st.csr_get_w_type(3)
+    assert st.bind_cheapest(1) == 1 and st.bind_cheapest(2) == 2
+    with pytest.raises(pgq.PgqError, match="Need to initialize CSR before doing cheapest path"):
+        st.bind_cheapest(0)
+    st2 = pgq.PgqState()
+    st2.create_csr_vertex(0, 2, [0, 1], [1, 0])
+    with pytest.raises(pgq.PgqError, match="Non-existent/non-unique vertices detected"):  # non-unique-vertices.test:40-46
+        st2.create_csr_edge(0, 2, 1, 2, [0], [1], [0])
+    with pytest.raises(pgq.PgqError, match="Need to initialize CSR before doing shortest path"):
+        pgq.PgqState().iterativelength(0, 5, [0], [1])
+
+
+def test_query_end_drops_bound_csrs():
+    lay = load_golden("student_csr_layout.json")
+    s, d, e = directed_rows(lay["edges"])
+    st = pgq.PgqState()
+    st.build_csr(0, 5, s, d, e)
+    st.build_csr(7, 5, s, d, e)
+    st.bind_search(0)  # IterativeLengthBind schedules deletion (iterative_length_function_data.cpp:27)
+    st.query_end()
+    with pytest.raises(pgq.PgqError):
+        st.get_csr_v(0)
+    assert len(st.get_csr_v(7)) == 7
+
+
+def test_search_without_gpu_fails_loudly():
+    import ctypes
+    if pgq.load_hip().pgq_device_count() > 0:
+        pytest.skip("a GPU is present")
+    lay = load_golden("student_csr_layout.json")
+    s, d, e = directed_rows(lay["edges"])
+    st = pgq.PgqState()
+    st.build_csr(0, 5, s, d, e)
+    with pytest.raises(pgq.PgqError, match="needs a HIP device"):
+        st.iterativelength(0, 5, [0], [3])
+    del ctypes

@@ -47,6 +47,9 @@ struct Options {
 	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel
 	int cheapest_lanes = 64;
 	int trace = 0;          // per-level line on stderr
+	int probe = 1;          // destination probe before each expansion
+	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
+	int pull_parts = 32768; // edge-balanced vertex ranges for the bottom-up kernel
 };
 Options &options();
 
@@ -96,6 +99,8 @@ struct pgq_csr {
 	pgq::HubItem *pull_hubs = nullptr; // device
 	int32_t *pull_hub_vertices = nullptr;
 	int64_t n_pull_hub_items = 0, n_pull_hub_vertices = 0;
+	int32_t *pull_parts = nullptr; // n_pull_parts+1 vertex boundaries, equal in-edge weight per part
+	int n_pull_parts = 0;
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
 	int64_t bytes = 0;

@@ -127,7 +127,7 @@ __global__ void k_scatter_results(int64_t n, const u32 *__restrict__ sidx, const
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	u32 p = sidx[i];
-	out_len[p] = (int64_t)sres[i];
+	out_len[p] = sres[i] < 0 ? -1 : (int64_t)sres[i]; // -1 open at exhaustion, -2 proven unreachable: both NULL
 	if (out_off) out_off[p] = soff[i];
 }
 
@@ -135,8 +135,9 @@ __global__ void k_scatter_results(int64_t n, const u32 *__restrict__ sidx, const
 
 template <int WD>
 __global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_t base, const int64_t *__restrict__ off,
-                             u64 *__restrict__ front0, u64 *__restrict__ seen, u64 *__restrict__ active,
-                             u64 *__restrict__ q, u32 qcap, int64_t chunk, Counters *__restrict__ cnt) {
+                             u64 *__restrict__ front0, u32 *__restrict__ nz0, u64 *__restrict__ seen,
+                             u64 *__restrict__ active, u64 *__restrict__ q, u32 qcap, int64_t chunk,
+                             Counters *__restrict__ cnt) {
 	int64_t g = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const bool ok = g < U && g < base + 64 * WD;
 	int v = 0;
@@ -146,6 +147,7 @@ __global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_
 		int l = (int)(g - base);
 		u64 bit = 1ull << (l & 63);
 		atomicOr(&front0[(size_t)v * WD + (l >> 6)], bit);
+		atomicOr(&nz0[v], 1u << (l >> 6));
 		atomicOr(&seen[(size_t)v * WD + (l >> 6)], bit);
 		atomicOr(&active[l >> 6], bit);
 		deg = off[v + 1] - off[v];
@@ -163,10 +165,12 @@ __global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_
 template <int WD>
 __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                               const u64 *__restrict__ visit, u64 *__restrict__ seen,
-                                              u64 *__restrict__ next, const u64 *__restrict__ active,
-                                              const u64 *__restrict__ qcur, int par, u32 *__restrict__ qflag,
-                                              u32 epoch, u64 *__restrict__ qnext, u32 qcap, int64_t chunk,
-                                              Counters *__restrict__ cnt) {
+                                              u64 *__restrict__ next, u32 *__restrict__ nz_next,
+                                              const u64 *__restrict__ active, const u64 *__restrict__ qcur, int par,
+                                              u32 *__restrict__ qflag, u32 epoch, u64 *__restrict__ qnext, u32 qcap,
+                                              int64_t chunk, int stop_limit, Counters *__restrict__ cnt) {
+	// the probe already answered (or the host will defer) what is left of the batch: skip the expansion
+	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	const int lane = threadIdx.x & 63;
 	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
 						u64 fr = nb & ~old;
 						if (fr) {
 							atomicOr(&next[(size_t)n * WD + w], fr);
+							atomicOr(&nz_next[n], 1u << w);
 							enq = true;
 						}
 					}
@@ -230,19 +235,22 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
 // zero the frontier words of the vertices just expanded (keeps the 2-buffer ring sparse-clean)
 template <int WD>
 __global__ void k_clear_items(const u64 *__restrict__ qcur, int par, u32 qcap, u64 *__restrict__ visit,
-                              const Counters *__restrict__ cnt) {
+                              u32 *__restrict__ nz, const Counters *__restrict__ cnt) {
 	const u32 nq = min(cnt->q_count[par], qcap);
 	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (; t < (int64_t)nq * WD; t += stride) {
 		u64 item = qcur[t / WD];
-		if ((item >> 32) == 0) visit[(size_t)(u32)item * WD + (t % WD)] = 0;
+		if ((item >> 32) == 0) {
+			visit[(size_t)(u32)item * WD + (t % WD)] = 0;
+			if (t % WD == 0) nz[(u32)item] = 0;
+		}
 	}
 }
 
 // frontier queue from a dense frontier (bottom-up level followed by a top-down level)
 template <int WD>
-__global__ void k_queue_from_dense(const u64 *__restrict__ front, int64_t V, const int64_t *__restrict__ off,
+__global__ void k_queue_from_dense(const u32 *__restrict__ nz, int64_t V, const int64_t *__restrict__ off,
                                    int64_t chunk, u64 *__restrict__ q, u32 qcap, int par, Counters *__restrict__ cnt) {
 	int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -251,10 +259,7 @@ __global__ void k_queue_from_dense(const u64 *__restrict__ front, int64_t V, con
 		bool take = false;
 		int64_t deg = 0;
 		if (v < V) {
-			u64 any = 0;
-#pragma unroll
-			for (int w = 0; w < WD; w++) any |= front[(size_t)v * WD + w];
-			take = any != 0;
+			take = nz[v] != 0;
 			if (take) deg = off[v + 1] - off[v];
 		}
 		enqueue_items(take, (int)v, deg, chunk, q, qcap, &cnt->q_count[par]);
@@ -269,37 +274,51 @@ __global__ void k_queue_from_dense(const u64 *__restrict__ front, int64_t V, con
 // wanted lanes are already all seen is skipped; scanning stops early once every wanted lane is covered.
 template <int WD>
 __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
-                                              const int64_t *__restrict__ off, const u64 *__restrict__ visit,
-                                              u64 *__restrict__ seen, u64 *__restrict__ next,
+                                              const int64_t *__restrict__ off, const int32_t *__restrict__ parts,
+                                              int n_parts, const u64 *__restrict__ visit,
+                                              const u32 *__restrict__ nz_cur, u64 *__restrict__ seen,
+                                              u64 *__restrict__ next, u32 *__restrict__ nz_next,
                                               const u64 *__restrict__ active, int V, int64_t hub_threshold,
-                                              Counters *__restrict__ cnt) {
+                                              int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NS = 64 / WD;
 	__shared__ u64 red[4][4];
+	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	const int lane = threadIdx.x & 63;
 	const int word = lane & (WD - 1);
 	const int slot = lane / WD;
 	const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nwaves = (gridDim.x * blockDim.x) >> 6;
 	const u64 act = active[word];
-	u64 nf = 0, mf = 0, scanned = 0;
-	for (int n = wave; n < V; n += nwaves) {
+	u64 nf = 0, mf = 0, scanned = 0, gath = 0;
+	// vertices are pre-cut into n_parts contiguous ranges of equal in-edge count (built at upload), dealt
+	// round-robin to the waves: balanced for skewed degree distributions, consecutive adjacency per wave
+	for (int p = wave; p < n_parts; p += nwaves)
+	for (int n = parts[p]; n < parts[p + 1]; n++) {
 		const int64_t b = roff[n], e = roff[n + 1];
 		if (e - b > hub_threshold) continue; // handled by k_pull_hub
 		const u64 s = seen[(size_t)n * WD + word];
 		const u64 want = act & ~s;
 		if (!__any(want != 0) || b == e) {
 			if (lane < WD) next[(size_t)n * WD + lane] = 0;
+			if (lane == 0) nz_next[n] = 0;
 			continue;
 		}
 		u64 acc = 0;
 		for (int64_t base = b; base < e; base += 64) {
 			const int c64 = (int)min((int64_t)64, e - base);
 			const int nb = lane < c64 ? radj[base + lane] : 0;
+			// which lane-words of that in-neighbour are non-empty (4-byte lookup, L2 resident) ...
+			const u32 nzb = lane < c64 ? nz_cur[nb] : 0u;
 #pragma unroll
 			for (int r = 0; r < WD; r++) {
 				const int j = r * NS + slot;
 				const int nbj = __shfl(nb, j);
-				if (j < c64) acc |= visit[(size_t)nbj * WD + word];
+				const u32 nzj = __shfl(nzb, j);
+				// ... gather only words that are non-empty there and still wanted here
+				if (want != 0 && ((nzj >> word) & 1u)) {
+					acc |= visit[(size_t)nbj * WD + word];
+					gath++;
+				}
 			}
 			scanned += (u64)c64;
 			if (base + 64 < e) {
@@ -316,38 +335,44 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 			next[(size_t)n * WD + lane] = fresh;
 			if (fresh) seen[(size_t)n * WD + lane] = s | fresh;
 		}
-		if (__any(fresh != 0)) {
+		const u64 fm = __ballot(lane < WD && fresh != 0);
+		if (lane == 0) nz_next[n] = (u32)fm;
+		if (fm) {
 			nf += 1;
 			mf += (u64)(off[n + 1] - off[n]);
 		}
 	}
+	// per-lane gather counts -> wave total
+	for (int o = 32; o > 0; o >>= 1) gath += __shfl_down(gath, o);
 	// block reduction of the wave-uniform counters, one atomic set per block
 	const int wib = threadIdx.x >> 6;
 	if (lane == 0) {
 		red[wib][0] = nf;
 		red[wib][1] = mf;
 		red[wib][2] = scanned;
+		red[wib][3] = gath;
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		u64 a = 0, bsum = 0, c = 0;
+		u64 a = 0, bsum = 0, c = 0, g = 0;
 		for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
 			a += red[k][0];
 			bsum += red[k][1];
 			c += red[k][2];
+			g += red[k][3];
 		}
 		if (a) atomicAdd(&cnt->front_vertices, (u32)a);
 		if (bsum) atomicAdd(&cnt->front_edges, bsum);
-		if (c) {
-			atomicAdd(&cnt->edges_scanned, c);
-			atomicAdd(&cnt->word_gathers, c * WD);
-		}
+		if (c) atomicAdd(&cnt->edges_scanned, c);
+		if (g) atomicAdd(&cnt->word_gathers, g);
 	}
 }
 
 // high in-degree vertices: zero next, OR partial results per slice, then fold into seen
 template <int WD>
-__global__ void k_pull_hub_zero(const int32_t *__restrict__ hubs, int64_t nh, u64 *__restrict__ next) {
+__global__ void k_pull_hub_zero(const int32_t *__restrict__ hubs, int64_t nh, u64 *__restrict__ next,
+                                int stop_limit, const Counters *__restrict__ cnt) {
+	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t < nh * WD) next[(size_t)hubs[t / WD] * WD + (t % WD)] = 0;
 }
@@ -355,9 +380,11 @@ __global__ void k_pull_hub_zero(const int32_t *__restrict__ hubs, int64_t nh, u6
 template <int WD>
 __global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ items, int64_t n_items,
                                                   const int32_t *__restrict__ radj, const u64 *__restrict__ visit,
-                                                  const u64 *__restrict__ seen, u64 *__restrict__ next,
-                                                  const u64 *__restrict__ active, Counters *__restrict__ cnt) {
+                                                  const u32 *__restrict__ nz_cur, const u64 *__restrict__ seen,
+                                                  u64 *__restrict__ next, const u64 *__restrict__ active,
+                                                  int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NS = 64 / WD;
+	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	const int lane = threadIdx.x & 63;
 	const int word = lane & (WD - 1);
 	const int slot = lane / WD;
@@ -368,15 +395,20 @@ __global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ it
 	const u64 want = active[word] & ~seen[(size_t)n * WD + word];
 	u64 have = next[(size_t)n * WD + word]; // other slices may already have covered it
 	if (__all(((have & want) == want))) return;
-	u64 acc = 0, scanned = 0;
+	u64 acc = 0, scanned = 0, gath = 0;
 	for (int64_t base = it.begin; base < it.end; base += 64) {
 		const int c64 = (int)min((int64_t)64, it.end - base);
 		const int nb = lane < c64 ? radj[base + lane] : 0;
+		const u32 nzb = lane < c64 ? nz_cur[nb] : 0u;
 #pragma unroll
 		for (int r = 0; r < WD; r++) {
 			const int j = r * NS + slot;
 			const int nbj = __shfl(nb, j);
-			if (j < c64) acc |= visit[(size_t)nbj * WD + word];
+			const u32 nzj = __shfl(nzb, j);
+			if (want != 0 && ((nzj >> word) & 1u)) {
+				acc |= visit[(size_t)nbj * WD + word];
+				gath++;
+			}
 		}
 		scanned += (u64)c64;
 		if (base + 64 < it.end) {
@@ -390,25 +422,31 @@ __global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ it
 	acc = wave_or_slots(acc, WD);
 	const u64 fresh = acc & want;
 	if (lane < WD && fresh) atomicOr(&next[(size_t)n * WD + lane], fresh);
+	for (int o = 32; o > 0; o >>= 1) gath += __shfl_down(gath, o);
 	if (lane == 0) {
 		atomicAdd(&cnt->edges_scanned, scanned);
-		atomicAdd(&cnt->word_gathers, scanned * WD);
+		atomicAdd(&cnt->word_gathers, gath);
 	}
 }
 
 template <int WD>
 __global__ void k_pull_hub_fold(const int32_t *__restrict__ hubs, int64_t nh, const int64_t *__restrict__ off,
-                                u64 *__restrict__ seen, const u64 *__restrict__ next, Counters *__restrict__ cnt) {
+                                u64 *__restrict__ seen, const u64 *__restrict__ next, u32 *__restrict__ nz_next,
+                                int stop_limit, Counters *__restrict__ cnt) {
+	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (h >= nh) return;
 	const int n = hubs[h];
-	u64 any = 0;
+	u32 any = 0;
 #pragma unroll
 	for (int w = 0; w < WD; w++) {
 		u64 f = next[(size_t)n * WD + w];
-		if (f) seen[(size_t)n * WD + w] |= f;
-		any |= f;
+		if (f) {
+			seen[(size_t)n * WD + w] |= f;
+			any |= 1u << w;
+		}
 	}
+	nz_next[n] = any;
 	if (any) {
 		atomicAdd(&cnt->front_vertices, 1u);
 		atomicAdd(&cnt->front_edges, (u64)(off[n + 1] - off[n]));
@@ -422,7 +460,7 @@ __global__ void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, c
                          u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
 	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	bool open = false;
-	if (i < hi && sres[i] < 0) {
+	if (i < hi && sres[i] == -1) {
 		const u32 l = skey[i] - base_lane;
 		const u64 bit = 1ull << (l & 63);
 		if (seen[(size_t)sdst[i] * WD + (l >> 6)] & bit) {
@@ -434,6 +472,82 @@ __global__ void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, c
 	}
 	const u64 m = __ballot(open);
 	if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt->unresolved, (u32)__popcll(m));
+}
+
+
+// ---- destination probe ----------------------------------------------------------------------------------------------
+// Evaluates the bottom-up step only where it matters for the answer: a still-open pair (lane l, dst d) has hop
+// count `level` iff some in-neighbour of d carries lane l in the frontier of level-1.  One wavefront per pair.
+// Run before a level is expanded, it answers pairs one full expansion earlier than iterativelength.cpp:119-129
+// does (same values: the frontier of level-1 is exactly the set at distance level-1).
+template <int WD>
+__global__ __launch_bounds__(256) void k_probe(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
+                                               const int32_t *__restrict__ sdst, int32_t *__restrict__ sres,
+                                               u32 base_lane, const u64 *__restrict__ front,
+                                               const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
+                                               const int32_t *__restrict__ radj, int level,
+                                               u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
+	__shared__ u32 open_in_block;
+	if (threadIdx.x == 0) open_in_block = 0;
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int64_t i = lo + (int64_t)__builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	if (i < hi && sres[i] == -1) {
+		const u32 l = skey[i] - base_lane;
+		const int w = (int)(l >> 6);
+		const u64 bit = 1ull << (l & 63);
+		const int d = sdst[i];
+		bool found = false;
+		const int64_t b = roff[d], e = roff[d + 1];
+		if (b == e) { // nothing points at dst: unreachable, no search needed (reported as NULL like :133-139)
+			if (lane == 0) sres[i] = -2;
+			goto done;
+		}
+		for (int64_t base = b; base < e && !found; base += 64) {
+			const int64_t j = base + lane;
+			bool hit = false;
+			if (j < e) {
+				const int v = radj[j];
+				if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
+			}
+			found = __any(hit);
+		}
+		if (lane == 0) {
+			if (found) {
+				sres[i] = level;
+			} else {
+				atomicOr(&active_next[w], bit);
+				atomicAdd(&open_in_block, 1u);
+			}
+		}
+	}
+done:
+	__syncthreads();
+	if (threadIdx.x == 0 && open_in_block) atomicAdd(&cnt->unresolved, open_in_block);
+}
+
+// ---- straggler deferral ------------------------------------------------------------------------------------------------
+// When only a handful of pairs of a wide batch are still open, expanding another level for all 64*WD lanes is
+// wasted bandwidth: the open pairs are marked (-3), collected after the batch loop and searched again in a
+// narrow batch of their own (results are a pure function of (CSR, src, dst), so re-running them is exact).
+__global__ void k_mark_deferred(int64_t lo, int64_t hi, int32_t *__restrict__ sres) {
+	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < hi && sres[i] == -1) sres[i] = -3;
+}
+__global__ void k_collect_deferred(int64_t n, const int32_t *__restrict__ sres, const int32_t *__restrict__ ssrc,
+                                   const int32_t *__restrict__ sdst, int64_t *__restrict__ dsrc,
+                                   int64_t *__restrict__ ddst, u32 *__restrict__ didx, u32 *__restrict__ count) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || sres[i] != -3) return;
+	u32 p = atomicAdd(count, 1u);
+	dsrc[p] = ssrc[i];
+	ddst[p] = sdst[i];
+	didx[p] = (u32)i;
+}
+__global__ void k_apply_deferred(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
+                                 int32_t *__restrict__ sres) {
+	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < nd) sres[didx[j]] = dlen[j] < 0 ? -1 : (int32_t)dlen[j];
 }
 
 // ---- traversed-edge accounting (measurement only; bench.py's MTEPS numerator) -----------------------------------
@@ -553,9 +667,13 @@ Workspace::~Workspace() {
 	if (h_bstart) (void)hipHostFree(h_bstart);
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &active, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
-	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste })
+	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
+	                   &def_idx })
 		b->release();
-	for (auto &l : levels) l->buf.release();
+	for (auto &l : levels) {
+		l->buf.release();
+		l->nz.release();
+	}
 }
 
 static std::mutex g_ws_lock;
@@ -658,6 +776,8 @@ static int choose_words(int64_t unique_sources) {
 struct SearchOutput {
 	int64_t child_used = 0;
 	bool want_te = false; // fill ws->ste with per-row traversed-edge counts
+	int depth = 0;        // nesting level of the straggler pass
+	bool deferred = false;
 };
 static constexpr int kMaxTeLevels = 1024;
 
@@ -716,10 +836,13 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 			while (ws->levels.size() <= k) ws->levels.emplace_back(new LevelBuf());
 			return ws->levels[k].get();
 		};
+		const size_t nz_bytes = (size_t)std::max<int64_t>(V, 1) * 4;
 		auto make_zero = [&](LevelBuf *lb) -> int {
 			PGQ_TRY(lb->buf.reserve(words * 8));
+			PGQ_TRY(lb->nz.reserve(nz_bytes));
 			if (lb->dirty) {
 				PGQ_HIP_TRY(hipMemsetAsync(lb->buf.p, 0, words * 8, st));
+				PGQ_HIP_TRY(hipMemsetAsync(lb->nz.p, 0, nz_bytes, st));
 				lb->dirty = false;
 			}
 			return PGQ_OK;
@@ -732,8 +855,8 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		{
 			KernelTimer kt(st, K_PREP);
 			hipLaunchKernelGGL(k_init_batch<WD>, dim3(blocks_for(L)), dim3(256), 0, st, ws->usrc.as<int32_t>(), U,
-			                   (int64_t)base_lane, c->off, cur->buf.as<u64>(), ws->seen.as<u64>(), act_cur,
-			                   ws->qbuf[0].as<u64>(), qcap, chunk, d_cnt);
+			                   (int64_t)base_lane, c->off, cur->buf.as<u64>(), cur->nz.as<u32>(), ws->seen.as<u64>(),
+			                   act_cur, ws->qbuf[0].as<u64>(), qcap, chunk, d_cnt);
 			kt.stop();
 		}
 		cur->dirty = true;
@@ -749,19 +872,37 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		bool queue_valid = true; // qbuf[par] describes `cur`
 		int par = 0;
 		int levels_run = 0;
-		bool prev_pull = false;
+		// The destination probe answers a pair one expansion early; it costs one in-neighbour scan per open pair,
+		// so it is used while the batch has few pairs relative to the graph (not for cross products) and never in
+		// the traversed-edge accounting pass (which needs every level of every lane).
+		const bool use_probe = opt.probe && !outp.want_te && (hi - lo) * 4 <= std::max<int64_t>(V, 1);
+		// open pairs at or below this count stop the batch: 0 = everything answered, > 0 = defer the stragglers
+		int stop = -1;
+		if (use_probe) {
+			stop = 0;
+			if (opt.defer && !with_paths && outp.depth < 2) stop = (int)std::min<int64_t>(L / opt.defer, (hi - lo) / opt.defer);
+		}
 		for (int t = 1; unresolved > 0 && front_edges > 0; t++) {
 			LevelBuf *nxt = level_buf(t);
 			bool push = opt.force_mode == 1 || (opt.force_mode == 0 && (double)front_edges * opt.push_div < (double)E);
 			if (opt.force_mode == 2) push = false;
 			// reset the per-level counters but keep the queue counts
 			PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->front_vertices, 0, sizeof(Counters) - offsetof(Counters, front_vertices), st));
+			if (use_probe) {
+				PGQ_HIP_TRY(hipMemsetAsync(act_nxt, 0, 16 * 8, st));
+				KernelTimer kt(st, K_DETECT);
+				hipLaunchKernelGGL(k_probe<WD>, dim3(blocks_for((hi - lo) * 64)), dim3(256), 0, st, lo, hi,
+				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>(), base_lane,
+				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
+				kt.stop();
+				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
+			}
 			if (push) {
 				if (!queue_valid) {
 					PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->q_count[par], 0, 4, st));
 					KernelTimer kt(st, K_QUEUE);
 					hipLaunchKernelGGL(k_queue_from_dense<WD>, dim3(std::min(blocks_for(V), 16u * ncu)), dim3(256), 0, st,
-					                   cur->buf.as<u64>(), V, c->off, chunk, ws->qbuf[par].as<u64>(), qcap, par, d_cnt);
+					                   cur->nz.as<u32>(), V, c->off, chunk, ws->qbuf[par].as<u64>(), qcap, par, d_cnt);
 					kt.stop();
 				}
 				PGQ_TRY(make_zero(nxt));
@@ -770,70 +911,80 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 				{
 					KernelTimer kt(st, K_PUSH);
 					hipLaunchKernelGGL(k_push<WD>, dim3(push_grid), dim3(256), 0, st, c->off, c->adj, cur->buf.as<u64>(),
-					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, ws->qbuf[par].as<u64>(), par,
-					                   ws->qflag.as<u32>(), ws->epoch, ws->qbuf[par ^ 1].as<u64>(), qcap, chunk, d_cnt);
+					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur,
+					                   ws->qbuf[par].as<u64>(), par, ws->qflag.as<u32>(), ws->epoch,
+					                   ws->qbuf[par ^ 1].as<u64>(), qcap, chunk, stop, d_cnt);
 					kt.stop();
 				}
 				nxt->dirty = true;
 				if (!with_paths) {
 					KernelTimer kt(st, K_QUEUE);
 					hipLaunchKernelGGL(k_clear_items<WD>, dim3(4 * ncu), dim3(256), 0, st, ws->qbuf[par].as<u64>(), par,
-					                   qcap, cur->buf.as<u64>(), d_cnt);
+					                   qcap, cur->buf.as<u64>(), cur->nz.as<u32>(), d_cnt);
 					kt.stop();
 					cur->dirty = false;
 				}
 				par ^= 1;
 				queue_valid = true;
 				S.push_levels++;
-				prev_pull = false;
 			} else {
 				PGQ_TRY(nxt->buf.reserve(words * 8));
+				PGQ_TRY(nxt->nz.reserve(nz_bytes));
 				if (c->n_pull_hub_vertices > 0) {
 					KernelTimer kt(st, K_PULL_HUB);
 					hipLaunchKernelGGL(k_pull_hub_zero<WD>, dim3(blocks_for(c->n_pull_hub_vertices * WD)), dim3(256), 0,
-					                   st, c->pull_hub_vertices, c->n_pull_hub_vertices, nxt->buf.as<u64>());
+					                   st, c->pull_hub_vertices, c->n_pull_hub_vertices, nxt->buf.as<u64>(), stop, d_cnt);
 					hipLaunchKernelGGL(k_pull_hub<WD>, dim3(blocks_for(c->n_pull_hub_items * 64)), dim3(256), 0, st,
-					                   c->pull_hubs, c->n_pull_hub_items, c->radj, cur->buf.as<u64>(),
-					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, d_cnt);
+					                   c->pull_hubs, c->n_pull_hub_items, c->radj, cur->buf.as<u64>(), cur->nz.as<u32>(),
+					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, stop, d_cnt);
 					hipLaunchKernelGGL(k_pull_hub_fold<WD>, dim3(blocks_for(c->n_pull_hub_vertices)), dim3(256), 0, st,
 					                   c->pull_hub_vertices, c->n_pull_hub_vertices, c->off, ws->seen.as<u64>(),
-					                   nxt->buf.as<u64>(), d_cnt);
+					                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), stop, d_cnt);
 					kt.stop();
 				}
 				{
 					KernelTimer kt(st, K_PULL);
 					hipLaunchKernelGGL(k_pull<WD>, dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj, c->off,
-					                   cur->buf.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, (int)V,
-					                   chunk, d_cnt);
+					                   c->pull_parts, c->n_pull_parts, cur->buf.as<u64>(), cur->nz.as<u32>(),
+					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, (int)V, chunk,
+					                   stop, d_cnt);
 					kt.stop();
 				}
 				nxt->dirty = true;
 				queue_valid = false;
 				S.pull_levels++;
-				prev_pull = true;
 			}
-			(void)prev_pull;
 			if (outp.want_te) {
 				if (t >= kMaxTeLevels) return fail(PGQ_ERR_UNSUPPORTED, "traversed-edge accounting supports at most 1023 levels");
 				hipLaunchKernelGGL(k_lane_degree_sums<WD>, dim3(4 * ncu), dim3(256), 0, st, nxt->buf.as<u64>(), c->off, V,
 				                   ws->lane_sums.as<u64>() + (size_t)t * L);
 			}
-			// -- detect finished pairs, rebuild the active-lane mask
-			PGQ_HIP_TRY(hipMemsetAsync(act_nxt, 0, 16 * 8, st));
-			{
+			if (!use_probe) {
+				// -- detect finished pairs (iterativelength.cpp:119-129), rebuild the active-lane mask
+				PGQ_HIP_TRY(hipMemsetAsync(act_nxt, 0, 16 * 8, st));
 				KernelTimer kt(st, K_DETECT);
 				hipLaunchKernelGGL(k_detect<WD>, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
 				                   ws->sdst.as<int32_t>(), ws->sres.as<int32_t>(), base_lane, ws->seen.as<u64>(), t,
 				                   act_nxt, d_cnt);
 				kt.stop();
+				std::swap(act_cur, act_nxt);
 			}
-			std::swap(act_cur, act_nxt);
 			PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
 			PGQ_HIP_TRY(hipStreamSynchronize(st));
 			KernelTimer::flush();
 			const Counters &hc = *ws->h_cnt;
 			front_edges = hc.front_edges;
 			unresolved = hc.unresolved;
+			if (use_probe && unresolved <= (u32)stop) { // the expansion kernels returned immediately
+				if (push) S.push_levels--;
+				else S.pull_levels--;
+				if (unresolved > 0) {
+					hipLaunchKernelGGL(k_mark_deferred, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->sres.as<int32_t>());
+					outp.deferred = true;
+					S.deferred_pairs += unresolved;
+				}
+				break;
+			}
 			S.levels++;
 			S.edges_scanned += (int64_t)hc.edges_scanned;
 			S.word_gathers += (int64_t)hc.word_gathers;
@@ -842,7 +993,10 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 			if (push) {
 				S.algo_bytes[K_PUSH] += (double)hc.edges_scanned * 4.0 + (double)hc.word_gathers * 16.0;
 			} else {
-				S.algo_bytes[K_PULL] += (double)hc.edges_scanned * (4.0 + 8.0 * WD) + (double)V * (16.0 + 16.0 * WD);
+				// per scanned in-edge: 4 B adjacency + 4 B non-empty-word mask; per gathered lane-word 8 B; per vertex:
+				// offsets 16 B + seen/next words 16*WD B + mask 4 B
+				S.algo_bytes[K_PULL] += (double)hc.edges_scanned * 8.0 + (double)hc.word_gathers * 8.0 +
+				                        (double)V * (20.0 + 16.0 * WD);
 			}
 			if (opt.trace)
 				fprintf(stderr, "[pgq] batch %d level %d %s WD=%d front_v=%u front_e=%llu scanned=%llu gathers=%llu unresolved=%u push_ms=%.3f pull_ms=%.3f\n",
@@ -886,7 +1040,7 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 				d_child = ws->child.as<int64_t>();
 			}
 			if (!d_child_ext) d_child = ws->child.as<int64_t>();
-			if (fits && need > child_base && levels_run > 0) {
+			if (fits && need > child_base) {
 				std::vector<const u64 *> tab((size_t)levels_run + 1);
 				for (int t = 0; t <= levels_run; t++) tab[t] = ws->levels[t]->buf.as<u64>();
 				PGQ_TRY(ws->levels_tab.reserve(tab.size() * sizeof(u64 *)));
@@ -956,6 +1110,32 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	case 4: rc = run_batches<4>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
 	case 8: rc = run_batches<8>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
 	default: rc = run_batches<16>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
+	}
+	if (rc == PGQ_OK && outp.deferred) {
+		// second, narrow pass over the stragglers
+		PGQ_TRY(ws->def_src.reserve((size_t)n * 8));
+		PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
+		PGQ_TRY(ws->def_len.reserve((size_t)n * 8));
+		PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
+		u32 *d_count = reinterpret_cast<u32 *>(ws->counters.p);
+		PGQ_HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
+		hipLaunchKernelGGL(k_collect_deferred, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->sres.as<int32_t>(),
+		                   ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->def_src.as<int64_t>(),
+		                   ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
+		u32 nd = 0;
+		PGQ_HIP_TRY(hipMemcpyAsync(&nd, d_count, 4, hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		if (nd > 0) {
+			WorkspaceLease inner;
+			PGQ_TRY(inner.acquire());
+			SearchOutput so2;
+			so2.depth = outp.depth + 1;
+			S.pairs -= nd; // counted once
+			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
+			hipLaunchKernelGGL(k_apply_deferred, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd, ws->def_idx.as<u32>(),
+			                   ws->def_len.as<int64_t>(), ws->sres.as<int32_t>());
+		}
 	}
 	// results back to row order even when the child buffer overflowed (lengths are still right)
 	hipLaunchKernelGGL(k_scatter_results, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->sidx.as<u32>(), ws->sres.as<int32_t>(),

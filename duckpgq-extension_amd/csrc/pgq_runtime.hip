@@ -73,6 +73,9 @@ static int do_init(int device) {
 	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
 	env_int("PGQ_CHEAPEST_LANES", g_opt.cheapest_lanes);
 	env_int("PGQ_TRACE", g_opt.trace);
+	env_int("PGQ_PROBE", g_opt.probe);
+	env_int("PGQ_DEFER", g_opt.defer);
+	env_int("PGQ_PULL_PARTS", g_opt.pull_parts);
 	g_inited.store(1);
 	return PGQ_OK;
 }
@@ -319,6 +322,29 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
 		PGQ_HIP_TRY(hipMalloc(&c->pull_hub_vertices, hubs.size() * sizeof(int32_t)));
 		PGQ_HIP_TRY(hipMemcpy(c->pull_hub_vertices, hubs.data(), hubs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
+	// edge-balanced partition of the non-hub vertices for k_pull: weight = in-degree + 8 (per-vertex overhead)
+	{
+		int P = std::max(1, options().pull_parts);
+		if ((int64_t)P > std::max<int64_t>(V, 1)) P = (int)std::max<int64_t>(V, 1);
+		double total = 0;
+		for (int64_t v = 0; v < V; v++) {
+			int64_t d = h_roff[v + 1] - h_roff[v];
+			total += (d > chunk ? 0 : (double)d) + 8.0;
+		}
+		std::vector<int32_t> parts;
+		parts.reserve((size_t)P + 1);
+		parts.push_back(0);
+		double acc = 0, target = total / P;
+		for (int64_t v = 0; v < V; v++) {
+			int64_t d = h_roff[v + 1] - h_roff[v];
+			acc += (d > chunk ? 0 : (double)d) + 8.0;
+			if (acc >= target * (double)parts.size() && (int)parts.size() < P) parts.push_back((int32_t)(v + 1));
+		}
+		parts.push_back((int32_t)V);
+		c->n_pull_parts = (int)parts.size() - 1;
+		PGQ_HIP_TRY(hipMalloc(&c->pull_parts, parts.size() * sizeof(int32_t)));
+		PGQ_HIP_TRY(hipMemcpy(c->pull_parts, parts.data(), parts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	}
 	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
 	           (int64_t)items.size() * (int64_t)sizeof(HubItem);
 	return PGQ_OK;
@@ -335,6 +361,7 @@ static void destroy_csr(pgq_csr *c) {
 	(void)hipFree(c->rslot);
 	(void)hipFree(c->pull_hubs);
 	(void)hipFree(c->pull_hub_vertices);
+	(void)hipFree(c->pull_parts);
 	delete c;
 }
 
@@ -455,6 +482,9 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "blocks_per_cu") o.blocks_per_cu = atoi(value);
 	else if (k == "cheapest_lanes") o.cheapest_lanes = atoi(value);
 	else if (k == "trace") o.trace = atoi(value);
+	else if (k == "probe") o.probe = atoi(value);
+	else if (k == "defer") o.defer = atoi(value);
+	else if (k == "pull_parts") o.pull_parts = atoi(value);
 	else return fail(PGQ_ERR_INVALID_ARG, "unknown option: " + k);
 	return PGQ_OK;
 }

@@ -20,7 +20,8 @@ struct Counters {
 
 
 struct LevelBuf {
-	DevBuf buf;
+	DevBuf buf;        // frontier lane-words [V][WD]
+	DevBuf nz;         // per vertex: which of its WD words are non-empty (u32 bit mask)
 	bool dirty = true; // may hold non-zero words
 };
 
@@ -28,7 +29,7 @@ struct Workspace {
 	hipStream_t stream = nullptr;
 	DevBuf seen, qbuf[2], qflag, counters, active, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
-	    tflag, out_val, out_ok, lane_sums, ste;
+	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx;
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
 	int64_t *h_bstart = nullptr;

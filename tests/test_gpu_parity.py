@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _defaults():
-    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096)):
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8)):
         pgq.set_option(k, v)
     yield
 
@@ -130,12 +130,14 @@ def test_random_graph_all_variants(words, mode):
     n = 1500
     ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
     valid = rng.random(n) > 0.05
-    ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
     oln, ook = ora.lean_iterativelength(V, ps, pd)
     want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)]
-    assert lens(ln, ok) == want
-    paths = st.shortestpath(0, V, ps[:700], pd[:700])
-    assert paths == ora.lean_shortestpath(V, ps[:700], pd[:700])
+    opaths = ora.lean_shortestpath(V, ps[:700], pd[:700])
+    for probe in (1, 0):  # destination probe on / classic post-expansion detection
+        pgq.set_option("probe", probe)
+        ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
+        assert lens(ln, ok) == want
+        assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
 
 
 def test_shared_sources_cross_product():
@@ -245,3 +247,26 @@ def test_errors_from_the_device_layer():
         st.iterativelength(0, g["V"], [0], [99])
     with pytest.raises(pgq.PgqError, match="Need to initialize CSR before doing cheapest path"):
         st.cheapest_path_length(0, g["V"], [0], [1])
+
+
+def test_traversed_edges_accounting_matches_oracle():
+    # the MTEPS numerator bench.py reports: per-pair traversed edges, GPU accounting vs the oracle's own BFS
+    import torch
+    rng = np.random.default_rng(21)
+    V, E = 6000, 50000
+    s, d, e = random_graph(rng, V, E, skew=True)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    n = 3000
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    oln, ook, ote = ora.lean_iterativelength(V, ps, pd, with_te=True)
+    for words in (2, 16):
+        pgq.set_option("words", words)
+        d_src, d_dst = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+        d_len = torch.empty(n, dtype=torch.int64, device="cuda")
+        d_te = torch.empty(n, dtype=torch.int64, device="cuda")
+        dev.traversed_edges_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(), d_te.data_ptr())
+        ln = d_len.cpu().numpy()
+        assert ((ln >= 0) == ook).all() and (ln[ook] == oln[ook]).all()
+        assert (d_te.cpu().numpy() == ote).all()

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--push_div", default="12")
     ap.add_argument("--modes", default="0")
     ap.add_argument("--bpc", default="8")
+    ap.add_argument("--defer", default="8")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--trace", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/sweep.jsonl")
@@ -61,7 +62,9 @@ def main():
         for mode in [int(x) for x in a.modes.split(",")]:
             for bpc in [int(x) for x in a.bpc.split(",")]:
                 for words in [int(x) for x in a.words.split(",")]:
+                  for dfr in [int(x) for x in a.defer.split(",")]:
                     for pd_ in [float(x) for x in a.push_div.split(",")]:
+                        pgq.set_option("defer", dfr)
                         pgq.set_option("words", words)
                         pgq.set_option("push_div", pd_)
                         pgq.set_option("force_mode", mode)
@@ -78,7 +81,7 @@ def main():
                                 best = (dt, pgq.get_stats())
                         okk = bool((d_out.cpu().numpy() == ref).all())
                         dt, st = best
-                        row = {"graph": a.graph, "pairs": a.pairs, "words": words, "push_div": pd_, "mode": mode,
+                        row = {"graph": a.graph, "pairs": a.pairs, "words": words, "push_div": pd_, "mode": mode, "defer": dfr,
                                "bpc": bpc, "ms": dt * 1e3, "mteps": te / dt / 1e6, "pairs_per_s": a.pairs / dt,
                                "match": okk, "levels": st["levels"], "push": st["push_levels"],
                                "pull": st["pull_levels"], "kernel_ms": st["kernel_ms"],

@@ -40,16 +40,19 @@ int ensure_init();
 struct Options {
 	int words = 0;          // lane-words per vertex per batch (0 = auto: 1,2,4,8,16 by unique sources)
 	int max_words = 16;     // upper bound for auto
-	double push_div = 12.0; // top-down while frontier out-degree sum * push_div < E
+	double push_div = 24.0; // top-down while frontier out-degree sum * push_div < E
 	int profile = 0;        // per-kernel-class HIP event timing
 	int hub_chunk = 4096;   // adjacency entries per work item for high-degree vertices
 	int force_mode = 0;     // 0 adaptive, 1 always push, 2 always pull (tests)
+	int force_pull = 0;     // 0 adaptive, 1 always k_pull_sparse, 2 always k_pull (tests)
 	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel
 	int cheapest_lanes = 64;
 	int trace = 0;          // per-level line on stderr
 	int probe = 1;          // destination probe before each expansion
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
-	int pull_parts = 32768; // edge-balanced vertex ranges for the bottom-up kernel
+	int part_weight = 512;  // in-edges (+8 per vertex) per bottom-up work part
+	int sparse_unroll = 2;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)
+	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 };
 Options &options();
 
@@ -63,7 +66,8 @@ enum KClass {
 	K_DETECT = 5,    // per-pair destination test + active-lane mask
 	K_RECON = 6,     // path reconstruction
 	K_RELAX = 7,     // cheapest path relaxation
-	K_COUNT = 8
+	K_PULL_SPARSE = 8, // bottom-up expansion, edge-organised sparse variant
+	K_COUNT = 9
 };
 
 struct ThreadStats {
@@ -99,7 +103,7 @@ struct pgq_csr {
 	pgq::HubItem *pull_hubs = nullptr; // device
 	int32_t *pull_hub_vertices = nullptr;
 	int64_t n_pull_hub_items = 0, n_pull_hub_vertices = 0;
-	int32_t *pull_parts = nullptr; // n_pull_parts+1 vertex boundaries, equal in-edge weight per part
+	int32_t *pull_parts = nullptr; // n_pull_parts (begin,end) vertex ranges, no hubs inside, <= 32 vertices each
 	int n_pull_parts = 0;
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;

@@ -44,8 +44,10 @@ __device__ __forceinline__ u64 wave_or_slots(u64 x, int wd) {
 __device__ __forceinline__ void enqueue_items(bool take, int n, int64_t deg, int64_t chunk, u64 *__restrict__ q,
                                               u32 qcap, u32 *__restrict__ qcount) {
 	const int lane = threadIdx.x & 63;
+	// vertices without out-edges still get one (empty) item: the clear pass must see every frontier vertex,
+	// otherwise stale words would survive in the 2-buffer ring
 	u32 c = 0;
-	if (take && deg > 0) c = (u32)((deg + chunk - 1) / chunk);
+	if (take) c = deg > 0 ? (u32)((deg + chunk - 1) / chunk) : 1u;
 	if (!__any(c != 0)) return;
 	u32 incl = c;
 	for (int o = 1; o < 64; o <<= 1) {
@@ -153,6 +155,7 @@ __global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_
 		deg = off[v + 1] - off[v];
 		atomicAdd(&cnt->front_edges, (u64)deg);
 		atomicAdd(&cnt->front_vertices, 1u);
+		atomicAdd(&cnt->front_words, 1u);
 	}
 	enqueue_items(ok, v, deg, chunk, q, qcap, &cnt->q_count[0]);
 }
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
 	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
 	const u32 nq = min(cnt->q_count[par], qcap);
 	u64 scanned = 0, gathers = 0, mf = 0;
-	u32 nf = 0;
+	u32 nf = 0, nw = 0;
 	for (u32 i = wave; i < nq; i += nwaves) {
 		const u64 item = qcur[i];
 		const int v = (int)(u32)item;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
 						u64 fr = nb & ~old;
 						if (fr) {
 							atomicOr(&next[(size_t)n * WD + w], fr);
-							atomicOr(&nz_next[n], 1u << w);
+							if (!((atomicOr(&nz_next[n], 1u << w) >> w) & 1u)) nw++;
 							enq = true;
 						}
 					}
@@ -222,10 +225,12 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
 	// per-lane nf/mf, wave-uniform scanned/gathers
 	for (int o = 32; o > 0; o >>= 1) {
 		nf += __shfl_down(nf, o);
+		nw += __shfl_down(nw, o);
 		mf += __shfl_down(mf, o);
 	}
 	if (lane == 0) {
 		if (nf) atomicAdd(&cnt->front_vertices, nf);
+		if (nw) atomicAdd(&cnt->front_words, nw);
 		if (mf) atomicAdd(&cnt->front_edges, mf);
 		if (scanned) atomicAdd(&cnt->edges_scanned, scanned);
 		if (gathers) atomicAdd(&cnt->word_gathers, gathers);
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
                                               const u64 *__restrict__ active, int V, int64_t hub_threshold,
                                               int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NS = 64 / WD;
-	__shared__ u64 red[4][4];
+	__shared__ u64 red[4][5];
 	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	const int lane = threadIdx.x & 63;
 	const int word = lane & (WD - 1);
@@ -289,11 +294,11 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 	const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nwaves = (gridDim.x * blockDim.x) >> 6;
 	const u64 act = active[word];
-	u64 nf = 0, mf = 0, scanned = 0, gath = 0;
-	// vertices are pre-cut into n_parts contiguous ranges of equal in-edge count (built at upload), dealt
+	u64 nf = 0, mf = 0, scanned = 0, gath = 0, nwords = 0;
+	// vertices are pre-cut into small contiguous ranges of bounded in-edge count (built at upload), dealt
 	// round-robin to the waves: balanced for skewed degree distributions, consecutive adjacency per wave
 	for (int p = wave; p < n_parts; p += nwaves)
-	for (int n = parts[p]; n < parts[p + 1]; n++) {
+	for (int n = parts[2 * p]; n < parts[2 * p + 1]; n++) {
 		const int64_t b = roff[n], e = roff[n + 1];
 		if (e - b > hub_threshold) continue; // handled by k_pull_hub
 		const u64 s = seen[(size_t)n * WD + word];
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 		if (lane == 0) nz_next[n] = (u32)fm;
 		if (fm) {
 			nf += 1;
+			nwords += (u64)__popcll(fm);
 			mf += (u64)(off[n + 1] - off[n]);
 		}
 	}
@@ -351,16 +357,210 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 		red[wib][1] = mf;
 		red[wib][2] = scanned;
 		red[wib][3] = gath;
+		red[wib][4] = nwords;
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		u64 a = 0, bsum = 0, c = 0, g = 0;
+		u64 a = 0, bsum = 0, c = 0, g = 0, wsum = 0;
 		for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
 			a += red[k][0];
 			bsum += red[k][1];
 			c += red[k][2];
 			g += red[k][3];
+			wsum += red[k][4];
 		}
+		if (wsum) atomicAdd(&cnt->front_words, (u32)wsum);
+		if (a) atomicAdd(&cnt->front_vertices, (u32)a);
+		if (bsum) atomicAdd(&cnt->front_edges, bsum);
+		if (c) atomicAdd(&cnt->edges_scanned, c);
+		if (g) atomicAdd(&cnt->word_gathers, g);
+	}
+}
+
+// ---- bottom-up level, sparse variant ---------------------------------------------------------------------------------
+// While the frontier holds few lane-words (early levels, straggler batches) gathering from the dense
+// [V][WD] frontier array wastes a 128-byte fabric fetch per 8-byte word (measured: 2.8 GB fetched for 0.19 GB
+// of words at SF100 level 2).  The frontier is therefore first packed:
+//   bits[v/32]  1 bit per vertex "has any lane-word"      (V/8 bytes: L1/L2 resident)
+//   meta[v]     {non-empty-word mask, offset into cw}     (only valid where the bit is set)
+//   cw[]        the non-empty lane-words back to back     (frontier_words * 8 bytes: L2 resident)
+struct FrontMeta {
+	u32 nz;
+	u32 base;
+};
+
+template <int WD>
+__global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict__ nz, const u64 *__restrict__ front,
+                                                          int64_t V, FrontMeta *__restrict__ meta,
+                                                          u64 *__restrict__ cw, u32 *__restrict__ bits,
+                                                          u32 *__restrict__ total, u32 cap, int stop_limit,
+                                                          const Counters *__restrict__ cnt) {
+	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	const int lane = threadIdx.x & 63;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	const int64_t vmax = (V + 63) & ~63ll;
+	for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vmax; v += stride) {
+		const u32 m = v < V ? nz[v] : 0u;
+		const u64 any = __ballot(m != 0);
+		if (lane == 0) bits[v >> 5] = (u32)any;
+		if (lane == 32) bits[v >> 5] = (u32)(any >> 32);
+		if (!any) continue;
+		const u32 c = (u32)__popc(m);
+		u32 incl = c;
+		for (int o = 1; o < 64; o <<= 1) {
+			const u32 t = __shfl_up(incl, o);
+			if (lane >= o) incl += t;
+		}
+		u32 base = 0;
+		if (lane == 63) base = atomicAdd(total, incl);
+		base = __shfl(base, 63) + incl - c;
+		if (m) {
+			meta[v] = FrontMeta{ m, base };
+			u32 rest = m;
+			u32 k = 0;
+			while (rest) {
+				const int w = __ffs((int)rest) - 1;
+				rest &= rest - 1;
+				if (base + k < cap) cw[base + k] = front[(size_t)v * WD + w];
+				k++;
+			}
+		}
+	}
+}
+
+// The bottom-up recurrence organised by in-EDGE instead of by vertex: a wavefront owns a part (<= 32 consecutive
+// vertices, no hubs) and walks the part's contiguous in-adjacency, one entry per lane, UN x 64 entries in
+// flight.  A lane tests its in-neighbour's frontier bit, fetches the neighbour's {mask, offset}, and gathers only
+// the packed words that are non-empty there AND still wanted by the entry's owner vertex, OR-ing them into the
+// owner's row of an LDS accumulator (ds_or_b64).  seen/next rows of a part are contiguous -> coalesced
+// prologue/epilogue.  Same results as k_pull (next = OR of in-neighbours' frontier words & active & ~seen).
+template <int WD, int UN>
+__global__ __launch_bounds__(256) void k_pull_sparse(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                     const int64_t *__restrict__ off, const int32_t *__restrict__ parts,
+                                                     int n_parts, const u32 *__restrict__ bits,
+                                                     const FrontMeta *__restrict__ meta, const u64 *__restrict__ cw,
+                                                     u64 *__restrict__ seen, u64 *__restrict__ next,
+                                                     u32 *__restrict__ nz_next, const u64 *__restrict__ active,
+                                                     int stop_limit, Counters *__restrict__ cnt) {
+	constexpr int NV = 32;
+	__shared__ u64 s_acc[4][NV * WD];
+	__shared__ u32 s_row[4][NV + 1];
+	__shared__ u32 s_want[4][NV];
+	__shared__ u32 s_nzn[4][NV];
+	__shared__ u64 red[4][5];
+	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	const int lane = threadIdx.x & 63;
+	const int wib = threadIdx.x >> 6;
+	u64 *acc = s_acc[wib];
+	u32 *row = s_row[wib];
+	u32 *wantm = s_want[wib];
+	u32 *nzn = s_nzn[wib];
+	const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int nwaves = (gridDim.x * blockDim.x) >> 6;
+	u64 nf = 0, mf = 0, scanned = 0, gath = 0, nwords = 0;
+	for (int p = wave; p < n_parts; p += nwaves) {
+		const int v0 = parts[2 * p], v1 = parts[2 * p + 1];
+		const int nv = v1 - v0;
+		const int64_t e0 = roff[v0], e1 = roff[v1];
+		// -- prologue: row starts, wanted-word masks, zeroed accumulator
+		if (lane < NV) {
+			wantm[lane] = 0;
+			nzn[lane] = 0;
+		}
+		if (lane <= nv) row[lane] = (u32)(roff[v0 + lane] - e0);
+		__builtin_amdgcn_wave_barrier();
+		for (int idx = lane; idx < nv * WD; idx += 64) {
+			const int w = idx & (WD - 1);
+			const u64 s = seen[(size_t)v0 * WD + idx];
+			acc[idx] = 0;
+			if (active[w] & ~s) atomicOr(&wantm[idx / WD], 1u << w);
+		}
+		__builtin_amdgcn_wave_barrier();
+		// -- one in-edge per lane
+		for (int64_t base = e0; base < e1; base += 64 * UN) {
+			int nb[UN];
+			bool hot[UN];
+#pragma unroll
+			for (int k = 0; k < UN; k++) {
+				const int64_t e = base + 64 * k + lane;
+				nb[k] = e < e1 ? radj[e] : -1;
+			}
+#pragma unroll
+			for (int k = 0; k < UN; k++) hot[k] = nb[k] >= 0 && ((bits[nb[k] >> 5] >> (nb[k] & 31)) & 1u);
+#pragma unroll
+			for (int k = 0; k < UN; k++) {
+				if (!hot[k]) continue;
+				const FrontMeta mt = meta[nb[k]];
+				const u32 rel = (u32)(base + 64 * k + lane - e0);
+				int lo = 0, hi = nv; // owner = last j with row[j] <= rel
+				while (hi - lo > 1) {
+					const int mid = (lo + hi) >> 1;
+					if (row[mid] <= rel) lo = mid;
+					else hi = mid;
+				}
+				u32 m = mt.nz & wantm[lo];
+				while (m) {
+					const int w = __ffs((int)m) - 1;
+					m &= m - 1;
+					const u64 val = cw[mt.base + __popc(mt.nz & ((1u << w) - 1u))];
+					atomicOr(&acc[lo * WD + w], val);
+					gath++;
+				}
+			}
+			scanned += (u64)min((int64_t)(64 * UN), e1 - base);
+		}
+		__builtin_amdgcn_wave_barrier();
+		// -- epilogue: fold into seen/next (coalesced rows), non-empty-word masks, frontier stats
+		for (int idx = lane; idx < nv * WD; idx += 64) {
+			const int w = idx & (WD - 1);
+			const u64 a = acc[idx];
+			u64 fresh = 0;
+			if (a) { // untouched rows need no second look at seen
+				const u64 s = seen[(size_t)v0 * WD + idx];
+				fresh = a & active[w] & ~s;
+				if (fresh) {
+					seen[(size_t)v0 * WD + idx] = s | fresh;
+					atomicOr(&nzn[idx / WD], 1u << w);
+				}
+			}
+			next[(size_t)v0 * WD + idx] = fresh;
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (lane < nv) {
+			const u32 fm = nzn[lane];
+			nz_next[v0 + lane] = fm;
+			if (fm) {
+				nf += 1;
+				nwords += (u64)__popc(fm);
+				mf += (u64)(off[v0 + lane + 1] - off[v0 + lane]);
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		gath += __shfl_down(gath, o);
+		nf += __shfl_down(nf, o);
+		mf += __shfl_down(mf, o);
+		nwords += __shfl_down(nwords, o);
+	}
+	if (lane == 0) {
+		red[wib][0] = nf;
+		red[wib][1] = mf;
+		red[wib][2] = scanned;
+		red[wib][3] = gath;
+		red[wib][4] = nwords;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u64 a = 0, bsum = 0, c = 0, g = 0, wsum = 0;
+		for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
+			a += red[k][0];
+			bsum += red[k][1];
+			c += red[k][2];
+			g += red[k][3];
+			wsum += red[k][4];
+		}
+		if (wsum) atomicAdd(&cnt->front_words, (u32)wsum);
 		if (a) atomicAdd(&cnt->front_vertices, (u32)a);
 		if (bsum) atomicAdd(&cnt->front_edges, bsum);
 		if (c) atomicAdd(&cnt->edges_scanned, c);
@@ -448,6 +648,7 @@ __global__ void k_pull_hub_fold(const int32_t *__restrict__ hubs, int64_t nh, co
 	}
 	nz_next[n] = any;
 	if (any) {
+		atomicAdd(&cnt->front_words, (u32)__popc(any));
 		atomicAdd(&cnt->front_vertices, 1u);
 		atomicAdd(&cnt->front_edges, (u64)(off[n + 1] - off[n]));
 	}
@@ -668,7 +869,7 @@ Workspace::~Workspace() {
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &active, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx })
+	                   &def_idx, &cbits, &cmeta, &cwords })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -799,7 +1000,6 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 	PGQ_TRY(ws->qbuf[1].reserve((size_t)qcap * 8));
 	PGQ_TRY(ws->qflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
-	PGQ_TRY(ws->active.reserve(2 * 16 * 8));
 	if (outp.want_te) {
 		PGQ_TRY(ws->lane_sums.reserve((size_t)kMaxTeLevels * L * 8));
 		PGQ_TRY(ws->ste.reserve((size_t)n * 8));
@@ -830,7 +1030,7 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		// -- reset per-batch state
 		PGQ_HIP_TRY(hipMemsetAsync(ws->seen.p, 0, words * 8, st));
 		PGQ_HIP_TRY(hipMemsetAsync(ws->counters.p, 0, sizeof(Counters), st));
-		PGQ_HIP_TRY(hipMemsetAsync(ws->active.p, 0, 2 * 16 * 8, st));
+
 		auto level_buf = [&](int t) -> LevelBuf * {
 			size_t k = with_paths ? (size_t)t : (size_t)(t & 1);
 			while (ws->levels.size() <= k) ws->levels.emplace_back(new LevelBuf());
@@ -850,8 +1050,9 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		for (auto &lb : ws->levels) lb->dirty = true; // previous batch / call left them in an unknown state
 		LevelBuf *cur = level_buf(0);
 		PGQ_TRY(make_zero(cur));
-		u64 *act_cur = ws->active.as<u64>();
-		u64 *act_nxt = ws->active.as<u64>() + 16;
+		u64 *act_cur = &d_cnt->act[0][0]; // zeroed with the counter block above
+		u64 *act_nxt = &d_cnt->act[1][0];
+		int act_sel = 0;
 		{
 			KernelTimer kt(st, K_PREP);
 			hipLaunchKernelGGL(k_init_batch<WD>, dim3(blocks_for(L)), dim3(256), 0, st, ws->usrc.as<int32_t>(), U,
@@ -868,10 +1069,14 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
 		PGQ_HIP_TRY(hipStreamSynchronize(st));
 		u64 front_edges = ws->h_cnt->front_edges;
+		u32 front_words = ws->h_cnt->front_words;
+		u32 front_vertices = ws->h_cnt->front_vertices;
 		u32 unresolved = (u32)(hi - lo);
 		bool queue_valid = true; // qbuf[par] describes `cur`
 		int par = 0;
 		int levels_run = 0;
+		double active_frac = 1.0;
+		u32 last_cw_cap = 0;
 		// The destination probe answers a pair one expansion early; it costs one in-neighbour scan per open pair,
 		// so it is used while the batch has few pairs relative to the graph (not for cross products) and never in
 		// the traversed-edge accounting pass (which needs every level of every lane).
@@ -884,10 +1089,11 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		}
 		for (int t = 1; unresolved > 0 && front_edges > 0; t++) {
 			LevelBuf *nxt = level_buf(t);
+			bool sparse_level = false;
 			bool push = opt.force_mode == 1 || (opt.force_mode == 0 && (double)front_edges * opt.push_div < (double)E);
 			if (opt.force_mode == 2) push = false;
 			// reset the per-level counters but keep the queue counts
-			PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->front_vertices, 0, sizeof(Counters) - offsetof(Counters, front_vertices), st));
+			PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->front_vertices, 0, offsetof(Counters, act) - offsetof(Counters, front_vertices), st));
 			if (use_probe) {
 				PGQ_HIP_TRY(hipMemsetAsync(act_nxt, 0, 16 * 8, st));
 				KernelTimer kt(st, K_DETECT);
@@ -896,6 +1102,7 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
+				act_sel ^= 1;
 			}
 			if (push) {
 				if (!queue_valid) {
@@ -942,7 +1149,36 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 					                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), stop, d_cnt);
 					kt.stop();
 				}
-				{
+				// frontier sparse in lane-words, or few lane-words still wanted -> edge-organised sparse kernel
+				// expected wanted non-empty words per scanned in-edge: share of edges leaving frontier vertices x
+				// non-empty words per frontier vertex x share of lane-words that still hold an active lane
+				const double words_per_nb = (double)front_edges / (double)std::max<int64_t>(E, 1) *
+				                            ((double)front_words / (double)std::max<u32>(front_vertices, 1u)) * active_frac;
+				sparse_level = opt.force_pull == 1 || (opt.force_pull == 0 && words_per_nb < opt.sparse_below);
+				if (sparse_level) {
+					const u32 cw_cap = (u32)std::min<int64_t>((int64_t)front_words + 64, 0x7FFFFFF0ll);
+					last_cw_cap = cw_cap;
+					PGQ_TRY(ws->cbits.reserve(((size_t)V / 32 + 4) * 4));
+					PGQ_TRY(ws->cmeta.reserve((size_t)std::max<int64_t>(V, 1) * sizeof(FrontMeta)));
+					// sized generously once (2 words per vertex) so that growing frontiers do not reallocate per level
+					PGQ_TRY(ws->cwords.reserve(std::max<size_t>((size_t)cw_cap, 2 * (size_t)std::max<int64_t>(V, 1)) * 8));
+					u32 *d_total = reinterpret_cast<u32 *>(&d_cnt->pad);
+					PGQ_HIP_TRY(hipMemsetAsync(d_total, 0, 4, st));
+					KernelTimer kt(st, K_PULL_SPARSE);
+					hipLaunchKernelGGL(k_compact_frontier<WD>, dim3(std::min(blocks_for(V), 8u * ncu)), dim3(256), 0, st,
+					                   cur->nz.as<u32>(), cur->buf.as<u64>(), V, ws->cmeta.as<FrontMeta>(),
+					                   ws->cwords.as<u64>(), ws->cbits.as<u32>(), d_total, cw_cap, stop, d_cnt);
+#define PGQ_LAUNCH_SPARSE(UNR)                                                                                         \
+	hipLaunchKernelGGL((k_pull_sparse<WD, UNR>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj, c->off,          \
+	                   c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cmeta.as<FrontMeta>(),                 \
+	                   ws->cwords.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, stop, \
+	                   d_cnt)
+					if (opt.sparse_unroll >= 4) PGQ_LAUNCH_SPARSE(4);
+					else if (opt.sparse_unroll >= 2) PGQ_LAUNCH_SPARSE(2);
+					else PGQ_LAUNCH_SPARSE(1);
+#undef PGQ_LAUNCH_SPARSE
+					kt.stop();
+				} else {
 					KernelTimer kt(st, K_PULL);
 					hipLaunchKernelGGL(k_pull<WD>, dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj, c->off,
 					                   c->pull_parts, c->n_pull_parts, cur->buf.as<u64>(), cur->nz.as<u32>(),
@@ -968,13 +1204,24 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 				                   act_nxt, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt);
+				act_sel ^= 1;
 			}
 			PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
 			PGQ_HIP_TRY(hipStreamSynchronize(st));
 			KernelTimer::flush();
 			const Counters &hc = *ws->h_cnt;
+			if (sparse_level && hc.pad > last_cw_cap)
+				return fail(PGQ_ERR_HIP, "internal error: packed frontier holds " + std::to_string(hc.pad) +
+				                             " words, expected at most " + std::to_string(last_cw_cap));
 			front_edges = hc.front_edges;
+			front_words = hc.front_words;
+			front_vertices = hc.front_vertices;
 			unresolved = hc.unresolved;
+			{ // fraction of lane-words that still hold an active lane (drives the sparse/dense choice)
+				int nzw = 0;
+				for (int w = 0; w < WD; w++) nzw += hc.act[act_sel][w] != 0;
+				active_frac = (double)nzw / WD;
+			}
 			if (use_probe && unresolved <= (u32)stop) { // the expansion kernels returned immediately
 				if (push) S.push_levels--;
 				else S.pull_levels--;
@@ -994,15 +1241,16 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 				S.algo_bytes[K_PUSH] += (double)hc.edges_scanned * 4.0 + (double)hc.word_gathers * 16.0;
 			} else {
 				// per scanned in-edge: 4 B adjacency + 4 B non-empty-word mask; per gathered lane-word 8 B; per vertex:
-				// offsets 16 B + seen/next words 16*WD B + mask 4 B
-				S.algo_bytes[K_PULL] += (double)hc.edges_scanned * 8.0 + (double)hc.word_gathers * 8.0 +
-				                        (double)V * (20.0 + 16.0 * WD);
+				// offsets 16 B + seen/next words 16*WD B + mask 4 B (the sparse variant reads seen twice: 24*WD)
+				S.algo_bytes[sparse_level ? K_PULL_SPARSE : K_PULL] +=
+				    (double)hc.edges_scanned * 8.0 + (double)hc.word_gathers * 8.0 +
+				    (double)V * (20.0 + 16.0 * WD) + (sparse_level ? (double)hc.word_gathers * 8.0 + (double)V * 4.0 : 0.0);
 			}
 			if (opt.trace)
 				fprintf(stderr, "[pgq] batch %d level %d %s WD=%d front_v=%u front_e=%llu scanned=%llu gathers=%llu unresolved=%u push_ms=%.3f pull_ms=%.3f\n",
-				        b, t, push ? "push" : "pull", WD, hc.front_vertices, (unsigned long long)hc.front_edges,
+				        b, t, push ? "push" : (sparse_level ? "pull_sparse" : "pull"), WD, hc.front_vertices, (unsigned long long)hc.front_edges,
 				        (unsigned long long)hc.edges_scanned, (unsigned long long)hc.word_gathers, hc.unresolved,
-				        S.kernel_ms[K_PUSH], S.kernel_ms[K_PULL] + S.kernel_ms[K_PULL_HUB]);
+				        S.kernel_ms[K_PUSH], S.kernel_ms[K_PULL] + S.kernel_ms[K_PULL_HUB] + S.kernel_ms[K_PULL_SPARSE]);
 			cur = nxt;
 			levels_run = t;
 		}

@@ -70,12 +70,15 @@ static int do_init(int device) {
 	env_int("PGQ_PROFILE", g_opt.profile);
 	env_int("PGQ_HUB_CHUNK", g_opt.hub_chunk);
 	env_int("PGQ_FORCE_MODE", g_opt.force_mode);
+	env_int("PGQ_FORCE_PULL", g_opt.force_pull);
 	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
 	env_int("PGQ_CHEAPEST_LANES", g_opt.cheapest_lanes);
 	env_int("PGQ_TRACE", g_opt.trace);
 	env_int("PGQ_PROBE", g_opt.probe);
 	env_int("PGQ_DEFER", g_opt.defer);
-	env_int("PGQ_PULL_PARTS", g_opt.pull_parts);
+	env_int("PGQ_PART_WEIGHT", g_opt.part_weight);
+	env_double("PGQ_SPARSE_BELOW", g_opt.sparse_below);
+	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
 	g_inited.store(1);
 	return PGQ_OK;
 }
@@ -322,28 +325,39 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
 		PGQ_HIP_TRY(hipMalloc(&c->pull_hub_vertices, hubs.size() * sizeof(int32_t)));
 		PGQ_HIP_TRY(hipMemcpy(c->pull_hub_vertices, hubs.data(), hubs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
-	// edge-balanced partition of the non-hub vertices for k_pull: weight = in-degree + 8 (per-vertex overhead)
+	// Work partition for the bottom-up kernels: contiguous vertex ranges [begin,end) that never contain a hub,
+	// hold at most 32 vertices (LDS accumulator rows of k_pull_sparse) and at most `part_weight` of
+	// (in-degree + 8 per vertex).  Dealt round-robin to the waves: many small equal parts balance skewed graphs.
 	{
-		int P = std::max(1, options().pull_parts);
-		if ((int64_t)P > std::max<int64_t>(V, 1)) P = (int)std::max<int64_t>(V, 1);
-		double total = 0;
-		for (int64_t v = 0; v < V; v++) {
-			int64_t d = h_roff[v + 1] - h_roff[v];
-			total += (d > chunk ? 0 : (double)d) + 8.0;
-		}
+		const double wmax = (double)std::max(64, options().part_weight);
 		std::vector<int32_t> parts;
-		parts.reserve((size_t)P + 1);
-		parts.push_back(0);
-		double acc = 0, target = total / P;
+		int64_t begin = 0;
+		double acc = 0;
+		auto close = [&](int64_t end) {
+			if (end > begin) {
+				parts.push_back((int32_t)begin);
+				parts.push_back((int32_t)end);
+			}
+			begin = end;
+			acc = 0;
+		};
 		for (int64_t v = 0; v < V; v++) {
 			int64_t d = h_roff[v + 1] - h_roff[v];
-			acc += (d > chunk ? 0 : (double)d) + 8.0;
-			if (acc >= target * (double)parts.size() && (int)parts.size() < P) parts.push_back((int32_t)(v + 1));
+			if (d > chunk) { // hub: handled by k_pull_hub, never inside a part
+				close(v);
+				begin = v + 1;
+				continue;
+			}
+			double wv = (double)d + 8.0;
+			if (v > begin && (acc + wv > wmax || v - begin >= 32)) close(v);
+			acc += wv;
 		}
-		parts.push_back((int32_t)V);
-		c->n_pull_parts = (int)parts.size() - 1;
-		PGQ_HIP_TRY(hipMalloc(&c->pull_parts, parts.size() * sizeof(int32_t)));
-		PGQ_HIP_TRY(hipMemcpy(c->pull_parts, parts.data(), parts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+		close(V);
+		c->n_pull_parts = (int)(parts.size() / 2);
+		if (!parts.empty()) {
+			PGQ_HIP_TRY(hipMalloc(&c->pull_parts, parts.size() * sizeof(int32_t)));
+			PGQ_HIP_TRY(hipMemcpy(c->pull_parts, parts.data(), parts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+		}
 	}
 	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
 	           (int64_t)items.size() * (int64_t)sizeof(HubItem);
@@ -479,19 +493,22 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "profile") o.profile = atoi(value);
 	else if (k == "hub_chunk") o.hub_chunk = atoi(value);
 	else if (k == "force_mode") o.force_mode = atoi(value);
+	else if (k == "force_pull") o.force_pull = atoi(value);
 	else if (k == "blocks_per_cu") o.blocks_per_cu = atoi(value);
 	else if (k == "cheapest_lanes") o.cheapest_lanes = atoi(value);
 	else if (k == "trace") o.trace = atoi(value);
 	else if (k == "probe") o.probe = atoi(value);
 	else if (k == "defer") o.defer = atoi(value);
-	else if (k == "pull_parts") o.pull_parts = atoi(value);
+	else if (k == "part_weight") o.part_weight = atoi(value);
+	else if (k == "sparse_below") o.sparse_below = atof(value);
+	else if (k == "sparse_unroll") o.sparse_unroll = atoi(value);
 	else return fail(PGQ_ERR_INVALID_ARG, "unknown option: " + k);
 	return PGQ_OK;
 }
 
 const char *pgq_kclass_name(int k) {
 	static const char *names[K_COUNT] = { "prep",   "push",   "pull",  "pull_hub",
-		                                  "queue",  "detect", "recon", "relax" };
+		                                  "queue",  "detect", "recon", "relax", "pull_sparse" };
 	return (k >= 0 && k < K_COUNT) ? names[k] : nullptr;
 }
 int pgq_get_stats(pgq_stats_t *out) {

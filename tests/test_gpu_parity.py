@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _defaults():
-    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8)):
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8), ("force_pull", 0)):
         pgq.set_option(k, v)
     yield
 
@@ -133,8 +133,10 @@ def test_random_graph_all_variants(words, mode):
     oln, ook = ora.lean_iterativelength(V, ps, pd)
     want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)]
     opaths = ora.lean_shortestpath(V, ps[:700], pd[:700])
-    for probe in (1, 0):  # destination probe on / classic post-expansion detection
+    # destination probe on / classic post-expansion detection; adaptive / sparse-only / dense-only bottom-up kernel
+    for probe, force_pull in ((1, 0), (0, 1), (1, 2), (0, 0)):
         pgq.set_option("probe", probe)
+        pgq.set_option("force_pull", force_pull)
         ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
         assert lens(ln, ok) == want
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths

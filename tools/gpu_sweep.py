@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--modes", default="0")
     ap.add_argument("--bpc", default="8")
     ap.add_argument("--defer", default="8")
+    ap.add_argument("--force_pull", default="0")
+    ap.add_argument("--sparse_unroll", default="2")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--trace", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/sweep.jsonl")
@@ -63,8 +65,11 @@ def main():
             for bpc in [int(x) for x in a.bpc.split(",")]:
                 for words in [int(x) for x in a.words.split(",")]:
                   for dfr in [int(x) for x in a.defer.split(",")]:
-                    for pd_ in [float(x) for x in a.push_div.split(",")]:
+                   for fp in [int(x) for x in a.force_pull.split(",")]:
+                    for pd_, su in [(float(x), int(y)) for x in a.push_div.split(",") for y in a.sparse_unroll.split(",")]:
+                        pgq.set_option("sparse_unroll", su)
                         pgq.set_option("defer", dfr)
+                        pgq.set_option("force_pull", fp)
                         pgq.set_option("words", words)
                         pgq.set_option("push_div", pd_)
                         pgq.set_option("force_mode", mode)
@@ -81,14 +86,14 @@ def main():
                                 best = (dt, pgq.get_stats())
                         okk = bool((d_out.cpu().numpy() == ref).all())
                         dt, st = best
-                        row = {"graph": a.graph, "pairs": a.pairs, "words": words, "push_div": pd_, "mode": mode, "defer": dfr,
+                        row = {"graph": a.graph, "pairs": a.pairs, "words": words, "push_div": pd_, "mode": mode, "defer": dfr, "force_pull": fp, "sparse_unroll": su,
                                "bpc": bpc, "ms": dt * 1e3, "mteps": te / dt / 1e6, "pairs_per_s": a.pairs / dt,
                                "match": okk, "levels": st["levels"], "push": st["push_levels"],
                                "pull": st["pull_levels"], "kernel_ms": st["kernel_ms"],
                                "algo_gb": {k: v / 1e9 for k, v in st["algo_bytes"].items() if v},
                                "edges_scanned": st["edges_scanned"]}
                         kms = st["kernel_ms"]
-                        for k in ("pull", "push"):
+                        for k in ("pull", "push", "pull_sparse"):
                             if kms.get(k, 0) > 0:
                                 row[k + "_GBps"] = st["algo_bytes"][k] / 1e9 / (kms[k] / 1e3)
                         f.write(json.dumps(row) + "\n")

@@ -98,26 +98,18 @@ def main():
     pairs_per_gpu = a.pairs_per_gpu or {"snb_sf100": 8192, "rmat22": 1024, "snb_paths": 4096,
                                         "forest_cheapest": 4096}[a.workload]
     # ---- graph: rank 0 builds it, the others receive it over RCCL (CSR replicated on every GPU) ----------------
-    meta = torch.zeros(4, dtype=torch.int64, device=dev)
+    from duckpgq_extension_amd import sharding
+    arrays = None
+    name, gen_s = "", 0.0
     if rank == 0:
         name, V, off, adj, eid, w, gen_s = build_graph(a)
-        meta[:] = torch.tensor([V, len(adj), 0 if w is None else 1, 0])
-    if world > 1:
-        dist.broadcast(meta, 0)
-    V, E, has_w = int(meta[0]), int(meta[1]), int(meta[2])
-    if rank == 0:
-        t_off, t_adj = torch.from_numpy(off).to(dev), torch.from_numpy(adj).to(dev)
-        t_eid = torch.from_numpy(eid).to(dev)
-        t_w = torch.from_numpy(w).to(dev) if has_w else None
-    else:
-        name, gen_s = "", 0.0
-        t_off = torch.empty(V + 1, dtype=torch.int64, device=dev)
-        t_adj = torch.empty(E, dtype=torch.int64, device=dev)
-        t_eid = torch.empty(E, dtype=torch.int64, device=dev)
-        t_w = torch.empty(E, dtype=torch.int64, device=dev) if has_w else None
-    if world > 1:
-        for t in (t_off, t_adj, t_eid) + ((t_w,) if has_w else ()):
-            dist.broadcast(t, 0)
+        arrays = {"off": torch.from_numpy(off), "adj": torch.from_numpy(adj), "eid": torch.from_numpy(eid)}
+        if w is not None:
+            arrays["w"] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.int64))
+    arrays = sharding.broadcast_csr(arrays, dev)
+    t_off, t_adj, t_eid, t_w = arrays["off"], arrays["adj"], arrays["eid"], arrays.get("w")
+    has_w = t_w is not None
+    V, E = t_off.numel() - 1, t_adj.numel()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     csr = pgq.DeviceCSR.from_device_ptrs(V, t_off.data_ptr(), t_adj.data_ptr(), t_eid.data_ptr(),
@@ -130,13 +122,13 @@ def main():
     allp = np.random.default_rng(seed).integers(0, V, size=(total_pairs, 2))
     if a.workload == "forest_cheapest":  # destinations that are reachable at all: ancestors are rare, use edges' heads
         pass
-    mine = allp[rank * pairs_per_gpu:(rank + 1) * pairs_per_gpu]
+    lo, hi = sharding.shard_bounds(total_pairs, world, rank)
+    mine = allp[lo:hi]
     n = len(mine)
     d_src = torch.from_numpy(np.ascontiguousarray(mine[:, 0])).to(dev)
     d_dst = torch.from_numpy(np.ascontiguousarray(mine[:, 1])).to(dev)
     d_len = torch.empty(n, dtype=torch.int64, device=dev)
     d_te = torch.zeros(n, dtype=torch.int64, device=dev)
-    gathered = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(world)] if world > 1 else None
 
     child_cap = n * 64
     d_off = d_child = d_val = d_ok = None
@@ -157,7 +149,7 @@ def main():
         else:
             csr.iterativelength_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr())
         if world > 1:  # final RCCL gather of the per-pair results (xGMI)
-            dist.all_gather(gathered, d_val if a.workload == "forest_cheapest" else d_len)
+            sharding.gather_rows(d_val if a.workload == "forest_cheapest" else d_len, total_pairs)
 
     # ---- work units (outside the timed region) -----------------------------------------------------------------
     if a.workload != "forest_cheapest":
@@ -236,6 +228,12 @@ def main():
                          "launches": int(kl[dom]), "avg_launch_ms": kms[dom] / max(kl[dom], 1),
                          "algorithmic_bytes_per_launch": kb[dom] / max(kl[dom], 1),
                          "measured_copy_GBps": copy_gbps},
+            # every kernel class of the timed region: event ms per step, algorithmic GB/s, launches per step
+            "roofline_by_kernel": {k: {"ms_per_step": round(kms[k] / a.steps, 4),
+                                       "GBps": round(kb[k] / 1e9 / (kms[k] / 1e3), 1) if kb[k] > 0 else None,
+                                       "launches_per_step": kl[k] / a.steps}
+                                   for k in kms if kms[k] > 0},
+            "deferred_pairs_per_step": stats["deferred_pairs"] / max(a.steps, 1),
         }
         if not a.no_cpu_baseline and a.workload in ("snb_sf100", "rmat22"):
             out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, d_te, ref_len)

@@ -61,6 +61,9 @@ def load_hip():
     L.pgq_csr_upload.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.POINTER(C.c_void_p)]
     L.pgq_csr_upload_device.argtypes = L.pgq_csr_upload.argtypes
+    L.pgq_csr_build_device.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.POINTER(C.c_void_p)]
+    L.pgq_csr_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pgq_csr_free.argtypes = [C.c_void_p]
     for f in ("pgq_csr_num_vertices", "pgq_csr_num_edges", "pgq_csr_device_bytes"):
         getattr(L, f).restype = C.c_int64
@@ -230,6 +233,31 @@ class DeviceCSR:
                                             C.byref(h)))
         self.h = h
         return self
+
+    @classmethod
+    def build_from_device_rows(cls, V, n_rows, d_src, d_dst, d_edge_id=0, d_w=0, w_type=0):
+        """create_csr_vertex/create_csr_edge on the GPU: edge-table rows (device pointers) -> device CSR."""
+        self = cls.__new__(cls)
+        self.L = load_hip()
+        self.V = int(V)
+        self._owned = True
+        _check(self.L.pgq_init(-1))
+        h = C.c_void_p()
+        _check(self.L.pgq_csr_build_device(self.V, n_rows, C.c_void_p(d_src), C.c_void_p(d_dst),
+                                           C.c_void_p(d_edge_id or None), C.c_void_p(d_w or None), w_type, C.byref(h)))
+        self.h = h
+        return self
+
+    def download(self):
+        """(offsets[V+1], adj[E], edge_ids[E], w or None) as numpy, reference layout."""
+        E = self.num_edges
+        off = np.zeros(self.V + 1, dtype=np.int64)
+        adj = np.zeros(max(E, 1), dtype=np.int64)
+        eid = np.zeros(max(E, 1), dtype=np.int64)
+        wt = self.w_type
+        w = None if wt == 0 else np.zeros(max(E, 1), dtype=np.int64 if wt == 1 else np.float64)
+        _check(self.L.pgq_csr_download(self.h, _p(off), _p(adj), _p(eid), _p(w)))
+        return off, adj[:E], eid[:E], (None if w is None else w[:E])
 
     def close(self):
         if getattr(self, "h", None) and self._owned:

@@ -382,11 +382,12 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 // [V][WD] frontier array wastes a 128-byte fabric fetch per 8-byte word (measured: 2.8 GB fetched for 0.19 GB
 // of words at SF100 level 2).  The frontier is therefore first packed:
 //   bits[v/32]  1 bit per vertex "has any lane-word"      (V/8 bytes: L1/L2 resident)
-//   meta[v]     {non-empty-word mask, offset into cw}     (only valid where the bit is set)
-//   cw[]        the non-empty lane-words back to back     (frontier_words * 8 bytes: L2 resident)
-struct FrontMeta {
-	u32 nz;
-	u32 base;
+//   meta[v]     {non-empty-word mask, offset into cw, first non-empty word}   (only valid where the bit is set)
+//   cw[]        the 2nd.. non-empty lane-words back to back (L2 resident)
+struct __attribute__((aligned(16))) FrontMeta {
+	u32 nz;   // non-empty-word mask
+	u32 base; // offset of the 2nd.. non-empty words in cw
+	u64 w0;   // first non-empty word inline: single-word vertices (the common case) cost one 16-byte request
 };
 
 template <int WD>
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 		if (lane == 0) bits[v >> 5] = (u32)any;
 		if (lane == 32) bits[v >> 5] = (u32)(any >> 32);
 		if (!any) continue;
-		const u32 c = (u32)__popc(m);
+		const u32 c = m ? (u32)__popc(m) - 1u : 0u; // words beyond the first go to cw
 		u32 incl = c;
 		for (int o = 1; o < 64; o <<= 1) {
 			const u32 t = __shfl_up(incl, o);
@@ -415,8 +416,8 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 		if (lane == 63) base = atomicAdd(total, incl);
 		base = __shfl(base, 63) + incl - c;
 		if (m) {
-			meta[v] = FrontMeta{ m, base };
-			u32 rest = m;
+			u32 rest = m & (m - 1);
+			meta[v] = FrontMeta{ m, base, front[(size_t)v * WD + (__ffs((int)m) - 1)] };
 			u32 k = 0;
 			while (rest) {
 				const int w = __ffs((int)rest) - 1;
@@ -434,21 +435,26 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 // the packed words that are non-empty there AND still wanted by the entry's owner vertex, OR-ing them into the
 // owner's row of an LDS accumulator (ds_or_b64).  seen/next rows of a part are contiguous -> coalesced
 // prologue/epilogue.  Same results as k_pull (next = OR of in-neighbours' frontier words & active & ~seen).
-template <int WD, int UN>
-__global__ __launch_bounds__(256) void k_pull_sparse(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+template <int WD, int UN, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ parts,
                                                      int n_parts, const u32 *__restrict__ bits,
                                                      const FrontMeta *__restrict__ meta, const u64 *__restrict__ cw,
                                                      u64 *__restrict__ seen, u64 *__restrict__ next,
                                                      u32 *__restrict__ nz_next, const u64 *__restrict__ active,
-                                                     int stop_limit, Counters *__restrict__ cnt) {
+                                                     int lds_bit_words, int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NV = 32;
-	__shared__ u64 s_acc[4][NV * WD];
-	__shared__ u32 s_row[4][NV + 1];
-	__shared__ u32 s_want[4][NV];
-	__shared__ u32 s_nzn[4][NV];
-	__shared__ u64 red[4][5];
+	__shared__ u64 s_acc[WPB][NV * WD];
+	__shared__ u32 s_row[WPB][NV + 1];
+	__shared__ u32 s_want[WPB][NV];
+	__shared__ u32 s_nzn[WPB][NV];
+	__shared__ u64 red[WPB][5];
+	extern __shared__ u32 s_bits[]; // WPB == 16: the whole 1-bit frontier map (V/8 bytes) lives in LDS
 	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (WPB == 16) {
+		for (int i = threadIdx.x; i < lds_bit_words; i += WPB * 64) s_bits[i] = bits[i];
+		__syncthreads();
+	}
 	const int lane = threadIdx.x & 63;
 	const int wib = threadIdx.x >> 6;
 	u64 *acc = s_acc[wib];
@@ -486,7 +492,8 @@ __global__ __launch_bounds__(256) void k_pull_sparse(const int64_t *__restrict__
 				nb[k] = e < e1 ? radj[e] : -1;
 			}
 #pragma unroll
-			for (int k = 0; k < UN; k++) hot[k] = nb[k] >= 0 && ((bits[nb[k] >> 5] >> (nb[k] & 31)) & 1u);
+			for (int k = 0; k < UN; k++)
+				hot[k] = nb[k] >= 0 && (((WPB == 16 ? s_bits[nb[k] >> 5] : bits[nb[k] >> 5]) >> (nb[k] & 31)) & 1u);
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
 				if (!hot[k]) continue;
@@ -502,7 +509,8 @@ __global__ __launch_bounds__(256) void k_pull_sparse(const int64_t *__restrict__
 				while (m) {
 					const int w = __ffs((int)m) - 1;
 					m &= m - 1;
-					const u64 val = cw[mt.base + __popc(mt.nz & ((1u << w) - 1u))];
+					const int r = __popc(mt.nz & ((1u << w) - 1u));
+					const u64 val = r == 0 ? mt.w0 : cw[mt.base + r - 1];
 					atomicOr(&acc[lo * WD + w], val);
 					gath++;
 				}
@@ -1168,11 +1176,29 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 					hipLaunchKernelGGL(k_compact_frontier<WD>, dim3(std::min(blocks_for(V), 8u * ncu)), dim3(256), 0, st,
 					                   cur->nz.as<u32>(), cur->buf.as<u64>(), V, ws->cmeta.as<FrontMeta>(),
 					                   ws->cwords.as<u64>(), ws->cbits.as<u32>(), d_total, cw_cap, stop, d_cnt);
+					// graphs whose 1-bit frontier map fits in LDS (V <= 512K) run 1024-thread workgroups that keep it there
+					const int bit_words = (int)(V / 32 + 2);
+					const bool lds_map = opt.sparse_lds && (size_t)bit_words * 4 <= 64 * 1024;
 #define PGQ_LAUNCH_SPARSE(UNR)                                                                                         \
-	hipLaunchKernelGGL((k_pull_sparse<WD, UNR>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj, c->off,          \
-	                   c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cmeta.as<FrontMeta>(),                 \
-	                   ws->cwords.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, stop, \
-	                   d_cnt)
+	do {                                                                                                               \
+		if (lds_map) {                                                                                                 \
+			auto kfn = k_pull_sparse<WD, UNR, 16>;                                                                     \
+			static bool attr_set = false;                                                                              \
+			if (!attr_set) {                                                                                           \
+				(void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);   \
+				attr_set = true;                                                                                       \
+			}                                                                                                          \
+			hipLaunchKernelGGL(kfn, dim3(ncu), dim3(1024), (size_t)bit_words * 4, st, c->roff, c->radj, c->off,         \
+			                   c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cmeta.as<FrontMeta>(),         \
+			                   ws->cwords.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(),        \
+			                   act_cur, bit_words, stop, d_cnt);                                                       \
+		} else {                                                                                                       \
+			hipLaunchKernelGGL((k_pull_sparse<WD, UNR, 4>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj,       \
+			                   c->off, c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(),                            \
+			                   ws->cmeta.as<FrontMeta>(), ws->cwords.as<u64>(), ws->seen.as<u64>(),                    \
+			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, 0, stop, d_cnt);                        \
+		}                                                                                                              \
+	} while (0)
 					if (opt.sparse_unroll >= 4) PGQ_LAUNCH_SPARSE(4);
 					else if (opt.sparse_unroll >= 2) PGQ_LAUNCH_SPARSE(2);
 					else PGQ_LAUNCH_SPARSE(1);

@@ -79,6 +79,7 @@ static int do_init(int device) {
 	env_int("PGQ_PART_WEIGHT", g_opt.part_weight);
 	env_double("PGQ_SPARSE_BELOW", g_opt.sparse_below);
 	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
+	env_int("PGQ_SPARSE_LDS", g_opt.sparse_lds);
 	g_inited.store(1);
 	return PGQ_OK;
 }
@@ -238,6 +239,37 @@ template <typename T> __global__ void k_any_negative(const T *__restrict__ w, in
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (; i < E; i += stride)
 		if (w[i] < (T)0) *flag = 1;
+}
+
+
+// ---- CSR construction on the device (create_csr_vertex/create_csr_edge equivalent) -----------------------------
+__global__ void k_check_rows(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t n, int64_t V,
+                             u32 *__restrict__ key, u32 *__restrict__ idx, int *__restrict__ deg, int *__restrict__ bad) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		int64_t s = src[i], d = dst[i];
+		if (s < 0 || s >= V || d < 0 || d >= V) {
+			*bad = 1;
+			s = 0;
+		}
+		key[i] = (u32)s;
+		idx[i] = (u32)i;
+		atomicAdd(&deg[s], 1);
+	}
+}
+// slot i of the CSR holds row order[i]: gather dst / edge id / weight
+__global__ void k_gather_rows(const u32 *__restrict__ order, int64_t n, const int64_t *__restrict__ dst,
+                              const int64_t *__restrict__ eid, const int64_t *__restrict__ w,
+                              int64_t *__restrict__ adj64, int64_t *__restrict__ eid_out, int64_t *__restrict__ w_out) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		const u32 r = order[i];
+		adj64[i] = dst[r];
+		eid_out[i] = eid ? eid[r] : (int64_t)r;
+		if (w_out) w_out[i] = w[r];
+	}
 }
 
 static int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
@@ -472,6 +504,103 @@ int pgq_csr_upload_device(int64_t V, const int64_t *d_offsets, const int64_t *d_
                           const void *d_w, int w_type, pgq_csr_t **out) {
 	return upload_impl(V, d_offsets, d_adj, d_edge_ids, d_w, w_type, true, out);
 }
+
+int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const int64_t *d_dst,
+                         const int64_t *d_edge_id, const void *d_w, int w_type, pgq_csr_t **out) {
+	PGQ_TRY(ensure_init());
+	if (!out) return fail(PGQ_ERR_INVALID_ARG, "out handle pointer is NULL");
+	*out = nullptr;
+	if (V < 0 || V >= (1LL << 31) - 1) return fail(PGQ_ERR_INVALID_ARG, "V must be in [0, 2^31-1)");
+	if (n_rows < 0 || n_rows >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "edge rows must be in [0, 2^31)");
+	if (n_rows > 0 && (!d_src || !d_dst)) return fail(PGQ_ERR_INVALID_ARG, "NULL edge columns");
+	if (w_type < 0 || w_type > 2 || (w_type != 0 && !d_w)) return fail(PGQ_ERR_INVALID_ARG, "bad weight type / NULL weights");
+	const int64_t E = n_rows;
+	pgq_csr *c = new pgq_csr();
+	(void)hipGetDevice(&c->device);
+	c->V = V;
+	c->E = E;
+	c->w_type = w_type;
+	hipStream_t st = nullptr;
+	u32 *d_key = nullptr, *d_idx = nullptr, *d_skey = nullptr, *d_order = nullptr;
+	int *d_deg = nullptr, *d_bad = nullptr;
+	int64_t *d_deg64 = nullptr, *d_adj64 = nullptr;
+	void *d_tmp = nullptr;
+	auto body = [&]() -> int {
+		PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		const size_t En = (size_t)std::max<int64_t>(E, 1);
+		PGQ_HIP_TRY(hipMalloc(&d_key, En * 4));
+		PGQ_HIP_TRY(hipMalloc(&d_idx, En * 4));
+		PGQ_HIP_TRY(hipMalloc(&d_skey, En * 4));
+		PGQ_HIP_TRY(hipMalloc(&d_order, En * 4));
+		PGQ_HIP_TRY(hipMalloc(&d_deg, (size_t)(V + 1) * 4));
+		PGQ_HIP_TRY(hipMalloc(&d_bad, 4));
+		PGQ_HIP_TRY(hipMalloc(&d_deg64, (size_t)(V + 1) * 8));
+		PGQ_HIP_TRY(hipMalloc(&d_adj64, En * 8));
+		PGQ_HIP_TRY(hipMalloc(&c->off, (size_t)(V + 1) * 8));
+		PGQ_HIP_TRY(hipMalloc(&c->edge_ids, En * 8));
+		if (w_type != PGQ_W_NONE) PGQ_HIP_TRY(hipMalloc(&c->w, En * 8));
+		PGQ_HIP_TRY(hipMemsetAsync(d_deg, 0, (size_t)(V + 1) * 4, st));
+		PGQ_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+		if (E > 0)
+			hipLaunchKernelGGL(k_check_rows, dim3(grid_for(E)), dim3(256), 0, st, d_src, d_dst, E, V, d_key, d_idx, d_deg, d_bad);
+		// out-degree -> offsets (CsrInitializeEdge's prefix sum, csr_creation.cpp:57-59)
+		hipLaunchKernelGGL(k_widen, dim3((unsigned)((V + 1 + 255) / 256)), dim3(256), 0, st, d_deg, d_deg64, V, V + 1);
+		size_t tb = 0;
+		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_deg64, c->off, (int)(V + 1), st));
+		size_t sb = 0;
+		int end_bit = 1;
+		while ((1LL << end_bit) < V) end_bit++;
+		if (E > 0)
+			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, d_key, d_skey, d_idx, d_order, (int)E, 0, end_bit, st));
+		PGQ_HIP_TRY(hipMalloc(&d_tmp, std::max(tb, sb) + 16));
+		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_deg64, c->off, (int)(V + 1), st));
+		if (E > 0) {
+			// stable LSD radix sort by source == arrival order per vertex of the single-threaded reference
+			// (pos = ++v[src+1], csr_creation.cpp:132-138)
+			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, sb, d_key, d_skey, d_idx, d_order, (int)E, 0, end_bit, st));
+			hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(E)), dim3(256), 0, st, d_order, E, d_dst, d_edge_id,
+			                   (const int64_t *)d_w, d_adj64, c->edge_ids, (int64_t *)c->w);
+		}
+		int bad = 0;
+		PGQ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		if (bad) return fail(PGQ_ERR_INVALID_ARG, "edge endpoint out of range [0,V)");
+		return finish_upload(c, d_adj64, st);
+	};
+	int rc = body();
+	if (st) {
+		(void)hipStreamSynchronize(st);
+		(void)hipStreamDestroy(st);
+	}
+	for (void *p : { (void *)d_key, (void *)d_idx, (void *)d_skey, (void *)d_order, (void *)d_deg, (void *)d_bad,
+	                 (void *)d_deg64, (void *)d_adj64, d_tmp })
+		(void)hipFree(p);
+	if (rc != PGQ_OK) {
+		destroy_csr(c);
+		return rc;
+	}
+	*out = c;
+	return PGQ_OK;
+}
+
+int pgq_csr_download(const pgq_csr_t *c, int64_t *offsets, int64_t *adj, int64_t *edge_ids, void *w) {
+	PGQ_TRY(ensure_init());
+	if (!c) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (offsets) PGQ_HIP_TRY(hipMemcpy(offsets, c->off, (size_t)(c->V + 1) * 8, hipMemcpyDeviceToHost));
+	if (adj && c->E > 0) {
+		std::vector<int32_t> a32((size_t)c->E);
+		PGQ_HIP_TRY(hipMemcpy(a32.data(), c->adj, (size_t)c->E * 4, hipMemcpyDeviceToHost));
+		for (int64_t i = 0; i < c->E; i++) adj[i] = a32[i];
+	}
+	if (edge_ids && c->E > 0) {
+		if (c->edge_ids) PGQ_HIP_TRY(hipMemcpy(edge_ids, c->edge_ids, (size_t)c->E * 8, hipMemcpyDeviceToHost));
+		else
+			for (int64_t i = 0; i < c->E; i++) edge_ids[i] = i;
+	}
+	if (w && c->w && c->E > 0) PGQ_HIP_TRY(hipMemcpy(w, c->w, (size_t)c->E * 8, hipMemcpyDeviceToHost));
+	return PGQ_OK;
+}
+
 int pgq_csr_free(pgq_csr_t *csr) {
 	if (!csr) return PGQ_OK;
 	PGQ_TRY(ensure_init());
@@ -502,6 +631,7 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "part_weight") o.part_weight = atoi(value);
 	else if (k == "sparse_below") o.sparse_below = atof(value);
 	else if (k == "sparse_unroll") o.sparse_unroll = atoi(value);
+	else if (k == "sparse_lds") o.sparse_lds = atoi(value);
 	else return fail(PGQ_ERR_INVALID_ARG, "unknown option: " + k);
 	return PGQ_OK;
 }

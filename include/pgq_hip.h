@@ -81,6 +81,15 @@ int pgq_csr_upload(int64_t V, const int64_t *offsets, const int64_t *adj, const 
 /* Same, but the four arrays already live in device memory of the current device (they are copied). */
 int pgq_csr_upload_device(int64_t V, const int64_t *d_offsets, const int64_t *d_adj, const int64_t *d_edge_ids,
                           const void *d_w, int w_type, pgq_csr_t **out);
+/* CSR construction on the GPU from edge-table rows resident in HBM: what
+ * create_csr_vertex + create_csr_edge (src/core/functions/scalar/csr_creation.cpp:86-198) compute, with the slot
+ * order of the reference's single-threaded schedule (rows of one source keep their table order).  d_edge_id may be
+ * NULL (row index is the edge id); d_w: int64 or double column per w_type. */
+int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const int64_t *d_dst,
+                         const int64_t *d_edge_id, const void *d_w, int w_type, pgq_csr_t **out);
+/* Copies the device CSR back in the reference's layout (int64); any pointer may be NULL.  get_csr_v/e/w analogue
+ * (src/core/functions/table/pgq_scan.cpp:15-153) for the device-built CSR. */
+int pgq_csr_download(const pgq_csr_t *csr, int64_t *offsets, int64_t *adj, int64_t *edge_ids, void *w);
 int pgq_csr_free(pgq_csr_t *csr);
 int64_t pgq_csr_num_vertices(const pgq_csr_t *csr);
 int64_t pgq_csr_num_edges(const pgq_csr_t *csr);

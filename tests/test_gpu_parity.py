@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _defaults():
-    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8), ("force_pull", 0)):
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1)):
         pgq.set_option(k, v)
     yield
 
@@ -134,9 +134,10 @@ def test_random_graph_all_variants(words, mode):
     want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)]
     opaths = ora.lean_shortestpath(V, ps[:700], pd[:700])
     # destination probe on / classic post-expansion detection; adaptive / sparse-only / dense-only bottom-up kernel
-    for probe, force_pull in ((1, 0), (0, 1), (1, 2), (0, 0)):
+    for probe, force_pull, lds in ((1, 0, 1), (0, 1, 0), (1, 2, 1), (0, 1, 1)):
         pgq.set_option("probe", probe)
         pgq.set_option("force_pull", force_pull)
+        pgq.set_option("sparse_lds", lds)  # 1-bit frontier map in LDS (1024-thread groups) or in global memory
         ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
         assert lens(ln, ok) == want
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
@@ -272,3 +273,67 @@ def test_traversed_edges_accounting_matches_oracle():
         ln = d_len.cpu().numpy()
         assert ((ln >= 0) == ook).all() and (ln[ook] == oln[ook]).all()
         assert (d_te.cpu().numpy() == ote).all()
+
+
+@pytest.mark.slow
+def test_full_size_sf100_properties():
+    """BASELINE-size graph (SF100-shaped knows, 39.9 M CSR entries): properties that need no oracle run.
+    undirected symmetry d(s,t) == d(t,s); every reported path is a real path of the reported length whose
+    vertices sit at consecutive BFS distances; a bounded oracle sample agrees bit for bit."""
+    V, s, d = graphgen.snb_knows_like()
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    rng = np.random.default_rng(3)
+    n = 4096
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    ln, ok = dev.iterativelength(ps, pd)
+    ln_r, ok_r = dev.iterativelength(pd, ps)
+    assert (ok == ok_r).all() and (ln == ln_r).all()
+    paths = dev.shortestpath(ps, pd)
+    for i in range(n):
+        p = paths[i]
+        if not ok[i]:
+            assert p is None
+            continue
+        assert p is not None and len(p) == 2 * ln[i] + 1 and p[0] == ps[i] and p[-1] == pd[i]
+        for k in range(0, len(p) - 1, 2):  # edge id = CSR slot's edge rowid: slot must run from p[k] to p[k+2]
+            u, e, v = p[k], p[k + 1], p[k + 2]
+            row = adj[off[u]:off[u + 1]]
+            j = int(np.argmax(row == v))
+            assert row[j] == v and eid[off[u] + j] == e  # first slot of u holding v (shortest_path.cpp:23-30)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    oln, ook = ora.lean_iterativelength(V, ps[:256], pd[:256], nthreads=8)
+    assert (ook == ok[:256]).all() and (oln[ook] == ln[:256][ook]).all()
+    assert ora.lean_shortestpath(V, ps[:64], pd[:64]) == paths[:64]
+
+
+def test_device_csr_construction_matches_reference_layout():
+    # create_csr_vertex/create_csr_edge on the GPU (SURVEY §8f rank 1): same v/e/edge_ids/w arrays as the
+    # single-threaded reference schedule, golden layout of getpgschema.test:85-107 included
+    import torch
+    g = load_golden("student_csr_layout.json")
+    s, d, e = directed_rows(g["edges"])
+    ts, td = torch.from_numpy(s).cuda(), torch.from_numpy(d).cuda()  # keep the tensors alive across the call
+    dev = pgq.DeviceCSR.build_from_device_rows(g["V"], len(s), ts.data_ptr(), td.data_ptr())
+    off, adj, eid, _ = dev.download()
+    assert off.tolist() == g["csr_v"][:g["V"] + 1] and adj.tolist() == g["csr_e"]
+    rng = np.random.default_rng(17)
+    V, E = 5000, 60000
+    s, d, e = random_graph(rng, V, E, skew=True)
+    e = rng.permutation(E).astype(np.int64) + 1000  # arbitrary edge rowids
+    for w in (None, rng.integers(0, 1000, E), rng.random(E)):
+        ts, td, te = (torch.from_numpy(x).cuda() for x in (s, d, e))
+        tw = None if w is None else torch.from_numpy(w).cuda()
+        dev = pgq.DeviceCSR.build_from_device_rows(V, E, ts.data_ptr(), td.data_ptr(), te.data_ptr(),
+                                                   0 if tw is None else tw.data_ptr(),
+                                                   0 if w is None else (2 if w.dtype.kind == "f" else 1))
+        ora = OracleCSR.from_edges(V, s, d, e, w)
+        off, adj, eid, ww = dev.download()
+        assert (off == ora.v[:V + 1]).all() and (adj == ora.e).all() and (eid == ora.edge_ids).all()
+        if w is not None:
+            assert (ww == ora.w).all()
+        ps, pd = rng.integers(0, V, 500), rng.integers(0, V, 500)
+        assert dev.shortestpath(ps, pd) == ora.lean_shortestpath(V, ps, pd)
+    with pytest.raises(pgq.PgqError, match="out of range"):
+        bad = torch.from_numpy(np.array([0, V], dtype=np.int64)).cuda()
+        pgq.DeviceCSR.build_from_device_rows(V, 2, bad.data_ptr(), bad.data_ptr())

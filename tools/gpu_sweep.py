@@ -32,12 +32,13 @@ def main():
     ap.add_argument("--graph", default="snb")
     ap.add_argument("--pairs", type=int, default=8192)
     ap.add_argument("--words", default="4,8,16")
-    ap.add_argument("--push_div", default="12")
+    ap.add_argument("--push_div", default="24")
     ap.add_argument("--modes", default="0")
     ap.add_argument("--bpc", default="8")
     ap.add_argument("--defer", default="8")
     ap.add_argument("--force_pull", default="0")
-    ap.add_argument("--sparse_unroll", default="2")
+    ap.add_argument("--sparse_unroll", default="4")
+    ap.add_argument("--sparse_lds", default="1")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--trace", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/sweep.jsonl")
@@ -68,6 +69,7 @@ def main():
                    for fp in [int(x) for x in a.force_pull.split(",")]:
                     for pd_, su in [(float(x), int(y)) for x in a.push_div.split(",") for y in a.sparse_unroll.split(",")]:
                         pgq.set_option("sparse_unroll", su)
+                        pgq.set_option("sparse_lds", int(a.sparse_lds))
                         pgq.set_option("defer", dfr)
                         pgq.set_option("force_pull", fp)
                         pgq.set_option("words", words)

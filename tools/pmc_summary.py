@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Aggregates the rocprofv3 --pmc CSVs written by tools/collect_pmc.sh into per-kernel averages (per launch) and
+writes profiles/pmc_<workload>.json (bench.py reads hbm_bytes_per_launch from it for roofline.traffic).
+FETCH_SIZE/WRITE_SIZE are in KiB-ish units of 1024 B... rocprofv3 reports kilobytes; on gfx950 FETCH_SIZE under-counts
+wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM): the 2x correction is applied to reads."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "snb_sf100"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(set)
+for path in glob.glob(os.path.join(root, "gpurun_out", "prof", wl + "_*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pgq::", "")
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+out = {}
+for k, cs in agg.items():
+    d = {c: v / max(len(launches[(k, c)]), 1) for c, v in cs.items()}
+    if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+        d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
+    d["launches_profiled"] = max(len(v) for (kk, c), v in launches.items() if kk == k)
+    out[k] = d
+# bench.py looks kernels up by class name ("pull_sparse"): add aliases for the widest instantiation seen
+for cls in ("pull_sparse", "pull", "push", "pull_hub", "relax"):
+    cands = [k for k in out if k.startswith("k_" + cls + "<")]
+    if cands:
+        best = max(cands, key=lambda k: out[k].get("hbm_bytes_per_launch", 0) * out[k]["launches_profiled"])
+        out[cls] = dict(out[best], kernel=best)
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+json.dump(out, open(os.path.join(root, "profiles", "pmc_%s.json" % wl), "w"), indent=1, sort_keys=True)
+for k in sorted(out, key=lambda k: -out[k].get("hbm_bytes_per_launch", 0)):
+    if k.startswith("k_"):
+        print(k, {c: "%.4g" % v for c, v in out[k].items() if isinstance(v, float)})

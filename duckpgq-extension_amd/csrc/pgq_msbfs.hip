@@ -28,6 +28,7 @@
 #include <cstddef>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "pgq_search.h"
 
@@ -158,6 +159,24 @@ __global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_
 		atomicAdd(&cnt->front_words, 1u);
 	}
 	enqueue_items(ok, v, deg, chunk, q, qcap, &cnt->q_count[0]);
+}
+
+// one launch at the start of every level instead of several tiny memsets: per-level counters, the next
+// active-lane mask, and the frontier-queue counts a top-down level is about to fill
+__global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero_q0, int zero_q1) {
+	const int t = threadIdx.x;
+	if (t == 0) {
+		cnt->front_vertices = 0;
+		cnt->unresolved = 0;
+		cnt->front_edges = 0;
+		cnt->edges_scanned = 0;
+		cnt->word_gathers = 0;
+		cnt->front_words = 0;
+		cnt->pad = 0;
+		if (zero_q0) cnt->q_count[0] = 0;
+		if (zero_q1) cnt->q_count[1] = 0;
+	}
+	if (t < 16) cnt->act[act_zero][t] = 0;
 }
 
 // ---- top-down level ----------------------------------------------------------------------------------------------
@@ -991,8 +1010,10 @@ struct SearchOutput {
 static constexpr int kMaxTeLevels = 1024;
 
 template <int WD>
-static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool with_paths, int64_t *d_child_ext,
-                       int64_t child_cap_ext, SearchOutput &outp) {
+static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bstride, int64_t n, int64_t U,
+                       bool with_paths, int64_t *d_child_ext, int64_t child_cap_ext, SearchOutput &outp) {
+	// sh: the call's shared arrays (rows sorted by lane, per-row results, batch bounds); ws: this worker's private
+	// search state (seen, frontiers, queues, counters, stream).  Workers take batches b0, b0+bstride, ...
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V, E = c->E;
 	const Options &opt = options();
@@ -1010,15 +1031,14 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
 	if (outp.want_te) {
 		PGQ_TRY(ws->lane_sums.reserve((size_t)kMaxTeLevels * L * 8));
-		PGQ_TRY(ws->ste.reserve((size_t)n * 8));
-		PGQ_HIP_TRY(hipMemsetAsync(ws->ste.p, 0, (size_t)n * 8, st));
+		PGQ_TRY(sh->ste.reserve((size_t)n * 8));
+		PGQ_HIP_TRY(hipMemsetAsync(sh->ste.p, 0, (size_t)n * 8, st));
 	}
 	Counters *d_cnt = ws->counters.as<Counters>();
-	PGQ_TRY(batch_bounds(ws, n, L, nb));
 	PGQ_HIP_TRY(hipMemsetAsync(ws->qflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
 	ws->epoch = 0;
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
-	const int64_t *bs = ws->h_bstart;
+	const int64_t *bs = sh->h_bstart;
 
 	int64_t child_base = 0;
 	int64_t *d_child = d_child_ext;
@@ -1030,7 +1050,7 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 	const unsigned pull_grid = (unsigned)std::max(1, opt.blocks_per_cu) * ncu;
 	const unsigned push_grid = 8 * ncu;
 
-	for (int b = 0; b < nb; b++) {
+	for (int b = b0; b < nb; b += bstride) {
 		const int64_t lo = bs[b], hi = bs[b + 1];
 		if (lo == hi) continue;
 		const u32 base_lane = (u32)((int64_t)b * L);
@@ -1063,7 +1083,7 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		int act_sel = 0;
 		{
 			KernelTimer kt(st, K_PREP);
-			hipLaunchKernelGGL(k_init_batch<WD>, dim3(blocks_for(L)), dim3(256), 0, st, ws->usrc.as<int32_t>(), U,
+			hipLaunchKernelGGL(k_init_batch<WD>, dim3(blocks_for(L)), dim3(256), 0, st, sh->usrc.as<int32_t>(), U,
 			                   (int64_t)base_lane, c->off, cur->buf.as<u64>(), cur->nz.as<u32>(), ws->seen.as<u64>(),
 			                   act_cur, ws->qbuf[0].as<u64>(), qcap, chunk, d_cnt);
 			kt.stop();
@@ -1101,12 +1121,17 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 			bool push = opt.force_mode == 1 || (opt.force_mode == 0 && (double)front_edges * opt.push_div < (double)E);
 			if (opt.force_mode == 2) push = false;
 			// reset the per-level counters but keep the queue counts
-			PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->front_vertices, 0, offsetof(Counters, act) - offsetof(Counters, front_vertices), st));
+			{
+				const bool zq_cur = push && !queue_valid; // queue rebuilt from the dense frontier below
+				const int q_cur = par, q_nxt = par ^ 1;
+				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(64), 0, st, d_cnt, act_sel ^ 1,
+				                   (int)((push && q_nxt == 0) || (zq_cur && q_cur == 0)),
+				                   (int)((push && q_nxt == 1) || (zq_cur && q_cur == 1)));
+			}
 			if (use_probe) {
-				PGQ_HIP_TRY(hipMemsetAsync(act_nxt, 0, 16 * 8, st));
 				KernelTimer kt(st, K_DETECT);
 				hipLaunchKernelGGL(k_probe<WD>, dim3(blocks_for((hi - lo) * 64)), dim3(256), 0, st, lo, hi,
-				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>(), base_lane,
+				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
@@ -1114,14 +1139,12 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 			}
 			if (push) {
 				if (!queue_valid) {
-					PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->q_count[par], 0, 4, st));
 					KernelTimer kt(st, K_QUEUE);
 					hipLaunchKernelGGL(k_queue_from_dense<WD>, dim3(std::min(blocks_for(V), 16u * ncu)), dim3(256), 0, st,
 					                   cur->nz.as<u32>(), V, c->off, chunk, ws->qbuf[par].as<u64>(), qcap, par, d_cnt);
 					kt.stop();
 				}
 				PGQ_TRY(make_zero(nxt));
-				PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->q_count[par ^ 1], 0, 4, st));
 				ws->epoch++;
 				{
 					KernelTimer kt(st, K_PUSH);
@@ -1171,7 +1194,6 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 					// sized generously once (2 words per vertex) so that growing frontiers do not reallocate per level
 					PGQ_TRY(ws->cwords.reserve(std::max<size_t>((size_t)cw_cap, 2 * (size_t)std::max<int64_t>(V, 1)) * 8));
 					u32 *d_total = reinterpret_cast<u32 *>(&d_cnt->pad);
-					PGQ_HIP_TRY(hipMemsetAsync(d_total, 0, 4, st));
 					KernelTimer kt(st, K_PULL_SPARSE);
 					hipLaunchKernelGGL(k_compact_frontier<WD>, dim3(std::min(blocks_for(V), 8u * ncu)), dim3(256), 0, st,
 					                   cur->nz.as<u32>(), cur->buf.as<u64>(), V, ws->cmeta.as<FrontMeta>(),
@@ -1223,10 +1245,9 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 			}
 			if (!use_probe) {
 				// -- detect finished pairs (iterativelength.cpp:119-129), rebuild the active-lane mask
-				PGQ_HIP_TRY(hipMemsetAsync(act_nxt, 0, 16 * 8, st));
 				KernelTimer kt(st, K_DETECT);
-				hipLaunchKernelGGL(k_detect<WD>, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
-				                   ws->sdst.as<int32_t>(), ws->sres.as<int32_t>(), base_lane, ws->seen.as<u64>(), t,
+				hipLaunchKernelGGL(k_detect<WD>, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
+				                   sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane, ws->seen.as<u64>(), t,
 				                   act_nxt, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt);
@@ -1252,7 +1273,7 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 				if (push) S.push_levels--;
 				else S.pull_levels--;
 				if (unresolved > 0) {
-					hipLaunchKernelGGL(k_mark_deferred, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->sres.as<int32_t>());
+					hipLaunchKernelGGL(k_mark_deferred, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, sh->sres.as<int32_t>());
 					outp.deferred = true;
 					S.deferred_pairs += unresolved;
 				}
@@ -1281,15 +1302,15 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 			levels_run = t;
 		}
 		if (outp.want_te)
-			hipLaunchKernelGGL(k_pair_te, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
-			                   ws->sres.as<int32_t>(), base_lane, ws->lane_sums.as<u64>(), (int)L, levels_run + 1,
-			                   ws->ste.as<int64_t>());
+			hipLaunchKernelGGL(k_pair_te, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
+			                   sh->sres.as<int32_t>(), base_lane, ws->lane_sums.as<u64>(), (int)L, levels_run + 1,
+			                   sh->ste.as<int64_t>());
 		// -- paths for this batch
 		if (with_paths) {
 			const int64_t cnt_pairs = hi - lo;
 			h_res.resize(cnt_pairs);
 			h_off.resize(cnt_pairs);
-			PGQ_HIP_TRY(hipMemcpyAsync(h_res.data(), ws->sres.as<int32_t>() + lo, (size_t)cnt_pairs * 4,
+			PGQ_HIP_TRY(hipMemcpyAsync(h_res.data(), sh->sres.as<int32_t>() + lo, (size_t)cnt_pairs * 4,
 			                           hipMemcpyDeviceToHost, st));
 			PGQ_HIP_TRY(hipStreamSynchronize(st));
 			int64_t need = child_base;
@@ -1297,32 +1318,32 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 				h_off[i] = need;
 				if (h_res[i] > 0) need += 2 * (int64_t)h_res[i] + 1;
 			}
-			PGQ_HIP_TRY(hipMemcpyAsync(ws->soff.as<int64_t>() + lo, h_off.data(), (size_t)cnt_pairs * 8,
+			PGQ_HIP_TRY(hipMemcpyAsync(sh->soff.as<int64_t>() + lo, h_off.data(), (size_t)cnt_pairs * 8,
 			                           hipMemcpyHostToDevice, st));
 			bool fits = true;
 			if (d_child_ext) {
 				fits = need <= child_cap_ext;
-			} else if ((size_t)need * 8 > ws->child.cap) {
+			} else if ((size_t)need * 8 > sh->child.cap) {
 				// grow, preserving what earlier batches wrote
 				DevBuf bigger;
 				PGQ_TRY(bigger.reserve((size_t)need * 8 * 2));
 				if (child_base > 0)
-					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
+					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, sh->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
 				PGQ_HIP_TRY(hipStreamSynchronize(st));
-				ws->child.release();
-				ws->child = bigger;
-				d_child = ws->child.as<int64_t>();
+				sh->child.release();
+				sh->child = bigger;
+				d_child = sh->child.as<int64_t>();
 			}
-			if (!d_child_ext) d_child = ws->child.as<int64_t>();
+			if (!d_child_ext) d_child = sh->child.as<int64_t>();
 			if (fits && need > child_base) {
 				std::vector<const u64 *> tab((size_t)levels_run + 1);
 				for (int t = 0; t <= levels_run; t++) tab[t] = ws->levels[t]->buf.as<u64>();
-				PGQ_TRY(ws->levels_tab.reserve(tab.size() * sizeof(u64 *)));
-				PGQ_HIP_TRY(hipMemcpyAsync(ws->levels_tab.p, tab.data(), tab.size() * sizeof(u64 *), hipMemcpyHostToDevice, st));
+				PGQ_TRY(sh->levels_tab.reserve(tab.size() * sizeof(u64 *)));
+				PGQ_HIP_TRY(hipMemcpyAsync(sh->levels_tab.p, tab.data(), tab.size() * sizeof(u64 *), hipMemcpyHostToDevice, st));
 				KernelTimer kt(st, K_RECON);
 				hipLaunchKernelGGL(k_reconstruct<WD>, dim3(blocks_for(cnt_pairs * 64)), dim3(256), 0, st, lo, hi,
-				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>(),
-				                   ws->soff.as<int64_t>(), base_lane, (const u64 *const *)ws->levels_tab.p, c->roff,
+				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(),
+				                   sh->soff.as<int64_t>(), base_lane, (const u64 *const *)sh->levels_tab.p, c->roff,
 				                   c->radj, c->rslot, c->edge_ids, d_child);
 				kt.stop();
 				PGQ_HIP_TRY(hipStreamSynchronize(st)); // tab is a stack vector
@@ -1332,26 +1353,26 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 			child_base = need;
 		}
 	}
-	if (with_paths) {
+	if (with_paths && b0 == 0) {
 		// src == dst rows: [src]
 		const int64_t lo = bs[nb + 1], hi = bs[nb + 2];
 		if (hi > lo) {
 			int64_t need = child_base + (hi - lo);
 			bool fits = true;
 			if (d_child_ext) fits = need <= child_cap_ext;
-			else if ((size_t)need * 8 > ws->child.cap) {
+			else if ((size_t)need * 8 > sh->child.cap) {
 				DevBuf bigger;
 				PGQ_TRY(bigger.reserve((size_t)need * 8));
 				if (child_base > 0)
-					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
+					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, sh->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
 				PGQ_HIP_TRY(hipStreamSynchronize(st));
-				ws->child.release();
-				ws->child = bigger;
+				sh->child.release();
+				sh->child = bigger;
 			}
-			if (!d_child_ext) d_child = ws->child.as<int64_t>();
+			if (!d_child_ext) d_child = sh->child.as<int64_t>();
 			if (fits) {
 				hipLaunchKernelGGL(k_trivial_paths, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi,
-				                   ws->ssrc.as<int32_t>(), child_base, ws->soff.as<int64_t>(), d_child);
+				                   sh->ssrc.as<int32_t>(), child_base, sh->soff.as<int64_t>(), d_child);
 			} else {
 				child_overflow = true;
 			}
@@ -1360,7 +1381,25 @@ static int run_batches(pgq_csr *c, Workspace *ws, int64_t n, int64_t U, bool wit
 		outp.child_used = child_base;
 		if (child_overflow) return fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(child_base) + " elements");
 	}
+	PGQ_HIP_TRY(hipStreamSynchronize(st)); // other workers / the caller read sres next
+	KernelTimer::flush();
 	return PGQ_OK;
+}
+
+static void merge_stats(pgq_stats_t &into, const pgq_stats_t &from) {
+	into.batches += from.batches;
+	into.levels += from.levels;
+	into.push_levels += from.push_levels;
+	into.pull_levels += from.pull_levels;
+	into.edges_scanned += from.edges_scanned;
+	into.word_gathers += from.word_gathers;
+	into.frontier_vertices += from.frontier_vertices;
+	into.deferred_pairs += from.deferred_pairs;
+	for (int k = 0; k < PGQ_KCLASS_MAX; k++) {
+		into.algo_bytes[k] += from.algo_bytes[k];
+		into.kernel_ms[k] += from.kernel_ms[k];
+		into.launches[k] += from.launches[k];
+	}
 }
 
 // Lane assignment + sorting of the rows, then the templated batch loop; results scattered back to row order.
@@ -1377,13 +1416,54 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	S.unique_sources += U;
 	if (with_paths) PGQ_HIP_TRY(hipMemsetAsync(ws->soff.p, 0, (size_t)n * 8, st));
 	const int wd = choose_words(U);
-	int rc;
-	switch (wd) {
-	case 1: rc = run_batches<1>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
-	case 2: rc = run_batches<2>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
-	case 4: rc = run_batches<4>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
-	case 8: rc = run_batches<8>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
-	default: rc = run_batches<16>(c, ws, n, U, with_paths, d_child_ext, child_cap_ext, outp); break;
+	const int64_t Lb = 64 * (int64_t)wd;
+	const int nb = (int)((U + Lb - 1) / Lb);
+	PGQ_TRY(batch_bounds(ws, n, Lb, nb));
+	auto run = [&](Workspace *priv, int b0, int bstride, SearchOutput &o) -> int {
+		switch (wd) {
+		case 1: return run_batches<1>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
+		case 2: return run_batches<2>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
+		case 4: return run_batches<4>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
+		case 8: return run_batches<8>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
+		default: return run_batches<16>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
+		}
+	};
+	// Independent batches overlap on several streams (one host thread each): hides the per-level host round trip
+	// and fills the GPU during the short levels.  Paths and the accounting pass keep a single ordered worker.
+	int workers = std::max(1, std::min(options().streams, nb));
+	if (with_paths || outp.want_te) workers = 1;
+	int rc = PGQ_OK;
+	if (workers == 1) {
+		rc = run(ws, 0, 1, outp);
+	} else {
+		std::vector<WorkspaceLease> leases((size_t)workers - 1);
+		for (auto &l : leases) PGQ_TRY(l.acquire());
+		std::vector<int> rcs((size_t)workers, PGQ_OK);
+		std::vector<std::string> errs((size_t)workers);
+		std::vector<SearchOutput> outs((size_t)workers, outp);
+		std::vector<pgq_stats_t> wstats((size_t)workers);
+		std::vector<std::thread> pool;
+		for (int t = 1; t < workers; t++)
+			pool.emplace_back([&, t]() {
+				int r = ensure_init(); // binds the device for this host thread
+				if (r == PGQ_OK) {
+					(void)pgq_reset_stats();
+					r = run(leases[(size_t)t - 1].ws, t, workers, outs[(size_t)t]);
+				}
+				rcs[(size_t)t] = r;
+				if (r != PGQ_OK) errs[(size_t)t] = pgq_last_error();
+				wstats[(size_t)t] = tstats().s;
+			});
+		rcs[0] = run(ws, 0, workers, outs[0]);
+		for (auto &th : pool) th.join();
+		for (int t = 0; t < workers; t++) {
+			if (rcs[(size_t)t] != PGQ_OK && rc == PGQ_OK) {
+				rc = rcs[(size_t)t];
+				if (t > 0) set_error(errs[(size_t)t]);
+			}
+			outp.deferred = outp.deferred || outs[(size_t)t].deferred;
+			if (t > 0) merge_stats(S, wstats[(size_t)t]);
+		}
 	}
 	if (rc == PGQ_OK && outp.deferred) {
 		// second, narrow pass over the stragglers

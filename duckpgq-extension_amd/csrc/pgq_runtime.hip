@@ -80,6 +80,7 @@ static int do_init(int device) {
 	env_double("PGQ_SPARSE_BELOW", g_opt.sparse_below);
 	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
 	env_int("PGQ_SPARSE_LDS", g_opt.sparse_lds);
+	env_int("PGQ_STREAMS", g_opt.streams);
 	g_inited.store(1);
 	return PGQ_OK;
 }
@@ -632,6 +633,7 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "sparse_below") o.sparse_below = atof(value);
 	else if (k == "sparse_unroll") o.sparse_unroll = atoi(value);
 	else if (k == "sparse_lds") o.sparse_lds = atoi(value);
+	else if (k == "streams") o.streams = atoi(value);
 	else return fail(PGQ_ERR_INVALID_ARG, "unknown option: " + k);
 	return PGQ_OK;
 }

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _defaults():
-    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1)):
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2)):
         pgq.set_option(k, v)
     yield
 
@@ -135,6 +135,7 @@ def test_random_graph_all_variants(words, mode):
     opaths = ora.lean_shortestpath(V, ps[:700], pd[:700])
     # destination probe on / classic post-expansion detection; adaptive / sparse-only / dense-only bottom-up kernel
     for probe, force_pull, lds in ((1, 0, 1), (0, 1, 0), (1, 2, 1), (0, 1, 1)):
+        pgq.set_option("streams", 1 + (probe + lds) % 3)  # 1..3 concurrent batch workers
         pgq.set_option("probe", probe)
         pgq.set_option("force_pull", force_pull)
         pgq.set_option("sparse_lds", lds)  # 1-bit frontier map in LDS (1024-thread groups) or in global memory

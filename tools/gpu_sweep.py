@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--force_pull", default="0")
     ap.add_argument("--sparse_unroll", default="4")
     ap.add_argument("--sparse_lds", default="1")
+    ap.add_argument("--streams", default="2")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--trace", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/sweep.jsonl")
@@ -63,7 +64,8 @@ def main():
     pgq.set_option("trace", a.trace)
     with open(a.out, "a") as f:
         for mode in [int(x) for x in a.modes.split(",")]:
-            for bpc in [int(x) for x in a.bpc.split(",")]:
+            for bpc, nstr in [(int(x), int(y)) for x in a.bpc.split(",") for y in a.streams.split(",")]:
+                pgq.set_option("streams", nstr)
                 for words in [int(x) for x in a.words.split(",")]:
                   for dfr in [int(x) for x in a.defer.split(",")]:
                    for fp in [int(x) for x in a.force_pull.split(",")]:
@@ -89,7 +91,7 @@ def main():
                         okk = bool((d_out.cpu().numpy() == ref).all())
                         dt, st = best
                         row = {"graph": a.graph, "pairs": a.pairs, "words": words, "push_div": pd_, "mode": mode, "defer": dfr, "force_pull": fp, "sparse_unroll": su,
-                               "bpc": bpc, "ms": dt * 1e3, "mteps": te / dt / 1e6, "pairs_per_s": a.pairs / dt,
+                               "bpc": bpc, "streams": nstr, "ms": dt * 1e3, "mteps": te / dt / 1e6, "pairs_per_s": a.pairs / dt,
                                "match": okk, "levels": st["levels"], "push": st["push_levels"],
                                "pull": st["pull_levels"], "kernel_ms": st["kernel_ms"],
                                "algo_gb": {k: v / 1e9 for k, v in st["algo_bytes"].items() if v},

@@ -42,7 +42,8 @@ struct Options {
 	int max_words = 16;     // upper bound for auto
 	double push_div = 24.0; // top-down while frontier out-degree sum * push_div < E
 	int profile = 0;        // per-kernel-class HIP event timing
-	int hub_chunk = 4096;   // adjacency entries per work item for high-degree vertices
+	int hub_chunk = 4096;   // in-degree above which a vertex is split into slices for the bottom-up kernels
+	int push_chunk = 256;   // out-edges per top-down work item (short dependent chains per wavefront)
 	int force_mode = 0;     // 0 adaptive, 1 always push, 2 always pull (tests)
 	int force_pull = 0;     // 0 adaptive, 1 always k_pull_sparse, 2 always k_pull (tests)
 	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel

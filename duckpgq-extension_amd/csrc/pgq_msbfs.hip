@@ -66,8 +66,17 @@ __device__ __forceinline__ void enqueue_items(bool take, int n, int64_t deg, int
 
 // ---- lane assignment -------------------------------------------------------------------------------------------
 
+// A pair can only have a path if its source has an out-edge and (dst_rule) its destination an in-edge: everything
+// else is unreachable without a search (NULL, like the exhausted lanes of iterativelength.cpp:133-139) and takes no
+// lane — on directed R-MAT inputs that removes ~3/4 of the lanes.
+__device__ __forceinline__ bool pair_needs_search(int64_t s, int64_t d, const int64_t *__restrict__ off,
+                                                  const int64_t *__restrict__ roff, int dst_rule) {
+	return off[s + 1] > off[s] && (!dst_rule || roff[d + 1] > roff[d]);
+}
+
 __global__ void k_mark_sources(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                               u32 *__restrict__ flag, int64_t V, int *__restrict__ bad) {
+                               u32 *__restrict__ flag, int64_t V, const int64_t *__restrict__ off,
+                               const int64_t *__restrict__ roff, int dst_rule, int *__restrict__ bad) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	int64_t s = src[i], d = dst[i];
@@ -76,7 +85,7 @@ __global__ void k_mark_sources(int64_t n, const int64_t *__restrict__ src, const
 		*bad = 1;
 		return;
 	}
-	if (s != d) flag[s] = 1;
+	if (s != d && pair_needs_search(s, d, off, roff, dst_rule)) flag[s] = 1;
 }
 
 __global__ void k_compact_sources(int64_t V, const u32 *__restrict__ flag, const u32 *__restrict__ rank,
@@ -86,12 +95,17 @@ __global__ void k_compact_sources(int64_t V, const u32 *__restrict__ flag, const
 }
 
 __global__ void k_pair_keys(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                            const u32 *__restrict__ rank, u32 *__restrict__ key, u32 *__restrict__ idx) {
+                            const u32 *__restrict__ rank, const int64_t *__restrict__ off,
+                            const int64_t *__restrict__ roff, int dst_rule, int64_t V, u32 *__restrict__ key,
+                            u32 *__restrict__ idx) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	int64_t s = src[i];
+	int64_t s = src[i], d = dst[i];
 	u32 k = kNoLane;
-	if (s >= 0) k = (s == dst[i]) ? kTrivial : rank[s];
+	if (s >= 0 && s < V && d >= 0 && d < V) {
+		if (s == d) k = kTrivial;
+		else if (pair_needs_search(s, d, off, roff, dst_rule)) k = rank[s];
+	}
 	key[i] = k;
 	idx[i] = (u32)i;
 }
@@ -417,13 +431,29 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
                                                           const Counters *__restrict__ cnt) {
 	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	const int lane = threadIdx.x & 63;
-	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	const int64_t vmax = (V + 63) & ~63ll;
-	for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vmax; v += stride) {
+	// every wavefront owns one contiguous vertex range: pass 1 counts its packed words, ONE atomicAdd claims the
+	// range in cw (a per-64-vertices atomic serialised 65k times on R-MAT-22), pass 2 assigns offsets and copies
+	const int64_t wave = (int64_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
+	const int64_t per = ((V + nwaves - 1) / nwaves + 63) & ~63ll;
+	const int64_t v0 = wave * per, v1 = min(v0 + per, (V + 63) & ~63ll);
+	u32 mine = 0;
+	for (int64_t v = v0 + lane; v < v1; v += 64) {
+		const u32 m = v < V ? nz[v] : 0u;
+		if (m) mine += (u32)__popc(m) - 1u;
+	}
+	for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+	u32 run = 0;
+	if (mine) {
+		if (lane == 0) run = atomicAdd(total, mine);
+		run = __shfl(run, 0);
+	}
+	for (int64_t vb = v0; vb < v1; vb += 64) {
+		const int64_t v = vb + lane;
 		const u32 m = v < V ? nz[v] : 0u;
 		const u64 any = __ballot(m != 0);
-		if (lane == 0) bits[v >> 5] = (u32)any;
-		if (lane == 32) bits[v >> 5] = (u32)(any >> 32);
+		if (lane == 0) bits[vb >> 5] = (u32)any;
+		if (lane == 32) bits[(vb >> 5) + 1] = (u32)(any >> 32);
 		if (!any) continue;
 		const u32 c = m ? (u32)__popc(m) - 1u : 0u; // words beyond the first go to cw
 		u32 incl = c;
@@ -431,9 +461,8 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 			const u32 t = __shfl_up(incl, o);
 			if (lane >= o) incl += t;
 		}
-		u32 base = 0;
-		if (lane == 63) base = atomicAdd(total, incl);
-		base = __shfl(base, 63) + incl - c;
+		const u32 base = run + incl - c;
+		run += __shfl(incl, 63);
 		if (m) {
 			u32 rest = m & (m - 1);
 			meta[v] = FrontMeta{ m, base, front[(size_t)v * WD + (__ffs((int)m) - 1)] };
@@ -930,7 +959,8 @@ WorkspaceLease::~WorkspaceLease() {
 }
 
 // ---- lane assignment (host side) ------------------------------------------------------------------------------------
-int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out) {
+int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out,
+                  bool dst_rule) {
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V;
 	PGQ_TRY(ws->flag.reserve((size_t)(V + 1) * 4));
@@ -943,14 +973,15 @@ int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, co
 	PGQ_HIP_TRY(hipMemsetAsync(ws->flag.p, 0, (size_t)(V + 1) * 4, st));
 	PGQ_HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(Counters), st));
 	KernelTimer kt(st, K_PREP);
-	hipLaunchKernelGGL(k_mark_sources, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->flag.as<u32>(), V, d_bad);
+	hipLaunchKernelGGL(k_mark_sources, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->flag.as<u32>(), V, c->off, c->roff, dst_rule ? 1 : 0, d_bad);
 	size_t tmp = 0;
 	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ws->flag.as<u32>(), ws->rank.as<u32>(), (int)(V + 1), st));
 	PGQ_TRY(ws->scan_tmp.reserve(tmp + 16));
 	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp, ws->flag.as<u32>(), ws->rank.as<u32>(), (int)(V + 1), st));
 	if (V > 0)
 		hipLaunchKernelGGL(k_compact_sources, dim3(blocks_for(V)), dim3(256), 0, st, V, ws->flag.as<u32>(), ws->rank.as<u32>(), ws->usrc.as<int32_t>());
-	hipLaunchKernelGGL(k_pair_keys, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), ws->key.as<u32>(), ws->idx.as<u32>());
+	hipLaunchKernelGGL(k_pair_keys, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), c->off, c->roff, dst_rule ? 1 : 0, V,
+	                   ws->key.as<u32>(), ws->idx.as<u32>());
 	size_t stmp = 0;
 	PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, stmp, ws->key.as<u32>(), ws->skey.as<u32>(), ws->idx.as<u32>(), ws->sidx.as<u32>(), (int)n, 0, 32, st));
 	PGQ_TRY(ws->sort_tmp.reserve(stmp + 16));
@@ -1019,9 +1050,10 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 	const Options &opt = options();
 	const int64_t L = 64 * WD;
 	const int nb = (int)((U + L - 1) / L);
-	const int64_t chunk = c->hub_threshold;
+	const int64_t chunk = c->hub_threshold;                       // bottom-up: in-degree above this = hub
+	const int64_t pchunk = std::max(64, options().push_chunk);    // top-down: out-edges per queue item
 	const size_t words = (size_t)std::max<int64_t>(V, 1) * WD;
-	const u32 qcap = (u32)std::min<int64_t>(V + E / chunk + 128, 0xFFFFFF00ll);
+	const u32 qcap = (u32)std::min<int64_t>(V + E / pchunk + 128, 0xFFFFFF00ll);
 	pgq_stats_t &S = tstats().s;
 
 	PGQ_TRY(ws->seen.reserve(words * 8));
@@ -1085,7 +1117,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			KernelTimer kt(st, K_PREP);
 			hipLaunchKernelGGL(k_init_batch<WD>, dim3(blocks_for(L)), dim3(256), 0, st, sh->usrc.as<int32_t>(), U,
 			                   (int64_t)base_lane, c->off, cur->buf.as<u64>(), cur->nz.as<u32>(), ws->seen.as<u64>(),
-			                   act_cur, ws->qbuf[0].as<u64>(), qcap, chunk, d_cnt);
+			                   act_cur, ws->qbuf[0].as<u64>(), qcap, pchunk, d_cnt);
 			kt.stop();
 		}
 		cur->dirty = true;
@@ -1113,7 +1145,8 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		int stop = -1;
 		if (use_probe) {
 			stop = 0;
-			if (opt.defer && !with_paths && outp.depth < 2) stop = (int)std::min<int64_t>(L / opt.defer, (hi - lo) / opt.defer);
+			// a narrow batch is scan-bound: re-running its stragglers costs as much as finishing them here
+			if (opt.defer && !with_paths && outp.depth < 2 && WD >= 8) stop = (int)std::min<int64_t>(L / opt.defer, (hi - lo) / opt.defer);
 		}
 		for (int t = 1; unresolved > 0 && front_edges > 0; t++) {
 			LevelBuf *nxt = level_buf(t);
@@ -1141,7 +1174,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				if (!queue_valid) {
 					KernelTimer kt(st, K_QUEUE);
 					hipLaunchKernelGGL(k_queue_from_dense<WD>, dim3(std::min(blocks_for(V), 16u * ncu)), dim3(256), 0, st,
-					                   cur->nz.as<u32>(), V, c->off, chunk, ws->qbuf[par].as<u64>(), qcap, par, d_cnt);
+					                   cur->nz.as<u32>(), V, c->off, pchunk, ws->qbuf[par].as<u64>(), qcap, par, d_cnt);
 					kt.stop();
 				}
 				PGQ_TRY(make_zero(nxt));
@@ -1151,7 +1184,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					hipLaunchKernelGGL(k_push<WD>, dim3(push_grid), dim3(256), 0, st, c->off, c->adj, cur->buf.as<u64>(),
 					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur,
 					                   ws->qbuf[par].as<u64>(), par, ws->qflag.as<u32>(), ws->epoch,
-					                   ws->qbuf[par ^ 1].as<u64>(), qcap, chunk, stop, d_cnt);
+					                   ws->qbuf[par ^ 1].as<u64>(), qcap, pchunk, stop, d_cnt);
 					kt.stop();
 				}
 				nxt->dirty = true;
@@ -1412,7 +1445,8 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	if (n == 0) return PGQ_OK;
 	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
 	u32 U = 0;
-	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U));
+	// the accounting pass counts the full BFS of a pair even when dst has no in-edge, so it keeps those lanes
+	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U, !outp.want_te));
 	S.unique_sources += U;
 	if (with_paths) PGQ_HIP_TRY(hipMemsetAsync(ws->soff.p, 0, (size_t)n * 8, st));
 	const int wd = choose_words(U);

@@ -69,6 +69,7 @@ static int do_init(int device) {
 	env_double("PGQ_PUSH_DIV", g_opt.push_div);
 	env_int("PGQ_PROFILE", g_opt.profile);
 	env_int("PGQ_HUB_CHUNK", g_opt.hub_chunk);
+	env_int("PGQ_PUSH_CHUNK", g_opt.push_chunk);
 	env_int("PGQ_FORCE_MODE", g_opt.force_mode);
 	env_int("PGQ_FORCE_PULL", g_opt.force_pull);
 	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
@@ -346,8 +347,11 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
 		c->max_out_degree = std::max(c->max_out_degree, outdeg);
 		if (indeg > chunk) {
 			hubs.push_back((int32_t)v);
-			for (int64_t b = h_roff[v]; b < h_roff[v + 1]; b += chunk)
-				items.push_back({ (int32_t)v, 0, b, std::min(b + chunk, h_roff[v + 1]) });
+			// slices of a quarter chunk: a wavefront walks its slice 64 entries at a time (latency-bound), so more,
+			// shorter slices keep more of a hub's in-edges in flight
+			const int64_t slice = std::max<int64_t>(64, chunk / 4);
+			for (int64_t b = h_roff[v]; b < h_roff[v + 1]; b += slice)
+				items.push_back({ (int32_t)v, 0, b, std::min(b + slice, h_roff[v + 1]) });
 		}
 	}
 	c->n_pull_hub_items = (int64_t)items.size();
@@ -622,6 +626,7 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "push_div") o.push_div = atof(value);
 	else if (k == "profile") o.profile = atoi(value);
 	else if (k == "hub_chunk") o.hub_chunk = atoi(value);
+	else if (k == "push_chunk") o.push_chunk = atoi(value);
 	else if (k == "force_mode") o.force_mode = atoi(value);
 	else if (k == "force_pull") o.force_pull = atoi(value);
 	else if (k == "blocks_per_cu") o.blocks_per_cu = atoi(value);

@@ -57,7 +57,8 @@ static inline unsigned blocks_for(int64_t n, int block = 256) {
 
 // Assigns one lane per distinct source: fills ws->usrc (lane -> vertex), the row arrays sorted by lane
 // (skey/sidx/ssrc/sdst/sres) and returns the number of distinct sources in *U.
-int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U);
+int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U,
+                  bool dst_rule = true);
 // bstart (pinned host) <- sorted-row boundaries of nb batches of L lanes (+ trivial / NULL tails)
 int batch_bounds(Workspace *ws, int64_t n, int64_t L, int nb);
 

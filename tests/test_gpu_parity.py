@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _defaults():
-    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2)):
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2)):
         pgq.set_option(k, v)
     yield
 
@@ -127,6 +127,7 @@ def test_random_graph_all_variants(words, mode):
     pgq.set_option("words", words)
     pgq.set_option("force_mode", mode)
     pgq.set_option("hub_chunk", 64)  # exercise the split-vertex (hub) paths on a small graph
+    pgq.set_option("push_chunk", 64)
     n = 1500
     ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
     valid = rng.random(n) > 0.05

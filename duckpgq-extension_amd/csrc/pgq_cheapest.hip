@@ -110,6 +110,85 @@ __global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, 
 	if (lane == 0 && edges) atomicAdd(relaxed_edges, edges);
 }
 
+
+struct RelaxCounters {
+	u32 nq[2];
+	u32 tcount;
+	u32 rounds; // rounds executed by the last k_relax_small launch
+	u64 relaxed_edges;
+};
+
+#define PGQ_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PGQ_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// Small-frontier rounds without the host: ONE 1024-thread workgroup keeps relaxing round after round while the
+// queue of changed vertices stays <= `limit` (a forest / long chain advances one hop per round: 18 host round
+// trips per batch otherwise).  Everything another wavefront may have changed is read with agent-scope atomic
+// loads (distances are updated by L2 atomics, a plain load could hit a stale L1 line); rounds are separated by
+// __syncthreads().  Same relaxation and bookkeeping as k_relax.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_relax_small(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                      const T *__restrict__ w, int64_t *__restrict__ dist,
+                                                      u64 *__restrict__ dirty0, u64 *__restrict__ dirty1,
+                                                      int32_t *__restrict__ q0, int32_t *__restrict__ q1,
+                                                      RelaxCounters *__restrict__ rc, int par, u32 limit,
+                                                      u32 *__restrict__ qflag, u32 epoch0, u32 *__restrict__ tflag,
+                                                      u32 tepoch, int32_t *__restrict__ touched, int max_rounds) {
+	__shared__ u32 s_nq;
+	const int lane = threadIdx.x & 63;
+	const u32 wib = threadIdx.x >> 6;
+	const u32 nw = blockDim.x >> 6;
+	u64 edges = 0;
+	int round = 0;
+	for (; round < max_rounds; round++) {
+		if (threadIdx.x == 0) s_nq = PGQ_LD(&rc->nq[par]);
+		__syncthreads();
+		const u32 nq = s_nq;
+		if (nq == 0 || nq > limit) break;
+		if (threadIdx.x == 0) PGQ_ST(&rc->nq[par ^ 1], 0u);
+		__syncthreads();
+		u64 *dirty_cur = par ? dirty1 : dirty0, *dirty_nxt = par ? dirty0 : dirty1;
+		const int32_t *qcur = par ? q1 : q0;
+		int32_t *qnxt = par ? q0 : q1;
+		const u32 epoch = epoch0 + (u32)round;
+		for (u32 i = wib; i < nq; i += nw) {
+			const int v = PGQ_LD(&qcur[i]);
+			u64 mask = 0;
+			if (lane == 0) mask = atomicExch(&dirty_cur[v], 0ull);
+			mask = __shfl(mask, 0);
+			const bool mine = (mask >> lane) & 1ull;
+			const int64_t dvb = PGQ_LD(&dist[(size_t)v * LC + lane]);
+			const int64_t b = off[v], e = off[v + 1];
+			edges += (u64)(e - b);
+			for (int64_t k = b; k < e; k++) {
+				const int n = adj[k];
+				const T wt = w[k];
+				bool improved = false;
+				if (mine) {
+					int64_t cand;
+					if constexpr (std::is_same<T, double>::value) cand = __double_as_longlong(__longlong_as_double(dvb) + wt);
+					else cand = dvb + (int64_t)wt;
+					int64_t *dp = &dist[(size_t)n * LC + lane];
+					if (cand < PGQ_LD(dp)) {
+						const int64_t old = atomicMin((long long *)dp, (long long)cand);
+						improved = cand < old;
+					}
+				}
+				const u64 imask = __ballot(improved);
+				if (imask && lane == 0) {
+					atomicOr(&dirty_nxt[n], imask);
+					if (atomicExch(&qflag[n], epoch) != epoch) PGQ_ST(&qnxt[atomicAdd(&rc->nq[par ^ 1], 1u)], n);
+					if (atomicExch(&tflag[n], tepoch) != tepoch) touched[atomicAdd(&rc->tcount, 1u)] = n;
+				}
+			}
+		}
+		__syncthreads();
+		par ^= 1;
+	}
+	if (lane == 0 && edges) atomicAdd(&rc->relaxed_edges, edges);
+	if (threadIdx.x == 0) rc->rounds = (u32)round;
+}
+
 // results: out[row] = dist[dst][lane]; INF -> invalid.  Also trivial rows.
 __global__ void k_cheapest_results(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const u32 *__restrict__ sidx,
                                    const int32_t *__restrict__ sdst, u32 base_lane, const int64_t *__restrict__ dist,
@@ -145,12 +224,6 @@ __global__ void k_reset_touched(const int32_t *__restrict__ touched, const u32 *
 	for (; t < (int64_t)nt * LC; t += stride) dist[(size_t)touched[t / LC] * LC + (t % LC)] = inf_bits;
 }
 
-struct RelaxCounters {
-	u32 nq[2];
-	u32 tcount;
-	u32 pad;
-	u64 relaxed_edges;
-};
 
 template <typename T>
 static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
@@ -208,7 +281,29 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 			kt.stop();
 		}
 		int par = 0;
+		u32 nq_now = (u32)std::min<int64_t>(LC, (int64_t)U - base);
+		const u32 small_limit = (u32)std::max(0, options().relax_small_limit);
 		for (;;) {
+			if (nq_now <= small_limit) {
+				// few changed vertices: rounds loop on the device inside one workgroup
+				const int max_rounds = 4096;
+				KernelTimer kt(st, K_RELAX);
+				hipLaunchKernelGGL(k_relax_small<T>, dim3(1), dim3(1024), 0, st, c->off, c->adj, (const T *)c->w,
+				                   ws->dist.as<int64_t>(), ws->dirty[0].as<u64>(), ws->dirty[1].as<u64>(),
+				                   ws->qbuf[0].as<int32_t>(), ws->qbuf[1].as<int32_t>(), d_rc, par, small_limit,
+				                   ws->qflag.as<u32>(), epoch + 1, ws->tflag.as<u32>(), tepoch,
+				                   ws->touched.as<int32_t>(), max_rounds);
+				kt.stop();
+				PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
+				PGQ_HIP_TRY(hipStreamSynchronize(st));
+				KernelTimer::flush();
+				epoch += h_rc->rounds + 1;
+				S.levels += h_rc->rounds;
+				par ^= (int)(h_rc->rounds & 1u);
+				nq_now = h_rc->nq[par];
+				if (nq_now == 0) break;
+				if (nq_now <= small_limit && h_rc->rounds > 0) continue; // hit max_rounds: go again
+			}
 			epoch++;
 			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par ^ 1], 0, 4, st));
 			{
@@ -225,7 +320,8 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 			KernelTimer::flush();
 			S.levels++;
 			par ^= 1;
-			if (h_rc->nq[par] == 0) break;
+			nq_now = h_rc->nq[par];
+			if (nq_now == 0) break;
 		}
 		S.edges_scanned += (int64_t)h_rc->relaxed_edges;
 		S.algo_bytes[K_RELAX] += (double)h_rc->relaxed_edges * (4.0 + 8.0 + 2.0 * 8.0 * LC);

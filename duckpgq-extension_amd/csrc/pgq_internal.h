@@ -48,6 +48,7 @@ struct Options {
 	int force_pull = 0;     // 0 adaptive, 1 always k_pull_sparse, 2 always k_pull (tests)
 	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel
 	int cheapest_lanes = 64;
+	int relax_small_limit = 2048; // changed vertices at or below which relaxation rounds loop on the device
 	int trace = 0;          // per-level line on stderr
 	int probe = 1;          // destination probe before each expansion
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)

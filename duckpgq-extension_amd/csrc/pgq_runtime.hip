@@ -74,6 +74,7 @@ static int do_init(int device) {
 	env_int("PGQ_FORCE_PULL", g_opt.force_pull);
 	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
 	env_int("PGQ_CHEAPEST_LANES", g_opt.cheapest_lanes);
+	env_int("PGQ_RELAX_SMALL_LIMIT", g_opt.relax_small_limit);
 	env_int("PGQ_TRACE", g_opt.trace);
 	env_int("PGQ_PROBE", g_opt.probe);
 	env_int("PGQ_DEFER", g_opt.defer);
@@ -631,6 +632,7 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "force_pull") o.force_pull = atoi(value);
 	else if (k == "blocks_per_cu") o.blocks_per_cu = atoi(value);
 	else if (k == "cheapest_lanes") o.cheapest_lanes = atoi(value);
+	else if (k == "relax_small_limit") o.relax_small_limit = atoi(value);
 	else if (k == "trace") o.trace = atoi(value);
 	else if (k == "probe") o.probe = atoi(value);
 	else if (k == "defer") o.defer = atoi(value);

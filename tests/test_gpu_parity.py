@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _defaults():
-    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2)):
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2),
+                 ("relax_small_limit", 2048)):
         pgq.set_option(k, v)
     yield
 
@@ -213,6 +214,7 @@ def test_cheapest_path_bit_exact(kind):
     w = rng.integers(1, 1000, E) if kind == "int64" else rng.random(E) + 0.01
     st, ora = both(V, (s, d, e), w=w)
     for n in (1, 70, 300, 1500):
+        pgq.set_option("relax_small_limit", 0 if n == 300 else (50 if n == 70 else 2048))  # host rounds / mixed / device rounds
         ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
         out, ok = st.cheapest_path_length(0, V, ps, pd)
         lout, lok = ora.lean_cheapest_path_length(V, ps, pd)

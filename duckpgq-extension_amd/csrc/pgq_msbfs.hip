@@ -187,6 +187,7 @@ __global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero
 		cnt->word_gathers = 0;
 		cnt->front_words = 0;
 		cnt->pad = 0;
+		cnt->pad2 = 0;
 		if (zero_q0) cnt->q_count[0] = 0;
 		if (zero_q1) cnt->q_count[1] = 0;
 	}
@@ -427,32 +428,47 @@ template <int WD>
 __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict__ nz, const u64 *__restrict__ front,
                                                           int64_t V, FrontMeta *__restrict__ meta,
                                                           u64 *__restrict__ cw, u32 *__restrict__ bits,
-                                                          u32 *__restrict__ total, u32 cap, int stop_limit,
-                                                          const Counters *__restrict__ cnt) {
+                                                          u32 *__restrict__ bbase, u32 *__restrict__ totals, u32 cap,
+                                                          int stop_limit, const Counters *__restrict__ cnt) {
 	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	const int lane = threadIdx.x & 63;
-	// every wavefront owns one contiguous vertex range: pass 1 counts its packed words, ONE atomicAdd claims the
-	// range in cw (a per-64-vertices atomic serialised 65k times on R-MAT-22), pass 2 assigns offsets and copies
+	// every wavefront owns one contiguous vertex range: pass 1 counts its frontier vertices and packed words, two
+	// atomicAdds claim its slices of meta[] / cw[] (a per-64-vertices atomic serialised 65k times on R-MAT-22),
+	// pass 2 assigns positions and copies.  meta[] is dense: vertex v's record sits at
+	// bbase[v/64] + popcount(bits of the block below v), so the hot set of the gather is (frontier vertices) x 16 B
 	const int64_t wave = (int64_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
 	const int64_t per = ((V + nwaves - 1) / nwaves + 63) & ~63ll;
 	const int64_t v0 = wave * per, v1 = min(v0 + per, (V + 63) & ~63ll);
-	u32 mine = 0;
+	u32 myw = 0, myv = 0;
 	for (int64_t v = v0 + lane; v < v1; v += 64) {
 		const u32 m = v < V ? nz[v] : 0u;
-		if (m) mine += (u32)__popc(m) - 1u;
+		if (m) {
+			myw += (u32)__popc(m) - 1u;
+			myv += 1u;
+		}
 	}
-	for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-	u32 run = 0;
-	if (mine) {
-		if (lane == 0) run = atomicAdd(total, mine);
-		run = __shfl(run, 0);
+	for (int o = 32; o > 0; o >>= 1) {
+		myw += __shfl_xor(myw, o);
+		myv += __shfl_xor(myv, o);
+	}
+	u32 wrun = 0, vrun = 0;
+	if (myv) {
+		if (lane == 0) {
+			vrun = atomicAdd(&totals[0], myv);
+			wrun = myw ? atomicAdd(&totals[1], myw) : 0u;
+		}
+		vrun = __shfl(vrun, 0);
+		wrun = __shfl(wrun, 0);
 	}
 	for (int64_t vb = v0; vb < v1; vb += 64) {
 		const int64_t v = vb + lane;
 		const u32 m = v < V ? nz[v] : 0u;
 		const u64 any = __ballot(m != 0);
-		if (lane == 0) bits[vb >> 5] = (u32)any;
+		if (lane == 0) {
+			bits[vb >> 5] = (u32)any;
+			bbase[vb >> 6] = vrun;
+		}
 		if (lane == 32) bits[(vb >> 5) + 1] = (u32)(any >> 32);
 		if (!any) continue;
 		const u32 c = m ? (u32)__popc(m) - 1u : 0u; // words beyond the first go to cw
@@ -461,11 +477,12 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 			const u32 t = __shfl_up(incl, o);
 			if (lane >= o) incl += t;
 		}
-		const u32 base = run + incl - c;
-		run += __shfl(incl, 63);
+		const u32 base = wrun + incl - c;
+		wrun += __shfl(incl, 63);
 		if (m) {
+			const u32 slot = vrun + (u32)__popcll(any & ((1ull << lane) - 1ull));
 			u32 rest = m & (m - 1);
-			meta[v] = FrontMeta{ m, base, front[(size_t)v * WD + (__ffs((int)m) - 1)] };
+			meta[slot] = FrontMeta{ m, base, front[(size_t)v * WD + (__ffs((int)m) - 1)] };
 			u32 k = 0;
 			while (rest) {
 				const int w = __ffs((int)rest) - 1;
@@ -474,6 +491,7 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 				k++;
 			}
 		}
+		vrun += (u32)__popcll(any);
 	}
 }
 
@@ -487,6 +505,7 @@ template <int WD, int UN, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ parts,
                                                      int n_parts, const u32 *__restrict__ bits,
+                                                     const u32 *__restrict__ bbase,
                                                      const FrontMeta *__restrict__ meta, const u64 *__restrict__ cw,
                                                      u64 *__restrict__ seen, u64 *__restrict__ next,
                                                      u32 *__restrict__ nz_next, const u64 *__restrict__ active,
@@ -497,12 +516,18 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 	__shared__ u32 s_want[WPB][NV];
 	__shared__ u32 s_nzn[WPB][NV];
 	__shared__ u64 red[WPB][5];
-	extern __shared__ u32 s_bits[]; // WPB == 16: the whole 1-bit frontier map (V/8 bytes) lives in LDS
+	// WPB == 16: the 1-bit frontier map (V/8 bytes) and the per-64-vertex record bases (V/16 bytes) live in LDS
+	extern __shared__ u32 s_dyn[];
+	u32 *s_bits = s_dyn;
+	u32 *s_bbase = s_dyn + lds_bit_words;
 	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	if (WPB == 16) {
 		for (int i = threadIdx.x; i < lds_bit_words; i += WPB * 64) s_bits[i] = bits[i];
+		for (int i = threadIdx.x; i < lds_bit_words / 2; i += WPB * 64) s_bbase[i] = bbase[i];
 		__syncthreads();
 	}
+	const u32 *bt = WPB == 16 ? s_bits : bits;
+	const u32 *bb = WPB == 16 ? s_bbase : bbase;
 	const int lane = threadIdx.x & 63;
 	const int wib = threadIdx.x >> 6;
 	u64 *acc = s_acc[wib];
@@ -540,12 +565,21 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 				nb[k] = e < e1 ? radj[e] : -1;
 			}
 #pragma unroll
-			for (int k = 0; k < UN; k++)
-				hot[k] = nb[k] >= 0 && (((WPB == 16 ? s_bits[nb[k] >> 5] : bits[nb[k] >> 5]) >> (nb[k] & 31)) & 1u);
+			for (int k = 0; k < UN; k++) hot[k] = nb[k] >= 0 && ((bt[nb[k] >> 5] >> (nb[k] & 31)) & 1u);
+			// all UN record fetches are issued before any is consumed (independent 16-byte requests in flight)
+			FrontMeta mt[UN];
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
-				if (!hot[k]) continue;
-				const FrontMeta mt = meta[nb[k]];
+				mt[k].nz = 0;
+				if (hot[k]) { // record index = base of the 64-vertex block + frontier vertices below nb in the block
+					const int blk = nb[k] >> 6;
+					const u64 bw = (u64)bt[2 * blk] | ((u64)bt[2 * blk + 1] << 32);
+					mt[k] = meta[bb[blk] + (u32)__popcll(bw & ((1ull << (nb[k] & 63)) - 1ull))];
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < UN; k++) {
+				if (mt[k].nz == 0) continue;
 				const u32 rel = (u32)(base + 64 * k + lane - e0);
 				int lo = 0, hi = nv; // owner = last j with row[j] <= rel
 				while (hi - lo > 1) {
@@ -553,12 +587,12 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 					if (row[mid] <= rel) lo = mid;
 					else hi = mid;
 				}
-				u32 m = mt.nz & wantm[lo];
+				u32 m = mt[k].nz & wantm[lo];
 				while (m) {
 					const int w = __ffs((int)m) - 1;
 					m &= m - 1;
-					const int r = __popc(mt.nz & ((1u << w) - 1u));
-					const u64 val = r == 0 ? mt.w0 : cw[mt.base + r - 1];
+					const int r = __popc(mt[k].nz & ((1u << w) - 1u));
+					const u64 val = r == 0 ? mt[k].w0 : cw[mt[k].base + r - 1];
 					atomicOr(&acc[lo * WD + w], val);
 					gath++;
 				}
@@ -925,7 +959,7 @@ Workspace::~Workspace() {
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &active, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &cbits, &cmeta, &cwords })
+	                   &def_idx, &cbits, &cbbase, &cmeta, &cwords })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -1222,36 +1256,46 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				if (sparse_level) {
 					const u32 cw_cap = (u32)std::min<int64_t>((int64_t)front_words + 64, 0x7FFFFFF0ll);
 					last_cw_cap = cw_cap;
-					PGQ_TRY(ws->cbits.reserve(((size_t)V / 32 + 4) * 4));
+					const int bit_words = (int)(((V + 63) / 64) * 2 + 2); // even: 64-vertex blocks
+					PGQ_TRY(ws->cbits.reserve((size_t)bit_words * 4 + 64));
+					PGQ_TRY(ws->cbbase.reserve((size_t)bit_words * 2 + 64));
 					PGQ_TRY(ws->cmeta.reserve((size_t)std::max<int64_t>(V, 1) * sizeof(FrontMeta)));
 					// sized generously once (2 words per vertex) so that growing frontiers do not reallocate per level
 					PGQ_TRY(ws->cwords.reserve(std::max<size_t>((size_t)cw_cap, 2 * (size_t)std::max<int64_t>(V, 1)) * 8));
-					u32 *d_total = reinterpret_cast<u32 *>(&d_cnt->pad);
+					u32 *d_total = reinterpret_cast<u32 *>(&d_cnt->pad); // {frontier vertices, packed words}
 					KernelTimer kt(st, K_PULL_SPARSE);
 					hipLaunchKernelGGL(k_compact_frontier<WD>, dim3(std::min(blocks_for(V), 8u * ncu)), dim3(256), 0, st,
 					                   cur->nz.as<u32>(), cur->buf.as<u64>(), V, ws->cmeta.as<FrontMeta>(),
-					                   ws->cwords.as<u64>(), ws->cbits.as<u32>(), d_total, cw_cap, stop, d_cnt);
-					// graphs whose 1-bit frontier map fits in LDS (V <= 512K) run 1024-thread workgroups that keep it there
-					const int bit_words = (int)(V / 32 + 2);
-					const bool lds_map = opt.sparse_lds && (size_t)bit_words * 4 <= 64 * 1024;
+					                   ws->cwords.as<u64>(), ws->cbits.as<u32>(), ws->cbbase.as<u32>(), d_total, cw_cap,
+					                   stop, d_cnt);
+					// graphs whose frontier bit map + block bases fit in LDS beside the accumulators run 1024-thread
+					// workgroups that keep them there (SF100: 56 KB + 28 KB)
+					const size_t dyn_bytes = (size_t)bit_words * 4 + (size_t)bit_words * 2;
 #define PGQ_LAUNCH_SPARSE(UNR)                                                                                         \
 	do {                                                                                                               \
+		auto kfn = k_pull_sparse<WD, UNR, 16>;                                                                         \
+		static size_t static_lds = 0;                                                                                  \
+		if (!static_lds) {                                                                                             \
+			hipFuncAttributes fa;                                                                                      \
+			static_lds = hipFuncGetAttributes(&fa, (const void *)kfn) == hipSuccess ? fa.sharedSizeBytes + 1 : 1;      \
+		}                                                                                                              \
+		const bool lds_map = opt.sparse_lds && static_lds > 1 && static_lds + dyn_bytes + 256 <= 160 * 1024;           \
 		if (lds_map) {                                                                                                 \
-			auto kfn = k_pull_sparse<WD, UNR, 16>;                                                                     \
-			static bool attr_set = false;                                                                              \
-			if (!attr_set) {                                                                                           \
-				(void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);   \
-				attr_set = true;                                                                                       \
+			static size_t attr_bytes = 0;                                                                              \
+			if (attr_bytes < dyn_bytes) {                                                                              \
+				(void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+				                          (int)(160 * 1024 - static_lds));                                             \
+				attr_bytes = 160 * 1024;                                                                               \
 			}                                                                                                          \
-			hipLaunchKernelGGL(kfn, dim3(ncu), dim3(1024), (size_t)bit_words * 4, st, c->roff, c->radj, c->off,         \
-			                   c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cmeta.as<FrontMeta>(),         \
+			hipLaunchKernelGGL(kfn, dim3(ncu), dim3(1024), dyn_bytes, st, c->roff, c->radj, c->off, c->pull_parts,      \
+			                   c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(), ws->cmeta.as<FrontMeta>(),  \
 			                   ws->cwords.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(),        \
 			                   act_cur, bit_words, stop, d_cnt);                                                       \
 		} else {                                                                                                       \
 			hipLaunchKernelGGL((k_pull_sparse<WD, UNR, 4>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj,       \
-			                   c->off, c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(),                            \
+			                   c->off, c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(),      \
 			                   ws->cmeta.as<FrontMeta>(), ws->cwords.as<u64>(), ws->seen.as<u64>(),                    \
-			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, 0, stop, d_cnt);                        \
+			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, bit_words, stop, d_cnt);                \
 		}                                                                                                              \
 	} while (0)
 					if (opt.sparse_unroll >= 4) PGQ_LAUNCH_SPARSE(4);
@@ -1290,8 +1334,8 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			PGQ_HIP_TRY(hipStreamSynchronize(st));
 			KernelTimer::flush();
 			const Counters &hc = *ws->h_cnt;
-			if (sparse_level && hc.pad > last_cw_cap)
-				return fail(PGQ_ERR_HIP, "internal error: packed frontier holds " + std::to_string(hc.pad) +
+			if (sparse_level && hc.pad2 > last_cw_cap)
+				return fail(PGQ_ERR_HIP, "internal error: packed frontier holds " + std::to_string(hc.pad2) +
 				                             " words, expected at most " + std::to_string(last_cw_cap));
 			front_edges = hc.front_edges;
 			front_words = hc.front_words;

@@ -17,7 +17,9 @@ struct Counters {
 	u64 edges_scanned;   // adjacency entries read this level
 	u64 word_gathers;    // 8-byte lane-words gathered or RMW'd this level
 	u32 front_words;     // non-empty lane-words of the frontier just produced
-	u32 pad;
+	u32 pad;             // packed frontier: records written ...
+	u32 pad2;            // ... and overflow words written (k_compact_frontier totals)
+	u32 pad3;
 	u64 act[2][16];      // active-lane masks (lanes that still have open pairs), double buffered
 };
 
@@ -32,7 +34,7 @@ struct Workspace {
 	hipStream_t stream = nullptr;
 	DevBuf seen, qbuf[2], qflag, counters, active, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
-	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, cbits, cmeta, cwords;
+	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, cbits, cbbase, cmeta, cwords;
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
 	int64_t *h_bstart = nullptr;

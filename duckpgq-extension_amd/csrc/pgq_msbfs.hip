@@ -1264,7 +1264,8 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					PGQ_TRY(ws->cwords.reserve(std::max<size_t>((size_t)cw_cap, 2 * (size_t)std::max<int64_t>(V, 1)) * 8));
 					u32 *d_total = reinterpret_cast<u32 *>(&d_cnt->pad); // {frontier vertices, packed words}
 					KernelTimer kt(st, K_PULL_SPARSE);
-					hipLaunchKernelGGL(k_compact_frontier<WD>, dim3(std::min(blocks_for(V), 8u * ncu)), dim3(256), 0, st,
+					// >= 512 vertices per wavefront: two claims (atomicAdd) per wavefront, keep them few
+					hipLaunchKernelGGL(k_compact_frontier<WD>, dim3(std::min(blocks_for(V / 8 + 1), 2u * ncu)), dim3(256), 0, st,
 					                   cur->nz.as<u32>(), cur->buf.as<u64>(), V, ws->cmeta.as<FrontMeta>(),
 					                   ws->cwords.as<u64>(), ws->cbits.as<u32>(), ws->cbbase.as<u32>(), d_total, cw_cap,
 					                   stop, d_cnt);

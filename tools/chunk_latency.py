@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Latency of the chunk entry points (what a DuckDB worker thread sees per 2048-row DataChunk, host buffers in/out)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import duckpgq_extension_amd as pgq  # noqa: E402
+from duckpgq_extension_amd import graphgen  # noqa: E402
+
+V, s, d = graphgen.snb_knows_like()
+off, adj, eid = graphgen.csr_from_rows(V, s, d)
+t0 = time.perf_counter()
+dev = pgq.DeviceCSR(V, off, adj, eid)
+up = time.perf_counter() - t0
+rng = np.random.default_rng(7)
+out = {"csr_upload_host_arrays_ms": up * 1e3}
+for n in (1, 64, 2048):
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    for fn in ("iterativelength", "shortestpath"):
+        getattr(dev, fn)(ps, pd)
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            getattr(dev, fn)(ps, pd)
+            ts.append(time.perf_counter() - t)
+        out["%s_n%d_ms" % (fn, n)] = min(ts) * 1e3
+# the binder's shape: one source x all vertices (cross product), 2048-row chunks
+src = np.full(2048, 12345, dtype=np.int64)
+dst = np.arange(2048, dtype=np.int64)
+dev.iterativelength(src, dst)
+t = time.perf_counter()
+for _ in range(5):
+    dev.iterativelength(src, dst)
+out["iterativelength_1src_x_2048dst_ms"] = (time.perf_counter() - t) / 5 * 1e3
+print(json.dumps(out))

@@ -109,6 +109,7 @@ struct pgq_csr {
 	int64_t n_pull_hub_items = 0, n_pull_hub_vertices = 0;
 	int32_t *pull_parts = nullptr; // n_pull_parts (begin,end) vertex ranges, no hubs inside, <= 32 vertices each
 	int n_pull_parts = 0;
+	uint8_t *rown = nullptr; // E: owner vertex of every in-slot, as an index inside its part
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
 	int64_t bytes = 0;

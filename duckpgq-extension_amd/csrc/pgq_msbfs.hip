@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 // prologue/epilogue.  Same results as k_pull (next = OR of in-neighbours' frontier words & active & ~seen).
 template <int WD, int UN, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                          const uint8_t *__restrict__ rown,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ parts,
                                                      int n_parts, const u32 *__restrict__ bits,
                                                      const u32 *__restrict__ bbase,
@@ -512,7 +513,6 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
                                                      int lds_bit_words, int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NV = 32;
 	__shared__ u64 s_acc[WPB][NV * WD];
-	__shared__ u32 s_row[WPB][NV + 1];
 	__shared__ u32 s_want[WPB][NV];
 	__shared__ u32 s_nzn[WPB][NV];
 	__shared__ u64 red[WPB][5];
@@ -531,7 +531,6 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 	const int lane = threadIdx.x & 63;
 	const int wib = threadIdx.x >> 6;
 	u64 *acc = s_acc[wib];
-	u32 *row = s_row[wib];
 	u32 *wantm = s_want[wib];
 	u32 *nzn = s_nzn[wib];
 	const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -546,7 +545,6 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 			wantm[lane] = 0;
 			nzn[lane] = 0;
 		}
-		if (lane <= nv) row[lane] = (u32)(roff[v0 + lane] - e0);
 		__builtin_amdgcn_wave_barrier();
 		for (int idx = lane; idx < nv * WD; idx += 64) {
 			const int w = idx & (WD - 1);
@@ -557,12 +555,13 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 		__builtin_amdgcn_wave_barrier();
 		// -- one in-edge per lane
 		for (int64_t base = e0; base < e1; base += 64 * UN) {
-			int nb[UN];
+			int nb[UN], own[UN];
 			bool hot[UN];
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
 				const int64_t e = base + 64 * k + lane;
 				nb[k] = e < e1 ? radj[e] : -1;
+				own[k] = e < e1 ? (int)rown[e] : 0; // owner row inside the part, precomputed at upload
 			}
 #pragma unroll
 			for (int k = 0; k < UN; k++) hot[k] = nb[k] >= 0 && ((bt[nb[k] >> 5] >> (nb[k] & 31)) & 1u);
@@ -580,13 +579,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
 				if (mt[k].nz == 0) continue;
-				const u32 rel = (u32)(base + 64 * k + lane - e0);
-				int lo = 0, hi = nv; // owner = last j with row[j] <= rel
-				while (hi - lo > 1) {
-					const int mid = (lo + hi) >> 1;
-					if (row[mid] <= rel) lo = mid;
-					else hi = mid;
-				}
+				const int lo = own[k];
 				u32 m = mt[k].nz & wantm[lo];
 				while (m) {
 					const int w = __ffs((int)m) - 1;
@@ -1288,13 +1281,13 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				                          (int)(160 * 1024 - static_lds));                                             \
 				attr_bytes = 160 * 1024;                                                                               \
 			}                                                                                                          \
-			hipLaunchKernelGGL(kfn, dim3(ncu), dim3(1024), dyn_bytes, st, c->roff, c->radj, c->off, c->pull_parts,      \
+			hipLaunchKernelGGL(kfn, dim3(ncu), dim3(1024), dyn_bytes, st, c->roff, c->radj, c->rown, c->off, c->pull_parts,      \
 			                   c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(), ws->cmeta.as<FrontMeta>(),  \
 			                   ws->cwords.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(),        \
 			                   act_cur, bit_words, stop, d_cnt);                                                       \
 		} else {                                                                                                       \
 			hipLaunchKernelGGL((k_pull_sparse<WD, UNR, 4>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj,       \
-			                   c->off, c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(),      \
+			                   c->rown, c->off, c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(),      \
 			                   ws->cmeta.as<FrontMeta>(), ws->cwords.as<u64>(), ws->seen.as<u64>(),                    \
 			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, bit_words, stop, d_cnt);                \
 		}                                                                                                              \

@@ -275,6 +275,21 @@ __global__ void k_gather_rows(const u32 *__restrict__ order, int64_t n, const in
 	}
 }
 
+
+// rown[e] = index of in-slot e's owner vertex inside its bottom-up work part (0..31): lets k_pull_sparse find the
+// owner of an in-edge with one coalesced byte load instead of a binary search.  One wavefront per part.
+__global__ void k_fill_rown(const int64_t *__restrict__ roff, const int32_t *__restrict__ parts, int n_parts,
+                            uint8_t *__restrict__ rown) {
+	const int lane = threadIdx.x & 63;
+	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int nwaves = (gridDim.x * blockDim.x) >> 6;
+	for (int p = wave; p < n_parts; p += nwaves) {
+		const int v0 = parts[2 * p], v1 = parts[2 * p + 1];
+		for (int v = v0; v < v1; v++)
+			for (int64_t e = roff[v] + lane; e < roff[v + 1]; e += 64) rown[e] = (uint8_t)(v - v0);
+	}
+}
+
 static int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
 	int64_t g = (n + block - 1) / block;
 	if (g < 1) g = 1;
@@ -392,12 +407,16 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
 		}
 		close(V);
 		c->n_pull_parts = (int)(parts.size() / 2);
+		PGQ_HIP_TRY(hipMalloc(&c->rown, (size_t)std::max<int64_t>(E, 1)));
+		PGQ_HIP_TRY(hipMemset(c->rown, 0, (size_t)std::max<int64_t>(E, 1)));
 		if (!parts.empty()) {
 			PGQ_HIP_TRY(hipMalloc(&c->pull_parts, parts.size() * sizeof(int32_t)));
 			PGQ_HIP_TRY(hipMemcpy(c->pull_parts, parts.data(), parts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+			hipLaunchKernelGGL(k_fill_rown, dim3(256 * 8), dim3(256), 0, 0, c->roff, c->pull_parts, c->n_pull_parts, c->rown);
+			PGQ_HIP_TRY(hipDeviceSynchronize());
 		}
 	}
-	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
+	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8 + 1) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
 	           (int64_t)items.size() * (int64_t)sizeof(HubItem);
 	return PGQ_OK;
 }
@@ -414,6 +433,7 @@ static void destroy_csr(pgq_csr *c) {
 	(void)hipFree(c->pull_hubs);
 	(void)hipFree(c->pull_hub_vertices);
 	(void)hipFree(c->pull_parts);
+	(void)hipFree(c->rown);
 	delete c;
 }
 

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--snb-vertices", type=int, default=448626)
     ap.add_argument("--snb-friendships", type=int, default=19_940_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs timed on the CPU (0 = 8192 snb / 2048 rmat)")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--backend", default="nccl")
     return ap.parse_args()
@@ -247,18 +247,24 @@ def cpu_baseline(a, V, off, adj, eid, mine, d_te, ref_len):
     """The oracle's literal restatement of IterativeLengthFunction (reference memory layout and loops), driven in
     2048-row chunks, on a bounded sample of this rank's pairs.  Checker + baseline only — never on the product path."""
     from oracle.pgq_oracle import OracleCSR
-    ns = min(a.cpu_sample, len(mine))
+    ns = min(a.cpu_sample or (8192 if a.workload == "snb_sf100" else 2048), len(mine))
     ora = OracleCSR.adopt(V, off, adj, eid)
     t0 = time.perf_counter()
     ln, ok = ora.baseline_run("iterativelength", V, mine[:ns, 0], mine[:ns, 1], nthreads=a.cpu_threads)
     dt = time.perf_counter() - t0
+    # the same sample with one worker per 2048-row chunk: the most threads DuckDB's chunking could use on it
+    nchunks = max(1, (ns + 2047) // 2048)
+    t0 = time.perf_counter()
+    ora.baseline_run("iterativelength", V, mine[:ns, 0], mine[:ns, 1], nthreads=nchunks)
+    dt_mt = time.perf_counter() - t0
     gpu_len = ref_len[:ns].cpu().numpy()
     agree = bool(((gpu_len >= 0) == ok).all() and (gpu_len[ok] == ln[ok]).all())
     te = float(d_te[:ns].sum().item())
     return {"value": te / dt / 1e6, "unit": "MTEPS", "cores": a.cpu_threads, "kind": "port",
             "sample": "first %d pairs of rank 0's shard, literal 512-lane restatement (oracle/pgq_oracle.cpp), "
                       "%.1f s; results equal the GPU's: %s" % (ns, dt, agree),
-            "pairs_per_s": ns / dt, "host_cores_available": os.cpu_count()}
+            "pairs_per_s": ns / dt, "host_cores_available": os.cpu_count(),
+            "one_thread_per_chunk": {"threads": nchunks, "value": te / dt_mt / 1e6, "pairs_per_s": ns / dt_mt}}
 
 
 if __name__ == "__main__":

@@ -341,3 +341,39 @@ def test_device_csr_construction_matches_reference_layout():
     with pytest.raises(pgq.PgqError, match="out of range"):
         bad = torch.from_numpy(np.array([0, V], dtype=np.int64)).cuda()
         pgq.DeviceCSR.build_from_device_rows(V, 2, bad.data_ptr(), bad.data_ptr())
+
+
+def test_fuzz_tiny_graphs_against_literal_oracle():
+    """Many tiny graphs (self loops, duplicate and anti-parallel edges, isolated vertices, V=1, E=0, chains) through
+    the UDF mirror, every function against the literal restatement of the reference."""
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        V = int(rng.integers(1, 40))
+        E = int(rng.integers(0, 4 * V + 1))
+        if it % 7 == 0:  # a chain: deep BFS (many levels, tail handled top-down)
+            V = 64
+            s, d = np.arange(V - 1, dtype=np.int64), np.arange(1, V, dtype=np.int64)
+        else:
+            s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        e = np.arange(len(s), dtype=np.int64)
+        w = rng.integers(0, 9, len(s))
+        st, ora = both(V, (s, d, e), w=w)
+        n = int(rng.integers(1, 200))
+        ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        valid = rng.random(n) > 0.1
+        pgq.set_option("words", int(rng.choice([0, 1, 2, 16])))
+        pgq.set_option("streams", int(rng.integers(1, 4)))
+        ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
+        oln, ook = ora.iterativelength(V, ps, pd, src_valid=valid)
+        assert lens(ln, ok) == lens(oln, ook), (it, V, E)
+        assert st.shortestpath(0, V, ps, pd, src_valid=valid) == ora.shortestpath(V, ps, pd, src_valid=valid), (it, V, E)
+        if len(s):
+            out, cok = st.cheapest_path_length(0, V, ps[valid], pd[valid])
+            lout, lok = ora.lean_cheapest_path_length(V, ps[valid], pd[valid])
+            assert (cok == lok).all() and (out[cok] == lout[lok]).all(), (it, V, E)
+    # zero rows, all-NULL rows
+    st, ora = both(5, directed_rows(load_golden("student_directed.json")["edges"]))
+    ln, ok = st.iterativelength(0, 5, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    assert len(ln) == 0
+    ln, ok = st.iterativelength(0, 5, [1, 2, 3], [0, 0, 0], src_valid=[False, False, False])
+    assert not ok.any() and st.shortestpath(0, 5, [1, 2], [0, 0], src_valid=[False, False]) == [None, None]

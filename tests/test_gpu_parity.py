@@ -377,3 +377,39 @@ def test_fuzz_tiny_graphs_against_literal_oracle():
     assert len(ln) == 0
     ln, ok = st.iterativelength(0, 5, [1, 2, 3], [0, 0, 0], src_valid=[False, False, False])
     assert not ok.any() and st.shortestpath(0, 5, [1, 2], [0, 0], src_valid=[False, False]) == [None, None]
+
+
+def test_concurrent_callers_share_one_csr():
+    # DuckDB calls the UDFs from many worker threads over one shared read-only CSR (SURVEY §8b "Threading")
+    import threading
+    rng = np.random.default_rng(77)
+    V, E = 20000, 150000
+    s, d, e = random_graph(rng, V, E)
+    w = rng.integers(1, 100, E)
+    st, ora = both(V, (s, d, e), w=w)
+    jobs = []
+    for t in range(6):
+        ps, pd = rng.integers(0, V, 1500), rng.integers(0, V, 1500)
+        oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+        jobs.append((ps, pd, oln, ook, ora.lean_shortestpath(V, ps[:300], pd[:300]),
+                     ora.lean_cheapest_path_length(V, ps[:200], pd[:200])))
+    errors = []
+
+    def work(job):
+        try:
+            ps, pd, oln, ook, opaths, (cout, cok) = job
+            for _ in range(3):
+                ln, ok = st.iterativelength(0, V, ps, pd)
+                assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
+                assert st.shortestpath(0, V, ps[:300], pd[:300]) == opaths
+                out, okc = st.cheapest_path_length(0, V, ps[:200], pd[:200])
+                assert (okc == cok).all() and (out[okc] == cout[cok]).all()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []

@@ -38,8 +38,8 @@ int ensure_init();
 
 // ---- options --------------------------------------------------------------------------------------------
 struct Options {
-	int words = 0;          // lane-words per vertex per batch (0 = auto: 1,2,4,8,16 by unique sources)
-	int max_words = 16;     // upper bound for auto
+	int words = 0;          // lane-words per vertex per batch (0 = auto: 1,2,4,8,16,32 by unique sources)
+	int max_words = 32;     // upper bound for auto
 	double push_div = 24.0; // top-down while frontier out-degree sum * push_div < E
 	int profile = 0;        // per-kernel-class HIP event timing
 	int hub_chunk = 4096;   // in-degree above which a vertex is split into slices for the bottom-up kernels
@@ -107,7 +107,7 @@ struct pgq_csr {
 	pgq::HubItem *pull_hubs = nullptr; // device
 	int32_t *pull_hub_vertices = nullptr;
 	int64_t n_pull_hub_items = 0, n_pull_hub_vertices = 0;
-	int32_t *pull_parts = nullptr; // n_pull_parts (begin,end) vertex ranges, no hubs inside, <= 32 vertices each
+	int32_t *pull_parts = nullptr; // n_pull_parts (begin,end) vertex ranges, no hubs inside, <= 16 vertices each
 	int n_pull_parts = 0;
 	uint8_t *rown = nullptr; // E: owner vertex of every in-slot, as an index inside its part
 	int64_t hub_threshold = 0;

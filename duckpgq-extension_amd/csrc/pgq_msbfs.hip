@@ -191,7 +191,7 @@ __global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero
 		if (zero_q0) cnt->q_count[0] = 0;
 		if (zero_q1) cnt->q_count[1] = 0;
 	}
-	if (t < 16) cnt->act[act_zero][t] = 0;
+	if (t < 32) cnt->act[act_zero][t] = 0;
 }
 
 // ---- top-down level ----------------------------------------------------------------------------------------------
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
                                                      u64 *__restrict__ seen, u64 *__restrict__ next,
                                                      u32 *__restrict__ nz_next, const u64 *__restrict__ active,
                                                      int lds_bit_words, int stop_limit, Counters *__restrict__ cnt) {
-	constexpr int NV = 32;
+	constexpr int NV = 16; // vertices per part (host-built parts never hold more)
 	__shared__ u64 s_acc[WPB][NV * WD];
 	__shared__ u32 s_want[WPB][NV];
 	__shared__ u32 s_nzn[WPB][NV];
@@ -1052,7 +1052,8 @@ static int choose_words(int64_t unique_sources) {
 		wd = 1;
 		while (wd < o.max_words && (int64_t)wd * 64 < unique_sources) wd <<= 1;
 	}
-	if (wd != 1 && wd != 2 && wd != 4 && wd != 8 && wd != 16) wd = wd > 16 ? 16 : (wd > 8 ? 8 : (wd > 4 ? 4 : (wd > 2 ? 2 : 1)));
+	if (wd != 1 && wd != 2 && wd != 4 && wd != 8 && wd != 16 && wd != 32)
+		wd = wd > 32 ? 32 : (wd > 16 ? 16 : (wd > 8 ? 8 : (wd > 4 ? 4 : (wd > 2 ? 2 : 1))));
 	return wd;
 }
 
@@ -1497,7 +1498,8 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		case 2: return run_batches<2>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
 		case 4: return run_batches<4>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
 		case 8: return run_batches<8>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
-		default: return run_batches<16>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
+		case 16: return run_batches<16>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
+		default: return run_batches<32>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
 		}
 	};
 	// Independent batches overlap on several streams (one host thread each): hides the per-level host round trip

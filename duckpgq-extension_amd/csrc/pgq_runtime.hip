@@ -379,7 +379,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
 		PGQ_HIP_TRY(hipMemcpy(c->pull_hub_vertices, hubs.data(), hubs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
 	// Work partition for the bottom-up kernels: contiguous vertex ranges [begin,end) that never contain a hub,
-	// hold at most 32 vertices (LDS accumulator rows of k_pull_sparse) and at most `part_weight` of
+	// hold at most 16 vertices (LDS accumulator rows of k_pull_sparse) and at most `part_weight` of
 	// (in-degree + 8 per vertex).  Dealt round-robin to the waves: many small equal parts balance skewed graphs.
 	{
 		const double wmax = (double)std::max(64, options().part_weight);
@@ -402,7 +402,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
 				continue;
 			}
 			double wv = (double)d + 8.0;
-			if (v > begin && (acc + wv > wmax || v - begin >= 32)) close(v);
+			if (v > begin && (acc + wv > wmax || v - begin >= 16)) close(v);
 			acc += wv;
 		}
 		close(V);

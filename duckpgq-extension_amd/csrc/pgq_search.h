@@ -20,7 +20,7 @@ struct Counters {
 	u32 pad;             // packed frontier: records written ...
 	u32 pad2;            // ... and overflow words written (k_compact_frontier totals)
 	u32 pad3;
-	u64 act[2][16];      // active-lane masks (lanes that still have open pairs), double buffered
+	u64 act[2][32];      // active-lane masks (lanes that still have open pairs), double buffered
 };
 
 

@@ -118,7 +118,7 @@ def random_graph(rng, V, E, skew=False):
     return s, d, np.arange(E, dtype=np.int64)
 
 
-@pytest.mark.parametrize("words", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("words", [1, 2, 4, 8, 16, 32])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_random_graph_all_variants(words, mode):
     rng = np.random.default_rng(100 * words + mode)
@@ -182,7 +182,7 @@ def test_rmat18_and_snb_like_medium():
     n = 4096
     ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
     oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=8)
-    for words in (0, 4, 16):
+    for words in (0, 4, 32):
         pgq.set_option("words", words)
         ln, ok = dev.iterativelength(ps, pd)
         assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
@@ -268,7 +268,7 @@ def test_traversed_edges_accounting_matches_oracle():
     n = 3000
     ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
     oln, ook, ote = ora.lean_iterativelength(V, ps, pd, with_te=True)
-    for words in (2, 16):
+    for words in (2, 32):
         pgq.set_option("words", words)
         d_src, d_dst = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
         d_len = torch.empty(n, dtype=torch.int64, device="cuda")

@@ -810,6 +810,50 @@ done:
 	if (threadIdx.x == 0 && open_in_block) atomicAdd(&cnt->unresolved, open_in_block);
 }
 
+// Two-hop destination probe: a pair still open after k_probe(level) has hop count level+1 iff some in-neighbour u of
+// dst has an in-neighbour carrying the lane in the frontier of level-1.  One wavefront per open pair walks
+// N_in(dst) x N_in(u).  It runs only when few pairs are left (it replaces a full-width expansion that would serve
+// only them) and leaves a pair open when the walk would exceed `work_cap` in-edges (hub destinations).
+template <int WD>
+__global__ __launch_bounds__(256) void k_probe2(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
+                                                const int32_t *__restrict__ sdst, int32_t *__restrict__ sres,
+                                                u32 base_lane, const u64 *__restrict__ front,
+                                                const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
+                                                const int32_t *__restrict__ radj, int level, u32 run_below,
+                                                int64_t work_cap, Counters *__restrict__ cnt) {
+	const u32 open_now = cnt->unresolved;
+	if (open_now == 0 || open_now > run_below) return;
+	const int lane = threadIdx.x & 63;
+	const int64_t i = lo + (int64_t)__builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	if (i >= hi || sres[i] != -1) return;
+	const u32 l = skey[i] - base_lane;
+	const int w = (int)(l >> 6);
+	const u64 bit = 1ull << (l & 63);
+	const int d = sdst[i];
+	const int64_t b = roff[d], e = roff[d + 1];
+	int64_t work = 0;
+	bool found = false;
+	for (int64_t k = b; k < e && !found; k++) {
+		const int u = radj[k]; // wave-uniform
+		const int64_t ub = roff[u], ue = roff[u + 1];
+		work += ue - ub;
+		if (work > work_cap) return; // too expensive here: stays open for the regular expansion / deferral
+		for (int64_t base = ub; base < ue && !found; base += 64) {
+			const int64_t j = base + lane;
+			bool hit = false;
+			if (j < ue) {
+				const int v = radj[j];
+				if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
+			}
+			found = __any(hit);
+		}
+	}
+	if (found && lane == 0) {
+		sres[i] = level + 1;
+		atomicSub(&cnt->unresolved, 1u);
+	}
+}
+
 // ---- straggler deferral ------------------------------------------------------------------------------------------------
 // When only a handful of pairs of a wide batch are still open, expanding another level for all 64*WD lanes is
 // wasted bandwidth: the open pairs are marked (-3), collected after the batch loop and searched again in a
@@ -1194,6 +1238,11 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				hipLaunchKernelGGL(k_probe<WD>, dim3(blocks_for((hi - lo) * 64)), dim3(256), 0, st, lo, hi,
 				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
+				if (opt.probe2 && !with_paths)
+					hipLaunchKernelGGL(k_probe2<WD>, dim3(blocks_for((hi - lo) * 64)), dim3(256), 0, st, lo, hi,
+					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
+					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
+					                   (u32)std::min<int64_t>(L / 4, (hi - lo) / 4), (int64_t)opt.probe2_cap, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
 				act_sel ^= 1;

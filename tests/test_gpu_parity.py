@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _defaults():
     for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2),
-                 ("relax_small_limit", 2048)):
+                 ("relax_small_limit", 2048), ("probe2", 1)):
         pgq.set_option(k, v)
     yield
 
@@ -140,6 +140,7 @@ def test_random_graph_all_variants(words, mode):
         pgq.set_option("streams", 1 + (probe + lds) % 3)  # 1..3 concurrent batch workers
         pgq.set_option("probe", probe)
         pgq.set_option("force_pull", force_pull)
+        pgq.set_option("probe2", 1 - lds if probe else 1)  # two-hop destination probe on / off
         pgq.set_option("sparse_lds", lds)  # 1-bit frontier map in LDS (1024-thread groups) or in global memory
         ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
         assert lens(ln, ok) == want

@@ -237,37 +237,53 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
 						u64 old = atomicOr(sp, nb);
 						u64 fr = nb & ~old;
 						if (fr) {
-							atomicOr(&next[(size_t)n * WD + w], fr);
-							if (!((atomicOr(&nz_next[n], 1u << w) >> w) & 1u)) nw++;
-							enq = true;
+							// the first lane that makes this lane-word non-empty flags it in nz; the first that flags
+							// anything for n queues n (nz of the next level starts zeroed, so it doubles as "queued")
+							if (atomicOr(&next[(size_t)n * WD + w], fr) == 0) {
+								nw++;
+								if (atomicOr(&nz_next[n], 1u << w) == 0) enq = true;
+							}
 						}
 					}
 				}
 				gathers += (u64)min((int64_t)64, e - base);
 			}
-			if (enq) enq = qflag[n] != epoch && atomicExch(&qflag[n], epoch) != epoch;
 			int64_t deg = 0;
 			if (enq) {
 				deg = off[n + 1] - off[n];
 				mf += (u64)deg;
 				nf++;
 			}
-			enqueue_items(enq, n, deg, chunk, qnext, qcap, &cnt->q_count[par ^ 1]);
+			// no queue append here: one shared counter serialises ~10^4 wave-level appends per launch; if the next
+			// level is top-down again its queue is rebuilt from nz (k_queue_from_dense, a V-word scan)
 			scanned += (u64)min((int64_t)64, e - base);
 		}
 	}
-	// per-lane nf/mf, wave-uniform scanned/gathers
+	// per-lane nf/mf, wave-uniform scanned/gathers; one atomic set per block
 	for (int o = 32; o > 0; o >>= 1) {
 		nf += __shfl_down(nf, o);
 		nw += __shfl_down(nw, o);
 		mf += __shfl_down(mf, o);
 	}
+	__shared__ u64 red[4][5];
+	const int wib = threadIdx.x >> 6;
 	if (lane == 0) {
-		if (nf) atomicAdd(&cnt->front_vertices, nf);
-		if (nw) atomicAdd(&cnt->front_words, nw);
-		if (mf) atomicAdd(&cnt->front_edges, mf);
-		if (scanned) atomicAdd(&cnt->edges_scanned, scanned);
-		if (gathers) atomicAdd(&cnt->word_gathers, gathers);
+		red[wib][0] = nf;
+		red[wib][1] = nw;
+		red[wib][2] = mf;
+		red[wib][3] = scanned;
+		red[wib][4] = gathers;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u64 t[5] = { 0, 0, 0, 0, 0 };
+		for (int k = 0; k < (int)(blockDim.x >> 6); k++)
+			for (int j = 0; j < 5; j++) t[j] += red[k][j];
+		if (t[0]) atomicAdd(&cnt->front_vertices, (u32)t[0]);
+		if (t[1]) atomicAdd(&cnt->front_words, (u32)t[1]);
+		if (t[2]) atomicAdd(&cnt->front_edges, t[2]);
+		if (t[3]) atomicAdd(&cnt->edges_scanned, t[3]);
+		if (t[4]) atomicAdd(&cnt->word_gathers, t[4]);
 	}
 }
 
@@ -672,14 +688,15 @@ __global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ it
 	const int word = lane & (WD - 1);
 	const int slot = lane / WD;
 	const int64_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-	if (wave >= n_items) return;
-	const HubItem it = items[wave];
-	const int n = it.vertex;
-	const u64 want = active[word] & ~seen[(size_t)n * WD + word];
-	u64 have = next[(size_t)n * WD + word]; // other slices may already have covered it
-	if (__all(((have & want) == want))) return;
+	__shared__ u64 red[4][2];
 	u64 acc = 0, scanned = 0, gath = 0;
-	for (int64_t base = it.begin; base < it.end; base += 64) {
+	const bool live = wave < n_items;
+	const HubItem it = live ? items[wave] : HubItem{ 0, 0, 0, 0 };
+	const int n = it.vertex;
+	const u64 want = live ? (active[word] & ~seen[(size_t)n * WD + word]) : 0ull;
+	const u64 have = live ? next[(size_t)n * WD + word] : 0ull; // other slices may already have covered it
+	const bool skip = !live || __all(((have & want) == want));
+	for (int64_t base = it.begin; !skip && base < it.end; base += 64) {
 		const int c64 = (int)min((int64_t)64, it.end - base);
 		const int nb = lane < c64 ? radj[base + lane] : 0;
 		const u32 nzb = lane < c64 ? nz_cur[nb] : 0u;
@@ -704,11 +721,23 @@ __global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ it
 	}
 	acc = wave_or_slots(acc, WD);
 	const u64 fresh = acc & want;
-	if (lane < WD && fresh) atomicOr(&next[(size_t)n * WD + lane], fresh);
+	if (!skip && lane < WD && fresh) atomicOr(&next[(size_t)n * WD + lane], fresh);
+	// one atomic pair per block, not per slice: ~25k slices on R-MAT-22 serialised on two counters otherwise
 	for (int o = 32; o > 0; o >>= 1) gath += __shfl_down(gath, o);
+	const int wib = threadIdx.x >> 6;
 	if (lane == 0) {
-		atomicAdd(&cnt->edges_scanned, scanned);
-		atomicAdd(&cnt->word_gathers, gath);
+		red[wib][0] = scanned;
+		red[wib][1] = gath;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u64 a0 = 0, a1 = 0;
+		for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
+			a0 += red[k][0];
+			a1 += red[k][1];
+		}
+		if (a0) atomicAdd(&cnt->edges_scanned, a0);
+		if (a1) atomicAdd(&cnt->word_gathers, a1);
 	}
 }
 
@@ -1242,7 +1271,8 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					hipLaunchKernelGGL(k_probe2<WD>, dim3(blocks_for((hi - lo) * 64)), dim3(256), 0, st, lo, hi,
 					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
-					                   (u32)std::min<int64_t>(L / 4, (hi - lo) / 4), (int64_t)opt.probe2_cap, d_cnt);
+					                   (u32)std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),
+					                   (int64_t)opt.probe2_cap, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
 				act_sel ^= 1;
@@ -1272,8 +1302,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					kt.stop();
 					cur->dirty = false;
 				}
-				par ^= 1;
-				queue_valid = true;
+				queue_valid = false; // rebuilt from nz if the next level is top-down too
 				S.push_levels++;
 			} else {
 				PGQ_TRY(nxt->buf.reserve(words * 8));

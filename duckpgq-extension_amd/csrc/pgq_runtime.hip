@@ -80,6 +80,7 @@ static int do_init(int device) {
 	env_int("PGQ_DEFER", g_opt.defer);
 	env_int("PGQ_PROBE2", g_opt.probe2);
 	env_int("PGQ_PROBE2_CAP", g_opt.probe2_cap);
+	env_int("PGQ_PROBE2_DIV", g_opt.probe2_div);
 	env_int("PGQ_PART_WEIGHT", g_opt.part_weight);
 	env_double("PGQ_SPARSE_BELOW", g_opt.sparse_below);
 	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
@@ -660,6 +661,7 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "defer") o.defer = atoi(value);
 	else if (k == "probe2") o.probe2 = atoi(value);
 	else if (k == "probe2_cap") o.probe2_cap = atoi(value);
+	else if (k == "probe2_div") o.probe2_div = atoi(value);
 	else if (k == "part_weight") o.part_weight = atoi(value);
 	else if (k == "sparse_below") o.sparse_below = atof(value);
 	else if (k == "sparse_unroll") o.sparse_unroll = atoi(value);

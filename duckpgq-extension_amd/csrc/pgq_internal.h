@@ -53,7 +53,7 @@ struct Options {
 	int probe = 1;          // destination probe before each expansion
 	int probe2 = 1;         // two-hop destination probe when few pairs are left
 	int probe2_div = 4;     // ... when open pairs <= lanes / probe2_div
-	int probe2_cap = 1 << 18; // in-edges a two-hop probe may walk per pair
+	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
 	int part_weight = 1024; // in-edges (+8 per vertex) per bottom-up work part
 	int streams = 2;        // batches searched concurrently (one host thread + HIP stream each)

@@ -840,33 +840,50 @@ done:
 }
 
 // Two-hop destination probe: a pair still open after k_probe(level) has hop count level+1 iff some in-neighbour u of
-// dst has an in-neighbour carrying the lane in the frontier of level-1.  One wavefront per open pair walks
-// N_in(dst) x N_in(u).  It runs only when few pairs are left (it replaces a full-width expansion that would serve
-// only them) and leaves a pair open when the walk would exceed `work_cap` in-edges (hub destinations).
+// dst has an in-neighbour carrying the lane in the frontier of level-1.  One 1024-thread workgroup per open pair:
+// it first sums the in-degrees of N_in(dst); if the walk N_in(dst) x N_in(u) would exceed `work_cap` in-edges (hub
+// destinations) the pair is left open for the regular expansion / deferral, otherwise the 16 wavefronts split the
+// u's and stop as soon as one finds a hit.  Runs only when few pairs are left (it replaces a full-width
+// expansion that would serve only them).
 template <int WD>
-__global__ __launch_bounds__(256) void k_probe2(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
-                                                const int32_t *__restrict__ sdst, int32_t *__restrict__ sres,
-                                                u32 base_lane, const u64 *__restrict__ front,
-                                                const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
-                                                const int32_t *__restrict__ radj, int level, u32 run_below,
-                                                int64_t work_cap, Counters *__restrict__ cnt) {
+__global__ __launch_bounds__(1024) void k_probe2(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
+                                                 const int32_t *__restrict__ sdst, int32_t *__restrict__ sres,
+                                                 u32 base_lane, const u64 *__restrict__ front,
+                                                 const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
+                                                 const int32_t *__restrict__ radj, int level, u32 run_below,
+                                                 int64_t work_cap, Counters *__restrict__ cnt) {
+	__shared__ unsigned long long s_work;
+	__shared__ int s_found;
 	const u32 open_now = cnt->unresolved;
 	if (open_now == 0 || open_now > run_below) return;
-	const int lane = threadIdx.x & 63;
-	const int64_t i = lo + (int64_t)__builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int64_t i = lo + blockIdx.x;
 	if (i >= hi || sres[i] != -1) return;
+	const int lane = threadIdx.x & 63;
+	const int wib = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	if (threadIdx.x == 0) {
+		s_work = 0;
+		s_found = 0;
+	}
+	__syncthreads();
 	const u32 l = skey[i] - base_lane;
 	const int w = (int)(l >> 6);
 	const u64 bit = 1ull << (l & 63);
 	const int d = sdst[i];
 	const int64_t b = roff[d], e = roff[d + 1];
-	int64_t work = 0;
-	bool found = false;
-	for (int64_t k = b; k < e && !found; k++) {
+	unsigned long long mine = 0;
+	for (int64_t k = b + threadIdx.x; k < e; k += blockDim.x) {
+		const int u = radj[k];
+		mine += (unsigned long long)(roff[u + 1] - roff[u]);
+	}
+	for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+	if (lane == 0 && mine) atomicAdd(&s_work, mine);
+	__syncthreads();
+	if ((int64_t)s_work > work_cap) return; // too expensive here: the pair stays open
+	for (int64_t k = b + wib; k < e; k += nw) {
+		if (*(volatile int *)&s_found) break;
 		const int u = radj[k]; // wave-uniform
 		const int64_t ub = roff[u], ue = roff[u + 1];
-		work += ue - ub;
-		if (work > work_cap) return; // too expensive here: stays open for the regular expansion / deferral
+		bool found = false;
 		for (int64_t base = ub; base < ue && !found; base += 64) {
 			const int64_t j = base + lane;
 			bool hit = false;
@@ -876,8 +893,13 @@ __global__ __launch_bounds__(256) void k_probe2(int64_t lo, int64_t hi, const u3
 			}
 			found = __any(hit);
 		}
+		if (found) {
+			if (lane == 0) s_found = 1;
+			break;
+		}
 	}
-	if (found && lane == 0) {
+	__syncthreads();
+	if (threadIdx.x == 0 && s_found) {
 		sres[i] = level + 1;
 		atomicSub(&cnt->unresolved, 1u);
 	}
@@ -1268,7 +1290,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
 				if (opt.probe2 && !with_paths)
-					hipLaunchKernelGGL(k_probe2<WD>, dim3(blocks_for((hi - lo) * 64)), dim3(256), 0, st, lo, hi,
+					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)(hi - lo)), dim3(1024), 0, st, lo, hi,
 					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
 					                   (u32)std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),

@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
                                               const u64 *__restrict__ visit, u64 *__restrict__ seen,
                                               u64 *__restrict__ next, u32 *__restrict__ nz_next,
                                               const u64 *__restrict__ active, const u64 *__restrict__ qcur, int par,
-                                              u32 *__restrict__ qflag, u32 epoch, u64 *__restrict__ qnext, u32 qcap,
-                                              int64_t chunk, int stop_limit, Counters *__restrict__ cnt) {
+                                              u32 qcap, int64_t chunk, int stop_limit,
+                                              Counters *__restrict__ cnt) {
 	// the probe already answered (or the host will defer) what is left of the batch: skip the expansion
 	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	const int lane = threadIdx.x & 63;
@@ -1182,7 +1182,6 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 	PGQ_TRY(ws->seen.reserve(words * 8));
 	PGQ_TRY(ws->qbuf[0].reserve((size_t)qcap * 8));
 	PGQ_TRY(ws->qbuf[1].reserve((size_t)qcap * 8));
-	PGQ_TRY(ws->qflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
 	if (outp.want_te) {
 		PGQ_TRY(ws->lane_sums.reserve((size_t)kMaxTeLevels * L * 8));
@@ -1190,8 +1189,6 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		PGQ_HIP_TRY(hipMemsetAsync(sh->ste.p, 0, (size_t)n * 8, st));
 	}
 	Counters *d_cnt = ws->counters.as<Counters>();
-	PGQ_HIP_TRY(hipMemsetAsync(ws->qflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
-	ws->epoch = 0;
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	const int64_t *bs = sh->h_bstart;
 
@@ -1307,13 +1304,11 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					kt.stop();
 				}
 				PGQ_TRY(make_zero(nxt));
-				ws->epoch++;
 				{
 					KernelTimer kt(st, K_PUSH);
 					hipLaunchKernelGGL(k_push<WD>, dim3(push_grid), dim3(256), 0, st, c->off, c->adj, cur->buf.as<u64>(),
 					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur,
-					                   ws->qbuf[par].as<u64>(), par, ws->qflag.as<u32>(), ws->epoch,
-					                   ws->qbuf[par ^ 1].as<u64>(), qcap, pchunk, stop, d_cnt);
+					                   ws->qbuf[par].as<u64>(), par, qcap, pchunk, stop, d_cnt);
 					kt.stop();
 				}
 				nxt->dirty = true;

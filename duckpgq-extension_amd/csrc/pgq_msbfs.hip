@@ -924,9 +924,12 @@ __global__ void k_collect_deferred(int64_t n, const int32_t *__restrict__ sres, 
 	didx[p] = (u32)i;
 }
 __global__ void k_apply_deferred(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
-                                 int32_t *__restrict__ sres) {
+                                 int32_t *__restrict__ sres, const int64_t *__restrict__ doff,
+                                 int64_t *__restrict__ soff, int64_t child_base) {
 	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j < nd) sres[didx[j]] = dlen[j] < 0 ? -1 : (int32_t)dlen[j];
+	if (j >= nd) return;
+	sres[didx[j]] = dlen[j] < 0 ? -1 : (int32_t)dlen[j];
+	if (soff && dlen[j] >= 0) soff[didx[j]] = child_base + doff[j]; // straggler paths were appended at child_base
 }
 
 // ---- traversed-edge accounting (measurement only; bench.py's MTEPS numerator) -----------------------------------
@@ -1047,7 +1050,7 @@ Workspace::~Workspace() {
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &active, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &cbits, &cbbase, &cmeta, &cwords })
+	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -1266,7 +1269,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		if (use_probe) {
 			stop = 0;
 			// a narrow batch is scan-bound: re-running its stragglers costs as much as finishing them here
-			if (opt.defer && !with_paths && outp.depth < 2 && WD >= 8) stop = (int)std::min<int64_t>(L / opt.defer, (hi - lo) / opt.defer);
+			if (opt.defer && outp.depth < 2 && WD >= 8) stop = (int)std::min<int64_t>(L / opt.defer, (hi - lo) / opt.defer);
 		}
 		for (int t = 1; unresolved > 0 && front_edges > 0; t++) {
 			LevelBuf *nxt = level_buf(t);
@@ -1654,10 +1657,46 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			SearchOutput so2;
 			so2.depth = outp.depth + 1;
 			S.pairs -= nd; // counted once
-			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
-			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
-			hipLaunchKernelGGL(k_apply_deferred, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd, ws->def_idx.as<u32>(),
-			                   ws->def_len.as<int64_t>(), ws->sres.as<int32_t>());
+			if (!with_paths) {
+				PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+				                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
+				hipLaunchKernelGGL(k_apply_deferred, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd,
+				                   ws->def_idx.as<u32>(), ws->def_len.as<int64_t>(), ws->sres.as<int32_t>(), nullptr,
+				                   nullptr, (int64_t)0);
+			} else {
+				// the stragglers' paths land in the inner workspace's child buffer; append them to ours
+				PGQ_TRY(ws->def_off.reserve((size_t)nd * 8));
+				PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+				                      ws->def_len.as<int64_t>(), true, ws->def_off.as<int64_t>(), nullptr, 0, so2));
+				const int64_t base = outp.child_used, need = base + so2.child_used;
+				int64_t *d_child = d_child_ext;
+				if (d_child_ext) {
+					if (need > child_cap_ext) {
+						outp.child_used = need;
+						rc = fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(need) + " elements");
+					}
+				} else {
+					if ((size_t)need * 8 > ws->child.cap) {
+						DevBuf bigger;
+						PGQ_TRY(bigger.reserve((size_t)need * 8));
+						if (base > 0) PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)base * 8, hipMemcpyDeviceToDevice, st));
+						PGQ_HIP_TRY(hipStreamSynchronize(st));
+						ws->child.release();
+						ws->child = bigger;
+					}
+					d_child = ws->child.as<int64_t>();
+				}
+				if (rc == PGQ_OK) {
+					if (so2.child_used > 0)
+						PGQ_HIP_TRY(hipMemcpyAsync(d_child + base, inner.ws->child.p, (size_t)so2.child_used * 8,
+						                           hipMemcpyDeviceToDevice, st));
+					hipLaunchKernelGGL(k_apply_deferred, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd,
+					                   ws->def_idx.as<u32>(), ws->def_len.as<int64_t>(), ws->sres.as<int32_t>(),
+					                   ws->def_off.as<int64_t>(), ws->soff.as<int64_t>(), base);
+					PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+					outp.child_used = need;
+				}
+			}
 		}
 	}
 	// results back to row order even when the child buffer overflowed (lengths are still right)

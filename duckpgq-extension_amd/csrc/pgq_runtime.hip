@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "pgq_internal.h"
 
@@ -300,8 +301,107 @@ static int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
 	return (int)g;
 }
 
+// ---- pageable host memory -> HBM through pinned staging rings, several host threads ---------------------------
+// A plain hipMemcpy from DuckDB's pageable vectors stages through one pinned buffer on one thread (~2.5 GB/s
+// measured: 260 ms for the 0.64 GB SF100 CSR — far more than the search itself).  Here T threads each own a slice,
+// a 2-slot pinned ring and a stream; the adjacency is narrowed to int32 while it is staged (half the PCIe bytes).
+struct PinnedPool {
+	std::mutex lock;
+	std::vector<void *> free_blocks;
+	static constexpr size_t kBlock = 4u << 20;
+	void *get() {
+		{
+			std::lock_guard<std::mutex> g(lock);
+			if (!free_blocks.empty()) {
+				void *p = free_blocks.back();
+				free_blocks.pop_back();
+				return p;
+			}
+		}
+		void *p = nullptr;
+		if (hipHostMalloc(&p, kBlock) != hipSuccess) return nullptr;
+		return p;
+	}
+	void put(void *p) {
+		std::lock_guard<std::mutex> g(lock);
+		free_blocks.push_back(p);
+	}
+};
+static PinnedPool g_pinned;
+
+// mode 0: raw bytes; mode 1: int64 -> int32 narrowing with range check [0, V) (elements counted in int64s)
+static int staged_upload(void *d_dst, const void *h_src, size_t n_elems, size_t elem_bytes, int mode, int64_t V,
+                         std::atomic<int> *bad) {
+	if (n_elems == 0) return PGQ_OK;
+	const size_t out_elem = mode == 1 ? 4 : elem_bytes;
+	const size_t per_block = PinnedPool::kBlock / std::max<size_t>(elem_bytes, 8);
+	const size_t nblocks = (n_elems + per_block - 1) / per_block;
+	int T = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), nblocks);
+	std::vector<int> rcs((size_t)T, PGQ_OK);
+	std::vector<std::string> errs((size_t)T);
+	auto worker = [&](int t) {
+		auto run = [&]() -> int {
+			PGQ_TRY(ensure_init());
+			hipStream_t st = nullptr;
+			PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+			void *slot[2] = { g_pinned.get(), g_pinned.get() };
+			hipEvent_t ev[2] = { nullptr, nullptr };
+			int rc = PGQ_OK;
+			if (!slot[0] || !slot[1]) rc = fail(PGQ_ERR_OOM, "hipHostMalloc of a staging block failed");
+			for (int k = 0; k < 2 && rc == PGQ_OK; k++)
+				if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) rc = fail(PGQ_ERR_HIP, "hipEventCreate failed");
+			size_t it = 0;
+			for (size_t b = (size_t)t; b < nblocks && rc == PGQ_OK; b += (size_t)T, it++) {
+				const int s = (int)(it & 1);
+				if (it >= 2 && hipEventSynchronize(ev[s]) != hipSuccess) rc = fail(PGQ_ERR_HIP, "hipEventSynchronize failed");
+				const size_t lo = b * per_block, cnt = std::min(per_block, n_elems - lo);
+				if (mode == 1) {
+					const int64_t *src = static_cast<const int64_t *>(h_src) + lo;
+					int32_t *dst = static_cast<int32_t *>(slot[s]);
+					bool oob = false;
+					for (size_t i = 0; i < cnt; i++) {
+						const int64_t x = src[i];
+						oob |= x < 0 || x >= V;
+						dst[i] = (int32_t)x;
+					}
+					if (oob) bad->store(1);
+				} else {
+					memcpy(slot[s], static_cast<const char *>(h_src) + lo * elem_bytes, cnt * elem_bytes);
+				}
+				if (rc == PGQ_OK && hipMemcpyAsync(static_cast<char *>(d_dst) + lo * out_elem, slot[s], cnt * out_elem,
+				                                   hipMemcpyHostToDevice, st) != hipSuccess)
+					rc = fail(PGQ_ERR_HIP, "hipMemcpyAsync (staged upload) failed");
+				if (rc == PGQ_OK) (void)hipEventRecord(ev[s], st);
+			}
+			(void)hipStreamSynchronize(st);
+			for (int k = 0; k < 2; k++) {
+				if (ev[k]) (void)hipEventDestroy(ev[k]);
+				if (slot[k]) g_pinned.put(slot[k]);
+			}
+			(void)hipStreamDestroy(st);
+			return rc;
+		};
+		rcs[(size_t)t] = run();
+		if (rcs[(size_t)t] != PGQ_OK) errs[(size_t)t] = t_err;
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
+	worker(0);
+	for (auto &th : pool) th.join();
+	for (int t = 0; t < T; t++)
+		if (rcs[(size_t)t] != PGQ_OK) return fail(rcs[(size_t)t], errs[(size_t)t]);
+	return PGQ_OK;
+}
+
+// in-degree histogram of an already narrowed adjacency
+__global__ void k_hist_adj32(const int32_t *__restrict__ adj32, int *__restrict__ rcnt, int64_t E) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < E; i += stride) atomicAdd(&rcnt[adj32[i]], 1);
+}
+
 // Builds everything derived from (off, adj64) that already sit in device memory.
-static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
+static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { // d_adj64 == nullptr: c->adj is set
 	const int64_t V = c->V, E = c->E;
 	int *d_flag = nullptr;
 	PGQ_HIP_TRY(hipMalloc(&d_flag, 2 * sizeof(int)));
@@ -312,12 +412,13 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) {
 	int *d_cnt = nullptr;
 	PGQ_HIP_TRY(hipMalloc(&d_cnt, (size_t)(V + 1) * sizeof(int)));
 	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(V + 1) * sizeof(int), st));
-	PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
+	if (!c->adj) PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
 	PGQ_HIP_TRY(hipMalloc(&c->radj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
 	PGQ_HIP_TRY(hipMalloc(&c->rslot, (size_t)std::max<int64_t>(E, 1) * sizeof(int64_t)));
 	PGQ_HIP_TRY(hipMalloc(&c->roff, (size_t)(V + 1) * sizeof(int64_t)));
 	if (E > 0) {
-		hipLaunchKernelGGL(k_narrow_adj, dim3(grid_for(E)), dim3(256), 0, st, d_adj64, c->adj, d_cnt, E, V, d_flag);
+		if (d_adj64) hipLaunchKernelGGL(k_narrow_adj, dim3(grid_for(E)), dim3(256), 0, st, d_adj64, c->adj, d_cnt, E, V, d_flag);
+		else hipLaunchKernelGGL(k_hist_adj32, dim3(grid_for(E)), dim3(256), 0, st, c->adj, d_cnt, E);
 	}
 	// in-degree -> roff by exclusive scan
 	int64_t *d_deg64 = nullptr;
@@ -466,13 +567,8 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 		PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 		PGQ_HIP_TRY(hipMalloc(&c->off, (size_t)(V + 1) * sizeof(int64_t)));
 		PGQ_HIP_TRY(hipMemcpyAsync(c->off, offsets, (size_t)(V + 1) * sizeof(int64_t), kind, st));
-		if (E > 0) {
-			if (on_device) {
-				d_adj64 = const_cast<int64_t *>(adj);
-			} else {
-				PGQ_HIP_TRY(hipMalloc(&d_adj64, (size_t)E * sizeof(int64_t)));
-				PGQ_HIP_TRY(hipMemcpyAsync(d_adj64, adj, (size_t)E * sizeof(int64_t), kind, st));
-			}
+		if (E > 0 && on_device) {
+			d_adj64 = const_cast<int64_t *>(adj);
 			if (edge_ids) {
 				PGQ_HIP_TRY(hipMalloc(&c->edge_ids, (size_t)E * sizeof(int64_t)));
 				PGQ_HIP_TRY(hipMemcpyAsync(c->edge_ids, edge_ids, (size_t)E * sizeof(int64_t), kind, st));
@@ -480,6 +576,20 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 			if (w_type != PGQ_W_NONE) {
 				PGQ_HIP_TRY(hipMalloc(&c->w, (size_t)E * 8));
 				PGQ_HIP_TRY(hipMemcpyAsync(c->w, w, (size_t)E * 8, kind, st));
+			}
+		} else if (E > 0) {
+			// pageable host arrays: staged through pinned rings by several threads, adjacency narrowed on the way
+			std::atomic<int> oob { 0 };
+			PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)E * sizeof(int32_t)));
+			PGQ_TRY(staged_upload(c->adj, adj, (size_t)E, 8, 1, V, &oob));
+			if (oob.load()) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: adjacency out of [0,V)");
+			if (edge_ids) {
+				PGQ_HIP_TRY(hipMalloc(&c->edge_ids, (size_t)E * sizeof(int64_t)));
+				PGQ_TRY(staged_upload(c->edge_ids, edge_ids, (size_t)E, 8, 0, V, &oob));
+			}
+			if (w_type != PGQ_W_NONE) {
+				PGQ_HIP_TRY(hipMalloc(&c->w, (size_t)E * 8));
+				PGQ_TRY(staged_upload(c->w, w, (size_t)E, 8, 0, V, &oob));
 			}
 		}
 		return finish_upload(c, d_adj64, st);

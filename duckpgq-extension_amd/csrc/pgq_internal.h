@@ -56,6 +56,7 @@ struct Options {
 	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
 	int part_weight = 1024; // in-edges (+8 per vertex) per bottom-up work part
+	int upload_threads = 2;  // host threads staging a pageable CSR through pinned rings
 	int streams = 2;        // batches searched concurrently (one host thread + HIP stream each)
 	int sparse_lds = 1;     // keep the 1-bit frontier map in LDS when it fits (1024-thread workgroups)
 	int sparse_unroll = 4;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -87,6 +88,7 @@ static int do_init(int device) {
 	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
 	env_int("PGQ_SPARSE_LDS", g_opt.sparse_lds);
 	env_int("PGQ_STREAMS", g_opt.streams);
+	env_int("PGQ_UPLOAD_THREADS", g_opt.upload_threads);
 	g_inited.store(1);
 	return PGQ_OK;
 }
@@ -294,6 +296,17 @@ __global__ void k_fill_rown(const int64_t *__restrict__ roff, const int32_t *__r
 	}
 }
 
+struct UploadTrace {
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	void mark(const char *what) {
+		if (!options().trace) return;
+		(void)hipDeviceSynchronize();
+		auto t1 = std::chrono::steady_clock::now();
+		fprintf(stderr, "[pgq] upload %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+		t0 = t1;
+	}
+};
+
 static int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
 	int64_t g = (n + block - 1) / block;
 	if (g < 1) g = 1;
@@ -336,7 +349,8 @@ static int staged_upload(void *d_dst, const void *h_src, size_t n_elems, size_t 
 	const size_t out_elem = mode == 1 ? 4 : elem_bytes;
 	const size_t per_block = PinnedPool::kBlock / std::max<size_t>(elem_bytes, 8);
 	const size_t nblocks = (n_elems + per_block - 1) / per_block;
-	int T = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), nblocks);
+	int T = (int)std::min<size_t>(std::min<size_t>((size_t)std::max(1, options().upload_threads),
+	                                             std::max(1u, std::thread::hardware_concurrency())), nblocks);
 	std::vector<int> rcs((size_t)T, PGQ_OK);
 	std::vector<std::string> errs((size_t)T);
 	auto worker = [&](int t) {
@@ -393,6 +407,22 @@ static int staged_upload(void *d_dst, const void *h_src, size_t n_elems, size_t 
 	return PGQ_OK;
 }
 
+// device -> pageable host through one pinned block at a time (a pageable hipMemcpy D2H ran at ~0.6 GB/s here)
+static int staged_download(void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {
+	void *blk = g_pinned.get();
+	if (!blk) return fail(PGQ_ERR_OOM, "hipHostMalloc of a staging block failed");
+	int rc = PGQ_OK;
+	for (size_t lo = 0; lo < bytes && rc == PGQ_OK; lo += PinnedPool::kBlock) {
+		const size_t cnt = std::min(PinnedPool::kBlock, bytes - lo);
+		if (hipMemcpyAsync(blk, static_cast<const char *>(d_src) + lo, cnt, hipMemcpyDeviceToHost, st) != hipSuccess ||
+		    hipStreamSynchronize(st) != hipSuccess)
+			rc = fail(PGQ_ERR_HIP, "staged download failed");
+		else memcpy(static_cast<char *>(h_dst) + lo, blk, cnt);
+	}
+	g_pinned.put(blk);
+	return rc;
+}
+
 // in-degree histogram of an already narrowed adjacency
 __global__ void k_hist_adj32(const int32_t *__restrict__ adj32, int *__restrict__ rcnt, int64_t E) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,6 +433,7 @@ __global__ void k_hist_adj32(const int32_t *__restrict__ adj32, int *__restrict_
 // Builds everything derived from (off, adj64) that already sit in device memory.
 static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { // d_adj64 == nullptr: c->adj is set
 	const int64_t V = c->V, E = c->E;
+	UploadTrace tr;
 	int *d_flag = nullptr;
 	PGQ_HIP_TRY(hipMalloc(&d_flag, 2 * sizeof(int)));
 	PGQ_HIP_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
@@ -420,6 +451,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 		if (d_adj64) hipLaunchKernelGGL(k_narrow_adj, dim3(grid_for(E)), dim3(256), 0, st, d_adj64, c->adj, d_cnt, E, V, d_flag);
 		else hipLaunchKernelGGL(k_hist_adj32, dim3(grid_for(E)), dim3(256), 0, st, c->adj, d_cnt, E);
 	}
+	tr.mark("allocs + histogram");
 	// in-degree -> roff by exclusive scan
 	int64_t *d_deg64 = nullptr;
 	PGQ_HIP_TRY(hipMalloc(&d_deg64, (size_t)(V + 1) * sizeof(int64_t)));
@@ -442,11 +474,12 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 			hipLaunchKernelGGL(k_any_negative<double>, dim3(grid_for(E)), dim3(256), 0, st, (const double *)c->w, E,
 			                   d_flag + 1);
 	}
+	tr.mark("scan + reverse scatter");
 	// degrees back to the host for the hub work lists
 	std::vector<int64_t> h_roff((size_t)V + 1), h_off((size_t)V + 1);
 	int h_flag[2] = { 0, 0 };
-	PGQ_HIP_TRY(hipMemcpyAsync(h_roff.data(), c->roff, (size_t)(V + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipMemcpyAsync(h_off.data(), c->off, (size_t)(V + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PGQ_TRY(staged_download(h_roff.data(), c->roff, (size_t)(V + 1) * sizeof(int64_t), st));
+	PGQ_TRY(staged_download(h_off.data(), c->off, (size_t)(V + 1) * sizeof(int64_t), st));
 	PGQ_HIP_TRY(hipMemcpyAsync(h_flag, d_flag, sizeof(h_flag), hipMemcpyDeviceToHost, st));
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	(void)hipFree(d_flag);
@@ -456,6 +489,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	if (h_flag[0]) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: offsets not monotone or adjacency out of [0,V)");
 	c->has_negative_weight = h_flag[1] != 0;
 
+	tr.mark("degrees to host");
 	const int64_t chunk = std::max(64, options().hub_chunk);
 	c->hub_threshold = chunk;
 	std::vector<HubItem> items;
@@ -520,6 +554,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 			PGQ_HIP_TRY(hipDeviceSynchronize());
 		}
 	}
+	tr.mark("hubs, parts, owner bytes");
 	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8 + 1) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
 	           (int64_t)items.size() * (int64_t)sizeof(HubItem);
 	return PGQ_OK;
@@ -580,12 +615,15 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 		} else if (E > 0) {
 			// pageable host arrays: staged through pinned rings by several threads, adjacency narrowed on the way
 			std::atomic<int> oob { 0 };
+			UploadTrace tr;
 			PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)E * sizeof(int32_t)));
 			PGQ_TRY(staged_upload(c->adj, adj, (size_t)E, 8, 1, V, &oob));
+			tr.mark("adjacency staged+narrowed");
 			if (oob.load()) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: adjacency out of [0,V)");
 			if (edge_ids) {
 				PGQ_HIP_TRY(hipMalloc(&c->edge_ids, (size_t)E * sizeof(int64_t)));
 				PGQ_TRY(staged_upload(c->edge_ids, edge_ids, (size_t)E, 8, 0, V, &oob));
+				tr.mark("edge ids staged");
 			}
 			if (w_type != PGQ_W_NONE) {
 				PGQ_HIP_TRY(hipMalloc(&c->w, (size_t)E * 8));
@@ -777,6 +815,7 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "sparse_unroll") o.sparse_unroll = atoi(value);
 	else if (k == "sparse_lds") o.sparse_lds = atoi(value);
 	else if (k == "streams") o.streams = atoi(value);
+	else if (k == "upload_threads") o.upload_threads = atoi(value);
 	else return fail(PGQ_ERR_INVALID_ARG, "unknown option: " + k);
 	return PGQ_OK;
 }

@@ -47,7 +47,6 @@ struct Options {
 	int force_mode = 0;     // 0 adaptive, 1 always push, 2 always pull (tests)
 	int force_pull = 0;     // 0 adaptive, 1 always k_pull_sparse, 2 always k_pull (tests)
 	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel
-	int cheapest_lanes = 64;
 	int relax_small_limit = 2048; // changed vertices at or below which relaxation rounds loop on the device
 	int trace = 0;          // per-level line on stderr
 	int probe = 1;          // destination probe before each expansion
@@ -105,8 +104,7 @@ struct pgq_csr {
 	// reverse CSR (in-neighbours), built on device at upload
 	int64_t *roff = nullptr; // V+1
 	int32_t *radj = nullptr; // E  source vertex of the in-edge
-	int64_t *rslot = nullptr; // E  forward slot of the in-edge (lazily built for shortestpath)
-	std::mutex lazy_lock;
+	int64_t *rslot = nullptr; // E  forward slot of the in-edge (path reconstruction)
 	// high in-degree vertices split into work items for the bottom-up kernel
 	pgq::HubItem *pull_hubs = nullptr; // device
 	int32_t *pull_hub_vertices = nullptr;

@@ -5,23 +5,30 @@
 //   * its batch driver IterativeLengthFunction  src/core/functions/scalar/iterativelength.cpp:34-143
 //   * the parent-tracking kernel + driver       src/core/functions/scalar/shortest_path.cpp:12-41, :43-207
 //
-// Design (DESIGN.md has the long form):
-//   * a batch holds L = 64*WD searches ("lanes"); a lane is one *distinct source vertex*, every (src,dst)
+// Design (DESIGN.md §3 has the long form and the measured numbers):
+//   * a batch holds L = 64*WD searches ("lanes", WD <= 32); a lane is one *distinct source vertex*, every (src,dst)
 //     pair with that source reads its answer from the lane (results are a pure function of (CSR,src,dst),
-//     SURVEY.md §8e).  State per vertex is WD contiguous 64-bit lane-words: seen[V][WD], frontier[V][WD].
-//   * a level is either TOP-DOWN (k_push: one wavefront per frontier vertex, one lane per out-neighbour,
-//     scalar loop over the non-empty lane-words; atomicOr into seen/next) or BOTTOM-UP (k_pull: one
-//     wavefront per vertex, WD adjacent lanes gather the WD contiguous lane-words of one in-neighbour, so a
-//     wave instruction fetches 64/WD full 8*WD-byte segments; no atomics, the `next &= ~seen; seen |= next`
-//     sweep of iterativelength.cpp:26-30 is fused in).  The host picks per level from the frontier's
-//     out-degree sum (direction-optimising BFS).
-//   * vertices whose (in-)degree exceeds `hub_chunk` are split into fixed-size work items.
+//     SURVEY.md §8e); pairs that cannot have a path (source without out-edges, destination without in-edges) are
+//     answered NULL without a lane.  State per vertex is WD contiguous 64-bit lane-words: seen[V][WD],
+//     frontier[V][WD], plus nz[V] = which of the WD words are non-empty.
+//   * a level is expanded TOP-DOWN (k_push: one wavefront per 256-out-edge work item, one lane per out-neighbour,
+//     scalar loop over the non-empty lane-words, atomicOr into seen/next), BOTTOM-UP DENSE (k_pull: one wavefront
+//     per vertex, WD adjacent lanes gather the WD contiguous lane-words of one in-neighbour — 64/WD full
+//     8*WD-byte segments per instruction, no atomics, the `next &= ~seen; seen |= next` sweep of
+//     iterativelength.cpp:26-30 fused in) or BOTTOM-UP SPARSE (k_compact_frontier + k_pull_sparse: frontier packed
+//     into a bit map + dense 16-byte records, recurrence organised by in-edge with an LDS accumulator, bit map and
+//     block bases resident in LDS when they fit).  The host picks per level from the frontier's out-degree sum and
+//     lane-word density.
+//   * vertices whose in-degree exceeds `hub_chunk` are split into slices (k_pull_hub*).
+//   * lengths come from destination probes (k_probe: is an in-neighbour of dst in the previous frontier?; k_probe2:
+//     two hops, for the last few open pairs) or, for cross-product shaped calls, from seen[dst] after the level
+//     exactly like iterativelength.cpp:119-129 (k_detect).  Stragglers of a wide batch are re-run in a narrow one.
+//   * independent batches are searched concurrently by worker threads on separate HIP streams.
 //   * shortestpath keeps every level's frontier bitmap instead of the reference's two 8 KiB/vertex parent
 //     arrays (shortest_path.cpp:82-83) and rebuilds each path backwards with the reference's tie-break:
 //     parent(x) = smallest frontier vertex of the previous level with an edge to x, edge = first CSR slot of
 //     that parent holding x (shortest_path.cpp:21-31) — i.e. the in-edge of x with the smallest forward slot
 //     whose source is in the previous frontier.
-//   * lengths are detected per pair each level from seen[dst] exactly like iterativelength.cpp:119-129.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -1047,7 +1054,7 @@ Workspace::~Workspace() {
 	if (stream) (void)hipStreamDestroy(stream);
 	if (h_cnt) (void)hipHostFree(h_cnt);
 	if (h_bstart) (void)hipHostFree(h_bstart);
-	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &active, &flag, &rank, &usrc, &key, &idx, &skey,
+	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
 	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords })

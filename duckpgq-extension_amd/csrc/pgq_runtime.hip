@@ -75,7 +75,6 @@ static int do_init(int device) {
 	env_int("PGQ_FORCE_MODE", g_opt.force_mode);
 	env_int("PGQ_FORCE_PULL", g_opt.force_pull);
 	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
-	env_int("PGQ_CHEAPEST_LANES", g_opt.cheapest_lanes);
 	env_int("PGQ_RELAX_SMALL_LIMIT", g_opt.relax_small_limit);
 	env_int("PGQ_TRACE", g_opt.trace);
 	env_int("PGQ_PROBE", g_opt.probe);
@@ -802,7 +801,6 @@ int pgq_set_option(const char *key, const char *value) {
 	else if (k == "force_mode") o.force_mode = atoi(value);
 	else if (k == "force_pull") o.force_pull = atoi(value);
 	else if (k == "blocks_per_cu") o.blocks_per_cu = atoi(value);
-	else if (k == "cheapest_lanes") o.cheapest_lanes = atoi(value);
 	else if (k == "relax_small_limit") o.relax_small_limit = atoi(value);
 	else if (k == "trace") o.trace = atoi(value);
 	else if (k == "probe") o.probe = atoi(value);

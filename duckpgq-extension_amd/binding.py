@@ -104,7 +104,8 @@ def load_udf():
     L.pgq_udf_create_csr_edge.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, Vec, Vec,
                                           Vec, C.POINTER(Vec), C.c_int, C.c_void_p, C.c_void_p]
     L.pgq_udf_bind_search.argtypes = [C.c_void_p, C.c_int32]
-    for f in ("pgq_udf_iterativelength", "pgq_udf_iterativelength2", "pgq_udf_cheapest_path_length",
+    for f in ("pgq_udf_iterativelength", "pgq_udf_iterativelength2", "pgq_udf_iterativelengthbidirectional",
+              "pgq_udf_cheapest_path_length",
               "pgq_udf_reachability"):
         getattr(L, f).argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, Vec, Vec, C.c_void_p, C.c_void_p]
     L.pgq_udf_shortestpath.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, Vec, Vec, C.c_void_p, C.c_void_p,
@@ -415,7 +416,8 @@ class PgqState:
     def iterativelength(self, csr_id, V, src, dst, src_valid=None, src_sel=None, dst_sel=None, variant=1):
         n = len(src_sel) if src_sel is not None else len(src)
         out = np.zeros(n, dtype=np.int64)
-        fn = self.U.pgq_udf_iterativelength if variant == 1 else self.U.pgq_udf_iterativelength2
+        fn = {1: self.U.pgq_udf_iterativelength, 2: self.U.pgq_udf_iterativelength2,
+              3: self.U.pgq_udf_iterativelengthbidirectional}[variant]
         ok = self._search(fn, csr_id, V, src, dst, src_valid, src_sel, dst_sel, None, out)
         return out, ok
 

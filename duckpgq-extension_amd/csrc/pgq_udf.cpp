@@ -267,6 +267,11 @@ int pgq_udf_iterativelength2(pgq_state_t *s, int32_t id, int64_t V, int64_t n, p
 	return pgq_udf_iterativelength(s, id, V, n, src, dst, out, out_valid);
 }
 
+int pgq_udf_iterativelengthbidirectional(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
+                                         int64_t *out, uint64_t *out_valid) {
+	return pgq_udf_iterativelength(s, id, V, n, src, dst, out, out_valid);
+}
+
 int pgq_udf_shortestpath(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                          uint64_t *out_offset, uint64_t *out_length, uint64_t *out_valid, const int64_t **out_child,
                          uint64_t *out_child_len) {

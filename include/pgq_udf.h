@@ -11,6 +11,7 @@
  *   pgq_udf_bind_search             IterativeLengthBind          src/core/functions/function_data/iterative_length_function_data.cpp:18-30
  *   pgq_udf_iterativelength         IterativeLengthFunction      src/core/functions/scalar/iterativelength.cpp:34-143
  *   pgq_udf_iterativelength2        IterativeLength2Function     src/core/functions/scalar/iterativelength2.cpp:33-130 (same results)
+ *   pgq_udf_iterativelengthbidirectional  IterativeLengthBidirectionalFunction  src/core/functions/scalar/iterativelength_bidirectional.cpp:43-153 (intended semantics)
  *   pgq_udf_shortestpath            ShortestPathFunction         src/core/functions/scalar/shortest_path.cpp:43-207
  *   pgq_udf_bind_cheapest           CheapestPathLengthBind       src/core/functions/function_data/cheapest_path_length_function_data.cpp:7-32
  *   pgq_udf_cheapest_path_length    CheapestPathLengthFunction   src/core/functions/scalar/cheapest_path_length.cpp:138-163
@@ -51,6 +52,12 @@ int pgq_udf_iterativelength(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq
                             int64_t *out, uint64_t *out_valid);
 int pgq_udf_iterativelength2(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                              int64_t *out, uint64_t *out_valid);
+/* iterativelengthbidirectional(id, V, src, dst) -> BIGINT (src/core/functions/scalar/iterativelength_bidirectional.cpp:43-153).
+ * The reference alternates a source-side and a destination-side BFS but indexes its inputs through a uint8_t* and
+ * walks the forward CSR on the destination side: untested, parity unpinned.  What it intends to
+ * return is the hop count, which is what this entry point returns (same values as pgq_udf_iterativelength). */
+int pgq_udf_iterativelengthbidirectional(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
+                                         int64_t *out, uint64_t *out_valid);
 int pgq_udf_shortestpath(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                          uint64_t *out_offset, uint64_t *out_length, uint64_t *out_valid, const int64_t **out_child,
                          uint64_t *out_child_len);
@@ -58,7 +65,9 @@ int pgq_udf_shortestpath(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq_ve
 int pgq_udf_bind_cheapest(pgq_state_t *, int32_t id, int *ret_type);
 int pgq_udf_cheapest_path_length(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                                  void *out, uint64_t *out_valid);
-/* boolean reachability with the semantics the reference intends (reachability.cpp:165-254 indexes its inputs
+/* reachability(id, is_variant, V, src, dst) -> BOOL; the reference's BOOL argument only selects one of its three
+ * internal BFS modes (reachability.cpp:154-163) and does not change the result, so it is not part of this call.
+ * Boolean reachability with the semantics the reference intends (reachability.cpp:165-254 indexes its inputs
  * through a uint8_t* and has no test: parity unpinned): out[i] = 1 iff a path exists
  * (src == dst counts as reachable). */
 int pgq_udf_reachability(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,

@@ -99,8 +99,9 @@ def test_null_selection_and_reachability():
     assert lens(ln, ok) == [2, 3, 3, 1, 0]
     r, rok = st.reachability(0, V, src, dst, src_valid=valid)
     assert r.tolist() == [True, False, True, True, False] and rok.tolist() == [True, False, True, True, True]
-    ln2, ok2 = st.iterativelength(0, V, src, dst, src_valid=valid, variant=2)
-    assert (ln2 == ln_ref(ora, V, src, dst, valid)[0]).all()
+    for variant in (2, 3):  # iterativelength2 / iterativelengthbidirectional surfaces: same hop counts
+        ln2, ok2 = st.iterativelength(0, V, src, dst, src_valid=valid, variant=variant)
+        assert (ln2 == ln_ref(ora, V, src, dst, valid)[0]).all()
 
 
 def ln_ref(ora, V, src, dst, valid):

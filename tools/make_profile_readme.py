@@ -87,6 +87,13 @@ L += ["", "## Optimisation history on the default workload (8192 pairs, ms per c
       "| + finer top-down items, contention-free packing | 6.5 | |",
       "| + owner index per in-edge (no binary search), 2048-lane batches (WD=32) | 5.5 | the sparse kernel is issue-bound: fewer instructions, better lane use |",
       "| + two-hop destination probe | 4.1 | distance-4 pairs answered from the level-2 frontier: no straggler pass |",
-      "| + top-down level without the shared queue counter | 3.6 | ~10^4 serialised atomicAdds per launch removed |", ""]
+      "| + top-down level without the shared queue counter | 3.6 | ~10^4 serialised atomicAdds per launch removed |", "",
+      "R-MAT-22 (1024 pairs): 117 ms (first version, one wavefront per vertex dealt round-robin: R-MAT's id/degree "
+      "correlation left a few wavefronts with all hubs) -> 12.1 ms (edge-balanced work parts, dead-destination marking) "
+      "-> 6.9 ms (no lanes for pairs that cannot have a path: 1024 pairs -> 220 lanes, WD=4) -> 3.5 ms on the sweep's "
+      "pair set / 8.7 ms on bench.py's (two-hop probe, contention-free hub statistics).",
+      "shortestpath on SF100 (4096 pairs, full [v,e,...] reconstruction): 8.1 -> 3.7 ms (sparse level 2, straggler "
+      "deferral with path append).  cheapest_path_length on the 2^24-vertex reply forest (4096 pairs): 35.5 -> 4.6 ms "
+      "(device-side rounds for small frontiers, no lanes for unreachable pairs).", ""]
 open(os.path.join(root, "profiles", "README.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[:30]))

@@ -1734,6 +1734,17 @@ void pgq_thread_release(void) {
 	t_child.shrink_to_fit();
 }
 
+int pgq_release_cached_memory(void) {
+	PGQ_TRY(ensure_init());
+	std::vector<Workspace *> drop;
+	{
+		std::lock_guard<std::mutex> g(g_ws_lock);
+		drop.swap(g_ws_free);
+	}
+	for (Workspace *w : drop) delete w;
+	return PGQ_OK;
+}
+
 int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t *d_out_len) {
 	PGQ_TRY(ensure_init());

@@ -80,6 +80,7 @@ def load_hip():
     L.pgq_cheapest_path_length_bulk_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_void_p]
     L.pgq_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    L.pgq_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
     L.pgq_get_stats.argtypes = [C.POINTER(Stats)]
     L.pgq_measure_copy_bandwidth.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_double)]
     _hip = L
@@ -159,6 +160,12 @@ def make_vec(data, sel=None, valid=None, keep=None):
 
 def set_option(key, value):
     _check(load_hip().pgq_set_option(str(key).encode(), str(value).encode()))
+
+
+def get_option(key):
+    v = C.c_double(0.0)
+    _check(load_hip().pgq_get_option(str(key).encode(), C.byref(v)))
+    return v.value
 
 
 def kclass_names():

@@ -56,8 +56,10 @@ struct Options {
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
 	int part_weight = 1024; // in-edges (+8 per vertex) per bottom-up work part
 	int upload_threads = 2;  // host threads staging a pageable CSR through pinned rings
-	int streams = 2;        // batches searched concurrently (one host thread + HIP stream each)
+	int streams = 3;        // batches searched concurrently (one host thread + HIP stream each)
 	int sparse_lds = 1;     // keep the 1-bit frontier map in LDS when it fits (1024-thread workgroups)
+	int sparse_spill = 3;   // accumulate trips after which k_pull_sparse spreads the remaining words over the wavefront
+	int sparse_pw = 1;      // packed words per chunk fetched per accumulate trip in k_pull_sparse (1..3)
 	int sparse_unroll = 4;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 };

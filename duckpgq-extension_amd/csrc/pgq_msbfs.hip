@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 // the packed words that are non-empty there AND still wanted by the entry's owner vertex, OR-ing them into the
 // owner's row of an LDS accumulator (ds_or_b64).  seen/next rows of a part are contiguous -> coalesced
 // prologue/epilogue.  Same results as k_pull (next = OR of in-neighbours' frontier words & active & ~seen).
-template <int WD, int UN, int WPB>
+template <int WD, int UN, int WPB, int PW>
 __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                           const uint8_t *__restrict__ rown,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ parts,
@@ -533,12 +533,15 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
                                                      const FrontMeta *__restrict__ meta, const u64 *__restrict__ cw,
                                                      u64 *__restrict__ seen, u64 *__restrict__ next,
                                                      u32 *__restrict__ nz_next, const u64 *__restrict__ active,
-                                                     int lds_bit_words, int stop_limit, Counters *__restrict__ cnt) {
+                                                     int lds_bit_words, int spill_after, int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NV = 16; // vertices per part (host-built parts never hold more)
 	__shared__ u64 s_acc[WPB][NV * WD];
 	__shared__ u32 s_want[WPB][NV];
 	__shared__ u32 s_nzn[WPB][NV];
 	__shared__ u64 red[WPB][5];
+	constexpr int QCAP = 128; // spill queue entries per wavefront
+	__shared__ u32 s_queue[WPB][QCAP];
+	static_assert(NV * WD <= 512 && UN <= 4, "spill descriptor layout");
 	// WPB == 16: the 1-bit frontier map (V/8 bytes) and the per-64-vertex record bases (V/16 bytes) live in LDS
 	extern __shared__ u32 s_dyn[];
 	u32 *s_bits = s_dyn;
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 	u64 *acc = s_acc[wib];
 	u32 *wantm = s_want[wib];
 	u32 *nzn = s_nzn[wib];
+	u32 *queue = s_queue[wib];
 	const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nwaves = (gridDim.x * blockDim.x) >> 6;
 	u64 nf = 0, mf = 0, scanned = 0, gath = 0, nwords = 0;
@@ -563,6 +567,14 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 		const int v0 = parts[2 * p], v1 = parts[2 * p + 1];
 		const int nv = v1 - v0;
 		const int64_t e0 = roff[v0], e1 = roff[v1];
+		// first adjacency entries requested ahead of the prologue's own loads
+		int nbn[UN], ownn[UN];
+#pragma unroll
+		for (int k = 0; k < UN; k++) {
+			const int64_t e = e0 + 64 * k + lane;
+			nbn[k] = e < e1 ? radj[e] : -1;
+			ownn[k] = e < e1 ? (int)rown[e] : 0; // owner row inside the part, precomputed at upload
+		}
 		// -- prologue: row starts, wanted-word masks, zeroed accumulator
 		if (lane < NV) {
 			wantm[lane] = 0;
@@ -582,9 +594,17 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 			bool hot[UN];
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
-				const int64_t e = base + 64 * k + lane;
-				nb[k] = e < e1 ? radj[e] : -1;
-				own[k] = e < e1 ? (int)rown[e] : 0; // owner row inside the part, precomputed at upload
+				nb[k] = nbn[k];
+				own[k] = ownn[k];
+			}
+			// the next trip's adjacency entries are requested before this trip's dependent fetches are waited for
+			if (base + 64 * UN < e1) {
+#pragma unroll
+				for (int k = 0; k < UN; k++) {
+					const int64_t e = base + 64 * UN + 64 * k + lane;
+					nbn[k] = e < e1 ? radj[e] : -1;
+					ownn[k] = e < e1 ? (int)rown[e] : 0;
+				}
 			}
 #pragma unroll
 			for (int k = 0; k < UN; k++) hot[k] = nb[k] >= 0 && ((bt[nb[k] >> 5] >> (nb[k] & 31)) & 1u);
@@ -599,18 +619,92 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 					mt[k] = meta[bb[blk] + (u32)__popcll(bw & ((1ull << (nb[k] & 63)) - 1ull))];
 				}
 			}
+			u32 m[UN], anym = 0;
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
-				if (mt[k].nz == 0) continue;
-				const int lo = own[k];
-				u32 m = mt[k].nz & wantm[lo];
-				while (m) {
-					const int w = __ffs((int)m) - 1;
-					m &= m - 1;
-					const int r = __popc(mt[k].nz & ((1u << w) - 1u));
-					const u64 val = r == 0 ? mt[k].w0 : cw[mt[k].base + r - 1];
-					atomicOr(&acc[lo * WD + w], val);
-					gath++;
+				m[k] = mt[k].nz ? (mt[k].nz & wantm[own[k]]) : 0u;
+				gath += (u64)__popc(m[k]);
+				anym |= m[k];
+			}
+			// PW wanted words of every chunk per trip: the UN x PW packed-word fetches of a trip are all in flight
+			// before the first is waited for (a per-chunk, per-word loop paid one L2 round trip per word: measured
+			// 4.40 -> 3.02 ms of kernel time per bench step at UN = 4, PW = 2)
+			auto trip = [&]() {
+				u64 val[UN * PW];
+				int idx[UN * PW];
+#pragma unroll
+				for (int k = 0; k < UN; k++) {
+#pragma unroll
+					for (int j = 0; j < PW; j++) {
+						idx[k * PW + j] = -1;
+						val[k * PW + j] = 0;
+						if (m[k]) {
+							const int w = __ffs((int)m[k]) - 1;
+							m[k] &= m[k] - 1;
+							const int r = __popc(mt[k].nz & ((1u << w) - 1u));
+							idx[k * PW + j] = own[k] * WD + w;
+							val[k * PW + j] = r == 0 ? mt[k].w0 : cw[mt[k].base + r - 1];
+						}
+					}
+				}
+				anym = 0;
+#pragma unroll
+				for (int k = 0; k < UN; k++) {
+#pragma unroll
+					for (int j = 0; j < PW; j++)
+						if (idx[k * PW + j] >= 0) atomicOr(&acc[idx[k * PW + j]], val[k * PW + j]);
+					anym |= m[k];
+				}
+			};
+			int trips = 0;
+			while (trips < spill_after && __any(anym != 0)) {
+				trip();
+				trips++;
+			}
+			// The word counts have a long tail (SF100 level 2: 2.5 wanted words per hot entry on average, 10.7 for the
+			// fullest of 256), so after spill_after trips most lanes idle while a few still hold many words.  What is
+			// left is spread over the whole wavefront: every lane writes a 4-byte descriptor per remaining word into a
+			// per-wave LDS queue (position = exclusive prefix sum of the counts), then lane j serves descriptor j.
+			if (__any(anym != 0)) {
+				u32 c = 0;
+#pragma unroll
+				for (int k = 0; k < UN; k++) c += (u32)__popc(m[k]);
+				u32 incl = c;
+#pragma unroll
+				for (int o = 1; o < 64; o <<= 1) {
+					const u32 t = __shfl_up(incl, o);
+					if (lane >= o) incl += t;
+				}
+				const u32 total = __shfl(incl, 63);
+				if (trips > 0 && total <= (u32)QCAP) {
+					u32 pos = incl - c;
+#pragma unroll
+					for (int k = 0; k < UN; k++) {
+						u32 mm = m[k];
+						while (mm) { // descriptor: accumulator index | source lane << 9 | chunk << 15 | word rank << 17
+							const int w = __ffs((int)mm) - 1;
+							mm &= mm - 1;
+							const u32 r = (u32)__popc(mt[k].nz & ((1u << w) - 1u)); // >= 1: the inline word went in trip 1
+							queue[pos++] = (u32)(own[k] * WD + w) | ((u32)lane << 9) | ((u32)k << 15) | (r << 17);
+						}
+						m[k] = 0;
+					}
+					__builtin_amdgcn_wave_barrier();
+					for (u32 jb = 0; jb < total; jb += 64) {
+						const bool on = jb + lane < total;
+						const u32 d = on ? queue[jb + lane] : 0u;
+						const int sl = (int)((d >> 9) & 63u), kk = (int)((d >> 15) & 3u);
+						u32 cbase = 0;
+#pragma unroll
+						for (int k = 0; k < UN; k++) {
+							const u32 t = (u32)__shfl((int)mt[k].base, sl);
+							if (k == kk) cbase = t;
+						}
+						if (on) atomicOr(&acc[d & 511u], cw[cbase + (d >> 17) - 1u]);
+					}
+					__builtin_amdgcn_wave_barrier();
+				} else {
+					while (__any(anym != 0)) trip();
 				}
 			}
 			scanned += (u64)min((int64_t)(64 * UN), e1 - base);
@@ -1371,9 +1465,9 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					// graphs whose frontier bit map + block bases fit in LDS beside the accumulators run 1024-thread
 					// workgroups that keep them there (SF100: 56 KB + 28 KB)
 					const size_t dyn_bytes = (size_t)bit_words * 4 + (size_t)bit_words * 2;
-#define PGQ_LAUNCH_SPARSE(UNR)                                                                                         \
+#define PGQ_LAUNCH_SPARSE(UNR, VR)                                                                                       \
 	do {                                                                                                               \
-		auto kfn = k_pull_sparse<WD, UNR, 16>;                                                                         \
+		auto kfn = k_pull_sparse<WD, UNR, 16, VR>;                                                                            \
 		static size_t static_lds = 0;                                                                                  \
 		if (!static_lds) {                                                                                             \
 			hipFuncAttributes fa;                                                                                      \
@@ -1390,17 +1484,25 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			hipLaunchKernelGGL(kfn, dim3(ncu), dim3(1024), dyn_bytes, st, c->roff, c->radj, c->rown, c->off, c->pull_parts,      \
 			                   c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(), ws->cmeta.as<FrontMeta>(),  \
 			                   ws->cwords.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(),        \
-			                   act_cur, bit_words, stop, d_cnt);                                                       \
+			                   act_cur, bit_words, opt.sparse_spill, stop, d_cnt);                                     \
 		} else {                                                                                                       \
-			hipLaunchKernelGGL((k_pull_sparse<WD, UNR, 4>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj,       \
+			hipLaunchKernelGGL((k_pull_sparse<WD, UNR, 4, VR>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj,       \
 			                   c->rown, c->off, c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(),      \
 			                   ws->cmeta.as<FrontMeta>(), ws->cwords.as<u64>(), ws->seen.as<u64>(),                    \
-			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, bit_words, stop, d_cnt);                \
+			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, bit_words, opt.sparse_spill, stop, d_cnt); \
 		}                                                                                                              \
 	} while (0)
-					if (opt.sparse_unroll >= 4) PGQ_LAUNCH_SPARSE(4);
-					else if (opt.sparse_unroll >= 2) PGQ_LAUNCH_SPARSE(2);
-					else PGQ_LAUNCH_SPARSE(1);
+					const int pw = std::max(1, std::min(3, opt.sparse_pw));
+					if (opt.sparse_unroll >= 4) {
+						if (pw == 1) PGQ_LAUNCH_SPARSE(4, 1);
+						else if (pw == 2) PGQ_LAUNCH_SPARSE(4, 2);
+						else PGQ_LAUNCH_SPARSE(4, 3);
+					} else if (opt.sparse_unroll >= 2) {
+						if (pw == 1) PGQ_LAUNCH_SPARSE(2, 1);
+						else PGQ_LAUNCH_SPARSE(2, 2);
+					} else {
+						PGQ_LAUNCH_SPARSE(1, 2);
+					}
 #undef PGQ_LAUNCH_SPARSE
 					kt.stop();
 				} else {

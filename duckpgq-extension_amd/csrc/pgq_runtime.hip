@@ -86,6 +86,8 @@ static int do_init(int device) {
 	env_double("PGQ_SPARSE_BELOW", g_opt.sparse_below);
 	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
 	env_int("PGQ_SPARSE_LDS", g_opt.sparse_lds);
+	env_int("PGQ_SPARSE_PW", g_opt.sparse_pw);
+	env_int("PGQ_SPARSE_SPILL", g_opt.sparse_spill);
 	env_int("PGQ_STREAMS", g_opt.streams);
 	env_int("PGQ_UPLOAD_THREADS", g_opt.upload_threads);
 	g_inited.store(1);
@@ -788,34 +790,67 @@ int64_t pgq_csr_num_edges(const pgq_csr_t *csr) { return csr ? csr->E : -1; }
 int pgq_csr_w_type(const pgq_csr_t *csr) { return csr ? csr->w_type : -1; }
 int64_t pgq_csr_device_bytes(const pgq_csr_t *csr) { return csr ? csr->bytes : -1; }
 
+} // extern "C"
+
+namespace {
+// one table for pgq_set_option / pgq_get_option
+struct OptRef {
+	const char *name;
+	int *i;
+	double *d;
+};
+std::vector<OptRef> option_table() {
+	Options &o = options();
+	return {
+		{ "words", &o.words, nullptr },
+		{ "max_words", &o.max_words, nullptr },
+		{ "push_div", nullptr, &o.push_div },
+		{ "profile", &o.profile, nullptr },
+		{ "hub_chunk", &o.hub_chunk, nullptr },
+		{ "push_chunk", &o.push_chunk, nullptr },
+		{ "force_mode", &o.force_mode, nullptr },
+		{ "force_pull", &o.force_pull, nullptr },
+		{ "blocks_per_cu", &o.blocks_per_cu, nullptr },
+		{ "relax_small_limit", &o.relax_small_limit, nullptr },
+		{ "trace", &o.trace, nullptr },
+		{ "probe", &o.probe, nullptr },
+		{ "defer", &o.defer, nullptr },
+		{ "probe2", &o.probe2, nullptr },
+		{ "probe2_cap", &o.probe2_cap, nullptr },
+		{ "probe2_div", &o.probe2_div, nullptr },
+		{ "part_weight", &o.part_weight, nullptr },
+		{ "sparse_below", nullptr, &o.sparse_below },
+		{ "sparse_unroll", &o.sparse_unroll, nullptr },
+		{ "sparse_lds", &o.sparse_lds, nullptr },
+		{ "sparse_pw", &o.sparse_pw, nullptr },
+		{ "sparse_spill", &o.sparse_spill, nullptr },
+		{ "streams", &o.streams, nullptr },
+		{ "upload_threads", &o.upload_threads, nullptr },
+	};
+}
+} // namespace
+
+extern "C" {
+
 int pgq_set_option(const char *key, const char *value) {
 	if (!key || !value) return fail(PGQ_ERR_INVALID_ARG, "NULL option");
-	std::string k(key);
-	Options &o = options();
-	if (k == "words") o.words = atoi(value);
-	else if (k == "max_words") o.max_words = atoi(value);
-	else if (k == "push_div") o.push_div = atof(value);
-	else if (k == "profile") o.profile = atoi(value);
-	else if (k == "hub_chunk") o.hub_chunk = atoi(value);
-	else if (k == "push_chunk") o.push_chunk = atoi(value);
-	else if (k == "force_mode") o.force_mode = atoi(value);
-	else if (k == "force_pull") o.force_pull = atoi(value);
-	else if (k == "blocks_per_cu") o.blocks_per_cu = atoi(value);
-	else if (k == "relax_small_limit") o.relax_small_limit = atoi(value);
-	else if (k == "trace") o.trace = atoi(value);
-	else if (k == "probe") o.probe = atoi(value);
-	else if (k == "defer") o.defer = atoi(value);
-	else if (k == "probe2") o.probe2 = atoi(value);
-	else if (k == "probe2_cap") o.probe2_cap = atoi(value);
-	else if (k == "probe2_div") o.probe2_div = atoi(value);
-	else if (k == "part_weight") o.part_weight = atoi(value);
-	else if (k == "sparse_below") o.sparse_below = atof(value);
-	else if (k == "sparse_unroll") o.sparse_unroll = atoi(value);
-	else if (k == "sparse_lds") o.sparse_lds = atoi(value);
-	else if (k == "streams") o.streams = atoi(value);
-	else if (k == "upload_threads") o.upload_threads = atoi(value);
-	else return fail(PGQ_ERR_INVALID_ARG, "unknown option: " + k);
-	return PGQ_OK;
+	for (const OptRef &r : option_table()) {
+		if (strcmp(r.name, key) != 0) continue;
+		if (r.i) *r.i = atoi(value);
+		else *r.d = atof(value);
+		return PGQ_OK;
+	}
+	return fail(PGQ_ERR_INVALID_ARG, std::string("unknown option: ") + key);
+}
+
+int pgq_get_option(const char *key, double *value) {
+	if (!key || !value) return fail(PGQ_ERR_INVALID_ARG, "NULL option");
+	for (const OptRef &r : option_table()) {
+		if (strcmp(r.name, key) != 0) continue;
+		*value = r.i ? (double)*r.i : *r.d;
+		return PGQ_OK;
+	}
+	return fail(PGQ_ERR_INVALID_ARG, std::string("unknown option: ") + key);
 }
 
 const char *pgq_kclass_name(int k) {

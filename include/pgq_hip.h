@@ -143,6 +143,8 @@ int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_
 /* Knobs (also readable from the environment at pgq_init: PGQ_WORDS, PGQ_PUSH_DIV, PGQ_PROFILE ...).
  * key/value strings; returns PGQ_ERR_INVALID_ARG for unknown keys. */
 int pgq_set_option(const char *key, const char *value);
+/* Current value of a knob (integers are returned as doubles). */
+int pgq_get_option(const char *key, double *value);
 
 /* Per-thread counters of the searches run since the last reset, and per-kernel-class HIP-event time
  * (only accumulated while option "profile" = "1"). */

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--force_pull", default="0")
     ap.add_argument("--sparse_unroll", default="4")
     ap.add_argument("--sparse_lds", default="1")
+    ap.add_argument("--sparse_pw", default="2")
+    ap.add_argument("--extra", default="", help="key=value[,key=value] options set once")
     ap.add_argument("--streams", default="2")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--trace", type=int, default=0)
@@ -61,16 +63,21 @@ def main():
     print("TE=%d reachable=%d mean_len=%.2f" % (te, int((ref >= 0).sum()), ref[ref > 0].mean()), flush=True)
     print("copy bw GB/s:", pgq.copy_bandwidth_gbps(1 << 30, 5), flush=True)
     pgq.set_option("profile", 1)
+    for kv in [x for x in a.extra.split(",") if x]:
+        k, v = kv.split("=")
+        pgq.set_option(k, float(v) if "." in v else int(v))
     pgq.set_option("trace", a.trace)
     with open(a.out, "a") as f:
         for mode in [int(x) for x in a.modes.split(",")]:
             for bpc, nstr in [(int(x), int(y)) for x in a.bpc.split(",") for y in a.streams.split(",")]:
+              for mw in [0]:
                 pgq.set_option("streams", nstr)
                 for words in [int(x) for x in a.words.split(",")]:
                   for dfr in [int(x) for x in a.defer.split(",")]:
                    for fp in [int(x) for x in a.force_pull.split(",")]:
-                    for pd_, su in [(float(x), int(y)) for x in a.push_div.split(",") for y in a.sparse_unroll.split(",")]:
+                    for pd_, su, sv in [(float(x), int(y), int(z)) for x in a.push_div.split(",") for y in a.sparse_unroll.split(",") for z in a.sparse_pw.split(",")]:
                         pgq.set_option("sparse_unroll", su)
+                        pgq.set_option("sparse_pw", sv)
                         pgq.set_option("sparse_lds", int(a.sparse_lds))
                         pgq.set_option("defer", dfr)
                         pgq.set_option("force_pull", fp)
@@ -90,7 +97,7 @@ def main():
                                 best = (dt, pgq.get_stats())
                         okk = bool((d_out.cpu().numpy() == ref).all())
                         dt, st = best
-                        row = {"graph": a.graph, "pairs": a.pairs, "words": words, "push_div": pd_, "mode": mode, "defer": dfr, "force_pull": fp, "sparse_unroll": su,
+                        row = {"graph": a.graph, "pairs": a.pairs, "words": words, "push_div": pd_, "mode": mode, "defer": dfr, "force_pull": fp, "sparse_unroll": su, "sparse_pw": sv, "extra": a.extra,
                                "bpc": bpc, "streams": nstr, "ms": dt * 1e3, "mteps": te / dt / 1e6, "pairs_per_s": a.pairs / dt,
                                "match": okk, "levels": st["levels"], "push": st["push_levels"],
                                "pull": st["pull_levels"], "kernel_ms": st["kernel_ms"],

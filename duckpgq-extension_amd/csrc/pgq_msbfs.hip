@@ -439,13 +439,14 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 // [V][WD] frontier array wastes a 128-byte fabric fetch per 8-byte word (measured: 2.8 GB fetched for 0.19 GB
 // of words at SF100 level 2).  The frontier is therefore first packed:
 //   bits[v/32]  1 bit per vertex "has any lane-word"      (V/8 bytes: L1/L2 resident)
-//   meta[v]     {non-empty-word mask, offset into cw, first non-empty word}   (only valid where the bit is set)
-//   cw[]        the 2nd.. non-empty lane-words back to back (L2 resident)
-struct __attribute__((aligned(16))) FrontMeta {
+//   meta[]      dense 32-byte records {non-empty-word mask, offset into cw, first three non-empty words}
+//   cw[]        the 4th.. non-empty lane-words back to back (L2 resident)
+struct __attribute__((aligned(32))) FrontMeta {
 	u32 nz;   // non-empty-word mask
-	u32 base; // offset of the 2nd.. non-empty words in cw
-	u64 w0;   // first non-empty word inline: single-word vertices (the common case) cost one 16-byte request
+	u32 base; // offset of the 4th.. non-empty words in cw
+	u64 w[3]; // first three non-empty words inline: 86 % of the hot in-edges at SF100 level 2 need no second fetch
 };
+constexpr int kInlineWords = 3;
 
 template <int WD>
 __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict__ nz, const u64 *__restrict__ front,
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 	for (int64_t v = v0 + lane; v < v1; v += 64) {
 		const u32 m = v < V ? nz[v] : 0u;
 		if (m) {
-			myw += (u32)__popc(m) - 1u;
+			myw += (u32)max((int)__popc(m) - kInlineWords, 0);
 			myv += 1u;
 		}
 	}
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 		}
 		if (lane == 32) bits[(vb >> 5) + 1] = (u32)(any >> 32);
 		if (!any) continue;
-		const u32 c = m ? (u32)__popc(m) - 1u : 0u; // words beyond the first go to cw
+		const u32 c = (u32)max((int)__popc(m) - kInlineWords, 0); // words beyond the inline ones go to cw
 		u32 incl = c;
 		for (int o = 1; o < 64; o <<= 1) {
 			const u32 t = __shfl_up(incl, o);
@@ -504,8 +505,16 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
 		wrun += __shfl(incl, 63);
 		if (m) {
 			const u32 slot = vrun + (u32)__popcll(any & ((1ull << lane) - 1ull));
-			u32 rest = m & (m - 1);
-			meta[slot] = FrontMeta{ m, base, front[(size_t)v * WD + (__ffs((int)m) - 1)] };
+			FrontMeta rec;
+			rec.nz = m;
+			rec.base = base;
+			u32 rest = m;
+#pragma unroll
+			for (int r = 0; r < kInlineWords; r++) {
+				rec.w[r] = rest ? front[(size_t)v * WD + (__ffs((int)rest) - 1)] : 0ull;
+				rest &= rest - 1;
+			}
+			meta[slot] = rec;
 			u32 k = 0;
 			while (rest) {
 				const int w = __ffs((int)rest) - 1;
@@ -567,14 +576,39 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 		const int v0 = parts[2 * p], v1 = parts[2 * p + 1];
 		const int nv = v1 - v0;
 		const int64_t e0 = roff[v0], e1 = roff[v1];
-		// first adjacency entries requested ahead of the prologue's own loads
-		int nbn[UN], ownn[UN];
+		// In-adjacency entries of a trip: UN == 4 reads them as one aligned 16-byte group (+ one 4-byte group of owner
+		// rows) per lane — entry (lane, k) is slot base + 4*lane + k —, otherwise entry (lane, k) is base + 64*k + lane.
+		// The first trip is requested ahead of the prologue's own loads.
+		const int64_t eb0 = UN == 4 ? (e0 & ~3ll) : e0;
+		int nbn[UN];
+		u32 ownn[UN];
+		auto fetch_adj = [&](int64_t base) {
+			if constexpr (UN == 4) {
+				const int64_t e = base + 4 * lane;
+				int4 v = make_int4(-1, -1, -1, -1);
+				u32 o = 0;
+				if (e < e1) { // may run up to 3 entries past e1: both arrays are padded
+					v = *reinterpret_cast<const int4 *>(radj + e);
+					o = *reinterpret_cast<const u32 *>(rown + e);
+				}
+				nbn[0] = (e >= e0 && e < e1) ? v.x : -1;
+				nbn[1] = (e + 1 >= e0 && e + 1 < e1) ? v.y : -1;
+				nbn[2] = (e + 2 >= e0 && e + 2 < e1) ? v.z : -1;
+				nbn[3] = (e + 3 >= e0 && e + 3 < e1) ? v.w : -1;
+				ownn[0] = o & 255u;
+				ownn[1] = (o >> 8) & 255u;
+				ownn[2] = (o >> 16) & 255u;
+				ownn[3] = o >> 24;
+			} else {
 #pragma unroll
-		for (int k = 0; k < UN; k++) {
-			const int64_t e = e0 + 64 * k + lane;
-			nbn[k] = e < e1 ? radj[e] : -1;
-			ownn[k] = e < e1 ? (int)rown[e] : 0; // owner row inside the part, precomputed at upload
-		}
+				for (int k = 0; k < UN; k++) {
+					const int64_t e = base + 64 * k + lane;
+					nbn[k] = e < e1 ? radj[e] : -1;
+					ownn[k] = e < e1 ? (u32)rown[e] : 0u; // owner row inside the part, precomputed at upload
+				}
+			}
+		};
+		fetch_adj(eb0);
 		// -- prologue: row starts, wanted-word masks, zeroed accumulator
 		if (lane < NV) {
 			wantm[lane] = 0;
@@ -589,23 +623,16 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 		}
 		__builtin_amdgcn_wave_barrier();
 		// -- one in-edge per lane
-		for (int64_t base = e0; base < e1; base += 64 * UN) {
+		for (int64_t base = eb0; base < e1; base += 64 * UN) {
 			int nb[UN], own[UN];
 			bool hot[UN];
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
 				nb[k] = nbn[k];
-				own[k] = ownn[k];
+				own[k] = (int)ownn[k];
 			}
 			// the next trip's adjacency entries are requested before this trip's dependent fetches are waited for
-			if (base + 64 * UN < e1) {
-#pragma unroll
-				for (int k = 0; k < UN; k++) {
-					const int64_t e = base + 64 * UN + 64 * k + lane;
-					nbn[k] = e < e1 ? radj[e] : -1;
-					ownn[k] = e < e1 ? (int)rown[e] : 0;
-				}
-			}
+			if (base + 64 * UN < e1) fetch_adj(base + 64 * UN);
 #pragma unroll
 			for (int k = 0; k < UN; k++) hot[k] = nb[k] >= 0 && ((bt[nb[k] >> 5] >> (nb[k] & 31)) & 1u);
 			// all UN record fetches are issued before any is consumed (independent 16-byte requests in flight)
@@ -619,16 +646,25 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 					mt[k] = meta[bb[blk] + (u32)__popcll(bw & ((1ull << (nb[k] & 63)) - 1ull))];
 				}
 			}
+			// The first three non-empty words of a neighbour travel inside its record: they are OR-ed straight-line, no
+			// second fetch (SF100 level 2: 86 % of the hot entries hold <= 3 words).
 			u32 m[UN], anym = 0;
 #pragma unroll
 			for (int k = 0; k < UN; k++) {
 				m[k] = mt[k].nz ? (mt[k].nz & wantm[own[k]]) : 0u;
 				gath += (u64)__popc(m[k]);
+				u32 rest = mt[k].nz;
+#pragma unroll
+				for (int r = 0; r < kInlineWords; r++) {
+					const u32 low = rest & (0u - rest);
+					if (m[k] & low) atomicOr(&acc[own[k] * WD + (__ffs((int)low) - 1)], mt[k].w[r]);
+					rest ^= low;
+				}
+				m[k] &= rest; // what is left has word rank >= 3 and lives in cw
 				anym |= m[k];
 			}
-			// PW wanted words of every chunk per trip: the UN x PW packed-word fetches of a trip are all in flight
-			// before the first is waited for (a per-chunk, per-word loop paid one L2 round trip per word: measured
-			// 4.40 -> 3.02 ms of kernel time per bench step at UN = 4, PW = 2)
+			// Fallback for the words beyond the inline ones: one word of every chunk per trip, all cw fetches of a trip
+			// in flight before the first is waited for.
 			auto trip = [&]() {
 				u64 val[UN * PW];
 				int idx[UN * PW];
@@ -643,7 +679,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 							m[k] &= m[k] - 1;
 							const int r = __popc(mt[k].nz & ((1u << w) - 1u));
 							idx[k * PW + j] = own[k] * WD + w;
-							val[k * PW + j] = r == 0 ? mt[k].w0 : cw[mt[k].base + r - 1];
+							val[k * PW + j] = cw[mt[k].base + r - kInlineWords];
 						}
 					}
 				}
@@ -656,15 +692,11 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 					anym |= m[k];
 				}
 			};
-			int trips = 0;
-			while (trips < spill_after && __any(anym != 0)) {
-				trip();
-				trips++;
-			}
 			// The word counts have a long tail (SF100 level 2: 2.5 wanted words per hot entry on average, 10.7 for the
-			// fullest of 256), so after spill_after trips most lanes idle while a few still hold many words.  What is
-			// left is spread over the whole wavefront: every lane writes a 4-byte descriptor per remaining word into a
-			// per-wave LDS queue (position = exclusive prefix sum of the counts), then lane j serves descriptor j.
+			// fullest of 256), so a per-lane loop over the remaining words leaves most lanes idle behind a few.  They
+			// are spread over the whole wavefront instead: every lane writes a 4-byte descriptor per remaining word into
+			// a per-wave LDS queue (position = exclusive prefix sum of the counts), then lane j serves descriptor j —
+			// one wait for all of them.
 			if (__any(anym != 0)) {
 				u32 c = 0;
 #pragma unroll
@@ -676,7 +708,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 					if (lane >= o) incl += t;
 				}
 				const u32 total = __shfl(incl, 63);
-				if (trips > 0 && total <= (u32)QCAP) {
+				if (spill_after > 0 && total <= (u32)QCAP) {
 					u32 pos = incl - c;
 #pragma unroll
 					for (int k = 0; k < UN; k++) {
@@ -684,7 +716,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 						while (mm) { // descriptor: accumulator index | source lane << 9 | chunk << 15 | word rank << 17
 							const int w = __ffs((int)mm) - 1;
 							mm &= mm - 1;
-							const u32 r = (u32)__popc(mt[k].nz & ((1u << w) - 1u)); // >= 1: the inline word went in trip 1
+							const u32 r = (u32)__popc(mt[k].nz & ((1u << w) - 1u)); // >= kInlineWords
 							queue[pos++] = (u32)(own[k] * WD + w) | ((u32)lane << 9) | ((u32)k << 15) | (r << 17);
 						}
 						m[k] = 0;
@@ -700,14 +732,14 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 							const u32 t = (u32)__shfl((int)mt[k].base, sl);
 							if (k == kk) cbase = t;
 						}
-						if (on) atomicOr(&acc[d & 511u], cw[cbase + (d >> 17) - 1u]);
+						if (on) atomicOr(&acc[d & 511u], cw[cbase + (d >> 17) - (u32)kInlineWords]);
 					}
 					__builtin_amdgcn_wave_barrier();
 				} else {
 					while (__any(anym != 0)) trip();
 				}
 			}
-			scanned += (u64)min((int64_t)(64 * UN), e1 - base);
+			scanned += (u64)(min(base + 64 * UN, e1) - max(base, e0));
 		}
 		__builtin_amdgcn_wave_barrier();
 		// -- epilogue: fold into seen/next (coalesced rows), non-empty-word masks, frontier stats

@@ -445,7 +445,8 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	PGQ_HIP_TRY(hipMalloc(&d_cnt, (size_t)(V + 1) * sizeof(int)));
 	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(V + 1) * sizeof(int), st));
 	if (!c->adj) PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
-	PGQ_HIP_TRY(hipMalloc(&c->radj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
+	// +4 entries: k_pull_sparse reads the in-adjacency as aligned 16-byte groups
+	PGQ_HIP_TRY(hipMalloc(&c->radj, (size_t)(std::max<int64_t>(E, 1) + 4) * sizeof(int32_t)));
 	PGQ_HIP_TRY(hipMalloc(&c->rslot, (size_t)std::max<int64_t>(E, 1) * sizeof(int64_t)));
 	PGQ_HIP_TRY(hipMalloc(&c->roff, (size_t)(V + 1) * sizeof(int64_t)));
 	if (E > 0) {
@@ -546,8 +547,8 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 		}
 		close(V);
 		c->n_pull_parts = (int)(parts.size() / 2);
-		PGQ_HIP_TRY(hipMalloc(&c->rown, (size_t)std::max<int64_t>(E, 1)));
-		PGQ_HIP_TRY(hipMemset(c->rown, 0, (size_t)std::max<int64_t>(E, 1)));
+		PGQ_HIP_TRY(hipMalloc(&c->rown, (size_t)std::max<int64_t>(E, 1) + 8)); // read as aligned 4-byte groups
+		PGQ_HIP_TRY(hipMemset(c->rown, 0, (size_t)std::max<int64_t>(E, 1) + 8));
 		if (!parts.empty()) {
 			PGQ_HIP_TRY(hipMalloc(&c->pull_parts, parts.size() * sizeof(int32_t)));
 			PGQ_HIP_TRY(hipMemcpy(c->pull_parts, parts.data(), parts.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _defaults():
-    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2), ("sparse_pw", 2), ("sparse_unroll", 4), ("sparse_spill", 2),
+    for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2), ("sparse_pw", 1), ("sparse_unroll", 2), ("sparse_spill", 3),
                  ("relax_small_limit", 2048), ("probe2", 1)):
         pgq.set_option(k, v)
     yield

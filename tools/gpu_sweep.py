@@ -37,9 +37,9 @@ def main():
     ap.add_argument("--bpc", default="8")
     ap.add_argument("--defer", default="8")
     ap.add_argument("--force_pull", default="0")
-    ap.add_argument("--sparse_unroll", default="4")
+    ap.add_argument("--sparse_unroll", default="2")
     ap.add_argument("--sparse_lds", default="1")
-    ap.add_argument("--sparse_pw", default="2")
+    ap.add_argument("--sparse_pw", default="1")
     ap.add_argument("--extra", default="", help="key=value[,key=value] options set once")
     ap.add_argument("--streams", default="2")
     ap.add_argument("--reps", type=int, default=2)

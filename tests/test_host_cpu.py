@@ -98,3 +98,18 @@ def test_search_without_gpu_fails_loudly():
     with pytest.raises(pgq.PgqError, match="needs a HIP device"):
         st.iterativelength(0, 5, [0], [3])
     del ctypes
+
+
+def test_options_round_trip_and_unknown_key():
+    """pgq_set_option / pgq_get_option share one table (no GPU needed); unknown keys are an error, not ignored."""
+    import duckpgq_extension_amd as pgq
+    for key, value in (("streams", 2), ("sparse_below", 2.5), ("sparse_spill", 0), ("words", 16)):
+        before = pgq.get_option(key)
+        pgq.set_option(key, value)
+        assert pgq.get_option(key) == value
+        pgq.set_option(key, int(before) if float(before).is_integer() and key != "sparse_below" else before)
+        assert pgq.get_option(key) == before
+    with pytest.raises(pgq.PgqError):
+        pgq.set_option("no_such_knob", 1)
+    with pytest.raises(pgq.PgqError):
+        pgq.get_option("no_such_knob")

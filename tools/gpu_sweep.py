@@ -70,7 +70,6 @@ def main():
     with open(a.out, "a") as f:
         for mode in [int(x) for x in a.modes.split(",")]:
             for bpc, nstr in [(int(x), int(y)) for x in a.bpc.split(",") for y in a.streams.split(",")]:
-              for mw in [0]:
                 pgq.set_option("streams", nstr)
                 for words in [int(x) for x in a.words.split(",")]:
                   for dfr in [int(x) for x in a.defer.split(",")]:

@@ -58,8 +58,8 @@ struct Options {
 	int upload_threads = 2;  // host threads staging a pageable CSR through pinned rings
 	int streams = 3;        // batches searched concurrently (one host thread + HIP stream each)
 	int sparse_lds = 1;     // keep the 1-bit frontier map in LDS when it fits (1024-thread workgroups)
-	int sparse_spill = 3;   // accumulate trips after which k_pull_sparse spreads the remaining words over the wavefront
-	int sparse_pw = 1;      // packed words per chunk fetched per accumulate trip in k_pull_sparse (1..3)
+	int sparse_spill = 3;   // > 0: words beyond a record's inline ones go through the per-wave LDS queue; 0: per-lane trips (tests)
+	int sparse_pw = 1;      // packed words per chunk fetched per trip of k_pull_sparse's fallback loop (1..3)
 	int sparse_unroll = 2;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 };

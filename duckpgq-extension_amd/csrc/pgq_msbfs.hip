@@ -16,8 +16,9 @@
 //     per vertex, WD adjacent lanes gather the WD contiguous lane-words of one in-neighbour — 64/WD full
 //     8*WD-byte segments per instruction, no atomics, the `next &= ~seen; seen |= next` sweep of
 //     iterativelength.cpp:26-30 fused in) or BOTTOM-UP SPARSE (k_compact_frontier + k_pull_sparse: frontier packed
-//     into a bit map + dense 16-byte records, recurrence organised by in-edge with an LDS accumulator, bit map and
-//     block bases resident in LDS when they fit).  The host picks per level from the frontier's out-degree sum and
+//     into a bit map + dense 32-byte records holding the first three words, recurrence organised by in-edge with
+//     an LDS accumulator, long-tail words spread over the wavefront through an LDS queue, bit map and block bases
+//     resident in LDS when they fit).  The host picks per level from the frontier's out-degree sum and
 //     lane-word density.
 //   * vertices whose in-degree exceeds `hub_chunk` are split into slices (k_pull_hub*).
 //   * lengths come from destination probes (k_probe: is an in-neighbour of dst in the previous frontier?; k_probe2:

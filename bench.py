@@ -234,6 +234,11 @@ def main():
                 "graph_gen_s": round(gen_s, 1), "csr_upload_ms": round(upload_s * 1e3, 2)},
             "pairs_per_s": pairs_per_s,
             "traversed_edges_per_step": te_total,
+            # logical edges (value) vs the in/out-edges the kernels physically scanned in the timed region
+            "mteps_physical": float(tot[1]) / elapsed / 1e6,
+            "physical_edges_scanned_per_step": float(tot[1]) / a.steps,
+            # the CSR dies at QueryEnd: one query = one upload (device-resident arrays here) + the searches
+            "ms_per_step_incl_csr_upload": elapsed / a.steps * 1e3 + upload_s * 1e3,
             "levels_per_step": stats["levels"] / max(a.steps, 1),
             "push_pull_levels": [stats["push_levels"] // max(a.steps, 1), stats["pull_levels"] // max(a.steps, 1)],
             "kernel_ms_per_step": {k: round(v / a.steps, 4) for k, v in kms.items() if v},

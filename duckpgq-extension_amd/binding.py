@@ -488,6 +488,15 @@ class PgqState:
         self.U.pgq_udf_scan_csr_e(self.s, csr_id, _p(out), n)
         return out[:n]
 
+    def get_csr_w(self, csr_id):
+        """get_csr_w (pgq_scan.cpp:113-153): int64 or float64 by the CSR's weight type."""
+        n = self.U.pgq_udf_scan_csr_w(self.s, csr_id, None, 0)
+        if n < 0:
+            raise PgqError(self.U.pgq_udf_last_error().decode())
+        out = np.zeros(max(n, 1), dtype=np.float64 if self.csr_get_w_type(csr_id) == 2 else np.int64)
+        self.U.pgq_udf_scan_csr_w(self.s, csr_id, _p(out), n)
+        return out[:n]
+
     def device_csr(self, csr_id):
         h = self.U.pgq_udf_device_csr(self.s, csr_id)
         if not h:

@@ -113,3 +113,29 @@ def test_options_round_trip_and_unknown_key():
         pgq.set_option("no_such_knob", 1)
     with pytest.raises(pgq.PgqError):
         pgq.get_option("no_such_knob")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_host_csr_build_fuzz_matches_oracle(seed):
+    """create_csr_vertex + create_csr_edge of the host mirror against the oracle's restatement of
+    csr_creation.cpp:14-198 on random multigraphs (self loops, parallel edges, isolated vertices, ragged chunking):
+    v, e and w must be equal entry by entry — the slot order decides which parallel edge shortestpath reports."""
+    from oracle.pgq_oracle import OracleCSR
+    rng = np.random.default_rng(500 + seed)
+    V = int(rng.integers(1, 400))
+    E = int(rng.integers(0, 6000))
+    s = rng.integers(0, V, E)
+    d = rng.integers(0, V, E)
+    if E:
+        s[: E // 10] = s[0]  # one heavy source
+    eid = rng.permutation(E).astype(np.int64)
+    w = [None, rng.integers(0, 1000, E), rng.random(E) * 10][seed % 3]
+    st = pgq.PgqState()
+    st.build_csr(7, V, s, d, eid, w)
+    ora = OracleCSR.from_edges(V, s, d, eid, w)
+    assert st.get_csr_v(7).tolist() == ora.v.tolist()
+    n = int(ora.v[V]) if V else 0
+    assert st.get_csr_e(7)[:n].tolist() == ora.e[:n].tolist()
+    assert st.csr_get_w_type(7) == ora.w_type
+    if w is not None:
+        assert st.get_csr_w(7)[:n].tolist() == ora.w[:n].tolist()

@@ -259,7 +259,7 @@ def main():
                                    for k in kms if kms[k] > 0},
             "deferred_pairs_per_step": stats["deferred_pairs"] / max(a.steps, 1),
         }
-        if not a.no_cpu_baseline and a.workload in ("snb_sf100", "rmat22"):
+        if not a.no_cpu_baseline and world == 1 and a.workload in ("snb_sf100", "rmat22"):  # rank 0, N=1 only
             out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, d_te, ref_len)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -49,10 +49,11 @@ struct HostCSR {
 	size_t vsize = 0;
 	std::vector<int64_t> e, edge_ids, w;
 	std::vector<double> w_double;
-	bool initialized_v = false, initialized_e = false, initialized_w = false;
-	pgq_csr_t *device = nullptr;
+	// read outside csr_lock by the double-checked initialisation the reference uses (csr_creation.cpp:15,44,64)
+	std::atomic<bool> initialized_v { false }, initialized_e { false }, initialized_w { false };
+	std::atomic<pgq_csr_t *> device { nullptr };
 	~HostCSR() {
-		if (device) pgq_csr_free(device);
+		if (device.load()) pgq_csr_free(device.load());
 	}
 };
 

@@ -139,3 +139,41 @@ def test_host_csr_build_fuzz_matches_oracle(seed):
     assert st.csr_get_w_type(7) == ora.w_type
     if w is not None:
         assert st.get_csr_w(7)[:n].tolist() == ora.w[:n].tolist()
+
+
+def test_host_csr_edge_chunks_from_concurrent_threads():
+    """DuckDB runs create_csr_edge chunks on several worker threads (atomic slot claim, csr_creation.cpp:132-138):
+    offsets must equal the single-threaded build and every vertex must hold the same multiset of (dst, edge id, w);
+    only the order inside a vertex may differ.  ctypes releases the GIL, so the calls really overlap."""
+    import threading
+    rng = np.random.default_rng(77)
+    V, E, chunk = 300, 40000, 2048
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    s[:5000] = 3  # contended vertex
+    eid = np.arange(E, dtype=np.int64)
+    w = rng.integers(0, 100, E)
+    ref = pgq.PgqState()
+    ref.build_csr(0, V, s, d, eid, w)
+    st = pgq.PgqState()
+    cnt = np.bincount(s, minlength=V).astype(np.int64)
+    e_sum = int(st.create_csr_vertex(0, V, np.arange(V), cnt).sum())
+    chunks = [slice(lo, lo + chunk) for lo in range(0, E, chunk)]
+    errors = []
+
+    def worker(k):
+        try:
+            for sl in chunks[k::4]:
+                st.create_csr_edge(0, V, e_sum, E, s[sl], d[sl], eid[sl], w[sl])
+        except Exception as ex:  # pragma: no cover
+            errors.append(ex)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert errors == []
+    v = st.get_csr_v(0)
+    assert v.tolist() == ref.get_csr_v(0).tolist()
+    e, ew, re_, rw = st.get_csr_e(0), st.get_csr_w(0), ref.get_csr_e(0), ref.get_csr_w(0)
+    for x in range(V):
+        lo, hi = int(v[x]), int(v[x + 1])
+        assert sorted(zip(e[lo:hi].tolist(), ew[lo:hi].tolist())) == sorted(zip(re_[lo:hi].tolist(), rw[lo:hi].tolist()))

@@ -60,6 +60,11 @@ for w in ("snb_sf100", "rmat22"):
         L.append("| `%s` | %s | %.1f | %s |" % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"],
                                                  float(r["AverageNs"]) / 1e3, r["Percentage"]))
     L.append("")
+L += ["Reading the two together: `bench.py`'s class timer brackets `k_compact_frontier` + `k_pull_sparse` of the 40 "
+      "launches inside the timed region (three batches overlapping: ≈ 0.98 ms per pair of kernels); rocprofv3 averages "
+      "`k_pull_sparse` alone over all 64 launches of the process — 48 overlapped ones (warm-up + timed region, "
+      "≈ 0.85–0.9 ms), 12 from the untimed one-batch-in-flight pass (≈ 0.44 ms, `roofline.isolated`) and 4 from the "
+      "traversed-edge accounting pass — hence 0.76 ms.", ""]
 L += ["## PMC (per launch averages, `profiles/pmc_<workload>.json`)", ""]
 for w in ("snb_sf100", "rmat22"):
     p = os.path.join(root, "profiles", "pmc_%s.json" % w)

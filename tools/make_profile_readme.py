@@ -62,9 +62,11 @@ for w in ("snb_sf100", "rmat22"):
     L.append("")
 L += ["Reading the two together: `bench.py`'s class timer brackets `k_compact_frontier` + `k_pull_sparse` of the 40 "
       "launches inside the timed region (three batches overlapping: ≈ 0.98 ms per pair of kernels); rocprofv3 averages "
-      "`k_pull_sparse` alone over all 64 launches of the process — 48 overlapped ones (warm-up + timed region, "
-      "≈ 0.85–0.9 ms), 12 from the untimed one-batch-in-flight pass (≈ 0.44 ms, `roofline.isolated`) and 4 from the "
-      "traversed-edge accounting pass — hence 0.76 ms.", ""]
+      "`k_pull_sparse` alone over all 64 launches of the process: 12 of them belong to the untimed one-batch-in-flight "
+      "pass (≈ 0.44 ms each, `roofline.isolated` minus the 0.055 ms compaction), which leaves ≈ 0.83 ms for each of the "
+      "52 overlapped ones (warm-up, timed region, traversed-edge accounting pass).  The event-bracketed figure is "
+      "higher (0.98 − 0.055 = 0.93 ms) because HIP events also see the time a launch waits behind the other streams' "
+      "kernels.", ""]
 L += ["## PMC (per launch averages, `profiles/pmc_<workload>.json`)", ""]
 for w in ("snb_sf100", "rmat22"):
     p = os.path.join(root, "profiles", "pmc_%s.json" % w)

@@ -198,3 +198,30 @@ def test_cheapest_path_literal_vs_lean():
     ps, pd = e[:64, 0], e[:64, 1]
     out, ok = c.cheapest_path_length(rep["V"], ps, pd)
     assert ok.all() and (out == w[:64]).all()  # forest: the only path child->parent is the edge itself
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_literal_vs_lean_multigraphs(seed):
+    """The GPU parity tests at scale lean on the *lean* oracle; this pins it against the *literal* restatement
+    (the one checked against the reference's golden vectors) on random multigraphs with parallel edges, self loops,
+    isolated vertices, a heavy source, NULL rows and zero weights — lengths, full paths, cheapest distances."""
+    rng = np.random.default_rng(900 + seed)
+    V = int(rng.integers(2, 260))
+    E = int(rng.integers(1, 5 * V))
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    s[: E // 8] = s[0]
+    d[E // 2: E // 2 + E // 10] = s[E // 2: E // 2 + E // 10]  # self loops
+    eid = rng.permutation(E).astype(np.int64)
+    n = int(rng.integers(1, 1400))
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    valid = rng.random(n) > 0.1
+    c = build(V, (s, d, eid))
+    ln, ok = c.iterativelength(V, ps, pd, src_valid=valid)
+    lln, lok = c.lean_iterativelength(V, ps, pd)
+    assert (ok == (lok & valid)).all() and (ln[ok] == lln[ok]).all()
+    assert c.shortestpath(V, ps[:520], pd[:520]) == c.lean_shortestpath(V, ps[:520], pd[:520])
+    w = rng.integers(0, 20, E) if seed % 2 == 0 else np.round(rng.random(E) * 4, 2)
+    cw = build(V, (s, d, eid), w=w)
+    out, cok = cw.cheapest_path_length(V, ps[:300], pd[:300])
+    lout, lcok = cw.lean_cheapest_path_length(V, ps[:300], pd[:300])
+    assert (cok == lcok).all() and (out[cok] == lout[cok]).all()

@@ -62,6 +62,8 @@ struct Options {
 	int sparse_pw = 1;      // packed words per chunk fetched per trip of k_pull_sparse's fallback loop (1..3)
 	int sparse_unroll = 2;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
+	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
+	int lanes_unroll = 4;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
 };
 Options &options();
 
@@ -114,6 +116,7 @@ struct pgq_csr {
 	int32_t *pull_parts = nullptr; // n_pull_parts (begin,end) vertex ranges, no hubs inside, <= 16 vertices each
 	int n_pull_parts = 0;
 	uint8_t *rown = nullptr; // E: owner vertex of every in-slot, as an index inside its part
+	uint32_t *rpk = nullptr; // E (+ padding): radj | rown << 28, one word per in-slot for k_pull_lanes (null if V >= 2^28)
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
 	int64_t bytes = 0;

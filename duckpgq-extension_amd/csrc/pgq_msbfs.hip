@@ -1184,7 +1184,7 @@ Workspace::~Workspace() {
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords })
+	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -1407,7 +1407,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		}
 		for (int t = 1; unresolved > 0 && front_edges > 0; t++) {
 			LevelBuf *nxt = level_buf(t);
-			bool sparse_level = false;
+			bool sparse_level = false, lanes_level = false;
 			bool push = opt.force_mode == 1 || (opt.force_mode == 0 && (double)front_edges * opt.push_div < (double)E);
 			if (opt.force_mode == 2) push = false;
 			// reset the per-level counters but keep the queue counts
@@ -1479,7 +1479,13 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				const double words_per_nb = (double)front_edges / (double)std::max<int64_t>(E, 1) *
 				                            ((double)front_words / (double)std::max<u32>(front_vertices, 1u)) * active_frac;
 				sparse_level = opt.force_pull == 1 || (opt.force_pull == 0 && words_per_nb < opt.sparse_below);
-				if (sparse_level) {
+				lanes_level = sparse_level && opt.lanes && c->rpk != nullptr;
+				if (lanes_level) {
+					KernelTimer kt(st, K_PULL_SPARSE);
+					PGQ_TRY(pull_lanes_level(c, ws, WD, cur->buf.as<u64>(), cur->nz.as<u32>(), ws->seen.as<u64>(),
+					                         nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, stop, d_cnt));
+					kt.stop();
+				} else if (sparse_level) {
 					const u32 cw_cap = (u32)std::min<int64_t>((int64_t)front_words + 64, 0x7FFFFFF0ll);
 					last_cw_cap = cw_cap;
 					const int bit_words = (int)(((V + 63) / 64) * 2 + 2); // even: 64-vertex blocks
@@ -1569,7 +1575,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			PGQ_HIP_TRY(hipStreamSynchronize(st));
 			KernelTimer::flush();
 			const Counters &hc = *ws->h_cnt;
-			if (sparse_level && hc.pad2 > last_cw_cap)
+			if (sparse_level && !lanes_level && hc.pad2 > last_cw_cap)
 				return fail(PGQ_ERR_HIP, "internal error: packed frontier holds " + std::to_string(hc.pad2) +
 				                             " words, expected at most " + std::to_string(last_cw_cap));
 			front_edges = hc.front_edges;
@@ -1601,13 +1607,16 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			} else {
 				// per scanned in-edge: 4 B adjacency + 4 B non-empty-word mask; per gathered lane-word 8 B; per vertex:
 				// offsets 16 B + seen/next words 16*WD B + mask 4 B (the sparse variant reads seen twice: 24*WD)
+				if (lanes_level) // 4 B per in-slot, one 16-byte record per in-edge leaving a frontier vertex, seen read + next/seen written
+					S.algo_bytes[K_PULL_SPARSE] += (double)hc.edges_scanned * 4.0 + (double)hc.word_gathers * 16.0 + (double)V * (4.0 + 24.0 * WD);
+				else
 				S.algo_bytes[sparse_level ? K_PULL_SPARSE : K_PULL] +=
 				    (double)hc.edges_scanned * 8.0 + (double)hc.word_gathers * 8.0 +
 				    (double)V * (20.0 + 16.0 * WD) + (sparse_level ? (double)hc.word_gathers * 8.0 + (double)V * 4.0 : 0.0);
 			}
 			if (opt.trace)
 				fprintf(stderr, "[pgq] batch %d level %d %s WD=%d front_v=%u front_e=%llu scanned=%llu gathers=%llu unresolved=%u push_ms=%.3f pull_ms=%.3f\n",
-				        b, t, push ? "push" : (sparse_level ? "pull_sparse" : "pull"), WD, hc.front_vertices, (unsigned long long)hc.front_edges,
+				        b, t, push ? "push" : (lanes_level ? "pull_lanes" : (sparse_level ? "pull_sparse" : "pull")), WD, hc.front_vertices, (unsigned long long)hc.front_edges,
 				        (unsigned long long)hc.edges_scanned, (unsigned long long)hc.word_gathers, hc.unresolved,
 				        S.kernel_ms[K_PUSH], S.kernel_ms[K_PULL] + S.kernel_ms[K_PULL_HUB] + S.kernel_ms[K_PULL_SPARSE]);
 			cur = nxt;

@@ -89,6 +89,8 @@ static int do_init(int device) {
 	env_int("PGQ_SPARSE_PW", g_opt.sparse_pw);
 	env_int("PGQ_SPARSE_SPILL", g_opt.sparse_spill);
 	env_int("PGQ_STREAMS", g_opt.streams);
+	env_int("PGQ_LANES", g_opt.lanes);
+	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
 	env_int("PGQ_UPLOAD_THREADS", g_opt.upload_threads);
 	g_inited.store(1);
 	return PGQ_OK;
@@ -286,14 +288,17 @@ __global__ void k_gather_rows(const u32 *__restrict__ order, int64_t n, const in
 // rown[e] = index of in-slot e's owner vertex inside its bottom-up work part (0..31): lets k_pull_sparse find the
 // owner of an in-edge with one coalesced byte load instead of a binary search.  One wavefront per part.
 __global__ void k_fill_rown(const int64_t *__restrict__ roff, const int32_t *__restrict__ parts, int n_parts,
-                            uint8_t *__restrict__ rown) {
+                            const int32_t *__restrict__ radj, uint8_t *__restrict__ rown, uint32_t *__restrict__ rpk) {
 	const int lane = threadIdx.x & 63;
 	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const int nwaves = (gridDim.x * blockDim.x) >> 6;
 	for (int p = wave; p < n_parts; p += nwaves) {
 		const int v0 = parts[2 * p], v1 = parts[2 * p + 1];
 		for (int v = v0; v < v1; v++)
-			for (int64_t e = roff[v] + lane; e < roff[v + 1]; e += 64) rown[e] = (uint8_t)(v - v0);
+			for (int64_t e = roff[v] + lane; e < roff[v + 1]; e += 64) {
+				rown[e] = (uint8_t)(v - v0);
+				if (rpk) rpk[e] = (uint32_t)radj[e] | ((uint32_t)(v - v0) << 28); // k_pull_lanes: one word per in-slot
+			}
 	}
 }
 
@@ -549,15 +554,19 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 		c->n_pull_parts = (int)(parts.size() / 2);
 		PGQ_HIP_TRY(hipMalloc(&c->rown, (size_t)std::max<int64_t>(E, 1) + 8)); // read as aligned 4-byte groups
 		PGQ_HIP_TRY(hipMemset(c->rown, 0, (size_t)std::max<int64_t>(E, 1) + 8));
+		if (V < (1ll << 28)) { // in-slots of hubs keep 0 (never read); padded for the 4 x 64-entry trips of k_pull_lanes
+			PGQ_HIP_TRY(hipMalloc(&c->rpk, (size_t)(std::max<int64_t>(E, 1) + 2048) * sizeof(uint32_t)));
+			PGQ_HIP_TRY(hipMemset(c->rpk, 0, (size_t)(std::max<int64_t>(E, 1) + 2048) * sizeof(uint32_t)));
+		}
 		if (!parts.empty()) {
 			PGQ_HIP_TRY(hipMalloc(&c->pull_parts, parts.size() * sizeof(int32_t)));
 			PGQ_HIP_TRY(hipMemcpy(c->pull_parts, parts.data(), parts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-			hipLaunchKernelGGL(k_fill_rown, dim3(256 * 8), dim3(256), 0, 0, c->roff, c->pull_parts, c->n_pull_parts, c->rown);
+			hipLaunchKernelGGL(k_fill_rown, dim3(256 * 8), dim3(256), 0, 0, c->roff, c->pull_parts, c->n_pull_parts, c->radj, c->rown, c->rpk);
 			PGQ_HIP_TRY(hipDeviceSynchronize());
 		}
 	}
 	tr.mark("hubs, parts, owner bytes");
-	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8 + 1) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
+	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8 + 1 + (c->rpk ? 4 : 0)) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
 	           (int64_t)items.size() * (int64_t)sizeof(HubItem);
 	return PGQ_OK;
 }
@@ -575,6 +584,7 @@ static void destroy_csr(pgq_csr *c) {
 	(void)hipFree(c->pull_hub_vertices);
 	(void)hipFree(c->pull_parts);
 	(void)hipFree(c->rown);
+	(void)hipFree(c->rpk);
 	delete c;
 }
 
@@ -826,6 +836,8 @@ std::vector<OptRef> option_table() {
 		{ "sparse_pw", &o.sparse_pw, nullptr },
 		{ "sparse_spill", &o.sparse_spill, nullptr },
 		{ "streams", &o.streams, nullptr },
+		{ "lanes", &o.lanes, nullptr },
+		{ "lanes_unroll", &o.lanes_unroll, nullptr },
 		{ "upload_threads", &o.upload_threads, nullptr },
 	};
 }

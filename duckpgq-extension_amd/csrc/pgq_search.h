@@ -34,7 +34,7 @@ struct Workspace {
 	hipStream_t stream = nullptr;
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
-	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords;
+	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords, lblk, lrec;
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
 	int64_t *h_bstart = nullptr;
@@ -56,6 +56,11 @@ struct WorkspaceLease {
 static inline unsigned blocks_for(int64_t n, int block = 256) {
 	return (unsigned)std::max<int64_t>(1, (n + block - 1) / block);
 }
+
+// One sparse bottom-up level in lane-list form (pgq_lanes.hip): packs the frontier (front/nz) and expands it into
+// next/nz_next/seen on ws->stream; per-level statistics go to d_cnt like the other level kernels.
+int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const u32 *nz, u64 *seen, u64 *next,
+                     u32 *nz_next, const u64 *active, int stop, Counters *d_cnt);
 
 // Assigns one lane per distinct source: fills ws->usrc (lane -> vertex), the row arrays sorted by lane
 // (skey/sidx/ssrc/sdst/sres) and returns the number of distinct sources in *U.

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _defaults():
     for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2), ("sparse_pw", 1), ("sparse_unroll", 2), ("sparse_spill", 3),
-                 ("relax_small_limit", 2048), ("probe2", 1)):
+                 ("relax_small_limit", 2048), ("probe2", 1), ("lanes", 1), ("lanes_unroll", 4)):
         pgq.set_option(k, v)
     yield
 
@@ -137,8 +137,12 @@ def test_random_graph_all_variants(words, mode):
     want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)]
     opaths = ora.lean_shortestpath(V, ps[:700], pd[:700])
     # destination probe on / classic post-expansion detection; adaptive / sparse-only / dense-only bottom-up kernel
-    for probe, force_pull, lds, pw, unroll, spill in ((1, 0, 1, 2, 4, 2), (0, 1, 0, 1, 2, 1), (1, 2, 1, 2, 4, 2), (0, 1, 1, 3, 4, 99),
-                                                     (0, 1, 1, 2, 1, 0), (0, 1, 1, 1, 4, 1)):
+    # lanes: sparse levels run k_pull_lanes (lane-list records) / k_pull_sparse (packed lane-words)
+    for probe, force_pull, lds, pw, unroll, spill, lanes in ((1, 0, 1, 2, 4, 2, 1), (0, 1, 0, 1, 2, 1, 0), (1, 2, 1, 2, 4, 2, 1), (0, 1, 1, 3, 4, 99, 0),
+                                                            (0, 1, 1, 2, 1, 0, 0), (0, 1, 1, 1, 4, 1, 0), (0, 1, 1, 1, 4, 1, 1),
+                                                            (0, 1, 0, 1, 2, 1, 1), (1, 1, 1, 1, 1, 1, 1), (1, 1, 0, 1, 4, 1, 1)):
+        pgq.set_option("lanes", lanes)
+        pgq.set_option("lanes_unroll", unroll)
         pgq.set_option("sparse_spill", spill)    # trips before the remaining words are spread over the wavefront
         pgq.set_option("streams", 1 + (probe + lds) % 3)  # 1..3 concurrent batch workers
         pgq.set_option("sparse_pw", pw)          # packed words per chunk per accumulate trip in k_pull_sparse

@@ -63,7 +63,7 @@ struct Options {
 	int sparse_unroll = 2;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
-	int lanes_unroll = 4;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
+	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
 };
 Options &options();
 

@@ -34,6 +34,7 @@ struct __attribute__((aligned(16))) BlkInfo {
 };
 
 constexpr int kLaneFields = 10;     // 12-bit lane ids per record
+constexpr int kGroupBlocks = 8;     // 64-vertex blocks per group (one k_compact_lanes wavefront writes whole groups)
 constexpr u32 kOverflowCount = 255; // record count byte: lanes do not fit, read the dense row instead
 
 // ---- frontier packing -----------------------------------------------------------------------------------------------
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(256) void k_compact_lanes(const u32 *__restrict__ n
 	const int lane = threadIdx.x & 63;
 	const int64_t wave = (int64_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
-	const int64_t per = ((V + nwaves - 1) / nwaves + 63) & ~63ll;
+	// ranges are whole groups of kGroupBlocks blocks: k_pull_lanes keeps 16-bit bases relative to the group's first block
+	const int64_t per = ((V + nwaves - 1) / nwaves + 64 * kGroupBlocks - 1) / (64 * kGroupBlocks) * (64 * kGroupBlocks);
 	const int64_t v0 = wave * per, v1 = min(v0 + per, (V + 63) & ~63ll);
 	u32 myv = 0;
 	for (int64_t v = v0 + lane; v < v1; v += 64) myv += (v < V && nz[v] != 0) ? 1u : 0u;
@@ -79,7 +81,9 @@ __global__ __launch_bounds__(256) void k_compact_lanes(const u32 *__restrict__ n
 				const u64 w1 = WD == 2 ? front[(size_t)v * WD + 1] : 0ull;
 				rec = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
 			} else {
+				// w: ids 2..9 packed 12 bits each (96 bits); x: ids 0 and 1 with the count byte on top
 				unsigned __int128 r = 0;
+				u32 first = 0;
 				u32 count = 0;
 				bool ovf = __popc(m) > kLaneFields;
 				u32 rest = m;
@@ -94,12 +98,14 @@ __global__ __launch_bounds__(256) void k_compact_lanes(const u32 *__restrict__ n
 					while (x) {
 						const int b = __ffsll((long long)x) - 1;
 						x &= x - 1;
-						r |= (unsigned __int128)(u32)(w * 64 + b) << (12 * count);
+						const u32 id = (u32)(w * 64 + b);
+						if (count < 2) first |= id << (12 * count);
+						else r |= (unsigned __int128)id << (12 * (count - 2));
 						count++;
 					}
 				}
 				const u32 cb = ovf ? kOverflowCount : count;
-				rec = make_uint4((u32)r, (u32)(r >> 32), (u32)(r >> 64), ((u32)(r >> 96) & 0x00FFFFFFu) | (cb << 24));
+				rec = make_uint4((u32)r, (u32)(r >> 32), (u32)(r >> 64), first | (cb << 24));
 			}
 			recs[slot] = rec;
 		}
@@ -108,27 +114,29 @@ __global__ __launch_bounds__(256) void k_compact_lanes(const u32 *__restrict__ n
 }
 
 // ---- the level kernel ----------------------------------------------------------------------------------------------
-template <int F> __device__ __forceinline__ u32 lane_field(u32 r0, u32 r1, u32 r2, u32 r3) {
-	constexpr int bit = 12 * F, w = bit >> 5, sh = bit & 31;
-	const u32 a = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
+// lane id J (2..9) of a record's tail words (ids 2..9 packed 12 bits each in three words)
+template <int J> __device__ __forceinline__ u32 tail_field(u32 t0, u32 t1, u32 t2) {
+	constexpr int bit = 12 * (J - 2), w = bit >> 5, sh = bit & 31;
+	const u32 a = w == 0 ? t0 : (w == 1 ? t1 : t2);
 	if constexpr (sh <= 20) {
 		return (a >> sh) & 0xFFFu;
 	} else {
-		const u32 b = w == 0 ? r1 : (w == 1 ? r2 : r3);
+		const u32 b = w == 0 ? t1 : t2;
 		return __builtin_amdgcn_alignbit(b, a, sh) & 0xFFFu;
 	}
 }
 
-template <int WD, int F> struct FieldLoop {
-	// sets accumulator bit (owner row, lane id F) for the lanes whose record holds more than F ids; stops at the
-	// first F no lane of the wavefront needs
-	static __device__ __forceinline__ void run(u32 *acc32, u32 ownbase, u32 r0, u32 r1, u32 r2, u32 r3, u32 count) {
-		if (!__any(count > (u32)F)) return;
-		if (count > (u32)F) {
-			const u32 id = lane_field<F>(r0, r1, r2, r3);
-			atomicOr(&acc32[ownbase + (id >> 5)], 1u << (id & 31u));
-		}
-		if constexpr (F + 1 < kLaneFields) FieldLoop<WD, F + 1>::run(acc32, ownbase, r0, r1, r2, r3, count);
+__device__ __forceinline__ void set_lane_bit(u32 *acc32, u32 ownbase, u32 id) {
+	atomicOr(&acc32[ownbase + (id >> 5)], 1u << (id & 31u));
+}
+
+template <int J> struct TailLoop {
+	// sets accumulator bit (owner row, lane id J) for the lanes whose record holds more than J ids; stops at the
+	// first J no lane of the wavefront needs
+	static __device__ __forceinline__ void run(u32 *acc32, u32 ownbase, u32 t0, u32 t1, u32 t2, u32 count) {
+		if (!__any(count > (u32)J)) return;
+		if (count > (u32)J) set_lane_bit(acc32, ownbase, tail_field<J>(t0, t1, t2));
+		if constexpr (J + 1 < kLaneFields) TailLoop<J + 1>::run(acc32, ownbase, t0, t1, t2, count);
 	}
 };
 
@@ -166,18 +174,25 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 	constexpr int NV = 16; // vertices per part (host-built parts never hold more; the owner row is 4 bits of rpk)
 	constexpr int VEC = WD >= 2 ? 2 : 1;
 	constexpr int RPL = (NV * WD / VEC + 63) / 64; // row vectors per lane
+	constexpr int QCAP = 64; // tail queue entries per wavefront
 	__shared__ __attribute__((aligned(16))) u64 s_acc[WPB][NV * WD];
+	__shared__ __attribute__((aligned(16))) uint4 s_queue[WPB][QCAP];
 	__shared__ u32 s_nzn[WPB][NV];
 	__shared__ u64 red[WPB][5];
-	extern __shared__ u64 s_dyn[]; // LDSMAP: n_blk bit-map words, then n_blk record bases
+	// LDSMAP: n_blk bit-map words, n_blk 16-bit record bases relative to their group of kGroupBlocks blocks (records of
+	// a group are contiguous: one k_compact_lanes wavefront wrote them), one 32-bit base per group
+	extern __shared__ u64 s_dyn[];
 	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
 	u64 *s_bits = s_dyn;
-	u32 *s_base = reinterpret_cast<u32 *>(s_dyn + n_blk);
+	unsigned short *s_base = reinterpret_cast<unsigned short *>(s_dyn + n_blk);
+	u32 *s_super = reinterpret_cast<u32 *>(s_base + ((n_blk + 1) & ~1));
 	if constexpr (LDSMAP) {
 		for (int i = threadIdx.x; i < n_blk; i += WPB * 64) {
 			const BlkInfo bi = blk[i];
+			const u32 sb = blk[i & ~(kGroupBlocks - 1)].base;
 			s_bits[i] = bi.bits;
-			s_base[i] = bi.base;
+			s_base[i] = (unsigned short)(bi.base - sb);
+			if ((i & (kGroupBlocks - 1)) == 0) s_super[i / kGroupBlocks] = sb;
 		}
 		__syncthreads();
 	}
@@ -189,6 +204,7 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 	u64 *acc = s_acc[wib];
 	u32 *acc32 = reinterpret_cast<u32 *>(acc);
 	u32 *nzn = s_nzn[wib];
+	uint4 *queue = s_queue[wib];
 	const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nwaves = (gridDim.x * blockDim.x) >> 6;
 	u64 nf = 0, mf = 0, scanned = 0, gath = 0, nwords = 0;
@@ -212,14 +228,6 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 		for (int k = 0; k < UN; k++) ca[k] = rpk[e0 + 64 * k + lane];
 #pragma unroll
 		for (int k = 0; k < UN; k++) cb[k] = rpk[e0 + T + 64 * k + lane];
-		// the part's seen rows (contiguous) are requested now and consumed by the epilogue
-		rowv sv[RPL];
-#pragma unroll
-		for (int i = 0; i < RPL; i++) {
-			const int idx = (lane + 64 * i) * VEC;
-			sv[i] = RowVec<VEC>::zero();
-			if (idx < nv * WD) sv[i] = *reinterpret_cast<const rowv *>(seen + (size_t)v0 * WD + idx);
-		}
 		for (int idx = lane; idx < nv * WD; idx += 64) acc[idx] = 0;
 		if (lane < NV) nzn[lane] = 0;
 		__builtin_amdgcn_wave_barrier();
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 				const u32 b = (c[k] & 0x0FFFFFFFu) >> 6;
 				if constexpr (LDSMAP) {
 					bw[k] = s_bits[b];
-					bb[k] = s_base[b];
+					bb[k] = (u32)s_base[b] + s_super[b / kGroupBlocks];
 				} else {
 					const BlkInfo bi = blk[b];
 					bw[k] = bi.bits;
@@ -256,6 +264,19 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 #pragma unroll
 			for (int k = 0; k < UN; k++) c[k] = rpk[base + 2 * T + 64 * k + lane];
 		};
+		// Lane ids 0 and 1 of a record are set by the lane that fetched it.  Ids 2..9 exist for few entries (SF100
+		// level 2: 16 % of the in-edges) but for at least one of nearly every 64, so a per-lane loop would run all ten
+		// rounds at ~10 % lane use: those entries are queued in LDS instead (three tail words + owner row + count) and
+		// served 64 at a time, one queue entry per lane (the queue fills across trips and is drained when full and at the
+		// end of the part).
+		u32 qn = 0; // queue fill, wave-uniform
+		auto drain = [&]() {
+			if (qn == 0) return;
+			uint4 e = make_uint4(0, 0, 0, 0);
+			if ((u32)lane < qn) e = queue[lane];
+			TailLoop<2>::run(acc32, (e.w >> 8) * (2 * WD), e.x, e.y, e.z, e.w & 0xFFu);
+			qn = 0;
+		};
 		auto consume = [&](const u32 (&kept)[UN], const u32 (&q0)[UN], const u32 (&q1)[UN], const u32 (&q2)[UN],
 		                   const u32 (&q3)[UN], u32 hotmask) {
 #pragma unroll
@@ -276,7 +297,19 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 				} else {
 					const u32 cb8 = hot ? q3[k] >> 24 : 0u;
 					const u32 count = cb8 == kOverflowCount ? 0u : cb8;
-					FieldLoop<WD, 0>::run(acc32, own * (2 * WD), q0[k], q1[k], q2[k], q3[k], count);
+					const u32 ownbase = own * (2 * WD);
+					if (count > 0) set_lane_bit(acc32, ownbase, q3[k] & 0xFFFu);
+					if (count > 1) set_lane_bit(acc32, ownbase, (q3[k] >> 12) & 0xFFFu);
+					const u64 tm = __ballot(count > 2);
+					if (tm) {
+						const u32 nt = (u32)__popcll(tm);
+						if (qn + nt > (u32)QCAP) drain();
+						if (count > 2) {
+							const u32 pos = qn + __builtin_amdgcn_mbcnt_hi((u32)(tm >> 32), __builtin_amdgcn_mbcnt_lo((u32)tm, 0u));
+							queue[pos] = make_uint4(q0[k], q1[k], q2[k], (own << 8) | count);
+						}
+						qn += nt;
+					}
 					// a neighbour carrying more lanes than a record holds: OR its dense row (WD contiguous words)
 					u64 om = __ballot(cb8 == kOverflowCount);
 					while (om) {
@@ -295,20 +328,27 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 		u32 kb[UN], b0[UN], b1[UN], b2[UN], b3[UN], hotb;
 		issue(e0, ca, ka, a0, a1, a2, a3, hota);
 		for (int base = e0;; base += 2 * T) {
-			const bool more1 = base + T < e1;
-			if (more1) issue(base + T, cb, kb, b0, b1, b2, b3, hotb);
+			// the look-ahead issue is unconditional: past e1 every lane is masked (no record request), whereas a
+			// branch around it would make the compiler copy the in-flight registers at the join and wait for them
+			issue(base + T, cb, kb, b0, b1, b2, b3, hotb);
 			consume(ka, a0, a1, a2, a3, hota);
-			if (!more1) break;
-			const bool more2 = base + 2 * T < e1;
-			if (more2) issue(base + 2 * T, ca, ka, a0, a1, a2, a3, hota);
+			if (base + T >= e1) break;
+			issue(base + 2 * T, ca, ka, a0, a1, a2, a3, hota);
 			consume(kb, b0, b1, b2, b3, hotb);
-			if (!more2) break;
+			if (base + 2 * T >= e1) break;
 		}
+		drain();
 		scanned += (u64)(e1 - e0);
 		__builtin_amdgcn_wave_barrier();
 		// -- epilogue: fold into seen/next (contiguous rows, VEC words per lane), non-empty-word masks, frontier stats
-		rowv fresh[RPL], upd[RPL];
+		rowv sv[RPL], fresh[RPL], upd[RPL];
 		u32 fbits[RPL];
+#pragma unroll
+		for (int i = 0; i < RPL; i++) { // the part's seen rows are contiguous: all requests go out before the first fold
+			const int idx = (lane + 64 * i) * VEC;
+			sv[i] = RowVec<VEC>::zero();
+			if (idx < nv * WD) sv[i] = *reinterpret_cast<const rowv *>(seen + (size_t)v0 * WD + idx);
+		}
 #pragma unroll
 		for (int i = 0; i < RPL; i++) { // all rows are folded before the first store: a store's source registers
 			const int idx = (lane + 64 * i) * VEC; // cannot be reused until it has left, which would serialise the rows
@@ -397,7 +437,7 @@ static int launch_lanes(pgq_csr *c, Workspace *ws, const u64 *front, const u32 *
 		static_lds.store(sl);
 	}
 	const u32 rec_bytes = (u32)std::min<int64_t>(std::max<int64_t>(V, 1) * 16, 0x7FFFFFF0ll);
-	const size_t dyn_bytes = (size_t)n_blk * 12 + 16;
+	const size_t dyn_bytes = (size_t)n_blk * 8 + (size_t)((n_blk + 1) & ~1) * 2 + (size_t)(n_blk / kGroupBlocks + 2) * 4 + 16;
 	const bool lds_map = opt.sparse_lds && sl > 1 && sl + dyn_bytes + 256 <= 160 * 1024;
 	if (lds_map) {
 		static std::atomic<int> attr_set { 0 };

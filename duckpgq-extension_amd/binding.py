@@ -23,7 +23,7 @@ class Stats(C.Structure):
     _fields_ = [("batches", C.c_int64), ("levels", C.c_int64), ("push_levels", C.c_int64),
                 ("pull_levels", C.c_int64), ("edges_scanned", C.c_int64), ("word_gathers", C.c_int64),
                 ("frontier_vertices", C.c_int64), ("unique_sources", C.c_int64), ("pairs", C.c_int64),
-                ("deferred_pairs", C.c_int64),
+                ("deferred_pairs", C.c_int64), ("meet_pairs", C.c_int64),
                 ("algo_bytes", C.c_double * KCLASS_MAX), ("kernel_ms", C.c_double * KCLASS_MAX),
                 ("launches", C.c_int64 * KCLASS_MAX)]
 
@@ -183,7 +183,7 @@ def get_stats():
     st = Stats()
     _check(load_hip().pgq_get_stats(C.byref(st)))
     names = kclass_names()
-    d = {f: getattr(st, f) for f, _ in Stats._fields_[:10]}
+    d = {f: getattr(st, f) for f, t in Stats._fields_ if t is C.c_int64}
     d["algo_bytes"] = {n: st.algo_bytes[i] for i, n in enumerate(names)}
     d["kernel_ms"] = {n: st.kernel_ms[i] for i, n in enumerate(names)}
     d["launches"] = {n: st.launches[i] for i, n in enumerate(names)}

@@ -52,6 +52,7 @@ struct Options {
 	int probe = 1;          // destination probe before each expansion
 	int probe2 = 1;         // two-hop destination probe when few pairs are left
 	int probe2_div = 4;     // ... when open pairs <= lanes / probe2_div
+	int probe2_abs = 512;   // ... or when at most this many pairs are open, whatever the batch width
 	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
 	int part_weight = 1024; // in-edges (+8 per vertex) per bottom-up work part
@@ -62,6 +63,12 @@ struct Options {
 	int sparse_pw = 1;      // packed words per chunk fetched per trip of k_pull_sparse's fallback loop (1..3)
 	int sparse_unroll = 2;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
+	int meet = 1;           // iterativelength: answer pairs at distance <= 3 by the pair-centric pre-pass (k_meet3) when cheaper
+	int meet_cap = 1 << 16; // adjacency entries a pair's two-hop walk may scan; beyond: left to the MS-BFS path
+	int meet_light = 1 << 16; // a row whose walk is longer is cut into slices of about this many entries (one wavefront each)
+	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
+	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
+	double meet_bias = 1.0; // pre-pass runs while its estimated bytes <= meet_bias x the MS-BFS estimate
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
 	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
 };
@@ -78,7 +85,8 @@ enum KClass {
 	K_RECON = 6,     // path reconstruction
 	K_RELAX = 7,     // cheapest path relaxation
 	K_PULL_SPARSE = 8, // bottom-up expansion, edge-organised sparse variant
-	K_COUNT = 9
+	K_MEET = 9,      // pair-centric two-hop pre-pass (pgq_meet.hip)
+	K_COUNT = 10
 };
 
 struct ThreadStats {
@@ -119,6 +127,7 @@ struct pgq_csr {
 	uint32_t *rpk = nullptr; // E (+ padding): radj | rown << 28, one word per in-slot for k_pull_lanes (null if V >= 2^28)
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
+	double two_hop_mean = 0; // mean over vertices of in-degree x out-degree = expected two-hop walk of a random endpoint
 	int64_t bytes = 0;
 	bool has_negative_weight = false;
 };

@@ -1,0 +1,619 @@
+// pgq_meet.hip — pair-centric pre-pass of iterativelength: hop counts 1..3 straight from the CSR (k_meet3).
+//
+// What it computes is exactly what IterativeLengthFunction reports (iterativelength.cpp:34-143): the BFS distance of
+// (src, dst), which is a pure function of (CSR, src, dst).  A pair has
+//     distance 1  iff  dst in N_out(src)
+//     distance 2  iff  N_out(src) and N_in(dst) intersect
+//     distance 3  iff  some out-neighbour of N_out(src) lies in N_in(dst)      (forward expansion)
+//                 iff  some in-neighbour of N_in(dst) lies in N_out(src)       (backward expansion)
+// and the smallest of these that holds is the answer.  On social graphs almost every random pair is that close (SF100
+// knows graph: 97 % of the pairs at distance <= 3), and deciding it costs the pair one scan of a two-hop
+// neighbourhood — on average 13.6 K adjacency entries from the cheaper side — instead of a share of a full-width
+// MS-BFS level over all 39.9 M in-edges.  One wavefront per pair:
+//   * the one-hop list of the side that is NOT expanded goes into a per-wavefront open-addressing hash table in LDS
+//     (1024 slots: lists of up to 512 vertices);
+//   * the other side's one-hop list is walked 64 vertices at a time (adjacency ranges fetched one per lane), the
+//     segments are streamed 16 bytes per lane per request with four requests in flight; every entry is one hash
+//     probe (LDS);
+//   * pairs whose lists are too long for the table or whose two-hop walk exceeds `meet_cap` entries stay open.
+// Rows it cannot answer (distance >= 4, unreachable, over the caps) are left to the MS-BFS path: the caller collects
+// them and runs the lane-batched search on them only.  Bound: HBM (segmented streaming of adjacency entries);
+// algorithmic bytes = 4 B per adjacency entry scanned + 16 B per expanded vertex (its offsets).
+#include <algorithm>
+#include <atomic>
+
+#include "pgq_search.h"
+
+namespace pgq {
+
+constexpr int kMeetSlots = 1024;            // hash slots per wavefront
+constexpr int kMeetSetMax = kMeetSlots / 2; // longest one-hop list the table takes (load factor <= 1/2)
+constexpr u32 kMeetEmpty = 0xFFFFFFFFu;
+constexpr int64_t kMeetOpen = -9;           // d_out marker: not answered here
+
+__device__ __forceinline__ u32 meet_hash(u32 x) { return (x * 0x9E3779B1u) >> 22; } // 10 bits
+
+__device__ __forceinline__ bool meet_lookup(const u32 *tab, u32 x) {
+	u32 h = meet_hash(x);
+	for (;;) {
+		const u32 t = tab[h];
+		if (t == x) return true;
+		if (t == kMeetEmpty) return false;
+		h = (h + 1) & (kMeetSlots - 1);
+	}
+}
+
+// one-probe pre-filter: 8192-bit map of the set (a set of ~100 vertices leaves ~1 % of the bits on), so that the four
+// entries a lane holds cost four independent LDS reads instead of four dependent hash-table walks
+constexpr int kMeetFilterWords = 256;
+__device__ __forceinline__ u32 meet_fhash(u32 x) { return (x * 0x9E3779B1u) >> 19; } // 13 bits
+__device__ __forceinline__ bool meet_probe4(const u32 *tab, const u32 *bm, const int4 v, bool k0, bool k1, bool k2, bool k3) {
+	const u32 h0 = meet_fhash((u32)v.x), h1 = meet_fhash((u32)v.y), h2 = meet_fhash((u32)v.z), h3 = meet_fhash((u32)v.w);
+	const u32 w0 = bm[h0 >> 5], w1 = bm[h1 >> 5], w2 = bm[h2 >> 5], w3 = bm[h3 >> 5];
+	bool f = false;
+	if (k0 && ((w0 >> (h0 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.x);
+	if (k1 && ((w1 >> (h1 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.y);
+	if (k2 && ((w2 >> (h2 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.z);
+	if (k3 && ((w3 >> (h3 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.w);
+	return f;
+}
+
+constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 atomics on one address take longer than the walks
+struct MeetCounters {
+	unsigned long long entries[kMeetStatSlots];  // adjacency entries scanned (both kinds of list)
+	unsigned long long vertices[kMeetStatSlots]; // vertices expanded (offset pairs fetched)
+	u32 n_slices;               // slices of heavy rows appended by the first launch
+	u32 bad;                    // an id outside [0, V)
+	u32 pad[2];
+};
+
+struct MeetSlice { // part of a heavy row's two-hop walk: positions [begin, end) of the expanded side's one-hop list
+	u32 row, begin, end, pad;
+};
+
+// One wavefront per work item.  An item costs ~6 dependent memory round trips before its walk starts (row, offsets,
+// one-hop lists, their offsets) and a single wavefront streams only ~4 KB per round trip, so (a) many items must be
+// in flight per CU (24 wavefronts, 5 KB of LDS each) and (b) a long walk must not stay on one wavefront: it would set
+// the kernel's duration.  First launch (SLICES = false): item = row; rows whose walk exceeds `light` entries are not
+// walked but cut into slices of ~`light` entries (written to the row's own slots of `slices`), their answer left open.  Second launch
+// (SLICES = true): item = slice; a slice that finds a witness stores 3 into its row.  Items are dealt round-robin (one
+// shared counter would serialise ~10^4 claims at 12-20 ns each: more than the walks take).
+template <bool SLICES>
+__global__ __launch_bounds__(256, 4) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                  int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                  const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                  int64_t *__restrict__ out, int64_t cap, int64_t light,
+                                                  MeetSlice *__restrict__ slices, u32 slices_per_row, MeetCounters *__restrict__ mc) {
+	__shared__ u32 s_tab[4][kMeetSlots];
+	__shared__ u32 s_bm[4][kMeetFilterWords];
+	const int lane = threadIdx.x & 63;
+	u32 *tab = s_tab[threadIdx.x >> 6];
+	u32 *bm = s_bm[threadIdx.x >> 6];
+	unsigned long long entries = 0; // wave-uniform
+	u32 vertices = 0;
+	const int64_t wave0 = (int64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
+	const int64_t n_items = SLICES ? n * (int64_t)slices_per_row : n;
+	for (int64_t it = wave0; it < n_items; it += nwaves) {
+		int64_t i = it;
+		int sl_begin = 0, sl_end = 0x7FFFFFFF;
+		if constexpr (SLICES) {
+			const MeetSlice sl = slices[it];
+			i = (int64_t)sl.row;
+			sl_begin = (int)sl.begin;
+			sl_end = (int)sl.end;
+		}
+		if constexpr (SLICES) {
+			if (i == 0xFFFFFFFFll) continue; // unused slot
+		} else {
+			if ((u32)lane < slices_per_row) slices[(size_t)i * slices_per_row + lane].row = 0xFFFFFFFFu;
+		}
+		const int64_t s = src[i], d = dst[i];
+		if constexpr (!SLICES) {
+			if (s < 0) { // NULL row (iterativelength.cpp:99-101)
+				if (lane == 0) out[i] = -1;
+				continue;
+			}
+			if (s >= V || d < 0 || d >= V) {
+				if (lane == 0) {
+					mc->bad = 1;
+					out[i] = -1;
+				}
+				continue;
+			}
+			if (s == d) { // iterativelength.cpp:102-103
+				if (lane == 0) out[i] = 0;
+				continue;
+			}
+		}
+		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
+		const int degS = se - so, degD = de - di;
+		if constexpr (!SLICES) {
+			if (degS == 0 || degD == 0) { // no path can exist: NULL like an exhausted search (iterativelength.cpp:133-139)
+				if (lane == 0) out[i] = -1;
+				continue;
+			}
+		}
+		// expand from the endpoint with the shorter list (its two-hop walk is the cheaper one, nearly always); the
+		// other endpoint's list is the set.  fwd: walk N_out(N_out(s)) against the set N_in(d).
+		bool fwd = degS <= degD;
+		if ((fwd ? degD : degS) > kMeetSetMax) fwd = !fwd;
+		const int set_n = fwd ? degD : degS;
+		const int exp_n = min(fwd ? degS : degD, sl_end);
+		if constexpr (!SLICES) {
+			if (set_n > kMeetSetMax) { // both lists too long for the table
+				if (lane == 0) out[i] = kMeetOpen;
+				continue;
+			}
+		}
+		const int32_t *set_adj = fwd ? radj + di : adj + so;   // the set side's one-hop list
+		const int32_t *exp_adj = fwd ? adj + so : radj + di;   // the expanded side's one-hop list
+		const int64_t *xoff = fwd ? off : roff;                // adjacency of the expanded side's direction
+		const int32_t *xadj = fwd ? adj : radj;
+		const u32 other = (u32)(fwd ? s : d);                  // distance 1: the set list contains the other endpoint
+		// both one-hop lists are requested together; the expanded side's first 64 vertices then ask for their ranges
+		const u32 v0 = sl_begin + lane < exp_n ? (u32)exp_adj[sl_begin + lane] : 0u;
+#pragma unroll
+		for (int k = 0; k < kMeetSlots / 64; k++) tab[k * 64 + lane] = kMeetEmpty;
+#pragma unroll
+		for (int k = 0; k < kMeetFilterWords / 64; k++) bm[k * 64 + lane] = 0;
+		int vb0 = 0, ve0 = 0;
+		if (sl_begin + lane < exp_n) {
+			vb0 = (int)xoff[v0];
+			ve0 = (int)xoff[v0 + 1];
+		}
+		__builtin_amdgcn_wave_barrier();
+		bool hit = false;
+		for (int pb = 0; pb < set_n; pb += 128) { // two rounds of 64 requested together
+			const u32 x0 = pb + lane < set_n ? (u32)set_adj[pb + lane] : kMeetEmpty;
+			const u32 x1 = pb + 64 + lane < set_n ? (u32)set_adj[pb + 64 + lane] : kMeetEmpty;
+#pragma unroll
+			for (int r = 0; r < 2; r++) {
+				const u32 x = r ? x1 : x0;
+				if (x != kMeetEmpty) {
+					hit |= x == other;
+					const u32 fh = meet_fhash(x);
+					atomicOr(&bm[fh >> 5], 1u << (fh & 31));
+					u32 h = meet_hash(x);
+					for (;;) {
+						const u32 old = atomicCAS(&tab[h], kMeetEmpty, x);
+						if (old == kMeetEmpty || old == x) break;
+						h = (h + 1) & (kMeetSlots - 1);
+					}
+				}
+			}
+		}
+		entries += (unsigned long long)set_n;
+		__builtin_amdgcn_wave_barrier();
+		if constexpr (!SLICES) {
+			if (__any(hit)) {
+				if (lane == 0) out[i] = 1;
+				continue;
+			}
+			// distance 2 and the size of the two-hop walk
+			int64_t work = ve0 - vb0;
+			if (lane < exp_n) hit |= meet_lookup(tab, v0);
+			for (int p = 64 + lane; p < exp_n; p += 64) {
+				const u32 v = (u32)exp_adj[p];
+				hit |= meet_lookup(tab, v);
+				work += xoff[v + 1] - xoff[v];
+			}
+			entries += (unsigned long long)exp_n;
+			vertices += (u32)exp_n;
+			if (__any(hit)) {
+				if (lane == 0) out[i] = 2;
+				continue;
+			}
+			for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
+			if (work > cap) {
+				if (lane == 0) out[i] = kMeetOpen;
+				continue;
+			}
+			if (work > light) { // cut into slices of about `light` entries (by vertex count: the walk is roughly uniform)
+				const u32 ns = (u32)min((int64_t)min(exp_n, (int)slices_per_row), (work + light - 1) / light);
+				if ((u32)lane < slices_per_row) { // the row's own slots: no shared append counter (it would serialise)
+					MeetSlice sl;
+					sl.row = (u32)lane < ns ? (u32)i : 0xFFFFFFFFu;
+					sl.begin = (u32)((int64_t)exp_n * lane / ns);
+					sl.end = (u32)((int64_t)exp_n * (lane + 1) / ns);
+					sl.pad = 0;
+					slices[(size_t)i * slices_per_row + lane] = sl;
+				}
+				if (lane == 0) out[i] = kMeetOpen; // a slice that finds a witness overwrites it
+				continue;
+			}
+		} else {
+			vertices += (u32)max(0, exp_n - sl_begin);
+		}
+		// distance 3: stream the adjacency segment of every expanded-side vertex, 16 bytes per lane per request, one
+		// hash probe per entry.  The segments of a round of 64 vertices form one flat sequence of 256-entry chunks walked
+		// by a wave-uniform cursor; four chunk requests are always in flight (a chunk's registers are refilled as soon
+		// as it has been probed).
+		bool found = false;
+		for (int pb = sl_begin; pb < exp_n && !found; pb += 64) {
+			const int cnt = min(64, exp_n - pb);
+			int vb = vb0, ve = ve0;
+			if (pb > sl_begin) {
+				vb = ve = 0;
+				if (lane < cnt) {
+					const u32 v = (u32)exp_adj[pb + lane];
+					vb = (int)xoff[v];
+					ve = (int)xoff[v + 1];
+				}
+			}
+			int j = -1, q = 0, e = 0, b = 0; // cursor: vertex j of the round, aligned position q of its segment [b, e)
+			auto seek = [&]() { // next vertex with a non-empty segment
+				for (j++; j < cnt; j++) {
+					b = __shfl(vb, j);
+					e = __shfl(ve, j);
+					if (e > b) {
+						q = b & ~3;
+						return;
+					}
+				}
+			};
+			seek();
+			constexpr int DEPTH = 4;
+			int4 x[DEPTH];
+			int xb[DEPTH], xe[DEPTH], xq[DEPTH]; // the segment and position a chunk was requested from (wave-uniform)
+			auto fetch = [&](int u) {
+				xq[u] = -1;
+				if (j < cnt) {
+					const int t = q + 4 * lane;
+					x[u] = make_int4(-1, -1, -1, -1);
+					if (t < e) x[u] = *reinterpret_cast<const int4 *>(xadj + t); // aligned; both adjacency arrays are padded
+					xb[u] = b;
+					xe[u] = e;
+					xq[u] = q;
+					entries += (unsigned long long)(min(e, q + 256) - max(b, q));
+					q += 256;
+					if (q >= e) seek();
+				}
+			};
+#pragma unroll
+			for (int u = 0; u < DEPTH; u++) fetch(u);
+			bool f = false;
+			for (;;) {
+				bool any_chunk = false;
+#pragma unroll
+				for (int u = 0; u < DEPTH; u++) {
+					if (xq[u] < 0) continue; // wave-uniform
+					any_chunk = true;
+					const int4 v = x[u];
+					const int t = xq[u] + 4 * lane, sb = xb[u], se2 = xe[u];
+					fetch(u);
+					f |= meet_probe4(tab, bm, v, t >= sb && t < se2, t + 1 >= sb && t + 1 < se2, t + 2 >= sb && t + 2 < se2,
+					                 t + 3 >= sb && t + 3 < se2);
+				}
+				found = __any(f);
+				if (found || !any_chunk) break;
+			}
+		}
+		if constexpr (SLICES) {
+			if (found && lane == 0) out[i] = 3;
+		} else {
+			if (lane == 0) out[i] = found ? 3 : kMeetOpen;
+		}
+	}
+	// one pair of atomics per workgroup, spread over the statistic slots
+	__shared__ unsigned long long s_stat[2];
+	if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+	__syncthreads();
+	if (lane == 0) {
+		if (entries) atomicAdd(&s_stat[0], entries);
+		if (vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
+		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
+	}
+}
+
+// ---- distance <= 4 with a vertex bit map in LDS (k_meet4) ---------------------------------------------------------
+// For the rows k_meet3 leaves open (distance 4, or lists / walks over its caps) on graphs whose vertex bit map fits in
+// LDS (V <= ~1.2 M): one 1024-thread workgroup per row marks the forward two-hop neighbourhood of src in the bit map
+// and tests the backward one- and two-hop neighbourhoods of dst against it:
+//     B = N_out(src)                    distance 1 iff dst in B;  distance 2 iff N_in(dst) meets B
+//     B += N_out(N_out(src))            distance 3 iff N_in(dst) meets B;  distance 4 iff N_in(N_in(dst)) meets B
+// (each test only runs when the smaller distances have been excluded, so the first that holds is the BFS distance).
+// The 16 wavefronts split the vertices of a one-hop list round-robin and stream their adjacency segments 16 bytes per
+// lane per request, four requests in flight each.  Rows whose two-hop walks exceed `cap` entries stay open.
+
+// Streams the adjacency segments of list[w], list[w + stride], ... (positions < list_n) and calls f(entry) for every
+// entry until stop() (wave-uniform) says so.  Returns the number of entries requested.
+template <typename F, typename Stop>
+__device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restrict__ list, int list_n, int w, int stride,
+                                                        const int64_t *__restrict__ xoff, const int32_t *__restrict__ xadj,
+                                                        F f, Stop stop) {
+	const int lane = threadIdx.x & 63;
+	unsigned long long entries = 0;
+	for (int pb = w; pb < list_n; pb += 64 * stride) {
+		int vb = 0, ve = 0;
+		const int p = pb + lane * stride;
+		if (p < list_n) {
+			const u32 v = (u32)list[p];
+			vb = (int)xoff[v];
+			ve = (int)xoff[v + 1];
+		}
+		const int cnt = min(64, (list_n - pb + stride - 1) / stride);
+		int j = -1, q = 0, e = 0, b = 0;
+		auto seek = [&]() {
+			for (j++; j < cnt; j++) {
+				b = __shfl(vb, j);
+				e = __shfl(ve, j);
+				if (e > b) {
+					q = b & ~3;
+					return;
+				}
+			}
+		};
+		seek();
+		constexpr int DEPTH = 4;
+		int4 x[DEPTH];
+		int xb[DEPTH], xe[DEPTH], xq[DEPTH];
+		auto fetch = [&](int u) {
+			xq[u] = -1;
+			if (j < cnt) {
+				const int t = q + 4 * lane;
+				x[u] = make_int4(-1, -1, -1, -1);
+				if (t < e) x[u] = *reinterpret_cast<const int4 *>(xadj + t);
+				xb[u] = b;
+				xe[u] = e;
+				xq[u] = q;
+				entries += (unsigned long long)(min(e, q + 256) - max(b, q));
+				q += 256;
+				if (q >= e) seek();
+			}
+		};
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++) fetch(u);
+		for (;;) {
+			bool any_chunk = false;
+#pragma unroll
+			for (int u = 0; u < DEPTH; u++) {
+				if (xq[u] < 0) continue;
+				any_chunk = true;
+				const int4 v = x[u];
+				const int t = xq[u] + 4 * lane, sb = xb[u], se = xe[u];
+				fetch(u);
+				if (t >= sb && t < se) f((u32)v.x);
+				if (t + 1 >= sb && t + 1 < se) f((u32)v.y);
+				if (t + 2 >= sb && t + 2 < se) f((u32)v.z);
+				if (t + 3 >= sb && t + 3 < se) f((u32)v.w);
+			}
+			if (!any_chunk || stop()) break;
+		}
+		if (stop()) break;
+	}
+	return entries;
+}
+
+__global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
+                                                int bm_words, MeetCounters *__restrict__ mc) {
+	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex
+	__shared__ int s_flag;
+	__shared__ unsigned long long s_work[2];
+	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	unsigned long long entries = 0;
+	u32 vertices = 0;
+	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+		__syncthreads(); // the previous row's flags and map are no longer read
+		const int64_t s = src[i], d = dst[i]; // rows left open by k_meet3: ids in range, src != dst, both have edges
+		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
+		const int degS = se - so, degD = de - di;
+		for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
+		if (tid == 0) {
+			s_flag = 0;
+			s_work[0] = s_work[1] = 0;
+		}
+		__syncthreads();
+		// B = N_out(src); sizes of both two-hop walks
+		unsigned long long wf = 0, wb = 0;
+		for (int p = tid; p < degS; p += 1024) {
+			const u32 v = (u32)adj[so + p];
+			atomicOr(&s_map[v >> 5], 1u << (v & 31));
+			wf += (unsigned long long)(off[v + 1] - off[v]);
+		}
+		for (int p = tid; p < degD; p += 1024) {
+			const u32 u = (u32)radj[di + p];
+			wb += (unsigned long long)(roff[u + 1] - roff[u]);
+		}
+		for (int o = 32; o > 0; o >>= 1) {
+			wf += __shfl_xor(wf, o);
+			wb += __shfl_xor(wb, o);
+		}
+		if (lane == 0) {
+			if (wf) atomicAdd(&s_work[0], wf);
+			if (wb) atomicAdd(&s_work[1], wb);
+		}
+		__syncthreads();
+		if (tid == 0) {
+			entries += (unsigned long long)(degS + degD);
+			vertices += (u32)(degS + degD);
+		}
+		if ((s_map[(u32)d >> 5] >> ((u32)d & 31)) & 1u) { // dst in N_out(src)
+			if (tid == 0) out_rows[didx[i]] = 1;
+			continue;
+		}
+		{ // distance 2: N_in(dst) meets B
+			bool hit = false;
+			for (int p = tid; p < degD; p += 1024) {
+				const u32 u = (u32)radj[di + p];
+				hit |= (s_map[u >> 5] >> (u & 31)) & 1u;
+			}
+			if (hit) s_flag = 1;
+		}
+		__syncthreads();
+		if (s_flag) {
+			if (tid == 0) out_rows[didx[i]] = 2;
+			continue;
+		}
+		if ((int64_t)s_work[0] > cap || (int64_t)s_work[1] > cap) {
+			if (tid == 0) out_rows[didx[i]] = kMeetOpen;
+			continue;
+		}
+		// B += N_out(N_out(src))
+		{
+			const unsigned long long e2 = meet_walk(adj + so, degS, wib, 16, off, adj,
+			                                        [&](u32 x) { atomicOr(&s_map[x >> 5], 1u << (x & 31)); }, []() { return false; });
+			if (lane == 0) entries += e2;
+		}
+		__syncthreads();
+		{ // distance 3: N_in(dst) meets B
+			bool hit = false;
+			for (int p = tid; p < degD; p += 1024) {
+				const u32 u = (u32)radj[di + p];
+				hit |= (s_map[u >> 5] >> (u & 31)) & 1u;
+			}
+			if (hit) s_flag = 1;
+		}
+		__syncthreads();
+		if (s_flag) {
+			if (tid == 0) out_rows[didx[i]] = 3;
+			continue;
+		}
+		// distance 4: N_in(N_in(dst)) meets B
+		bool f = false;
+		{
+			const unsigned long long e2 = meet_walk(radj + di, degD, wib, 16, roff, radj,
+			                                        [&](u32 x) { f |= (s_map[x >> 5] >> (x & 31)) & 1u; },
+			                                        [&]() {
+				                                        if (__any(f)) s_flag = 1;
+				                                        return *(volatile int *)&s_flag != 0;
+			                                        });
+			if (lane == 0) entries += e2;
+		}
+		if (__any(f)) s_flag = 1;
+		__syncthreads();
+		if (tid == 0) out_rows[didx[i]] = s_flag ? 4 : kMeetOpen;
+	}
+	__shared__ unsigned long long s_stat[2];
+	__syncthreads();
+	if (tid < 2) s_stat[tid] = 0;
+	__syncthreads();
+	for (int o = 32; o > 0; o >>= 1) entries += __shfl_xor(entries, o);
+	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
+	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
+	__syncthreads();
+	if (tid == 0) {
+		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
+		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
+	}
+}
+
+// rows the pre-pass left open, compacted for the lane-batched search (order does not matter: results are scattered
+// back through didx)
+__global__ void k_collect_open(int64_t n, const int64_t *__restrict__ out, const int64_t *__restrict__ src,
+                               const int64_t *__restrict__ dst, int64_t *__restrict__ dsrc, int64_t *__restrict__ ddst,
+                               u32 *__restrict__ didx, u32 *__restrict__ count) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool open = i < n && out[i] == kMeetOpen;
+	const u64 m = __ballot(open);
+	if (!m) return;
+	const int lane = threadIdx.x & 63;
+	u32 base = 0;
+	if (lane == 0) base = atomicAdd(count, (u32)__popcll(m));
+	base = __shfl(base, 0);
+	if (open) {
+		const u32 p = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+		dsrc[p] = src[i];
+		ddst[p] = dst[i];
+		didx[p] = (u32)i;
+	}
+}
+
+__global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
+                             int64_t *__restrict__ out) {
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < nd) out[didx[j]] = dlen[j];
+}
+
+// Runs the pre-pass over n rows resident in HBM; rows it answers get their hop count (or -1 for NULL) in d_out, the
+// others are compacted into ws->def_src/def_dst/def_idx and counted in *n_open.
+int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
+                 u32 *n_open) {
+	hipStream_t st = ws->stream;
+	pgq_stats_t &S = tstats().s;
+	PGQ_TRY(ws->meet_cnt.reserve(sizeof(MeetCounters) + 16));
+	PGQ_TRY(ws->def_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
+	PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
+	MeetCounters *mc = ws->meet_cnt.as<MeetCounters>();
+	u32 *d_count = reinterpret_cast<u32 *>(mc + 1);
+	PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
+	{
+		const Options &opt = options();
+		const int64_t cap = std::max(1, opt.meet_cap), light = std::max(256, opt.meet_light);
+		// every row owns cap/light + 1 slice slots (at most 64: one per lane of the wavefront that fills them)
+		const u32 slices_per_row = (u32)std::min<int64_t>(cap / light + 1, 64);
+		PGQ_TRY(ws->meet_slices.reserve((size_t)n * slices_per_row * sizeof(MeetSlice)));
+		KernelTimer kt(st, K_MEET);
+		const unsigned resident = 256 * 4; // workgroups of 4 wavefronts the chip holds at 16 wavefronts per CU
+		hipLaunchKernelGGL(k_meet3<false>, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 4 * resident)), dim3(256), 0, st, n,
+		                   d_src, d_dst, c->V, c->off, c->adj, c->roff, c->radj, d_out, cap, light,
+		                   ws->meet_slices.as<MeetSlice>(), slices_per_row, mc);
+		// second launch over every slice slot (unused ones are skipped)
+		hipLaunchKernelGGL(k_meet3<true>, dim3(4 * resident), dim3(256), 0, st, n, d_src, d_dst, c->V, c->off, c->adj,
+		                   c->roff, c->radj, d_out, cap, light, ws->meet_slices.as<MeetSlice>(), slices_per_row, mc);
+		kt.stop();
+	}
+	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
+	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
+	struct Host {
+		MeetCounters m;
+		u32 count, pad[3];
+	};
+	static thread_local Host h;
+	PGQ_HIP_TRY(hipMemcpyAsync(&h, mc, sizeof(h), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	if (h.m.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+	unsigned long long entries = 0, vertices = 0;
+	for (int k = 0; k < kMeetStatSlots; k++) {
+		entries += h.m.entries[k];
+		vertices += h.m.vertices[k];
+	}
+	// what is left (distance >= 4, or over k_meet3's caps): the LDS bit-map kernel, when the vertex bit map fits
+	const int bm_words = (int)((c->V + 31) / 32);
+	if (h.count > 0 && options().meet4 && (size_t)bm_words * 4 + 512 <= 150 * 1024) {
+		static std::atomic<int> attr_set { 0 };
+		if (!attr_set.load()) {
+			(void)hipFuncSetAttribute((const void *)k_meet4, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			attr_set.store(1);
+		}
+		const u32 nd = h.count;
+		PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
+		{
+			KernelTimer kt(st, K_MEET);
+			hipLaunchKernelGGL(k_meet4, dim3(std::min<u32>(nd, 256 * 4)), dim3(1024), (size_t)bm_words * 4, st, (int64_t)nd,
+			                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff, c->radj,
+			                   ws->def_idx.as<u32>(), d_out, (int64_t)std::max(1, options().meet4_cap), bm_words, mc);
+			kt.stop();
+		}
+		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
+		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
+		PGQ_HIP_TRY(hipMemcpyAsync(&h, mc, sizeof(h), hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		KernelTimer::flush();
+		for (int k = 0; k < kMeetStatSlots; k++) {
+			entries += h.m.entries[k];
+			vertices += h.m.vertices[k];
+		}
+	}
+	S.meet_pairs += n - (int64_t)h.count;
+	S.edges_scanned += (int64_t)entries;
+	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
+	*n_open = h.count;
+	return PGQ_OK;
+}
+
+int meet_apply(Workspace *ws, int64_t nd, const int64_t *d_len, int64_t *d_out) {
+	hipLaunchKernelGGL(k_apply_open, dim3(blocks_for(nd)), dim3(256), 0, ws->stream, nd, ws->def_idx.as<u32>(), d_len, d_out);
+	return PGQ_OK;
+}
+
+} // namespace pgq

@@ -1184,7 +1184,7 @@ Workspace::~Workspace() {
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec })
+	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_slices })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -1427,7 +1427,8 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)(hi - lo)), dim3(1024), 0, st, lo, hi,
 					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
-					                   (u32)std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),
+					                   (u32)std::max<int64_t>(std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),
+					                                       std::min<int64_t>(hi - lo, opt.probe2_abs)),
 					                   (int64_t)opt.probe2_cap, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
@@ -1732,9 +1733,41 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	S.pairs += n;
 	if (n == 0) return PGQ_OK;
 	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
+	// Pair-centric pre-pass: rows at distance <= 3 are answered from two-hop neighbourhood scans (pgq_meet.hip); only
+	// what it leaves open goes through the lane-batched search below.  It pays while the two-hop walks of all rows
+	// cost less than the MS-BFS levels they replace: bytes ~ rows x E[in-degree x out-degree] x 4 (the cheaper
+	// endpoint is expanded: ~0.6 of that) against ~16 B per edge per 2048-lane batch.
+	const Options &mopt = options();
+	const bool may_meet = mopt.meet && !with_paths && !outp.want_te && outp.depth == 0 && c->E > 0;
+	auto meet_pays = [&](int64_t distinct_sources) {
+		const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
+		const double batches = (double)((distinct_sources + 2047) / 2048);
+		return meet_bytes <= mopt.meet_bias * batches * (double)c->E * 16.0;
+	};
+	auto run_meet = [&]() -> int {
+		u32 nd = 0;
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd));
+		if (nd > 0) {
+			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
+			WorkspaceLease inner;
+			PGQ_TRY(inner.acquire());
+			SearchOutput so2;
+			so2.depth = outp.depth + 1;
+			S.pairs -= nd; // counted once
+			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
+			PGQ_TRY(meet_apply(ws, nd, ws->def_len.as<int64_t>(), d_out_len));
+			PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+		}
+		return PGQ_OK;
+	};
+	// few rows: decide without the lane assignment (every row taken as a distinct source: the pessimistic case for
+	// the pre-pass); many rows: the number of distinct sources decides (cross products share their lanes)
+	if (may_meet && n <= 16384 && meet_pays(std::min<int64_t>(n, c->V))) return run_meet();
 	u32 U = 0;
 	// the accounting pass counts the full BFS of a pair even when dst has no in-edge, so it keeps those lanes
 	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U, !outp.want_te));
+	if (may_meet && n > 16384 && U > 0 && meet_pays(U)) return run_meet();
 	S.unique_sources += U;
 	if (with_paths) PGQ_HIP_TRY(hipMemsetAsync(ws->soff.p, 0, (size_t)n * 8, st));
 	const int wd = choose_words(U);

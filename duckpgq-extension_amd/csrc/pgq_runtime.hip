@@ -82,6 +82,7 @@ static int do_init(int device) {
 	env_int("PGQ_PROBE2", g_opt.probe2);
 	env_int("PGQ_PROBE2_CAP", g_opt.probe2_cap);
 	env_int("PGQ_PROBE2_DIV", g_opt.probe2_div);
+	env_int("PGQ_PROBE2_ABS", g_opt.probe2_abs);
 	env_int("PGQ_PART_WEIGHT", g_opt.part_weight);
 	env_double("PGQ_SPARSE_BELOW", g_opt.sparse_below);
 	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
@@ -90,6 +91,12 @@ static int do_init(int device) {
 	env_int("PGQ_SPARSE_SPILL", g_opt.sparse_spill);
 	env_int("PGQ_STREAMS", g_opt.streams);
 	env_int("PGQ_LANES", g_opt.lanes);
+	env_int("PGQ_MEET", g_opt.meet);
+	env_int("PGQ_MEET_CAP", g_opt.meet_cap);
+	env_int("PGQ_MEET_LIGHT", g_opt.meet_light);
+	env_int("PGQ_MEET4", g_opt.meet4);
+	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
+	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
 	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
 	env_int("PGQ_UPLOAD_THREADS", g_opt.upload_threads);
 	g_inited.store(1);
@@ -449,7 +456,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	int *d_cnt = nullptr;
 	PGQ_HIP_TRY(hipMalloc(&d_cnt, (size_t)(V + 1) * sizeof(int)));
 	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(V + 1) * sizeof(int), st));
-	if (!c->adj) PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)std::max<int64_t>(E, 1) * sizeof(int32_t)));
+	if (!c->adj) PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)(std::max<int64_t>(E, 1) + 4) * sizeof(int32_t)));
 	// +4 entries: k_pull_sparse reads the in-adjacency as aligned 16-byte groups
 	PGQ_HIP_TRY(hipMalloc(&c->radj, (size_t)(std::max<int64_t>(E, 1) + 4) * sizeof(int32_t)));
 	PGQ_HIP_TRY(hipMalloc(&c->rslot, (size_t)std::max<int64_t>(E, 1) * sizeof(int64_t)));
@@ -506,6 +513,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 		int64_t outdeg = h_off[v + 1] - h_off[v];
 		c->max_in_degree = std::max(c->max_in_degree, indeg);
 		c->max_out_degree = std::max(c->max_out_degree, outdeg);
+		c->two_hop_mean += (double)indeg * (double)outdeg / (double)std::max<int64_t>(V, 1);
 		if (indeg > chunk) {
 			hubs.push_back((int32_t)v);
 			// slices of a quarter chunk: a wavefront walks its slice 64 entries at a time (latency-bound), so more,
@@ -628,7 +636,7 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 			// pageable host arrays: staged through pinned rings by several threads, adjacency narrowed on the way
 			std::atomic<int> oob { 0 };
 			UploadTrace tr;
-			PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)E * sizeof(int32_t)));
+			PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)(E + 4) * sizeof(int32_t))); // +4: k_meet3 reads aligned 16-byte groups
 			PGQ_TRY(staged_upload(c->adj, adj, (size_t)E, 8, 1, V, &oob));
 			tr.mark("adjacency staged+narrowed");
 			if (oob.load()) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: adjacency out of [0,V)");
@@ -829,6 +837,7 @@ std::vector<OptRef> option_table() {
 		{ "probe2", &o.probe2, nullptr },
 		{ "probe2_cap", &o.probe2_cap, nullptr },
 		{ "probe2_div", &o.probe2_div, nullptr },
+		{ "probe2_abs", &o.probe2_abs, nullptr },
 		{ "part_weight", &o.part_weight, nullptr },
 		{ "sparse_below", nullptr, &o.sparse_below },
 		{ "sparse_unroll", &o.sparse_unroll, nullptr },
@@ -837,6 +846,12 @@ std::vector<OptRef> option_table() {
 		{ "sparse_spill", &o.sparse_spill, nullptr },
 		{ "streams", &o.streams, nullptr },
 		{ "lanes", &o.lanes, nullptr },
+		{ "meet", &o.meet, nullptr },
+		{ "meet_cap", &o.meet_cap, nullptr },
+		{ "meet_light", &o.meet_light, nullptr },
+		{ "meet4", &o.meet4, nullptr },
+		{ "meet4_cap", &o.meet4_cap, nullptr },
+		{ "meet_bias", nullptr, &o.meet_bias },
 		{ "lanes_unroll", &o.lanes_unroll, nullptr },
 		{ "upload_threads", &o.upload_threads, nullptr },
 	};
@@ -868,7 +883,7 @@ int pgq_get_option(const char *key, double *value) {
 
 const char *pgq_kclass_name(int k) {
 	static const char *names[K_COUNT] = { "prep",   "push",   "pull",  "pull_hub",
-		                                  "queue",  "detect", "recon", "relax", "pull_sparse" };
+		                                  "queue",  "detect", "recon", "relax", "pull_sparse", "meet" };
 	return (k >= 0 && k < K_COUNT) ? names[k] : nullptr;
 }
 int pgq_get_stats(pgq_stats_t *out) {

@@ -34,7 +34,7 @@ struct Workspace {
 	hipStream_t stream = nullptr;
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
-	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords, lblk, lrec;
+	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_slices;
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
 	int64_t *h_bstart = nullptr;
@@ -61,6 +61,12 @@ static inline unsigned blocks_for(int64_t n, int block = 256) {
 // next/nz_next/seen on ws->stream; per-level statistics go to d_cnt like the other level kernels.
 int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const u32 *nz, u64 *seen, u64 *next,
                      u32 *nz_next, const u64 *active, int stop, Counters *d_cnt);
+
+// Pair-centric pre-pass (pgq_meet.hip): answers rows at distance <= 3 (and NULL / trivial / dead-end rows) into d_out,
+// compacts the others into ws->def_src/def_dst/def_idx; meet_apply scatters their lengths back.
+int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
+                 u32 *n_open);
+int meet_apply(Workspace *ws, int64_t nd, const int64_t *d_len, int64_t *d_out);
 
 // Assigns one lane per distinct source: fills ws->usrc (lane -> vertex), the row arrays sorted by lane
 // (skey/sidx/ssrc/sdst/sres) and returns the number of distinct sources in *U.

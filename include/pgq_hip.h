@@ -160,6 +160,7 @@ typedef struct pgq_stats {
 	int64_t unique_sources;   /* lanes used */
 	int64_t pairs;            /* rows handled */
 	int64_t deferred_pairs;   /* rows re-run in a narrow straggler batch */
+	int64_t meet_pairs;       /* rows answered by the pair-centric pre-pass (distance <= 3, NULL, trivial) */
 	double algo_bytes[PGQ_KCLASS_MAX]; /* algorithmic bytes per kernel class (DESIGN.md formulas) */
 	double kernel_ms[PGQ_KCLASS_MAX];  /* HIP-event time per kernel class (profile=1) */
 	int64_t launches[PGQ_KCLASS_MAX];

@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _defaults():
     for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2), ("sparse_pw", 1), ("sparse_unroll", 2), ("sparse_spill", 3),
-                 ("relax_small_limit", 2048), ("probe2", 1), ("lanes", 1), ("lanes_unroll", 4)):
+                 ("relax_small_limit", 2048), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
+                 # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
+                 # under test see them; the tests that exercise it switch it on themselves
+                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_light", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20)):
         pgq.set_option(k, v)
     yield
 
@@ -154,6 +157,59 @@ def test_random_graph_all_variants(words, mode):
         ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
         assert lens(ln, ok) == want
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
+
+
+@pytest.mark.parametrize("cap", [1 << 18, 3000, 1])
+def test_meet_prepass_matches_oracle(cap):
+    # k_meet3 (pgq_meet.hip): distances 1..3 from two-hop scans, everything else handed to the lane-batched search.
+    # cap = adjacency entries a pair may scan: small caps leave most rows to the MS-BFS path (both paths mixed)
+    rng = np.random.default_rng(77 + cap)
+    V, E = 6000, 60000
+    rows = random_graph(rng, V, E, skew=True)  # skewed: lists longer than the 512-entry hash table exist
+    st, ora = both(V, rows)
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_cap", cap)
+    pgq.set_option("meet_light", 256 if cap == 1 << 18 else 1 << 16)  # 256: most walks are cut into slices
+    pgq.set_option("meet_bias", 1e9)  # always take the pre-pass
+    pgq.set_option("meet4", 0 if cap == 1 else 1)  # k_meet4: LDS bit-map kernel for what k_meet3 leaves open
+    pgq.set_option("meet4_cap", 1 << 20 if cap != 3000 else 2000)
+    n = 3000
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    ps[:50] = pd[:50]  # src == dst rows
+    valid = rng.random(n) > 0.05
+    oln, ook = ora.lean_iterativelength(V, ps, pd)
+    want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)]
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
+    assert lens(ln, ok) == want
+    stats = pgq.get_stats()
+    assert stats["meet_pairs"] > 0
+    if cap == 1:
+        assert stats["levels"] > 0  # the MS-BFS path answered what the pre-pass left open
+    # a sparse directed graph: many dead ends and unreachable pairs, long distances
+    V2 = 4000
+    rows2 = random_graph(rng, V2, 5000)
+    st2, ora2 = both(V2, rows2, csr_id=1)
+    ps, pd = rng.integers(0, V2, 2000), rng.integers(0, V2, 2000)
+    oln, ook = ora2.lean_iterativelength(V2, ps, pd)
+    ln, ok = st2.iterativelength(1, V2, ps, pd)
+    assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+
+
+def test_meet_prepass_out_of_range_ids_rejected():
+    import torch
+    rng = np.random.default_rng(3)
+    V = 500
+    s, d, e = random_graph(rng, V, 3000)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_bias", 1e9)
+    d_src = torch.tensor([1, 2, V + 5], dtype=torch.int64).cuda()
+    d_dst = torch.tensor([3, 4, 5], dtype=torch.int64).cuda()
+    d_len = torch.empty(3, dtype=torch.int64, device="cuda")
+    with pytest.raises(pgq.PgqError):
+        dev.iterativelength_bulk_ptr(3, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr())
 
 
 def test_shared_sources_cross_product():

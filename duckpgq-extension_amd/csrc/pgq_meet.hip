@@ -58,6 +58,7 @@ __device__ __forceinline__ bool meet_probe4(const u32 *tab, const u32 *bm, const
 	return f;
 }
 
+constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so that a finished row frees its slot at once
 constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 atomics on one address take longer than the walks
 struct MeetCounters {
 	unsigned long long entries[kMeetStatSlots];  // adjacency entries scanned (both kinds of list)
@@ -79,13 +80,13 @@ struct MeetSlice { // part of a heavy row's two-hop walk: positions [begin, end)
 // (SLICES = true): item = slice; a slice that finds a witness stores 3 into its row.  Items are dealt round-robin (one
 // shared counter would serialise ~10^4 claims at 12-20 ns each: more than the walks take).
 template <bool SLICES>
-__global__ __launch_bounds__(256, 4) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                   int64_t *__restrict__ out, int64_t cap, int64_t light,
                                                   MeetSlice *__restrict__ slices, u32 slices_per_row, MeetCounters *__restrict__ mc) {
-	__shared__ u32 s_tab[4][kMeetSlots];
-	__shared__ u32 s_bm[4][kMeetFilterWords];
+	__shared__ u32 s_tab[kMeetWPB][kMeetSlots];
+	__shared__ u32 s_bm[kMeetWPB][kMeetFilterWords];
 	const int lane = threadIdx.x & 63;
 	u32 *tab = s_tab[threadIdx.x >> 6];
 	u32 *bm = s_bm[threadIdx.x >> 6];
@@ -552,12 +553,12 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		const u32 slices_per_row = (u32)std::min<int64_t>(cap / light + 1, 64);
 		PGQ_TRY(ws->meet_slices.reserve((size_t)n * slices_per_row * sizeof(MeetSlice)));
 		KernelTimer kt(st, K_MEET);
-		const unsigned resident = 256 * 4; // workgroups of 4 wavefronts the chip holds at 16 wavefronts per CU
-		hipLaunchKernelGGL(k_meet3<false>, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 4 * resident)), dim3(256), 0, st, n,
+		const unsigned resident = 256 * 16 / kMeetWPB; // workgroups the chip holds at 16 wavefronts per CU
+		hipLaunchKernelGGL(k_meet3<false>, dim3((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident)), dim3(64 * kMeetWPB), 0, st, n,
 		                   d_src, d_dst, c->V, c->off, c->adj, c->roff, c->radj, d_out, cap, light,
 		                   ws->meet_slices.as<MeetSlice>(), slices_per_row, mc);
 		// second launch over every slice slot (unused ones are skipped)
-		hipLaunchKernelGGL(k_meet3<true>, dim3(4 * resident), dim3(256), 0, st, n, d_src, d_dst, c->V, c->off, c->adj,
+		hipLaunchKernelGGL(k_meet3<true>, dim3(4 * resident), dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj,
 		                   c->roff, c->radj, d_out, cap, light, ws->meet_slices.as<MeetSlice>(), slices_per_row, mc);
 		kt.stop();
 	}

@@ -33,6 +33,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <cstring>
 #include <memory>
@@ -1205,8 +1206,13 @@ int WorkspaceLease::acquire() {
 	}
 	if (!ws) {
 		ws = new Workspace();
-		PGQ_HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
-		PGQ_HIP_TRY(hipHostMalloc((void **)&ws->h_cnt, sizeof(Counters)));
+		// a half-built workspace never reaches the pool
+		if (hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess ||
+		    hipHostMalloc((void **)&ws->h_cnt, sizeof(Counters)) != hipSuccess) {
+			delete ws;
+			ws = nullptr;
+			return fail(PGQ_ERR_HIP, "cannot create a search workspace (stream / pinned counter block)");
+		}
 	}
 	return PGQ_OK;
 }
@@ -1508,14 +1514,14 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 #define PGQ_LAUNCH_SPARSE(UNR, VR)                                                                                       \
 	do {                                                                                                               \
 		auto kfn = k_pull_sparse<WD, UNR, 16, VR>;                                                                            \
-		static size_t static_lds = 0;                                                                                  \
+		static std::atomic<size_t> static_lds { 0 };                                                                   \
 		if (!static_lds) {                                                                                             \
 			hipFuncAttributes fa;                                                                                      \
 			static_lds = hipFuncGetAttributes(&fa, (const void *)kfn) == hipSuccess ? fa.sharedSizeBytes + 1 : 1;      \
 		}                                                                                                              \
 		const bool lds_map = opt.sparse_lds && static_lds > 1 && static_lds + dyn_bytes + 256 <= 160 * 1024;           \
 		if (lds_map) {                                                                                                 \
-			static size_t attr_bytes = 0;                                                                              \
+			static std::atomic<size_t> attr_bytes { 0 };                                                               \
 			if (attr_bytes < dyn_bytes) {                                                                              \
 				(void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
 				                          (int)(160 * 1024 - static_lds));                                             \

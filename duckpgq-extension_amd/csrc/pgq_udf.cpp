@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <set>
 #include <string>
 #include <vector>
@@ -60,21 +61,25 @@ struct HostCSR {
 } // namespace
 
 struct pgq_state {
-	std::map<int32_t, std::unique_ptr<HostCSR>> csr_list;
+	std::map<int32_t, std::shared_ptr<HostCSR>> csr_list;
 	std::mutex csr_lock;
 	std::set<int32_t> csr_to_delete;
 };
 
 namespace {
 
-HostCSR *find_csr(pgq_state *s, int32_t id) {
+// A UDF call keeps its own reference for as long as it runs: delete_csr / QueryEnd / a replacing create_csr_vertex on
+// another thread only drop the registry's reference, so the host arrays and the device CSR (kernels may still be
+// reading it) outlive the call.
+typedef std::shared_ptr<HostCSR> CsrRef;
+CsrRef find_csr(pgq_state *s, int32_t id) {
 	std::lock_guard<std::mutex> g(s->csr_lock);
 	auto it = s->csr_list.find(id);
-	return it == s->csr_list.end() ? nullptr : it->second.get();
+	return it == s->csr_list.end() ? nullptr : it->second;
 }
 
 // lazy, once-per-CSR upload under csr_lock (many DuckDB threads hit the first search chunk together)
-pgq_csr_t *device_csr(pgq_state *s, HostCSR *c, int64_t V) {
+pgq_csr_t *device_csr(pgq_state *s, const CsrRef &c, int64_t V) {
 	std::lock_guard<std::mutex> g(s->csr_lock);
 	if (c->device) return c->device;
 	std::vector<int64_t> off((size_t)V + 1);
@@ -103,9 +108,9 @@ pgq_csr_t *device_csr(pgq_state *s, HostCSR *c, int64_t V) {
 	return h;
 }
 
-int search_prologue(pgq_state *s, int32_t id, int64_t V, HostCSR **out, pgq_csr_t **dev, const char *what) {
+int search_prologue(pgq_state *s, int32_t id, int64_t V, CsrRef *out, pgq_csr_t **dev, const char *what) {
 	if (!s) return fail("Invalid Input Error: NULL state");
-	HostCSR *c = find_csr(s, id);
+	CsrRef c = find_csr(s, id);
 	if (!c || !c->initialized_v) // iterativelength.cpp:44-51, shortest_path.cpp:49-58
 		return fail(std::string("Constraint Error: Need to initialize CSR before doing ") + what);
 	if ((int64_t)c->vsize != V + 2) return fail("Invalid Input Error: vertex count does not match the CSR");
@@ -176,14 +181,21 @@ int pgq_udf_create_csr_edge(pgq_state_t *s, int32_t id, int64_t V, int64_t e_sum
 		return fail("Constraint Error: Non-existent/non-unique vertices detected. Make sure all vertices referred by edge "
 		            "tables exist and are unique for path-finding queries.");
 	}
-	HostCSR *c = find_csr(s, id);
+	if (e_sum < 0) return fail("Invalid Input Error: negative edge count");
+	CsrRef c = find_csr(s, id);
 	if (!c || !c->initialized_v) return fail("Constraint Error: CSR vertices must be created before the edges");
 	if ((int64_t)c->vsize != V + 2) return fail("Invalid Input Error: vertex count does not match the CSR");
 	if (!c->initialized_e) { // CsrInitializeEdge :43-61
 		std::lock_guard<std::mutex> g(s->csr_lock);
 		if (!c->initialized_e) {
-			c->e.assign((size_t)e_sum, 0);
-			c->edge_ids.assign((size_t)e_sum, 0);
+			try { // no exception may cross the C ABI
+				c->e.assign((size_t)e_sum, 0);
+				c->edge_ids.assign((size_t)e_sum, 0);
+			} catch (const std::exception &) { // bad_alloc, length_error
+				c->e.clear();
+				c->edge_ids.clear();
+				return fail("Out of Memory Error: cannot allocate the CSR edge arrays");
+			}
 			for (int64_t i = 1; i < V + 2; i++) c->v[i] += c->v[i - 1];
 			c->initialized_e = true;
 		}
@@ -213,12 +225,19 @@ int pgq_udf_create_csr_edge(pgq_state_t *s, int32_t id, int64_t V, int64_t e_sum
 	if (!c->initialized_w) { // CsrInitializeWeight :63-84
 		std::lock_guard<std::mutex> g(s->csr_lock);
 		if (!c->initialized_w) {
-			if (w_type == PGQ_W_INT64) c->w.assign((size_t)e_sum, 0);
-			else if (w_type == PGQ_W_DOUBLE) c->w_double.assign((size_t)e_sum, 0.0);
-			else return fail("Not implemented Error: Unrecognized weight type detected.");
+			try {
+				if (w_type == PGQ_W_INT64) c->w.assign((size_t)e_sum, 0);
+				else if (w_type == PGQ_W_DOUBLE) c->w_double.assign((size_t)e_sum, 0.0);
+				else return fail("Not implemented Error: Unrecognized weight type detected.");
+			} catch (const std::exception &) { // bad_alloc, length_error
+				return fail("Out of Memory Error: cannot allocate the CSR weight array");
+			}
 			c->initialized_w = true;
 		}
 	}
+	// every chunk of one CSR carries the weight type the first chunk initialised (the other vector is empty)
+	if ((w_type == PGQ_W_INT64 ? c->w.size() : w_type == PGQ_W_DOUBLE ? c->w_double.size() : 0) != c->e.size())
+		return fail("Invalid Input Error: weight type differs from the one this CSR was initialised with");
 	View wgt(*wv);
 	for (int64_t r = 0; r < n; r++) { // :156-197
 		int64_t sp = src.pos(r), dp = dst.pos(r), ep = eid.pos(r), wp = wgt.pos(r);
@@ -254,7 +273,7 @@ int pgq_udf_bind_search(pgq_state_t *s, int32_t id) { // iterative_length_functi
 
 int pgq_udf_iterativelength(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                             int64_t *out, uint64_t *out_valid) {
-	HostCSR *c;
+	CsrRef c;
 	pgq_csr_t *d;
 	if (search_prologue(s, id, V, &c, &d, "shortest path")) return -1;
 	if (pgq_iterativelength(d, V, n, src, dst, out, out_valid) != PGQ_OK) return device_fail();
@@ -276,7 +295,7 @@ int pgq_udf_iterativelengthbidirectional(pgq_state_t *s, int32_t id, int64_t V, 
 int pgq_udf_shortestpath(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                          uint64_t *out_offset, uint64_t *out_length, uint64_t *out_valid, const int64_t **out_child,
                          uint64_t *out_child_len) {
-	HostCSR *c;
+	CsrRef c;
 	pgq_csr_t *d;
 	if (search_prologue(s, id, V, &c, &d, "shortest path")) return -1;
 	if (pgq_shortestpath(d, V, n, src, dst, out_offset, out_length, out_valid, out_child, out_child_len) != PGQ_OK)
@@ -288,7 +307,7 @@ int pgq_udf_shortestpath(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_v
 
 int pgq_udf_bind_cheapest(pgq_state_t *s, int32_t id, int *ret_type) { // cheapest_path_length_function_data.cpp:7-32
 	if (!s) return fail("Invalid Input Error: NULL state");
-	HostCSR *c = find_csr(s, id);
+	CsrRef c = find_csr(s, id);
 	if (!c) return fail("Constraint Error: CSR not found with ID " + std::to_string(id)); // duckpgq_state.cpp:183
 	{
 		std::lock_guard<std::mutex> g(s->csr_lock);
@@ -303,10 +322,11 @@ int pgq_udf_bind_cheapest(pgq_state_t *s, int32_t id, int *ret_type) { // cheape
 int pgq_udf_cheapest_path_length(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                                  void *out, uint64_t *out_valid) {
 	if (!s) return fail("Invalid Input Error: NULL state");
-	HostCSR *c = find_csr(s, id);
+	CsrRef c = find_csr(s, id);
 	if (!c) return fail("Constraint Error: CSR not found with ID " + std::to_string(id));
 	if (!(c->initialized_v && c->initialized_e && c->initialized_w))
 		return fail("Constraint Error: Need to initialize CSR before doing cheapest path");
+	if ((int64_t)c->vsize != V + 2) return fail("Invalid Input Error: vertex count does not match the CSR");
 	pgq_csr_t *d = device_csr(s, c, V);
 	if (!d) return device_fail();
 	if (pgq_cheapest_path_length(d, V, n, src, dst, out, out_valid) != PGQ_OK) return device_fail();
@@ -319,11 +339,12 @@ int pgq_udf_reachability(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_v
                          uint64_t *out_valid) {
 	std::vector<int64_t> len((size_t)n);
 	if (pgq_udf_iterativelength(s, id, V, n, src, dst, len.data(), out_valid)) return -1;
-	View sv(src);
+	View sv(src), dv(dst);
 	for (int64_t r = 0; r < n; r++) {
-		bool src_null = !sv.ok(sv.pos(r));
+		const bool any_null = !sv.ok(sv.pos(r)) || !dv.ok(dv.pos(r)); // a NULL endpoint gives NULL
 		out[r] = len[r] >= 0 ? 1 : 0;
-		if (!src_null) out_valid[r >> 6] |= 1ULL << (r & 63); // unreachable is FALSE, not NULL
+		if (!any_null) out_valid[r >> 6] |= 1ULL << (r & 63); // unreachable is FALSE, not NULL
+		else out_valid[r >> 6] &= ~(1ULL << (r & 63));
 	}
 	return 0;
 }
@@ -337,7 +358,7 @@ int pgq_udf_delete_csr(pgq_state_t *s, int32_t id, int *out_flag) { // csr_delet
 
 int pgq_udf_csr_get_w_type(pgq_state_t *s, int32_t id, int32_t *out) { // csr_get_w_type.cpp:16-36
 	if (!s) return fail("Invalid Input Error: NULL state");
-	HostCSR *c = find_csr(s, id);
+	CsrRef c = find_csr(s, id);
 	if (!c) return fail("Constraint Error: CSR not found with ID " + std::to_string(id));
 	if (!c->initialized_w) *out = PGQ_W_NONE;
 	else if (!c->w.empty()) *out = PGQ_W_INT64;
@@ -347,21 +368,21 @@ int pgq_udf_csr_get_w_type(pgq_state_t *s, int32_t id, int32_t *out) { // csr_ge
 }
 
 int64_t pgq_udf_scan_csr_v(pgq_state_t *s, int32_t id, int64_t *out, int64_t cap) { // pgq_scan.cpp:84-111
-	HostCSR *c = s ? find_csr(s, id) : nullptr;
+	CsrRef c = s ? find_csr(s, id) : nullptr;
 	if (!c) return fail("Constraint Error: CSR not found with ID " + std::to_string(id));
 	int64_t k = std::min<int64_t>(cap, (int64_t)c->vsize);
 	for (int64_t i = 0; i < k; i++) out[i] = c->v[i].load();
 	return (int64_t)c->vsize;
 }
 int64_t pgq_udf_scan_csr_e(pgq_state_t *s, int32_t id, int64_t *out, int64_t cap) { // pgq_scan.cpp:15-42
-	HostCSR *c = s ? find_csr(s, id) : nullptr;
+	CsrRef c = s ? find_csr(s, id) : nullptr;
 	if (!c) return fail("Constraint Error: CSR not found with ID " + std::to_string(id));
 	int64_t k = std::min<int64_t>(cap, (int64_t)c->e.size());
 	if (k > 0) memcpy(out, c->e.data(), (size_t)k * 8);
 	return (int64_t)c->e.size();
 }
 int64_t pgq_udf_scan_csr_w(pgq_state_t *s, int32_t id, void *out, int64_t cap) { // pgq_scan.cpp:113-153
-	HostCSR *c = s ? find_csr(s, id) : nullptr;
+	CsrRef c = s ? find_csr(s, id) : nullptr;
 	if (!c) return fail("Constraint Error: CSR not found with ID " + std::to_string(id));
 	const void *p = c->w.empty() ? (const void *)c->w_double.data() : (const void *)c->w.data();
 	int64_t sz = (int64_t)(c->w.empty() ? c->w_double.size() : c->w.size());
@@ -371,7 +392,7 @@ int64_t pgq_udf_scan_csr_w(pgq_state_t *s, int32_t id, void *out, int64_t cap) {
 }
 
 pgq_csr_t *pgq_udf_device_csr(pgq_state_t *s, int32_t id) {
-	HostCSR *c = s ? find_csr(s, id) : nullptr;
+	CsrRef c = s ? find_csr(s, id) : nullptr;
 	if (!c || !c->initialized_v) {
 		fail("Constraint Error: CSR not found with ID " + std::to_string(id));
 		return nullptr;

@@ -177,3 +177,22 @@ def test_host_csr_edge_chunks_from_concurrent_threads():
     for x in range(V):
         lo, hi = int(v[x]), int(v[x + 1])
         assert sorted(zip(e[lo:hi].tolist(), ew[lo:hi].tolist())) == sorted(zip(re_[lo:hi].tolist(), rw[lo:hi].tolist()))
+
+
+def test_udf_argument_checks_return_errors_instead_of_crashing():
+    # cheapest_path_length applies the same vertex-count check as the other search UDFs (a larger V would read past
+    # the host offsets); negative edge counts and a weight type that changes between chunks are rejected
+    lay = load_golden("student_csr_layout.json")
+    s, d, e = directed_rows(lay["edges"])
+    st = pgq.PgqState()
+    st.build_csr(0, 5, s, d, e, w=np.full(len(s), 3, dtype=np.int64))
+    with pytest.raises(pgq.PgqError, match="vertex count does not match the CSR"):
+        st.cheapest_path_length(0, 50_000_000, np.array([0]), np.array([1]))
+    with pytest.raises(pgq.PgqError, match="vertex count does not match the CSR"):
+        st.iterativelength(0, 50_000_000, np.array([0]), np.array([1]))
+    st.create_csr_vertex(1, 5, np.arange(5), np.bincount(s, minlength=5))
+    with pytest.raises(pgq.PgqError, match="negative edge count"):
+        st.create_csr_edge(1, 5, -1, -1, s, d, e)
+    st.create_csr_edge(1, 5, len(s), len(s), s[:3], d[:3], e[:3], w=np.ones(3, dtype=np.int64))
+    with pytest.raises(pgq.PgqError, match="weight type differs"):
+        st.create_csr_edge(1, 5, len(s), len(s), s[3:], d[3:], e[3:], w=np.ones(len(s) - 3, dtype=np.float64))

@@ -63,28 +63,19 @@ constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 at
 struct MeetCounters {
 	unsigned long long entries[kMeetStatSlots];  // adjacency entries scanned (both kinds of list)
 	unsigned long long vertices[kMeetStatSlots]; // vertices expanded (offset pairs fetched)
-	u32 n_slices;               // slices of heavy rows appended by the first launch
 	u32 bad;                    // an id outside [0, V)
-	u32 pad[2];
+	u32 pad[3];
 };
 
-struct MeetSlice { // part of a heavy row's two-hop walk: positions [begin, end) of the expanded side's one-hop list
-	u32 row, begin, end, pad;
-};
-
-// One wavefront per work item.  An item costs ~6 dependent memory round trips before its walk starts (row, offsets,
-// one-hop lists, their offsets) and a single wavefront streams only ~4 KB per round trip, so (a) many items must be
-// in flight per CU (24 wavefronts, 5 KB of LDS each) and (b) a long walk must not stay on one wavefront: it would set
-// the kernel's duration.  First launch (SLICES = false): item = row; rows whose walk exceeds `light` entries are not
-// walked but cut into slices of ~`light` entries (written to the row's own slots of `slices`), their answer left open.  Second launch
-// (SLICES = true): item = slice; a slice that finds a witness stores 3 into its row.  Items are dealt round-robin (one
-// shared counter would serialise ~10^4 claims at 12-20 ns each: more than the walks take).
-template <bool SLICES>
-__global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+// One wavefront per row.  A row costs ~6 dependent memory round trips before its walk starts (row, offsets, one-hop
+// lists, their offsets) and a single wavefront streams only ~4 KB per round trip, so what counts is how many rows a
+// CU has in flight (registers permitting: 5 KB of LDS each) — the workgroup is a single wavefront so that a finished
+// row frees its slot at once.  Rows are dealt round-robin (one shared counter would serialise ~10^4 claims at 12-20 ns
+// each: more than the walks take).
+__global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
-                                                  int64_t *__restrict__ out, int64_t cap, int64_t light,
-                                                  MeetSlice *__restrict__ slices, u32 slices_per_row, MeetCounters *__restrict__ mc) {
+                                                  int64_t *__restrict__ out, int64_t cap, MeetCounters *__restrict__ mc) {
 	__shared__ u32 s_tab[kMeetWPB][kMeetSlots];
 	__shared__ u32 s_bm[kMeetWPB][kMeetFilterWords];
 	const int lane = threadIdx.x & 63;
@@ -94,23 +85,9 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 	u32 vertices = 0;
 	const int64_t wave0 = (int64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
-	const int64_t n_items = SLICES ? n * (int64_t)slices_per_row : n;
-	for (int64_t it = wave0; it < n_items; it += nwaves) {
-		int64_t i = it;
-		int sl_begin = 0, sl_end = 0x7FFFFFFF;
-		if constexpr (SLICES) {
-			const MeetSlice sl = slices[it];
-			i = (int64_t)sl.row;
-			sl_begin = (int)sl.begin;
-			sl_end = (int)sl.end;
-		}
-		if constexpr (SLICES) {
-			if (i == 0xFFFFFFFFll) continue; // unused slot
-		} else {
-			if ((u32)lane < slices_per_row) slices[(size_t)i * slices_per_row + lane].row = 0xFFFFFFFFu;
-		}
+	for (int64_t i = wave0; i < n; i += nwaves) {
 		const int64_t s = src[i], d = dst[i];
-		if constexpr (!SLICES) {
+		{
 			if (s < 0) { // NULL row (iterativelength.cpp:99-101)
 				if (lane == 0) out[i] = -1;
 				continue;
@@ -129,7 +106,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 		}
 		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
 		const int degS = se - so, degD = de - di;
-		if constexpr (!SLICES) {
+		{
 			if (degS == 0 || degD == 0) { // no path can exist: NULL like an exhausted search (iterativelength.cpp:133-139)
 				if (lane == 0) out[i] = -1;
 				continue;
@@ -140,8 +117,8 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 		bool fwd = degS <= degD;
 		if ((fwd ? degD : degS) > kMeetSetMax) fwd = !fwd;
 		const int set_n = fwd ? degD : degS;
-		const int exp_n = min(fwd ? degS : degD, sl_end);
-		if constexpr (!SLICES) {
+		const int exp_n = fwd ? degS : degD;
+		{
 			if (set_n > kMeetSetMax) { // both lists too long for the table
 				if (lane == 0) out[i] = kMeetOpen;
 				continue;
@@ -153,13 +130,13 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 		const int32_t *xadj = fwd ? adj : radj;
 		const u32 other = (u32)(fwd ? s : d);                  // distance 1: the set list contains the other endpoint
 		// both one-hop lists are requested together; the expanded side's first 64 vertices then ask for their ranges
-		const u32 v0 = sl_begin + lane < exp_n ? (u32)exp_adj[sl_begin + lane] : 0u;
+		const u32 v0 = lane < exp_n ? (u32)exp_adj[lane] : 0u;
 #pragma unroll
 		for (int k = 0; k < kMeetSlots / 64; k++) tab[k * 64 + lane] = kMeetEmpty;
 #pragma unroll
 		for (int k = 0; k < kMeetFilterWords / 64; k++) bm[k * 64 + lane] = 0;
 		int vb0 = 0, ve0 = 0;
-		if (sl_begin + lane < exp_n) {
+		if (lane < exp_n) {
 			vb0 = (int)xoff[v0];
 			ve0 = (int)xoff[v0 + 1];
 		}
@@ -186,7 +163,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 		}
 		entries += (unsigned long long)set_n;
 		__builtin_amdgcn_wave_barrier();
-		if constexpr (!SLICES) {
+		{
 			if (__any(hit)) {
 				if (lane == 0) out[i] = 1;
 				continue;
@@ -210,31 +187,16 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 				if (lane == 0) out[i] = kMeetOpen;
 				continue;
 			}
-			if (work > light) { // cut into slices of about `light` entries (by vertex count: the walk is roughly uniform)
-				const u32 ns = (u32)min((int64_t)min(exp_n, (int)slices_per_row), (work + light - 1) / light);
-				if ((u32)lane < slices_per_row) { // the row's own slots: no shared append counter (it would serialise)
-					MeetSlice sl;
-					sl.row = (u32)lane < ns ? (u32)i : 0xFFFFFFFFu;
-					sl.begin = (u32)((int64_t)exp_n * lane / ns);
-					sl.end = (u32)((int64_t)exp_n * (lane + 1) / ns);
-					sl.pad = 0;
-					slices[(size_t)i * slices_per_row + lane] = sl;
-				}
-				if (lane == 0) out[i] = kMeetOpen; // a slice that finds a witness overwrites it
-				continue;
-			}
-		} else {
-			vertices += (u32)max(0, exp_n - sl_begin);
 		}
 		// distance 3: stream the adjacency segment of every expanded-side vertex, 16 bytes per lane per request, one
 		// hash probe per entry.  The segments of a round of 64 vertices form one flat sequence of 256-entry chunks walked
 		// by a wave-uniform cursor; four chunk requests are always in flight (a chunk's registers are refilled as soon
 		// as it has been probed).
 		bool found = false;
-		for (int pb = sl_begin; pb < exp_n && !found; pb += 64) {
+		for (int pb = 0; pb < exp_n && !found; pb += 64) {
 			const int cnt = min(64, exp_n - pb);
 			int vb = vb0, ve = ve0;
-			if (pb > sl_begin) {
+			if (pb > 0) {
 				vb = ve = 0;
 				if (lane < cnt) {
 					const u32 v = (u32)exp_adj[pb + lane];
@@ -245,8 +207,8 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 			int j = -1, q = 0, e = 0, b = 0; // cursor: vertex j of the round, aligned position q of its segment [b, e)
 			auto seek = [&]() { // next vertex with a non-empty segment
 				for (j++; j < cnt; j++) {
-					b = __shfl(vb, j);
-					e = __shfl(ve, j);
+					b = __builtin_amdgcn_readlane(vb, j); // wave-uniform: scalar registers
+					e = __builtin_amdgcn_readlane(ve, j);
 					if (e > b) {
 						q = b & ~3;
 						return;
@@ -254,7 +216,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 				}
 			};
 			seek();
-			constexpr int DEPTH = 4;
+			constexpr int DEPTH = 3;
 			int4 x[DEPTH];
 			int xb[DEPTH], xe[DEPTH], xq[DEPTH]; // the segment and position a chunk was requested from (wave-uniform)
 			auto fetch = [&](int u) {
@@ -290,11 +252,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, 4) void k_meet3(int64_t n, const int
 				if (found || !any_chunk) break;
 			}
 		}
-		if constexpr (SLICES) {
-			if (found && lane == 0) out[i] = 3;
-		} else {
-			if (lane == 0) out[i] = found ? 3 : kMeetOpen;
-		}
+		if (lane == 0) out[i] = found ? 3 : kMeetOpen;
 	}
 	// one pair of atomics per workgroup, spread over the statistic slots
 	__shared__ unsigned long long s_stat[2];
@@ -547,19 +505,11 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	u32 *d_count = reinterpret_cast<u32 *>(mc + 1);
 	PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
 	{
-		const Options &opt = options();
-		const int64_t cap = std::max(1, opt.meet_cap), light = std::max(256, opt.meet_light);
-		// every row owns cap/light + 1 slice slots (at most 64: one per lane of the wavefront that fills them)
-		const u32 slices_per_row = (u32)std::min<int64_t>(cap / light + 1, 64);
-		PGQ_TRY(ws->meet_slices.reserve((size_t)n * slices_per_row * sizeof(MeetSlice)));
+		const int64_t cap = std::max(1, options().meet_cap);
 		KernelTimer kt(st, K_MEET);
-		const unsigned resident = 256 * 16 / kMeetWPB; // workgroups the chip holds at 16 wavefronts per CU
-		hipLaunchKernelGGL(k_meet3<false>, dim3((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident)), dim3(64 * kMeetWPB), 0, st, n,
-		                   d_src, d_dst, c->V, c->off, c->adj, c->roff, c->radj, d_out, cap, light,
-		                   ws->meet_slices.as<MeetSlice>(), slices_per_row, mc);
-		// second launch over every slice slot (unused ones are skipped)
-		hipLaunchKernelGGL(k_meet3<true>, dim3(4 * resident), dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj,
-		                   c->roff, c->radj, d_out, cap, light, ws->meet_slices.as<MeetSlice>(), slices_per_row, mc);
+		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 4 rounds
+		hipLaunchKernelGGL(k_meet3, dim3((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident)),
+		                   dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff, c->radj, d_out, cap, mc);
 		kt.stop();
 	}
 	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,

@@ -93,7 +93,6 @@ static int do_init(int device) {
 	env_int("PGQ_LANES", g_opt.lanes);
 	env_int("PGQ_MEET", g_opt.meet);
 	env_int("PGQ_MEET_CAP", g_opt.meet_cap);
-	env_int("PGQ_MEET_LIGHT", g_opt.meet_light);
 	env_int("PGQ_MEET4", g_opt.meet4);
 	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
 	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
@@ -666,10 +665,21 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 	return PGQ_OK;
 }
 
-// simple float4 copy kernel for the measured HBM ceiling
-__global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, int64_t n) {
+// 16-byte copy kernel for the measured HBM ceiling: four independent non-temporal requests per thread per round
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, int64_t n) {
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i + 3 * stride < n; i += 4 * stride) {
+		uint4 v[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const unsigned long long *p = reinterpret_cast<const unsigned long long *>(in + i + k * stride);
+			const unsigned long long lo = __builtin_nontemporal_load(p), hi = __builtin_nontemporal_load(p + 1);
+			v[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) out[i + k * stride] = v[k];
+	}
 	for (; i < n; i += stride) out[i] = in[i];
 }
 
@@ -848,7 +858,6 @@ std::vector<OptRef> option_table() {
 		{ "lanes", &o.lanes, nullptr },
 		{ "meet", &o.meet, nullptr },
 		{ "meet_cap", &o.meet_cap, nullptr },
-		{ "meet_light", &o.meet_light, nullptr },
 		{ "meet4", &o.meet4, nullptr },
 		{ "meet4_cap", &o.meet4_cap, nullptr },
 		{ "meet_bias", nullptr, &o.meet_bias },

@@ -51,3 +51,33 @@ def gather_rows(local, total):
     parts = [torch.empty(per, dtype=local.dtype, device=local.device) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat(parts)[:total]
+
+
+def gather_paths(d_len, d_off, d_child, used, per):
+    """all_gather of shortestpath results: per-pair hop counts and list offsets (equal blocks of `per` rows, the last
+    shard padded) and the packed [v,e,v,...] payloads (ragged: sizes first, then blocks padded to the largest).
+    Returns (lengths, offsets into the concatenated payload, payload); offsets of rank r are shifted by the payload
+    sizes of the ranks before it."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return d_len, d_off, d_child[:used]
+    world = dist.get_world_size()
+    dev = d_len.device
+
+    def pad_to(t, k, fill):
+        return t if t.numel() >= k else torch.cat([t, torch.full((k - t.numel(),), fill, dtype=t.dtype, device=dev)])
+
+    lens = [torch.empty(per, dtype=d_len.dtype, device=dev) for _ in range(world)]
+    offs = [torch.empty(per, dtype=d_off.dtype, device=dev) for _ in range(world)]
+    dist.all_gather(lens, pad_to(d_len, per, -1))
+    dist.all_gather(offs, pad_to(d_off, per, 0))
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([used], dtype=torch.int64, device=dev))
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(max(sizes), 1)
+    blocks = [torch.empty(cap, dtype=d_child.dtype, device=dev) for _ in range(world)]
+    dist.all_gather(blocks, pad_to(d_child[:used], cap, 0))
+    base, shifted = 0, []
+    for r in range(world):
+        shifted.append(offs[r] + base)
+        base += sizes[r]
+    return torch.cat(lens), torch.cat(shifted), torch.cat([b[:k] for b, k in zip(blocks, sizes)])

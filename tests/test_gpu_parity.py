@@ -17,7 +17,7 @@ def _defaults():
                  ("relax_small_limit", 2048), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_light", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20)):
+                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20)):
         pgq.set_option(k, v)
     yield
 
@@ -169,7 +169,6 @@ def test_meet_prepass_matches_oracle(cap):
     st, ora = both(V, rows)
     pgq.set_option("meet", 1)
     pgq.set_option("meet_cap", cap)
-    pgq.set_option("meet_light", 256 if cap == 1 << 18 else 1 << 16)  # 256: most walks are cut into slices
     pgq.set_option("meet_bias", 1e9)  # always take the pre-pass
     pgq.set_option("meet4", 0 if cap == 1 else 1)  # k_meet4: LDS bit-map kernel for what k_meet3 leaves open
     pgq.set_option("meet4_cap", 1 << 20 if cap != 3000 else 2000)
@@ -479,3 +478,25 @@ def test_concurrent_callers_share_one_csr():
     for t in threads:
         t.join()
     assert errors == []
+
+
+def test_two_ranks_on_one_gpu_product_path():
+    """N > 1 with the PRODUCT on every rank: two processes share cuda:0 (gloo carries the collectives, RCCL needs one
+    GPU per rank), CSR broadcast, pairs sharded, results gathered; bench.py asserts every rank's lengths against the
+    accounting pass and prints one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["--workload", "snb_sf100", "--scaling", "strong"], ["--workload", "snb_paths"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+               "--warmup", "1", "--backend", "gloo", "--pairs-per-gpu", "3000", "--snb-vertices", "20000",
+               "--snb-friendships", "400000", "--no-cpu-baseline"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and out["value"] > 0
+        assert out["config"]["pairs_total"] == (3000 if "strong" in extra else 6000)

@@ -42,10 +42,27 @@ def _worker(rank, world, port, total, q):
     ln, ok = ora.lean_iterativelength(V, pairs[lo:hi, 0], pairs[lo:hi, 1])
     ln[~ok] = -1
     allr = sharding.gather_rows(torch.from_numpy(ln), total)
+    # path lists: packed per-rank payloads of different sizes, offsets relative to the rank's own buffer
+    paths = ora.lean_shortestpath(V, pairs[lo:hi, 0], pairs[lo:hi, 1])
+    offs, child = [], []
+    for pth in paths:
+        offs.append(len(child))
+        child.extend(pth or [])
+    per = (total + world - 1) // world
+    g_len, g_off, g_child = sharding.gather_paths(torch.from_numpy(ln), torch.tensor(offs, dtype=torch.int64),
+                                                  torch.tensor(child + [0] * 7, dtype=torch.int64), len(child), per)
     if rank == 0:
         ln1, ok1 = ora.lean_iterativelength(V, pairs[:, 0], pairs[:, 1])
         ln1[~ok1] = -1
-        q.put((allr.numpy().tolist() == ln1.tolist(), int(allr.numel())))
+        want = ora.lean_shortestpath(V, pairs[:, 0], pairs[:, 1])
+        got, k = [], 0
+        for r in range(world):  # gathered blocks are `per` rows each (the last one padded)
+            rlo, rhi = sharding.shard_bounds(total, world, r)
+            for j in range(rhi - rlo):
+                i = r * per + j
+                length = int(g_len[i])
+                got.append(None if length < 0 else g_child[int(g_off[i]):int(g_off[i]) + 2 * length + 1].tolist())
+        q.put((allr.numpy().tolist() == ln1.tolist() and got == want, int(allr.numel())))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -21,6 +21,7 @@
 // algorithmic bytes = 4 B per adjacency entry scanned + 16 B per expanded vertex (its offsets).
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 
 #include "pgq_search.h"
 
@@ -462,6 +463,66 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
 		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
 	}
+}
+
+// ---- how many distinct sources? ---------------------------------------------------------------------------------------
+// The pre-pass costs one two-hop walk per ROW, the lane-batched search one lane per distinct SOURCE: for cross-product
+// shaped inputs (few sources x many destinations, the binder's shape) the latter wins by orders of magnitude.  A
+// strided sample of the rows goes through an LDS hash set; the host inverts E[distinct] = U (1 - (1 - 1/U)^sample).
+constexpr int kSampleRows = 4096, kSampleSlots = 16384;
+__global__ __launch_bounds__(1024) void k_sample_sources(int64_t n, const int64_t *__restrict__ src, u32 *__restrict__ out) {
+	__shared__ u32 s_set[kSampleSlots];
+	__shared__ u32 s_count[2];
+	for (int k = threadIdx.x; k < kSampleSlots; k += 1024) s_set[k] = kMeetEmpty;
+	if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
+	__syncthreads();
+	const int64_t sample = n < kSampleRows ? n : kSampleRows;
+	u32 fresh = 0, rows = 0;
+	for (int64_t k = threadIdx.x; k < sample; k += 1024) {
+		const int64_t v = src[k * n / sample];
+		if (v < 0) continue; // NULL row
+		rows++;
+		const u32 x = (u32)v;
+		u32 h = (x * 0x9E3779B1u) >> 18; // 14 bits
+		for (;;) {
+			const u32 old = atomicCAS(&s_set[h], kMeetEmpty, x);
+			if (old == kMeetEmpty) fresh++;
+			if (old == kMeetEmpty || old == x) break;
+			h = (h + 1) & (kSampleSlots - 1);
+		}
+	}
+	if (fresh) atomicAdd(&s_count[0], fresh);
+	if (rows) atomicAdd(&s_count[1], rows);
+	__syncthreads();
+	if (threadIdx.x < 2) out[threadIdx.x] = s_count[threadIdx.x];
+}
+
+int estimate_distinct_sources(Workspace *ws, int64_t n, const int64_t *d_src, int64_t *estimate) {
+	hipStream_t st = ws->stream;
+	PGQ_TRY(ws->meet_cnt.reserve(sizeof(MeetCounters) + 16));
+	u32 *d_out = ws->meet_cnt.as<u32>();
+	hipLaunchKernelGGL(k_sample_sources, dim3(1), dim3(1024), 0, st, n, d_src, d_out);
+	u32 h[2] = { 0, 0 };
+	PGQ_HIP_TRY(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	const double d = h[0], s = h[1];
+	if (s < 1 || d < 1) {
+		*estimate = 1;
+		return PGQ_OK;
+	}
+	if (d >= s - 0.5) { // every sampled row had its own source
+		*estimate = n;
+		return PGQ_OK;
+	}
+	double lo = d, hi = (double)n; // E[distinct](U) is increasing in U
+	for (int it = 0; it < 60; it++) {
+		const double mid = 0.5 * (lo + hi);
+		const double e = mid * (1.0 - std::pow(1.0 - 1.0 / mid, s));
+		if (e < d) lo = mid;
+		else hi = mid;
+	}
+	*estimate = (int64_t)std::min<double>((double)n, std::ceil(hi));
+	return PGQ_OK;
 }
 
 // rows the pre-pass left open, compacted for the lane-batched search (order does not matter: results are scattered

@@ -1767,13 +1767,17 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		}
 		return PGQ_OK;
 	};
-	// few rows: decide without the lane assignment (every row taken as a distinct source: the pessimistic case for
-	// the pre-pass); many rows: the number of distinct sources decides (cross products share their lanes)
+	// few rows: every row is taken as a distinct source (the pessimistic case for the pre-pass); many rows: a sampled
+	// estimate of the distinct sources decides (cross products share their lanes)
 	if (may_meet && n <= 16384 && meet_pays(std::min<int64_t>(n, c->V))) return run_meet();
+	if (may_meet && n > 16384 && meet_pays(std::min<int64_t>(n, c->V))) { // worth a look at the sharing
+		int64_t est = n;
+		PGQ_TRY(estimate_distinct_sources(ws, n, d_src, &est));
+		if (meet_pays(std::min<int64_t>(est, c->V))) return run_meet();
+	}
 	u32 U = 0;
 	// the accounting pass counts the full BFS of a pair even when dst has no in-edge, so it keeps those lanes
 	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U, !outp.want_te));
-	if (may_meet && n > 16384 && U > 0 && meet_pays(U)) return run_meet();
 	S.unique_sources += U;
 	if (with_paths) PGQ_HIP_TRY(hipMemsetAsync(ws->soff.p, 0, (size_t)n * 8, st));
 	const int wd = choose_words(U);

@@ -67,6 +67,8 @@ int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const 
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open);
 int meet_apply(Workspace *ws, int64_t nd, const int64_t *d_len, int64_t *d_out);
+// Distinct sources among n rows, estimated from a 4096-row sample (decides pre-pass vs lane batches for large inputs).
+int estimate_distinct_sources(Workspace *ws, int64_t n, const int64_t *d_src, int64_t *estimate);
 
 // Assigns one lane per distinct source: fills ws->usrc (lane -> vertex), the row arrays sorted by lane
 // (skey/sidx/ssrc/sdst/sres) and returns the number of distinct sources in *U.

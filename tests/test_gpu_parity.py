@@ -195,6 +195,29 @@ def test_meet_prepass_matches_oracle(cap):
     assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
 
 
+def test_meet_prepass_large_inputs_cross_product_vs_distinct_sources():
+    # more than 16384 rows: a sampled estimate of the distinct sources decides between the pre-pass (one two-hop walk per
+    # row) and the lane batches (one lane per source)
+    rng = np.random.default_rng(12)
+    V, E = 20000, 200000
+    st, ora = both(V, random_graph(rng, V, E))
+    pgq.set_option("meet", 1)
+    srcs = rng.integers(0, V, 6)
+    ps = np.repeat(srcs, 3500)
+    pd = rng.integers(0, V, len(ps))
+    oln, ook = ora.lean_iterativelength(V, ps, pd)
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+    assert pgq.get_stats()["meet_pairs"] == 0 and pgq.get_stats()["levels"] > 0  # cross product: lane batches
+    ps, pd = rng.integers(0, V, 21000), rng.integers(0, V, 21000)
+    oln, ook = ora.lean_iterativelength(V, ps, pd)
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+    assert pgq.get_stats()["meet_pairs"] > 0  # distinct sources: pre-pass
+
+
 def test_meet_prepass_out_of_range_ids_rejected():
     import torch
     rng = np.random.default_rng(3)

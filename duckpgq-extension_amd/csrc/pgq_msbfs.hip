@@ -1303,6 +1303,7 @@ struct SearchOutput {
 	bool want_te = false; // fill ws->ste with per-row traversed-edge counts
 	int depth = 0;        // nesting level of the straggler pass
 	bool deferred = false;
+	bool overflow = false; // the caller's child buffer was too small (lengths are still complete)
 };
 static constexpr int kMaxTeLevels = 1024;
 
@@ -1707,7 +1708,9 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			child_base = need;
 		}
 		outp.child_used = child_base;
-		if (child_overflow) return fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(child_base) + " elements");
+		// not an early return: the straggler pass still has to run so that the lengths are complete and child_used
+		// reports everything the caller must provide
+		if (child_overflow) outp.overflow = true;
 	}
 	PGQ_HIP_TRY(hipStreamSynchronize(st)); // other workers / the caller read sres next
 	KernelTimer::flush();
@@ -1867,7 +1870,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 				if (d_child_ext) {
 					if (need > child_cap_ext) {
 						outp.child_used = need;
-						rc = fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(need) + " elements");
+						outp.overflow = true;
 					}
 				} else {
 					if ((size_t)need * 8 > ws->child.cap) {
@@ -1880,7 +1883,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 					}
 					d_child = ws->child.as<int64_t>();
 				}
-				if (rc == PGQ_OK) {
+				if (!outp.overflow) {
 					if (so2.child_used > 0)
 						PGQ_HIP_TRY(hipMemcpyAsync(d_child + base, inner.ws->child.p, (size_t)so2.child_used * 8,
 						                           hipMemcpyDeviceToDevice, st));
@@ -1888,6 +1891,11 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 					                   ws->def_idx.as<u32>(), ws->def_len.as<int64_t>(), ws->sres.as<int32_t>(),
 					                   ws->def_off.as<int64_t>(), ws->soff.as<int64_t>(), base);
 					PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+					outp.child_used = need;
+				} else { // lengths of the stragglers are still reported
+					hipLaunchKernelGGL(k_apply_deferred, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd,
+					                   ws->def_idx.as<u32>(), ws->def_len.as<int64_t>(), ws->sres.as<int32_t>(), nullptr,
+					                   nullptr, (int64_t)0);
 					outp.child_used = need;
 				}
 			}
@@ -1898,6 +1906,8 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	                   ws->soff.as<int64_t>(), d_out_len, with_paths ? d_out_off : nullptr);
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	KernelTimer::flush();
+	if (rc == PGQ_OK && outp.overflow)
+		rc = fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(outp.child_used) + " elements");
 	return rc;
 }
 

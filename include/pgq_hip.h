@@ -129,7 +129,8 @@ int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_
                                     int64_t *d_out_len, int64_t *d_out_te);
 /* d_out_len as above; paths are written packed into d_child (capacity child_cap int64), entry i at
  * d_out_offset[i] with 2*len+1 elements (no entry for NULL rows).  *child_used returns the elements needed;
- * PGQ_ERR_INVALID_ARG if child_cap was too small (nothing useful written then). */
+ * PGQ_ERR_INVALID_ARG if child_cap was too small: d_out_len is still complete and *child_used says what to provide,
+ * the child payload is not usable. */
 int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                  int64_t *d_out_len, int64_t *d_out_offset, int64_t *d_child, int64_t child_cap,
                                  int64_t *child_used);

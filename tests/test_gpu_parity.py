@@ -394,9 +394,124 @@ def test_full_size_sf100_properties():
             j = int(np.argmax(row == v))
             assert row[j] == v and eid[off[u] + j] == e  # first slot of u holding v (shortest_path.cpp:23-30)
     ora = OracleCSR.adopt(V, off, adj, eid)
-    oln, ook = ora.lean_iterativelength(V, ps[:256], pd[:256], nthreads=8)
-    assert (ook == ok[:256]).all() and (oln[ook] == ln[:256][ook]).all()
-    assert ora.lean_shortestpath(V, ps[:64], pd[:64]) == paths[:64]
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=16)
+    assert (ook == ok).all() and (oln[ook] == ln[ook]).all()
+    # 1024 full paths against the oracle: the min-id parent / first-slot tie-break of shortest_path.cpp:21-31
+    assert ora.lean_shortestpath(V, ps[:1024], pd[:1024]) == paths[:1024]
+    # the pair-centric pre-pass (k_meet3 / k_meet4) against the lane-batched search and the oracle, BASELINE configs[3]
+    # size: 65,536 pairs
+    import torch
+    allp = np.random.default_rng(4).integers(0, V, size=(65536, 2))
+    d_src, d_dst = torch.from_numpy(allp[:, 0].copy()).cuda(), torch.from_numpy(allp[:, 1].copy()).cuda()
+    d_a = torch.empty(65536, dtype=torch.int64, device="cuda")
+    d_b = torch.empty(65536, dtype=torch.int64, device="cuda")
+    pgq.set_option("meet", 1)
+    pgq.reset_stats()
+    dev.iterativelength_bulk_ptr(65536, d_src.data_ptr(), d_dst.data_ptr(), d_a.data_ptr())
+    assert pgq.get_stats()["meet_pairs"] > 60000
+    pgq.set_option("meet", 0)
+    dev.iterativelength_bulk_ptr(65536, d_src.data_ptr(), d_dst.data_ptr(), d_b.data_ptr())
+    assert bool((d_a == d_b).all())
+    oln, ook = ora.lean_iterativelength(V, allp[:8192, 0], allp[:8192, 1], nthreads=16)
+    got = d_a[:8192].cpu().numpy()
+    assert ((got >= 0) == ook).all() and (got[ook] == oln[ook]).all()
+
+
+@pytest.mark.slow
+def test_c2_rmat22_1024_pairs_matches_literal_oracle():
+    """BASELINE configs[1] at its stated scale: R-MAT scale 22 (4.2 M vertices, 67 M directed edges), 1024 pairs of
+    default_rng(2), iterativelength — lane-batched search and pre-pass against the literal 512-lane restatement."""
+    V, s, d = graphgen.rmat(22, seed=22)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    pairs = np.random.default_rng(2).integers(0, V, size=(1024, 2))
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    oln, ook = ora.baseline_run("iterativelength", V, pairs[:, 0], pairs[:, 1], nthreads=2)
+    for meet in (0, 1):
+        pgq.set_option("meet", meet)
+        pgq.set_option("meet_bias", 1e9)
+        ln, ok = dev.iterativelength(pairs[:, 0], pairs[:, 1])
+        assert (ok == ook).all() and (ln[ok] == oln[ook]).all()
+
+
+def test_c5_weighted_cheapest_path_at_scale_int64_and_double():
+    """BASELINE configs[4] shape: 4096 pairs with REACHABLE destinations (ancestors of the source) on a 2^20-vertex
+    reply forest, and 1024 pairs on a weighted SNB-like graph; int64 and double weights, against Dijkstra."""
+    rng = np.random.default_rng(55)
+    V, s, d = graphgen.reply_forest(1 << 20, seed=5)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    deg = np.diff(off)
+    cand = np.nonzero(deg > 0)[0]
+    src = cand[rng.integers(0, len(cand), 4096)]
+    dst = src.copy()
+    hops = rng.integers(1, 9, 4096)
+    for h in range(8):
+        move = (hops > h) & (deg[dst] > 0)
+        dst[move] = adj[off[dst[move]]]
+    dst[:256] = rng.integers(0, V, 256)  # some unreachable ones
+    for w in (rng.integers(1, 1000, len(adj)), rng.random(len(adj)) * 10.0):
+        dev = pgq.DeviceCSR(V, off, adj, eid, w)
+        ora = OracleCSR.adopt(V, off, adj, eid, w)
+        out, ok = dev.cheapest_path_length(src, dst)
+        want, wok = ora.lean_cheapest_path_length(V, src, dst)
+        assert (ok == wok).all() and (out[ok] == want[wok]).all() and ok.sum() > 3000
+    V2, s2, d2 = graphgen.snb_knows_like(20000, 400000, seed=9)
+    off2, adj2, eid2 = graphgen.csr_from_rows(V2, s2, d2)
+    ps, pd = rng.integers(0, V2, 1024), rng.integers(0, V2, 1024)
+    for w in (rng.integers(1, 100, len(adj2)), rng.random(len(adj2)) + 0.01):
+        dev = pgq.DeviceCSR(V2, off2, adj2, eid2, w)
+        ora = OracleCSR.adopt(V2, off2, adj2, eid2, w)
+        out, ok = dev.cheapest_path_length(ps, pd)
+        want, wok = ora.lean_cheapest_path_length(V2, ps, pd)
+        assert (ok == wok).all() and (out[ok] == want[wok]).all()
+
+
+def test_bulk_device_entry_points_match_chunk_api():
+    """pgq_shortestpath_bulk_device / pgq_cheapest_path_length_bulk_device (external child buffer, overflow return,
+    straggler append) against the chunk API and the oracle."""
+    import torch
+    rng = np.random.default_rng(8)
+    V, E = 30000, 400000
+    s, d, e = random_graph(rng, V, E, skew=True)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    w = rng.integers(1, 50, E)[eid]
+    dev = pgq.DeviceCSR(V, off, adj, eid, w)
+    ora = OracleCSR.adopt(V, off, adj, eid, w)
+    n = 6000
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    ps[:20] = pd[:20]
+    want = ora.lean_shortestpath(V, ps, pd)
+    d_src, d_dst = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+    d_len = torch.empty(n, dtype=torch.int64, device="cuda")
+    d_off = torch.zeros(n, dtype=torch.int64, device="cuda")
+    need = sum(len(p) for p in want if p is not None)
+    for words, defer in ((0, 8), (8, 2)):  # defer 2: stragglers of wide batches are appended by a narrow second pass
+        pgq.set_option("words", words)
+        pgq.set_option("defer", defer)
+        d_child = torch.empty(need + 16, dtype=torch.int64, device="cuda")
+        rc, used = dev.shortestpath_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(), d_off.data_ptr(),
+                                             d_child.data_ptr(), need + 16)
+        assert rc == 0 and used == need
+        ln, of, ch = d_len.cpu().numpy(), d_off.cpu().numpy(), d_child.cpu().numpy()
+        got = [None if ln[i] < 0 else ch[of[i]:of[i] + 2 * ln[i] + 1].tolist() for i in range(n)]
+        assert got == want
+        assert got == dev.shortestpath(ps, pd)
+        # too small a child buffer: error status, `used` reports what is needed, lengths are still right
+        small = torch.empty(need // 2, dtype=torch.int64, device="cuda")
+        rc, used = dev.shortestpath_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(), d_off.data_ptr(),
+                                             small.data_ptr(), need // 2)
+        assert rc != 0 and used == need
+        assert (d_len.cpu().numpy() == ln).all()
+    pgq.set_option("words", 0)
+    pgq.set_option("defer", 8)
+    d_val = torch.zeros(n, dtype=torch.int64, device="cuda")
+    d_ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dev.cheapest_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_val.data_ptr(), d_ok.data_ptr())
+    cw, cok = ora.lean_cheapest_path_length(V, ps, pd)
+    ok = d_ok.cpu().numpy().astype(bool)
+    assert (ok == cok).all() and (d_val.cpu().numpy()[ok] == cw[cok]).all()
+    out, ok2 = dev.cheapest_path_length(ps, pd)
+    assert (ok2 == cok).all() and (out[ok2] == cw[cok]).all()
 
 
 def test_device_csr_construction_matches_reference_layout():

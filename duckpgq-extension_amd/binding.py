@@ -79,6 +79,10 @@ def load_hip():
                                                C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.pgq_cheapest_path_length_bulk_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_void_p]
+    L.pgq_iterativelength_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pgq_init_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.pgq_init_mask.argtypes = [C.c_uint64]
+    L.pgq_csr_replicate.argtypes = [C.c_void_p]
     L.pgq_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.pgq_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
     L.pgq_get_stats.argtypes = [C.POINTER(Stats)]
@@ -188,6 +192,12 @@ def get_stats():
     d["kernel_ms"] = {n: st.kernel_ms[i] for i, n in enumerate(names)}
     d["launches"] = {n: st.launches[i] for i, n in enumerate(names)}
     return d
+
+
+def init_devices(devices):
+    arr = (C.c_int * len(devices))(*devices)
+    _check(load_hip().pgq_init_devices(arr, len(devices)))
+    return load_hip().pgq_num_enabled_devices()
 
 
 def reset_stats():
@@ -332,6 +342,16 @@ class DeviceCSR:
     def iterativelength_bulk_ptr(self, n, d_src, d_dst, d_out):
         _check(self.L.pgq_iterativelength_bulk_device(self.h, n, C.c_void_p(d_src), C.c_void_p(d_dst),
                                                       C.c_void_p(d_out)))
+
+    def iterativelength_multi(self, src, dst):
+        """Host arrays answered by every enabled device (pgq_init_devices): shards + in-library gather."""
+        src, dst = _i64(src), _i64(dst)
+        out = np.zeros(len(src), dtype=np.int64)
+        _check(self.L.pgq_iterativelength_multi(self.h, len(src), _p(src), _p(dst), _p(out)))
+        return out
+
+    def replicate(self):
+        _check(self.L.pgq_csr_replicate(self.h))
 
     def traversed_edges_bulk_ptr(self, n, d_src, d_dst, d_out_len, d_out_te):
         _check(self.L.pgq_traversed_edges_bulk_device(self.h, n, C.c_void_p(d_src), C.c_void_p(d_dst),

@@ -35,6 +35,10 @@ int fail(int code, const std::string &msg);
 	} while (0)
 
 int ensure_init();
+// the device this host thread works on (pgq_init's device unless a multi-device call bound the thread to another)
+int current_device();
+void bind_thread_device(int device); // < 0: back to the default
+const std::vector<int> &enabled_devices();
 
 // ---- options --------------------------------------------------------------------------------------------
 struct Options {
@@ -129,6 +133,10 @@ struct pgq_csr {
 	double two_hop_mean = 0; // mean over vertices of in-degree x out-degree = expected two-hop walk of a random endpoint
 	int64_t bytes = 0;
 	bool has_negative_weight = false;
+	// multi-GPU: copies of this CSR on the other enabled devices (pgq_csr_replicate), indexed like enabled_devices();
+	// entry = this object for its own device.  Owned by the primary.
+	std::vector<pgq_csr *> replicas;
+	bool is_replica = false;
 };
 
 namespace pgq {

@@ -1194,18 +1194,22 @@ Workspace::~Workspace() {
 }
 
 static std::mutex g_ws_lock;
-static std::vector<Workspace *> g_ws_free;
+static std::vector<Workspace *> g_ws_free; // every workspace remembers the device its buffers live on
 
 int WorkspaceLease::acquire() {
 	{
 		std::lock_guard<std::mutex> g(g_ws_lock);
-		if (!g_ws_free.empty()) {
-			ws = g_ws_free.back();
-			g_ws_free.pop_back();
-		}
+		const int dev = current_device();
+		for (size_t k = g_ws_free.size(); k-- > 0;)
+			if (g_ws_free[k]->device == dev) {
+				ws = g_ws_free[k];
+				g_ws_free.erase(g_ws_free.begin() + (long)k);
+				break;
+			}
 	}
 	if (!ws) {
 		ws = new Workspace();
+		ws->device = current_device();
 		// a half-built workspace never reaches the pool
 		if (hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess ||
 		    hipHostMalloc((void **)&ws->h_cnt, sizeof(Counters)) != hipSuccess) {
@@ -1219,7 +1223,7 @@ int WorkspaceLease::acquire() {
 WorkspaceLease::~WorkspaceLease() {
 	if (!ws) return;
 	std::lock_guard<std::mutex> g(g_ws_lock);
-	if (g_ws_free.size() < 8) g_ws_free.push_back(ws);
+	if (g_ws_free.size() < 8 * std::max<size_t>(1, enabled_devices().size())) g_ws_free.push_back(ws);
 	else delete ws;
 }
 
@@ -1812,8 +1816,10 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		std::vector<SearchOutput> outs((size_t)workers, outp);
 		std::vector<pgq_stats_t> wstats((size_t)workers);
 		std::vector<std::thread> pool;
+		const int dev = current_device();
 		for (int t = 1; t < workers; t++)
 			pool.emplace_back([&, t]() {
+				bind_thread_device(dev); // the caller's device (a multi-GPU shard may not be on the default one)
 				int r = ensure_init(); // binds the device for this host thread
 				if (r == PGQ_OK) {
 					(void)pgq_reset_stats();
@@ -1983,6 +1989,65 @@ int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src
 	SearchOutput so;
 	int rc = search_device(csr, lease.ws, n, d_src, d_dst, d_out_len, true, d_out_offset, d_child, child_cap, so);
 	if (child_used) *child_used = so.child_used;
+	return rc;
+}
+
+// Multi-GPU inside one process (the single DuckDB process the boundary targets): rows are cut into contiguous shards,
+// one host thread per enabled device runs the identical single-GPU path on its shard against that device's replica of
+// the CSR, and the results land in the caller's host array (the gather).  No collective inside the search
+// (results are a pure function of (CSR, src, dst)).
+int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (n < 0 || (n > 0 && (!src || !dst || !out_len))) return fail(PGQ_ERR_INVALID_ARG, "NULL array");
+	if (n == 0) return PGQ_OK;
+	PGQ_TRY(pgq_csr_replicate(csr));
+	const std::vector<int> devs = enabled_devices();
+	const int W = (int)devs.size();
+	const int64_t per = (n + W - 1) / W;
+	std::vector<int> rcs((size_t)W, PGQ_OK);
+	std::vector<std::string> errs((size_t)W);
+	std::vector<pgq_stats_t> wstats((size_t)W);
+	auto shard = [&](int k) -> int {
+		const int64_t lo = std::min<int64_t>((int64_t)k * per, n), hi = std::min<int64_t>(lo + per, n);
+		if (hi == lo) return PGQ_OK;
+		bind_thread_device(devs[(size_t)k]);
+		PGQ_TRY(ensure_init());
+		WorkspaceLease lease;
+		PGQ_TRY(lease.acquire());
+		Workspace *ws = lease.ws;
+		const size_t bytes = (size_t)(hi - lo) * 8;
+		PGQ_TRY(ws->in_src.reserve(bytes));
+		PGQ_TRY(ws->in_dst.reserve(bytes));
+		PGQ_TRY(ws->out_len.reserve(bytes));
+		PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, src + lo, bytes, hipMemcpyHostToDevice, ws->stream));
+		PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, dst + lo, bytes, hipMemcpyHostToDevice, ws->stream));
+		SearchOutput so;
+		PGQ_TRY(search_device(csr->replicas[(size_t)k], ws, hi - lo, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
+		                      ws->out_len.as<int64_t>(), false, nullptr, nullptr, 0, so));
+		PGQ_HIP_TRY(hipMemcpy(out_len + lo, ws->out_len.p, bytes, hipMemcpyDeviceToHost));
+		return PGQ_OK;
+	};
+	std::vector<std::thread> pool;
+	for (int k = 1; k < W; k++)
+		pool.emplace_back([&, k]() {
+			(void)pgq_reset_stats();
+			rcs[(size_t)k] = shard(k);
+			if (rcs[(size_t)k] != PGQ_OK) errs[(size_t)k] = pgq_last_error();
+			wstats[(size_t)k] = tstats().s;
+		});
+	rcs[0] = shard(0);
+	bind_thread_device(-1);
+	(void)ensure_init();
+	for (auto &th : pool) th.join();
+	int rc = PGQ_OK;
+	for (int k = 0; k < W; k++) {
+		if (rcs[(size_t)k] != PGQ_OK && rc == PGQ_OK) {
+			rc = rcs[(size_t)k];
+			if (k > 0) set_error(errs[(size_t)k]);
+		}
+		if (k > 0) merge_stats(tstats().s, wstats[(size_t)k]);
+	}
 	return rc;
 }
 

@@ -29,6 +29,11 @@ int fail(int code, const std::string &msg) {
 static std::mutex g_init_lock;
 static std::atomic<int> g_inited { 0 };
 static int g_device = 0;
+static std::vector<int> g_devices; // devices enabled for multi-GPU calls (pgq_init_devices); [g_device] by default
+static thread_local int t_device = -1;
+int current_device() { return t_device >= 0 ? t_device : g_device; }
+void bind_thread_device(int device) { t_device = device; }
+const std::vector<int> &enabled_devices() { return g_devices; }
 static Options g_opt;
 Options &options() { return g_opt; }
 
@@ -66,6 +71,7 @@ static int do_init(int device) {
 	e = hipSetDevice(device);
 	if (e != hipSuccess) return fail(PGQ_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
 	g_device = device;
+	if (g_devices.empty()) g_devices.push_back(device);
 	env_int("PGQ_WORDS", g_opt.words);
 	env_int("PGQ_MAX_WORDS", g_opt.max_words);
 	env_double("PGQ_PUSH_DIV", g_opt.push_div);
@@ -105,7 +111,7 @@ static int do_init(int device) {
 int ensure_init() {
 	if (!g_inited.load()) PGQ_TRY(do_init(-1));
 	// every host thread that calls in (DuckDB workers) must bind the device
-	hipError_t e = hipSetDevice(g_device);
+	hipError_t e = hipSetDevice(current_device());
 	if (e != hipSuccess) return fail(PGQ_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
 	return PGQ_OK;
 }
@@ -580,6 +586,9 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 
 static void destroy_csr(pgq_csr *c) {
 	if (!c) return;
+	if (!c->is_replica)
+		for (pgq_csr *r : c->replicas)
+			if (r && r != c) destroy_csr(r);
 	(void)hipFree(c->off);
 	(void)hipFree(c->adj);
 	(void)hipFree(c->edge_ids);
@@ -814,6 +823,106 @@ int pgq_csr_free(pgq_csr_t *csr) {
 	destroy_csr(csr);
 	return PGQ_OK;
 }
+int pgq_init_devices(const int *devices, int n) {
+	if (!devices || n < 1) return fail(PGQ_ERR_INVALID_ARG, "pgq_init_devices: empty device list");
+	PGQ_TRY(pgq_init(devices[0]));
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PGQ_ERR_NO_DEVICE, "no HIP device");
+	std::lock_guard<std::mutex> g(g_init_lock);
+	std::vector<int> list;
+	for (int k = 0; k < n; k++) {
+		if (devices[k] < 0 || devices[k] >= count) return fail(PGQ_ERR_INVALID_ARG, "pgq_init_devices: device index out of range");
+		list.push_back(devices[k]);
+	}
+	if (list[0] != g_device) return fail(PGQ_ERR_INVALID_ARG, "pgq_init_devices: the first device must be the one pgq_init bound");
+	for (int a : list)
+		for (int b : list)
+			if (a != b) {
+				int can = 0;
+				(void)hipSetDevice(a);
+				if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b, 0); // xGMI peer copies
+			}
+	(void)hipSetDevice(g_device);
+	g_devices = list;
+	return PGQ_OK;
+}
+int pgq_init_mask(uint64_t device_mask) {
+	std::vector<int> list;
+	for (int d = 0; d < 64; d++)
+		if ((device_mask >> d) & 1ull) list.push_back(d);
+	return pgq_init_devices(list.data(), (int)list.size());
+}
+int pgq_num_enabled_devices(void) { return (int)g_devices.size(); }
+
+// byte-for-byte copy of the device CSR (base arrays and everything derived at upload) to another device over xGMI
+static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
+	pgq_csr *r = new pgq_csr();
+	r->device = dev;
+	r->V = c->V;
+	r->E = c->E;
+	r->w_type = c->w_type;
+	r->n_pull_hub_items = c->n_pull_hub_items;
+	r->n_pull_hub_vertices = c->n_pull_hub_vertices;
+	r->n_pull_parts = c->n_pull_parts;
+	r->hub_threshold = c->hub_threshold;
+	r->max_out_degree = c->max_out_degree;
+	r->max_in_degree = c->max_in_degree;
+	r->two_hop_mean = c->two_hop_mean;
+	r->bytes = c->bytes;
+	r->has_negative_weight = c->has_negative_weight;
+	r->is_replica = true;
+	*out = r;
+	const size_t V1 = (size_t)c->V + 1, En = (size_t)std::max<int64_t>(c->E, 1);
+	auto copy = [&](void **dst, const void *src, size_t bytes) -> int {
+		*dst = nullptr;
+		if (!src || bytes == 0) return PGQ_OK;
+		PGQ_HIP_TRY(hipSetDevice(dev));
+		PGQ_HIP_TRY(hipMalloc(dst, bytes));
+		PGQ_HIP_TRY(hipMemcpyPeer(*dst, dev, src, c->device, bytes));
+		return PGQ_OK;
+	};
+	PGQ_TRY(copy((void **)&r->off, c->off, V1 * 8));
+	PGQ_TRY(copy((void **)&r->adj, c->adj, (En + 4) * 4));
+	PGQ_TRY(copy((void **)&r->edge_ids, c->edge_ids, En * 8));
+	PGQ_TRY(copy((void **)&r->w, c->w, En * 8));
+	PGQ_TRY(copy((void **)&r->roff, c->roff, V1 * 8));
+	PGQ_TRY(copy((void **)&r->radj, c->radj, (En + 4) * 4));
+	PGQ_TRY(copy((void **)&r->rslot, c->rslot, En * 8));
+	PGQ_TRY(copy((void **)&r->pull_hubs, c->pull_hubs, (size_t)c->n_pull_hub_items * sizeof(HubItem)));
+	PGQ_TRY(copy((void **)&r->pull_hub_vertices, c->pull_hub_vertices, (size_t)c->n_pull_hub_vertices * 4));
+	PGQ_TRY(copy((void **)&r->pull_parts, c->pull_parts, (size_t)c->n_pull_parts * 2 * 4));
+	PGQ_TRY(copy((void **)&r->rown, c->rown, En + 8));
+	PGQ_TRY(copy((void **)&r->rpk, c->rpk, (En + 2048) * 4));
+	PGQ_HIP_TRY(hipDeviceSynchronize());
+	return PGQ_OK;
+}
+
+int pgq_csr_replicate(pgq_csr_t *c) {
+	PGQ_TRY(ensure_init());
+	if (!c || c->is_replica) return fail(PGQ_ERR_INVALID_ARG, "pgq_csr_replicate: NULL or replica handle");
+	const std::vector<int> &devs = enabled_devices();
+	if (!c->replicas.empty()) return PGQ_OK; // already done
+	std::vector<pgq_csr *> reps(devs.size(), nullptr);
+	int rc = PGQ_OK;
+	bool self_used = false;
+	for (size_t k = 0; k < devs.size() && rc == PGQ_OK; k++) {
+		if (devs[k] == c->device && !self_used) {
+			reps[k] = c;
+			self_used = true;
+			continue;
+		}
+		rc = clone_csr(c, devs[k], &reps[k]);
+	}
+	(void)hipSetDevice(current_device());
+	if (rc != PGQ_OK) {
+		for (pgq_csr *r : reps)
+			if (r && r != c) destroy_csr(r);
+		return rc;
+	}
+	c->replicas = reps;
+	return PGQ_OK;
+}
+
 int64_t pgq_csr_num_vertices(const pgq_csr_t *csr) { return csr ? csr->V : -1; }
 int64_t pgq_csr_num_edges(const pgq_csr_t *csr) { return csr ? csr->E : -1; }
 int pgq_csr_w_type(const pgq_csr_t *csr) { return csr ? csr->w_type : -1; }

@@ -67,6 +67,13 @@ typedef struct pgq_vec {
 /* Idempotent. device < 0: use env PGQ_DEVICE, else LOCAL_RANK, else 0. */
 int pgq_init(int device);
 int pgq_device_count(void);
+/* Multi-GPU inside one process (SURVEY.md §8b `pgq_init(device_mask)`): enables several devices of this node for the
+ * *_multi entry points; the first one is the device pgq_init binds (single-device calls keep using it).  Peer access
+ * (xGMI) is enabled between them where the hardware allows.  pgq_init_devices accepts a repeated index (tests on a
+ * one-GPU box). */
+int pgq_init_devices(const int *devices, int n);
+int pgq_init_mask(uint64_t device_mask);
+int pgq_num_enabled_devices(void);
 const char *pgq_last_error(void);
 const char *pgq_version(void);
 
@@ -90,6 +97,9 @@ int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const 
 /* Copies the device CSR back in the reference's layout (int64); any pointer may be NULL.  get_csr_v/e/w analogue
  * (src/core/functions/table/pgq_scan.cpp:15-153) for the device-built CSR. */
 int pgq_csr_download(const pgq_csr_t *csr, int64_t *offsets, int64_t *adj, int64_t *edge_ids, void *w);
+/* Copies the device CSR (base arrays and everything derived at upload) to every other enabled device with peer copies
+ * over xGMI: the CSR is replicated, the pairs are sharded (north_star).  Idempotent; replicas die with the handle. */
+int pgq_csr_replicate(pgq_csr_t *csr);
 int pgq_csr_free(pgq_csr_t *csr);
 int64_t pgq_csr_num_vertices(const pgq_csr_t *csr);
 int64_t pgq_csr_num_edges(const pgq_csr_t *csr);
@@ -123,6 +133,9 @@ int pgq_release_cached_memory(void);
 /* d_src/d_dst/d_out_len: n int64 each in HBM.  d_out_len[i] = hop count, 0 for src==dst, -1 for NULL. */
 int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t *d_out_len);
+/* Rows in host memory, answered by all enabled devices: contiguous shards, one host thread and one CSR replica per
+ * device, results gathered into out_len (same values as pgq_iterativelength_bulk_device: hop count, 0, or -1). */
+int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len);
 /* Measurement helper: same search, additionally d_out_te[i] = edges traversed by pair i's own level-synchronous BFS
  * up to the level that reaches dst (all levels if unreachable) — the numerator of bench.py's MTEPS. */
 int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,

@@ -638,3 +638,28 @@ def test_two_ranks_on_one_gpu_product_path():
         out = json.loads(line)
         assert out["n_gpus"] == 2 and out["value"] > 0
         assert out["config"]["pairs_total"] == (3000 if "strong" in extra else 6000)
+
+
+def test_in_library_multi_gpu_shards_and_gathers():
+    """pgq_init_devices + pgq_csr_replicate + pgq_iterativelength_multi: one host thread and one CSR replica per enabled
+    device, contiguous shards, results gathered into one host array.  On a one-GPU box the device list names device 0
+    twice: two replicas (peer copy onto the same device), two shard threads, two workspaces."""
+    rng = np.random.default_rng(31)
+    V, E = 40000, 600000
+    s, d, e = random_graph(rng, V, E)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    n = 9001
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    ps[:5] = -1  # NULL rows
+    oln, ook = ora.lean_iterativelength(V, np.maximum(ps, 0), pd, nthreads=8)
+    want = np.where(ook & (ps >= 0), oln, -1)
+    assert pgq.init_devices([0, 0]) == 2
+    try:
+        for meet in (1, 0):
+            pgq.set_option("meet", meet)
+            got = dev.iterativelength_multi(ps, pd)
+            assert (got == want).all()
+    finally:
+        pgq.init_devices([0])

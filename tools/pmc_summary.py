@@ -27,10 +27,12 @@ for k, cs in agg.items():
     d["launches_profiled"] = max(len(v) for (kk, c), v in launches.items() if kk == k)
     out[k] = d
 # bench.py looks kernels up by class name ("pull_sparse"): add aliases for the widest instantiation seen
-for cls in ("pull_sparse", "pull", "push", "pull_hub", "relax"):
-    cands = [k for k in out if k.startswith("k_" + cls + "<")]
+for cls, prefixes in (("pull_sparse", ("k_pull_lanes<", "k_pull_sparse<")), ("pull", ("k_pull<",)), ("push", ("k_push<",)),
+                      ("pull_hub", ("k_pull_hub<",)), ("relax", ("k_relax<",)), ("meet", ("k_meet3", "k_meet4"))):
+    cands = [k for k in out if k.startswith(prefixes)]
     if cands:
-        best = max(cands, key=lambda k: out[k]["launches_profiled"])  # the instantiation the timed region launches most
+        # the kernel of the class that moves the most bytes per step (k_meet3 for "meet", the widest k_pull_lanes ...)
+        best = max(cands, key=lambda k: out[k].get("hbm_bytes_per_launch", 0) * out[k]["launches_profiled"])
         out[cls] = dict(out[best], kernel=best)
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", "pmc_%s.json" % wl), "w"), indent=1, sort_keys=True)

@@ -19,6 +19,8 @@
 // Rows it cannot answer (distance >= 4, unreachable, over the caps) are left to the MS-BFS path: the caller collects
 // them and runs the lane-batched search on them only.  Bound: HBM (segmented streaming of adjacency entries);
 // algorithmic bytes = 4 B per adjacency entry scanned + 16 B per expanded vertex (its offsets).
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -48,16 +50,30 @@ __device__ __forceinline__ bool meet_lookup(const u32 *tab, u32 x) {
 // entries a lane holds cost four independent LDS reads instead of four dependent hash-table walks
 constexpr int kMeetFilterWords = 256;
 __device__ __forceinline__ u32 meet_fhash(u32 x) { return (x * 0x9E3779B1u) >> 19; } // 13 bits
-__device__ __forceinline__ bool meet_probe4(const u32 *tab, const u32 *bm, const int4 v, bool k0, bool k1, bool k2, bool k3) {
+__device__ __forceinline__ u32 meet_probe4(const u32 *tab, const u32 *bm, const int4 v, bool k0, bool k1, bool k2, bool k3) {
 	const u32 h0 = meet_fhash((u32)v.x), h1 = meet_fhash((u32)v.y), h2 = meet_fhash((u32)v.z), h3 = meet_fhash((u32)v.w);
 	const u32 w0 = bm[h0 >> 5], w1 = bm[h1 >> 5], w2 = bm[h2 >> 5], w3 = bm[h3 >> 5];
-	bool f = false;
-	if (k0 && ((w0 >> (h0 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.x);
-	if (k1 && ((w1 >> (h1 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.y);
-	if (k2 && ((w2 >> (h2 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.z);
-	if (k3 && ((w3 >> (h3 & 31)) & 1u)) f |= meet_lookup(tab, (u32)v.w);
+	u32 f = 0; // bit k: entry k is in the set
+	if (k0 && ((w0 >> (h0 & 31)) & 1u) && meet_lookup(tab, (u32)v.x)) f |= 1u;
+	if (k1 && ((w1 >> (h1 & 31)) & 1u) && meet_lookup(tab, (u32)v.y)) f |= 2u;
+	if (k2 && ((w2 >> (h2 & 31)) & 1u) && meet_lookup(tab, (u32)v.z)) f |= 4u;
+	if (k3 && ((w3 >> (h3 & 31)) & 1u) && meet_lookup(tab, (u32)v.w)) f |= 8u;
 	return f;
 }
+
+__device__ __forceinline__ u64 wave_min_u64(u64 x) {
+	for (int o = 32; o > 0; o >>= 1) {
+		const u64 y = __shfl_xor(x, o);
+		x = y < x ? y : x;
+	}
+	return x;
+}
+
+// what the pre-pass knows about a row's shortest path: its inner vertices, chosen by the reference's tie-break
+// (shortest_path.cpp:21-31: parent = smallest vertex of the previous level with an edge to the child)
+struct MeetPath {
+	int32_t v1, v2, v3, pad;
+};
 
 constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so that a finished row frees its slot at once
 constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 atomics on one address take longer than the walks
@@ -73,10 +89,14 @@ struct MeetCounters {
 // CU has in flight (registers permitting: 5 KB of LDS each) — the workgroup is a single wavefront so that a finished
 // row frees its slot at once.  Rows are dealt round-robin (one shared counter would serialise ~10^4 claims at 12-20 ns
 // each: more than the walks take).
+// PATHS: also record the path's inner vertices (MeetPath) — the walk then has to see every witness (the tie-break
+// needs the smallest, not the first), so it has no early exit.
+template <bool PATHS>
 __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
-                                                  int64_t *__restrict__ out, int64_t cap, MeetCounters *__restrict__ mc) {
+                                                  int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
+                                                  MeetCounters *__restrict__ mc) {
 	__shared__ u32 s_tab[kMeetWPB][kMeetSlots];
 	__shared__ u32 s_bm[kMeetWPB][kMeetFilterWords];
 	const int lane = threadIdx.x & 63;
@@ -169,17 +189,22 @@ __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int
 				if (lane == 0) out[i] = 1;
 				continue;
 			}
-			// distance 2 and the size of the two-hop walk
+			// distance 2 (the middle vertex is the smallest common one) and the size of the two-hop walk
 			int64_t work = ve0 - vb0;
-			if (lane < exp_n) hit |= meet_lookup(tab, v0);
+			u32 mid = kMeetEmpty;
+			if (lane < exp_n && meet_lookup(tab, v0)) mid = v0;
 			for (int p = 64 + lane; p < exp_n; p += 64) {
 				const u32 v = (u32)exp_adj[p];
-				hit |= meet_lookup(tab, v);
+				if (meet_lookup(tab, v)) mid = min(mid, v);
 				work += xoff[v + 1] - xoff[v];
 			}
 			entries += (unsigned long long)exp_n;
 			vertices += (u32)exp_n;
-			if (__any(hit)) {
+			if (__any(mid != kMeetEmpty)) {
+				if constexpr (PATHS) {
+					const u32 m = (u32)wave_min_u64((u64)mid);
+					if (lane == 0) rec[i].v1 = (int32_t)m;
+				}
 				if (lane == 0) out[i] = 2;
 				continue;
 			}
@@ -194,24 +219,29 @@ __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int
 		// by a wave-uniform cursor; four chunk requests are always in flight (a chunk's registers are refilled as soon
 		// as it has been probed).
 		bool found = false;
+		u64 best = ~0ull; // PATHS: smallest (outer vertex << 32 | inner vertex) over all witnesses
 		for (int pb = 0; pb < exp_n && !found; pb += 64) {
 			const int cnt = min(64, exp_n - pb);
 			int vb = vb0, ve = ve0;
+			u32 vid = v0;
 			if (pb > 0) {
 				vb = ve = 0;
+				vid = 0;
 				if (lane < cnt) {
-					const u32 v = (u32)exp_adj[pb + lane];
-					vb = (int)xoff[v];
-					ve = (int)xoff[v + 1];
+					vid = (u32)exp_adj[pb + lane];
+					vb = (int)xoff[vid];
+					ve = (int)xoff[vid + 1];
 				}
 			}
 			int j = -1, q = 0, e = 0, b = 0; // cursor: vertex j of the round, aligned position q of its segment [b, e)
+			u32 cv = 0;                      // ... and that vertex's id
 			auto seek = [&]() { // next vertex with a non-empty segment
 				for (j++; j < cnt; j++) {
 					b = __builtin_amdgcn_readlane(vb, j); // wave-uniform: scalar registers
 					e = __builtin_amdgcn_readlane(ve, j);
 					if (e > b) {
 						q = b & ~3;
+						if constexpr (PATHS) cv = (u32)__builtin_amdgcn_readlane((int)vid, j);
 						return;
 					}
 				}
@@ -220,6 +250,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int
 			constexpr int DEPTH = 3;
 			int4 x[DEPTH];
 			int xb[DEPTH], xe[DEPTH], xq[DEPTH]; // the segment and position a chunk was requested from (wave-uniform)
+			u32 xv[DEPTH];                       // ... and the expanded vertex it belongs to
 			auto fetch = [&](int u) {
 				xq[u] = -1;
 				if (j < cnt) {
@@ -229,6 +260,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int
 					xb[u] = b;
 					xe[u] = e;
 					xq[u] = q;
+					xv[u] = cv;
 					entries += (unsigned long long)(min(e, q + 256) - max(b, q));
 					q += 256;
 					if (q >= e) seek();
@@ -236,7 +268,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int
 			};
 #pragma unroll
 			for (int u = 0; u < DEPTH; u++) fetch(u);
-			bool f = false;
+			u32 f = 0;
 			for (;;) {
 				bool any_chunk = false;
 #pragma unroll
@@ -245,12 +277,30 @@ __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int
 					any_chunk = true;
 					const int4 v = x[u];
 					const int t = xq[u] + 4 * lane, sb = xb[u], se2 = xe[u];
+					const u32 ev = xv[u];
 					fetch(u);
-					f |= meet_probe4(tab, bm, v, t >= sb && t < se2, t + 1 >= sb && t + 1 < se2, t + 2 >= sb && t + 2 < se2,
-					                 t + 3 >= sb && t + 3 < se2);
+					const u32 m = meet_probe4(tab, bm, v, t >= sb && t < se2, t + 1 >= sb && t + 1 < se2,
+					                          t + 2 >= sb && t + 2 < se2, t + 3 >= sb && t + 3 < se2);
+					f |= m;
+					if constexpr (PATHS) {
+						// fwd: entry = second vertex, expanded = first; bwd: expanded = second vertex, entry = first
+						auto key = [&](u32 entry) { return fwd ? ((u64)entry << 32 | ev) : ((u64)ev << 32 | entry); };
+						if (m & 1u) best = min(best, key((u32)v.x));
+						if (m & 2u) best = min(best, key((u32)v.y));
+						if (m & 4u) best = min(best, key((u32)v.z));
+						if (m & 8u) best = min(best, key((u32)v.w));
+					}
 				}
-				found = __any(f);
+				if constexpr (!PATHS) found = __any(f != 0);
 				if (found || !any_chunk) break;
+			}
+		}
+		if constexpr (PATHS) {
+			best = wave_min_u64(best);
+			found = best != ~0ull;
+			if (found && lane == 0) {
+				rec[i].v2 = (int32_t)(best >> 32);
+				rec[i].v1 = (int32_t)(u32)best;
 			}
 		}
 		if (lane == 0) out[i] = found ? 3 : kMeetOpen;
@@ -290,20 +340,23 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 	unsigned long long entries = 0;
 	for (int pb = w; pb < list_n; pb += 64 * stride) {
 		int vb = 0, ve = 0;
+		u32 vid = 0;
 		const int p = pb + lane * stride;
 		if (p < list_n) {
-			const u32 v = (u32)list[p];
-			vb = (int)xoff[v];
-			ve = (int)xoff[v + 1];
+			vid = (u32)list[p];
+			vb = (int)xoff[vid];
+			ve = (int)xoff[vid + 1];
 		}
 		const int cnt = min(64, (list_n - pb + stride - 1) / stride);
 		int j = -1, q = 0, e = 0, b = 0;
+		u32 cv = 0;
 		auto seek = [&]() {
 			for (j++; j < cnt; j++) {
-				b = __shfl(vb, j);
-				e = __shfl(ve, j);
+				b = __builtin_amdgcn_readlane(vb, j);
+				e = __builtin_amdgcn_readlane(ve, j);
 				if (e > b) {
 					q = b & ~3;
+					cv = (u32)__builtin_amdgcn_readlane((int)vid, j);
 					return;
 				}
 			}
@@ -312,6 +365,7 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 		constexpr int DEPTH = 4;
 		int4 x[DEPTH];
 		int xb[DEPTH], xe[DEPTH], xq[DEPTH];
+		u32 xv[DEPTH];
 		auto fetch = [&](int u) {
 			xq[u] = -1;
 			if (j < cnt) {
@@ -321,6 +375,7 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 				xb[u] = b;
 				xe[u] = e;
 				xq[u] = q;
+				xv[u] = cv;
 				entries += (unsigned long long)(min(e, q + 256) - max(b, q));
 				q += 256;
 				if (q >= e) seek();
@@ -336,11 +391,12 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 				any_chunk = true;
 				const int4 v = x[u];
 				const int t = xq[u] + 4 * lane, sb = xb[u], se = xe[u];
+				const u32 ev = xv[u];
 				fetch(u);
-				if (t >= sb && t < se) f((u32)v.x);
-				if (t + 1 >= sb && t + 1 < se) f((u32)v.y);
-				if (t + 2 >= sb && t + 2 < se) f((u32)v.z);
-				if (t + 3 >= sb && t + 3 < se) f((u32)v.w);
+				if (t >= sb && t < se) f((u32)v.x, ev);
+				if (t + 1 >= sb && t + 1 < se) f((u32)v.y, ev);
+				if (t + 2 >= sb && t + 2 < se) f((u32)v.z, ev);
+				if (t + 3 >= sb && t + 3 < se) f((u32)v.w, ev);
 			}
 			if (!any_chunk || stop()) break;
 		}
@@ -349,26 +405,32 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 	return entries;
 }
 
+template <bool PATHS>
 __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                 int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
-                                                const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
-                                                int bm_words, MeetCounters *__restrict__ mc) {
+                                                const u32 *__restrict__ didx, int64_t *__restrict__ out_rows,
+                                                MeetPath *__restrict__ rec_rows, int64_t cap, int bm_words,
+                                                MeetCounters *__restrict__ mc) {
 	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex
 	__shared__ int s_flag;
 	__shared__ unsigned long long s_work[2];
+	__shared__ unsigned long long s_best;
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 	unsigned long long entries = 0;
 	u32 vertices = 0;
+	auto bit = [&](u32 x) { return (s_map[x >> 5] >> (x & 31)) & 1u; };
 	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
 		__syncthreads(); // the previous row's flags and map are no longer read
 		const int64_t s = src[i], d = dst[i]; // rows left open by k_meet3: ids in range, src != dst, both have edges
+		const u32 row = didx[i];
 		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
 		const int degS = se - so, degD = de - di;
 		for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
 		if (tid == 0) {
 			s_flag = 0;
 			s_work[0] = s_work[1] = 0;
+			s_best = ~0ull;
 		}
 		__syncthreads();
 		// B = N_out(src); sizes of both two-hop walks
@@ -395,61 +457,115 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 			entries += (unsigned long long)(degS + degD);
 			vertices += (u32)(degS + degD);
 		}
-		if ((s_map[(u32)d >> 5] >> ((u32)d & 31)) & 1u) { // dst in N_out(src)
-			if (tid == 0) out_rows[didx[i]] = 1;
+		if (bit((u32)d)) { // dst in N_out(src)
+			if (tid == 0) out_rows[row] = 1;
 			continue;
 		}
-		{ // distance 2: N_in(dst) meets B
-			bool hit = false;
+		// the smallest vertex of N_in(dst) whose bit is set (distance 2: the middle vertex; distance 3: the second one)
+		auto min_in_neighbour_of_dst = [&]() {
+			u32 m = kMeetEmpty;
 			for (int p = tid; p < degD; p += 1024) {
 				const u32 u = (u32)radj[di + p];
-				hit |= (s_map[u >> 5] >> (u & 31)) & 1u;
+				if (bit(u)) m = min(m, u);
 			}
-			if (hit) s_flag = 1;
-		}
+			if (m != kMeetEmpty) atomicMin(&s_best, (unsigned long long)m);
+		};
+		// PATHS: first inner vertex = smallest in-neighbour of `v` that src points at.  The map is rebuilt as N_out(src).
+		auto first_inner_vertex = [&](u32 v) -> u32 {
+			__syncthreads();
+			for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
+			if (tid == 0) s_best = ~0ull;
+			__syncthreads();
+			for (int p = tid; p < degS; p += 1024) {
+				const u32 x = (u32)adj[so + p];
+				atomicOr(&s_map[x >> 5], 1u << (x & 31));
+			}
+			__syncthreads();
+			u32 m = kMeetEmpty;
+			const int vb = (int)roff[v], ve = (int)roff[v + 1];
+			for (int p = vb + tid; p < ve; p += 1024) {
+				const u32 y = (u32)radj[p];
+				if (bit(y)) m = min(m, y);
+			}
+			if (m != kMeetEmpty) atomicMin(&s_best, (unsigned long long)m);
+			__syncthreads();
+			return (u32)s_best;
+		};
+		min_in_neighbour_of_dst();
 		__syncthreads();
-		if (s_flag) {
-			if (tid == 0) out_rows[didx[i]] = 2;
+		if (s_best != ~0ull) {
+			if (tid == 0) {
+				out_rows[row] = 2;
+				if constexpr (PATHS) rec_rows[row].v1 = (int32_t)(u32)s_best;
+			}
 			continue;
 		}
 		if ((int64_t)s_work[0] > cap || (int64_t)s_work[1] > cap) {
-			if (tid == 0) out_rows[didx[i]] = kMeetOpen;
+			if (tid == 0) out_rows[row] = kMeetOpen;
 			continue;
 		}
 		// B += N_out(N_out(src))
 		{
 			const unsigned long long e2 = meet_walk(adj + so, degS, wib, 16, off, adj,
-			                                        [&](u32 x) { atomicOr(&s_map[x >> 5], 1u << (x & 31)); }, []() { return false; });
+			                                        [&](u32 x, u32) { atomicOr(&s_map[x >> 5], 1u << (x & 31)); },
+			                                        []() { return false; });
 			if (lane == 0) entries += e2;
 		}
 		__syncthreads();
-		{ // distance 3: N_in(dst) meets B
-			bool hit = false;
-			for (int p = tid; p < degD; p += 1024) {
-				const u32 u = (u32)radj[di + p];
-				hit |= (s_map[u >> 5] >> (u & 31)) & 1u;
-			}
-			if (hit) s_flag = 1;
-		}
+		min_in_neighbour_of_dst(); // distance 3: N_in(dst) meets B
 		__syncthreads();
-		if (s_flag) {
-			if (tid == 0) out_rows[didx[i]] = 3;
+		if (s_best != ~0ull) {
+			const u32 v2 = (u32)s_best;
+			if constexpr (PATHS) {
+				const u32 v1 = first_inner_vertex(v2);
+				if (tid == 0) {
+					rec_rows[row].v1 = (int32_t)v1;
+					rec_rows[row].v2 = (int32_t)v2;
+				}
+			}
+			if (tid == 0) out_rows[row] = 3;
 			continue;
 		}
-		// distance 4: N_in(N_in(dst)) meets B
-		bool f = false;
+		// distance 4: N_in(N_in(dst)) meets B.  PATHS: smallest (third vertex << 32 | second vertex) over all witnesses
 		{
-			const unsigned long long e2 = meet_walk(radj + di, degD, wib, 16, roff, radj,
-			                                        [&](u32 x) { f |= (s_map[x >> 5] >> (x & 31)) & 1u; },
-			                                        [&]() {
-				                                        if (__any(f)) s_flag = 1;
-				                                        return *(volatile int *)&s_flag != 0;
-			                                        });
+			bool f = false;
+			unsigned long long best = ~0ull;
+			const unsigned long long e2 = meet_walk(
+			    radj + di, degD, wib, 16, roff, radj,
+			    [&](u32 x, u32 ev) {
+				    if (bit(x)) {
+					    f = true;
+					    if constexpr (PATHS) best = min(best, (unsigned long long)ev << 32 | x);
+				    }
+			    },
+			    [&]() {
+				    if constexpr (PATHS) return false;
+				    if (__any(f)) s_flag = 1;
+				    return *(volatile int *)&s_flag != 0;
+			    });
 			if (lane == 0) entries += e2;
+			if (__any(f)) s_flag = 1;
+			if constexpr (PATHS) {
+				best = wave_min_u64(best);
+				if (lane == 0 && best != ~0ull) atomicMin(&s_best, best);
+			}
 		}
-		if (__any(f)) s_flag = 1;
 		__syncthreads();
-		if (tid == 0) out_rows[didx[i]] = s_flag ? 4 : kMeetOpen;
+		const bool found4 = s_flag != 0;
+		if constexpr (PATHS) {
+			if (found4) {
+				const unsigned long long key = s_best;
+				__syncthreads();
+				const u32 v3 = (u32)(key >> 32), v2 = (u32)key;
+				const u32 v1 = first_inner_vertex(v2);
+				if (tid == 0) {
+					rec_rows[row].v1 = (int32_t)v1;
+					rec_rows[row].v2 = (int32_t)v2;
+					rec_rows[row].v3 = (int32_t)v3;
+				}
+			}
+		}
+		if (tid == 0) out_rows[row] = found4 ? 4 : kMeetOpen;
 	}
 	__shared__ unsigned long long s_stat[2];
 	__syncthreads();
@@ -462,6 +578,49 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 	if (tid == 0) {
 		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
 		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
+	}
+}
+
+// ---- path emission -------------------------------------------------------------------------------------------------
+// [src, e1, v1, ..., ek, dst] for the rows the pre-pass answered (shortest_path.cpp:149-204): the edge of a hop is the
+// FIRST slot of the parent holding the child (shortest_path.cpp:23-30).  One wavefront per row.
+__global__ void k_path_counts(int64_t n, const int64_t *__restrict__ len, int64_t *__restrict__ cnt) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) cnt[i] = len[i] >= 0 ? 2 * len[i] + 1 : 0; // open (kMeetOpen) and NULL rows: nothing here
+}
+__global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                    const int64_t *__restrict__ len, const MeetPath *__restrict__ rec,
+                                                    const int64_t *__restrict__ poff, const int64_t *__restrict__ off,
+                                                    const int32_t *__restrict__ adj, const int64_t *__restrict__ edge_ids,
+                                                    int64_t *__restrict__ child, int64_t *__restrict__ out_off) {
+	const int lane = threadIdx.x & 63;
+	const int64_t i = (int64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	if (i >= n) return;
+	const int64_t k = len[i];
+	if (k < 0) return;
+	int64_t *out = child + poff[i];
+	if (lane == 0) out_off[i] = poff[i];
+	const MeetPath r = rec[i];
+	int64_t vs[5];
+	vs[0] = src[i];
+	vs[1] = k >= 2 ? r.v1 : dst[i];
+	vs[2] = k >= 3 ? r.v2 : dst[i];
+	vs[3] = k >= 4 ? r.v3 : dst[i];
+	vs[4] = dst[i];
+	if (lane == 0) out[0] = vs[0];
+	for (int h = 0; h < (int)k; h++) {
+		const int64_t p = vs[h], c = h + 1 == (int)k ? dst[i] : vs[h + 1];
+		int64_t slot = -1;
+		for (int64_t base = off[p]; base < off[p + 1] && slot < 0; base += 64) {
+			const int64_t t = base + lane;
+			const bool eq = t < off[p + 1] && (int64_t)adj[t] == c;
+			const u64 m = __ballot(eq);
+			if (m) slot = base + (__ffsll((long long)m) - 1);
+		}
+		if (lane == 0) {
+			out[2 * h + 1] = slot < 0 ? -1 : (edge_ids ? edge_ids[slot] : slot);
+			out[2 * h + 2] = c;
+		}
 	}
 }
 
@@ -555,10 +714,12 @@ __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int
 // Runs the pre-pass over n rows resident in HBM; rows it answers get their hop count (or -1 for NULL) in d_out, the
 // others are compacted into ws->def_src/def_dst/def_idx and counted in *n_open.
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open) {
+                 u32 *n_open, bool paths) {
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
 	PGQ_TRY(ws->meet_cnt.reserve(sizeof(MeetCounters) + 16));
+	if (paths) PGQ_TRY(ws->meet_rec.reserve((size_t)n * sizeof(MeetPath)));
+	MeetPath *rec = paths ? ws->meet_rec.as<MeetPath>() : nullptr;
 	PGQ_TRY(ws->def_src.reserve((size_t)n * 8));
 	PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
 	PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
@@ -569,8 +730,13 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		const int64_t cap = std::max(1, options().meet_cap);
 		KernelTimer kt(st, K_MEET);
 		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 4 rounds
-		hipLaunchKernelGGL(k_meet3, dim3((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident)),
-		                   dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff, c->radj, d_out, cap, mc);
+		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident));
+		if (paths)
+			hipLaunchKernelGGL(k_meet3<true>, grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,
+			                   c->radj, d_out, rec, cap, mc);
+		else
+			hipLaunchKernelGGL(k_meet3<false>, grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,
+			                   c->radj, d_out, rec, cap, mc);
 		kt.stop();
 	}
 	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
@@ -594,16 +760,22 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	if (h.count > 0 && options().meet4 && (size_t)bm_words * 4 + 512 <= 150 * 1024) {
 		static std::atomic<int> attr_set { 0 };
 		if (!attr_set.load()) {
-			(void)hipFuncSetAttribute((const void *)k_meet4, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			(void)hipFuncSetAttribute((const void *)k_meet4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			(void)hipFuncSetAttribute((const void *)k_meet4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 			attr_set.store(1);
 		}
 		const u32 nd = h.count;
 		PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
 		{
 			KernelTimer kt(st, K_MEET);
-			hipLaunchKernelGGL(k_meet4, dim3(std::min<u32>(nd, 256 * 4)), dim3(1024), (size_t)bm_words * 4, st, (int64_t)nd,
-			                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff, c->radj,
-			                   ws->def_idx.as<u32>(), d_out, (int64_t)std::max(1, options().meet4_cap), bm_words, mc);
+			if (paths)
+				hipLaunchKernelGGL(k_meet4<true>, dim3(std::min<u32>(nd, 256 * 4)), dim3(1024), (size_t)bm_words * 4, st,
+				                   (int64_t)nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff,
+				                   c->radj, ws->def_idx.as<u32>(), d_out, rec, (int64_t)std::max(1, options().meet4_cap), bm_words, mc);
+			else
+				hipLaunchKernelGGL(k_meet4<false>, dim3(std::min<u32>(nd, 256 * 4)), dim3(1024), (size_t)bm_words * 4, st,
+				                   (int64_t)nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff,
+				                   c->radj, ws->def_idx.as<u32>(), d_out, rec, (int64_t)std::max(1, options().meet4_cap), bm_words, mc);
 			kt.stop();
 		}
 		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
@@ -620,6 +792,47 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	S.edges_scanned += (int64_t)entries;
 	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
 	*n_open = h.count;
+	return PGQ_OK;
+}
+
+// Path lists of the rows the pre-pass answered: element counts -> exclusive scan -> *total; when d_child is given the
+// lists are written there (entry i at the scanned offset, also stored in d_out_off[i]).
+int meet_path_offsets(Workspace *ws, int64_t n, const int64_t *d_len, int64_t *total) {
+	hipStream_t st = ws->stream;
+	PGQ_TRY(ws->meet_poff.reserve((size_t)(n + 1) * 8 * 2));
+	int64_t *cnt = ws->meet_poff.as<int64_t>() + (n + 1), *poff = ws->meet_poff.as<int64_t>();
+	hipLaunchKernelGGL(k_path_counts, dim3(blocks_for(n)), dim3(256), 0, st, n, d_len, cnt);
+	PGQ_HIP_TRY(hipMemsetAsync(cnt + n, 0, 8, st));
+	size_t tmp = 0;
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt, poff, (int)(n + 1), st));
+	PGQ_TRY(ws->scan_tmp.reserve(tmp + 16));
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp, cnt, poff, (int)(n + 1), st));
+	PGQ_HIP_TRY(hipMemcpyAsync(total, poff + n, 8, hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	return PGQ_OK;
+}
+int meet_emit_paths(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, const int64_t *d_len,
+                    int64_t *d_child, int64_t *d_out_off) {
+	KernelTimer kt(ws->stream, K_RECON);
+	hipLaunchKernelGGL(k_emit_paths, dim3(blocks_for(n * 64)), dim3(256), 0, ws->stream, n, d_src, d_dst, d_len,
+	                   ws->meet_rec.as<MeetPath>(), ws->meet_poff.as<int64_t>(), c->off, c->adj, c->edge_ids, d_child, d_out_off);
+	kt.stop();
+	return PGQ_OK;
+}
+// lengths and list offsets (shifted by `base`: their payload was appended there) of the rows the lane-batched search
+// answered, scattered back to row order
+__global__ void k_apply_open_paths(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
+                                   const int64_t *__restrict__ doff, int64_t base, int64_t *__restrict__ out_len,
+                                   int64_t *__restrict__ out_off) {
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nd) return;
+	out_len[didx[j]] = dlen[j];
+	if (dlen[j] >= 0) out_off[didx[j]] = base + doff[j];
+}
+int meet_apply_paths(Workspace *ws, int64_t nd, const int64_t *d_len, const int64_t *d_off, int64_t base,
+                     int64_t *d_out_len, int64_t *d_out_off) {
+	hipLaunchKernelGGL(k_apply_open_paths, dim3(blocks_for(nd)), dim3(256), 0, ws->stream, nd, ws->def_idx.as<u32>(), d_len,
+	                   d_off, base, d_out_len, d_out_off);
 	return PGQ_OK;
 }
 

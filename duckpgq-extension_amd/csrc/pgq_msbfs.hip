@@ -1185,7 +1185,7 @@ Workspace::~Workspace() {
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt })
+	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -1751,13 +1751,56 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// cost less than the MS-BFS levels they replace: bytes ~ rows x E[in-degree x out-degree] x 4 (the cheaper
 	// endpoint is expanded: ~0.6 of that) against ~16 B per edge per 2048-lane batch.
 	const Options &mopt = options();
-	const bool may_meet = mopt.meet && !with_paths && !outp.want_te && outp.depth == 0 && c->E > 0;
+	const bool may_meet = mopt.meet && !outp.want_te && outp.depth == 0 && c->E > 0;
 	auto meet_pays = [&](int64_t distinct_sources) {
 		const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
 		const double batches = (double)((distinct_sources + 2047) / 2048);
 		return meet_bytes <= mopt.meet_bias * batches * (double)c->E * 16.0;
 	};
+	// shortestpath: the pre-pass also records each answered row's inner vertices (reference tie-break); their lists are
+	// packed first, the lists of the rows left to the lane-batched search are appended behind them
+	auto run_meet_paths = [&]() -> int {
+		u32 nd = 0;
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, true));
+		int64_t total = 0;
+		PGQ_TRY(meet_path_offsets(ws, n, d_out_len, &total));
+		WorkspaceLease inner;
+		SearchOutput so2;
+		if (nd > 0) {
+			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
+			PGQ_TRY(ws->def_off.reserve((size_t)nd * 8));
+			PGQ_TRY(inner.acquire());
+			so2.depth = outp.depth + 1;
+			S.pairs -= nd; // counted once
+			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+			                      ws->def_len.as<int64_t>(), true, ws->def_off.as<int64_t>(), nullptr, 0, so2));
+		}
+		const int64_t need = total + so2.child_used;
+		int64_t *d_child = d_child_ext;
+		if (d_child_ext) {
+			if (need > child_cap_ext) outp.overflow = true;
+		} else {
+			PGQ_TRY(ws->child.reserve((size_t)std::max<int64_t>(need, 1) * 8));
+			d_child = ws->child.as<int64_t>();
+		}
+		PGQ_HIP_TRY(hipMemsetAsync(d_out_off, 0, (size_t)n * 8, st));
+		if (!outp.overflow) {
+			PGQ_TRY(meet_emit_paths(c, ws, n, d_src, d_dst, d_out_len, d_child, d_out_off));
+			if (so2.child_used > 0)
+				PGQ_HIP_TRY(hipMemcpyAsync(d_child + total, inner.ws->child.p, (size_t)so2.child_used * 8,
+				                           hipMemcpyDeviceToDevice, st));
+		}
+		if (nd > 0)
+			PGQ_TRY(meet_apply_paths(ws, nd, ws->def_len.as<int64_t>(), ws->def_off.as<int64_t>(), total, d_out_len, d_out_off));
+		PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+		KernelTimer::flush();
+		outp.child_used = need;
+		if (outp.overflow)
+			return fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(need) + " elements");
+		return PGQ_OK;
+	};
 	auto run_meet = [&]() -> int {
+		if (with_paths) return run_meet_paths();
 		u32 nd = 0;
 		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd));
 		if (nd > 0) {

@@ -35,7 +35,7 @@ struct Workspace {
 	int device = 0; // where its buffers live (workspaces are pooled per device)
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
-	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt;
+	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff;
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
 	int64_t *h_bstart = nullptr;
@@ -66,7 +66,14 @@ int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const 
 // Pair-centric pre-pass (pgq_meet.hip): answers rows at distance <= 3 (and NULL / trivial / dead-end rows) into d_out,
 // compacts the others into ws->def_src/def_dst/def_idx; meet_apply scatters their lengths back.
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open);
+                 u32 *n_open, bool paths = false);
+// shortestpath through the pre-pass: element counts of the answered rows' lists -> offsets (ws->meet_poff) and *total;
+// the lists themselves ([src, e, v, ..., dst], first-slot edges); lengths + shifted offsets of the rows answered elsewhere
+int meet_path_offsets(Workspace *ws, int64_t n, const int64_t *d_len, int64_t *total);
+int meet_emit_paths(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, const int64_t *d_len,
+                    int64_t *d_child, int64_t *d_out_off);
+int meet_apply_paths(Workspace *ws, int64_t nd, const int64_t *d_len, const int64_t *d_off, int64_t base,
+                     int64_t *d_out_len, int64_t *d_out_off);
 int meet_apply(Workspace *ws, int64_t nd, const int64_t *d_len, int64_t *d_out);
 // Distinct sources among n rows, estimated from a 4096-row sample (decides pre-pass vs lane batches for large inputs).
 int estimate_distinct_sources(Workspace *ws, int64_t n, const int64_t *d_src, int64_t *estimate);

@@ -185,6 +185,13 @@ def test_meet_prepass_matches_oracle(cap):
     assert stats["meet_pairs"] > 0
     if cap == 1:
         assert stats["levels"] > 0  # the MS-BFS path answered what the pre-pass left open
+    # shortestpath through the pre-pass: inner vertices by the reference's tie-break (smallest parent, first slot),
+    # lists of the rows left to the lane-batched search appended behind them
+    pgq.reset_stats()
+    got = st.shortestpath(0, V, ps[:1500], pd[:1500], src_valid=valid[:1500])
+    opaths = ora.lean_shortestpath(V, ps[:1500], pd[:1500])
+    assert got == [p if vv else None for p, vv in zip(opaths, valid[:1500])]
+    assert pgq.get_stats()["meet_pairs"] > 0
     # a sparse directed graph: many dead ends and unreachable pairs, long distances
     V2 = 4000
     rows2 = random_graph(rng, V2, 5000)
@@ -193,6 +200,7 @@ def test_meet_prepass_matches_oracle(cap):
     oln, ook = ora2.lean_iterativelength(V2, ps, pd)
     ln, ok = st2.iterativelength(1, V2, ps, pd)
     assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+    assert st2.shortestpath(1, V2, ps, pd) == ora2.lean_shortestpath(V2, ps, pd)
 
 
 def test_meet_prepass_large_inputs_cross_product_vs_distinct_sources():
@@ -398,6 +406,9 @@ def test_full_size_sf100_properties():
     assert (ook == ok).all() and (oln[ook] == ln[ook]).all()
     # 1024 full paths against the oracle: the min-id parent / first-slot tie-break of shortest_path.cpp:21-31
     assert ora.lean_shortestpath(V, ps[:1024], pd[:1024]) == paths[:1024]
+    pgq.set_option("meet", 1)  # shortestpath through the pre-pass: same lists, BASELINE configs[2] size
+    assert dev.shortestpath(ps, pd) == paths
+    pgq.set_option("meet", 0)
     # the pair-centric pre-pass (k_meet3 / k_meet4) against the lane-batched search and the oracle, BASELINE configs[3]
     # size: 65,536 pairs
     import torch
@@ -485,9 +496,13 @@ def test_bulk_device_entry_points_match_chunk_api():
     d_len = torch.empty(n, dtype=torch.int64, device="cuda")
     d_off = torch.zeros(n, dtype=torch.int64, device="cuda")
     need = sum(len(p) for p in want if p is not None)
-    for words, defer in ((0, 8), (8, 2)):  # defer 2: stragglers of wide batches are appended by a narrow second pass
+    # defer 2: stragglers of wide batches are appended by a narrow second pass; meet: answered rows first, rest appended
+    for words, defer, meet in ((0, 8, 0), (8, 2, 0), (0, 8, 1)):
         pgq.set_option("words", words)
         pgq.set_option("defer", defer)
+        pgq.set_option("meet", meet)
+        pgq.set_option("meet_bias", 1e9)
+        pgq.set_option("meet_cap", 20000)
         d_child = torch.empty(need + 16, dtype=torch.int64, device="cuda")
         rc, used = dev.shortestpath_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(), d_off.data_ptr(),
                                              d_child.data_ptr(), need + 16)
@@ -504,6 +519,7 @@ def test_bulk_device_entry_points_match_chunk_api():
         assert (d_len.cpu().numpy() == ln).all()
     pgq.set_option("words", 0)
     pgq.set_option("defer", 8)
+    pgq.set_option("meet", 0)
     d_val = torch.zeros(n, dtype=torch.int64, device="cuda")
     d_ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
     dev.cheapest_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_val.data_ptr(), d_ok.data_ptr())

@@ -69,6 +69,7 @@ struct Options {
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 	int meet = 1;           // iterativelength: answer pairs at distance <= 3 by the pair-centric pre-pass (k_meet3) when cheaper
 	int meet_cap = 1 << 16; // adjacency entries a pair's two-hop walk may scan; beyond: left to the MS-BFS path
+	int meet_cap_paths = 1 << 12; // the same for shortestpath rows (their walks have no early exit; longer ones go to k_meet4)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
 	double meet_bias = 1.0; // pre-pass runs while its estimated bytes <= meet_bias x the MS-BFS estimate

@@ -92,7 +92,7 @@ struct MeetCounters {
 // PATHS: also record the path's inner vertices (MeetPath) — the walk then has to see every witness (the tie-break
 // needs the smallest, not the first), so it has no early exit.
 template <bool PATHS>
-__global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                   int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(64 * kMeetWPB, 6) void k_meet3(int64_t n, const int
 				}
 			};
 			seek();
-			constexpr int DEPTH = 3;
+			// PATHS walks every segment to the end: fewer wavefronts, more registers, four requests in flight
+			constexpr int DEPTH = PATHS ? 4 : 3;
 			int4 x[DEPTH];
 			int xb[DEPTH], xe[DEPTH], xq[DEPTH]; // the segment and position a chunk was requested from (wave-uniform)
 			u32 xv[DEPTH];                       // ... and the expanded vertex it belongs to
@@ -727,7 +728,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	u32 *d_count = reinterpret_cast<u32 *>(mc + 1);
 	PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
 	{
-		const int64_t cap = std::max(1, options().meet_cap);
+		const int64_t cap = std::max(1, paths ? options().meet_cap_paths : options().meet_cap);
 		KernelTimer kt(st, K_MEET);
 		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 4 rounds
 		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident));

@@ -99,6 +99,7 @@ static int do_init(int device) {
 	env_int("PGQ_LANES", g_opt.lanes);
 	env_int("PGQ_MEET", g_opt.meet);
 	env_int("PGQ_MEET_CAP", g_opt.meet_cap);
+	env_int("PGQ_MEET_CAP_PATHS", g_opt.meet_cap_paths);
 	env_int("PGQ_MEET4", g_opt.meet4);
 	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
 	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
@@ -967,6 +968,7 @@ std::vector<OptRef> option_table() {
 		{ "lanes", &o.lanes, nullptr },
 		{ "meet", &o.meet, nullptr },
 		{ "meet_cap", &o.meet_cap, nullptr },
+		{ "meet_cap_paths", &o.meet_cap_paths, nullptr },
 		{ "meet4", &o.meet4, nullptr },
 		{ "meet4_cap", &o.meet4_cap, nullptr },
 		{ "meet_bias", nullptr, &o.meet_bias },

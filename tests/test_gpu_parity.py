@@ -17,7 +17,7 @@ def _defaults():
                  ("relax_small_limit", 2048), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20)):
+                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 12), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20)):
         pgq.set_option(k, v)
     yield
 
@@ -169,6 +169,7 @@ def test_meet_prepass_matches_oracle(cap):
     st, ora = both(V, rows)
     pgq.set_option("meet", 1)
     pgq.set_option("meet_cap", cap)
+    pgq.set_option("meet_cap_paths", cap)
     pgq.set_option("meet_bias", 1e9)  # always take the pre-pass
     pgq.set_option("meet4", 0 if cap == 1 else 1)  # k_meet4: LDS bit-map kernel for what k_meet3 leaves open
     pgq.set_option("meet4_cap", 1 << 20 if cap != 3000 else 2000)

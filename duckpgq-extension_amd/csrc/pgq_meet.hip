@@ -29,6 +29,7 @@
 
 namespace pgq {
 
+typedef uint4 __attribute__((may_alias)) uint4_alias; // 16-byte clears of u32 tables (no type-based reordering)
 constexpr int kMeetSlots = 1024;            // hash slots per wavefront
 constexpr int kMeetSetMax = kMeetSlots / 2; // longest one-hop list the table takes (load factor <= 1/2)
 constexpr u32 kMeetEmpty = 0xFFFFFFFFu;
@@ -50,14 +51,20 @@ __device__ __forceinline__ bool meet_lookup(const u32 *tab, u32 x) {
 // entries a lane holds cost four independent LDS reads instead of four dependent hash-table walks
 constexpr int kMeetFilterWords = 256;
 __device__ __forceinline__ u32 meet_fhash(u32 x) { return (x * 0x9E3779B1u) >> 19; } // 13 bits
-__device__ __forceinline__ u32 meet_probe4(const u32 *tab, const u32 *bm, const int4 v, bool k0, bool k1, bool k2, bool k3) {
+// `valid`: bit k set = entry k lies inside the segment.  Returns the entries that are in the set (bit k).  The four
+// filter reads are independent and branch-free; only lanes holding a filter hit (~1 % of the entries) walk the table.
+__device__ __forceinline__ u32 meet_probe4(const u32 *tab, const u32 *bm, const int4 v, u32 valid) {
 	const u32 h0 = meet_fhash((u32)v.x), h1 = meet_fhash((u32)v.y), h2 = meet_fhash((u32)v.z), h3 = meet_fhash((u32)v.w);
 	const u32 w0 = bm[h0 >> 5], w1 = bm[h1 >> 5], w2 = bm[h2 >> 5], w3 = bm[h3 >> 5];
-	u32 f = 0; // bit k: entry k is in the set
-	if (k0 && ((w0 >> (h0 & 31)) & 1u) && meet_lookup(tab, (u32)v.x)) f |= 1u;
-	if (k1 && ((w1 >> (h1 & 31)) & 1u) && meet_lookup(tab, (u32)v.y)) f |= 2u;
-	if (k2 && ((w2 >> (h2 & 31)) & 1u) && meet_lookup(tab, (u32)v.z)) f |= 4u;
-	if (k3 && ((w3 >> (h3 & 31)) & 1u) && meet_lookup(tab, (u32)v.w)) f |= 8u;
+	u32 p = (((w0 >> (h0 & 31)) & 1u) | (((w1 >> (h1 & 31)) & 1u) << 1) | (((w2 >> (h2 & 31)) & 1u) << 2) |
+	         (((w3 >> (h3 & 31)) & 1u) << 3)) & valid;
+	u32 f = 0;
+	while (p) {
+		const u32 k = (u32)__ffs((int)p) - 1u;
+		p &= p - 1u;
+		const u32 x = k == 0 ? (u32)v.x : (k == 1 ? (u32)v.y : (k == 2 ? (u32)v.z : (u32)v.w));
+		if (meet_lookup(tab, x)) f |= 1u << k;
+	}
 	return f;
 }
 
@@ -97,8 +104,8 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                   int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
                                                   MeetCounters *__restrict__ mc) {
-	__shared__ u32 s_tab[kMeetWPB][kMeetSlots];
-	__shared__ u32 s_bm[kMeetWPB][kMeetFilterWords];
+	__shared__ __attribute__((aligned(16))) u32 s_tab[kMeetWPB][kMeetSlots];
+	__shared__ __attribute__((aligned(16))) u32 s_bm[kMeetWPB][kMeetFilterWords];
 	const int lane = threadIdx.x & 63;
 	u32 *tab = s_tab[threadIdx.x >> 6];
 	u32 *bm = s_bm[threadIdx.x >> 6];
@@ -153,9 +160,10 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
 		// both one-hop lists are requested together; the expanded side's first 64 vertices then ask for their ranges
 		const u32 v0 = lane < exp_n ? (u32)exp_adj[lane] : 0u;
 #pragma unroll
-		for (int k = 0; k < kMeetSlots / 64; k++) tab[k * 64 + lane] = kMeetEmpty;
+		for (int k = 0; k < kMeetSlots / 256; k++)
+			reinterpret_cast<uint4_alias *>(tab)[k * 64 + lane] = make_uint4(kMeetEmpty, kMeetEmpty, kMeetEmpty, kMeetEmpty);
 #pragma unroll
-		for (int k = 0; k < kMeetFilterWords / 64; k++) bm[k * 64 + lane] = 0;
+		for (int k = 0; k < kMeetFilterWords / 256; k++) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
 		int vb0 = 0, ve0 = 0;
 		if (lane < exp_n) {
 			vb0 = (int)xoff[v0];
@@ -277,11 +285,14 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
 					if (xq[u] < 0) continue; // wave-uniform
 					any_chunk = true;
 					const int4 v = x[u];
-					const int t = xq[u] + 4 * lane, sb = xb[u], se2 = xe[u];
+					const int cq = xq[u], t = cq + 4 * lane, sb = xb[u], se2 = xe[u];
 					const u32 ev = xv[u];
-					fetch(u);
-					const u32 m = meet_probe4(tab, bm, v, t >= sb && t < se2, t + 1 >= sb && t + 1 < se2,
-					                          t + 2 >= sb && t + 2 < se2, t + 3 >= sb && t + 3 < se2);
+					fetch(u); // refills x[u], xq[u], ...: everything about the current chunk was copied above
+					u32 valid = 0xFu; // a chunk inside its segment needs no per-entry range test (wave-uniform)
+					if (cq < sb || cq + 256 > se2)
+						valid = (u32)(t >= sb && t < se2) | ((u32)(t + 1 >= sb && t + 1 < se2) << 1) |
+						        ((u32)(t + 2 >= sb && t + 2 < se2) << 2) | ((u32)(t + 3 >= sb && t + 3 < se2) << 3);
+					const u32 m = meet_probe4(tab, bm, v, valid);
 					f |= m;
 					if constexpr (PATHS) {
 						// fwd: entry = second vertex, expanded = first; bwd: expanded = second vertex, entry = first

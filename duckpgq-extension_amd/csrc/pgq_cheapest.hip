@@ -225,9 +225,131 @@ __global__ void k_reset_touched(const int32_t *__restrict__ touched, const u32 *
 }
 
 
+// ---- chain pre-pass ----------------------------------------------------------------------------------------------------
+// While every vertex on the way has exactly one out-edge, the set of vertices reachable from src IS that chain: if dst
+// is on it the only path's cost is the answer (folded left to right like `dist[v] + w`, cheapest_path_length.cpp:29-36,
+// so int64 and double results are bit-identical), if the chain ends in a vertex without out-edges first, dst is
+// unreachable (NULL, :74-85).  Message-reply forests (BASELINE configs[4]) are answered entirely here; a row whose
+// chain reaches a vertex with several out-edges (or runs for `cap` steps: a cycle) is left to the batched relaxation.
+// One thread per row; ok = 2 marks "open".
+template <typename T>
+__global__ void k_chain_walk(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t V,
+                             const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const T *__restrict__ w,
+                             T *__restrict__ out, uint8_t *__restrict__ ok, int cap, u32 *__restrict__ counters) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int64_t s = src[i], d = dst[i];
+	out[i] = (T)0;
+	if (s < 0) {
+		ok[i] = 0;
+		return;
+	}
+	if (s >= V || d < 0 || d >= V) {
+		counters[1] = 1; // id out of range
+		ok[i] = 0;
+		return;
+	}
+	int64_t x = s;
+	T acc = (T)0;
+	for (int step = 0;; step++) {
+		if (x == d) {
+			out[i] = acc;
+			ok[i] = 1;
+			return;
+		}
+		const int64_t b = off[x], deg = off[x + 1] - b;
+		if (deg == 0) {
+			ok[i] = 0;
+			return;
+		}
+		if (deg > 1 || step >= cap) {
+			ok[i] = 2;
+			atomicAdd(&counters[0], 1u);
+			return;
+		}
+		acc = acc + w[b];
+		x = adj[b];
+	}
+}
+__global__ void k_collect_open_rows(int64_t n, const uint8_t *__restrict__ ok, const int64_t *__restrict__ src,
+                                    const int64_t *__restrict__ dst, int64_t *__restrict__ dsrc, int64_t *__restrict__ ddst,
+                                    u32 *__restrict__ didx, u32 *__restrict__ count) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool open = i < n && ok[i] == 2;
+	const u64 m = __ballot(open);
+	if (!m) return;
+	const int lane = threadIdx.x & 63;
+	u32 base = 0;
+	if (lane == 0) base = atomicAdd(count, (u32)__popcll(m));
+	base = __shfl(base, 0);
+	if (open) {
+		const u32 p = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+		dsrc[p] = src[i];
+		ddst[p] = dst[i];
+		didx[p] = (u32)i;
+	}
+}
+__global__ void k_apply_open_rows(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dval,
+                                  const uint8_t *__restrict__ dok, int64_t *__restrict__ out, uint8_t *__restrict__ ok) {
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nd) return;
+	out[didx[j]] = dval[j];
+	ok[didx[j]] = dok[j];
+}
+
 template <typename T>
 static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
-                           int64_t *d_out, uint8_t *d_ok) {
+                           int64_t *d_out, uint8_t *d_ok, bool chain);
+
+template <typename T>
+static int cheapest_with_chains(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                int64_t *d_out, uint8_t *d_ok) {
+	hipStream_t st = ws->stream;
+	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	u32 *d_cnt = reinterpret_cast<u32 *>(ws->counters.p); // [0] open rows, [1] bad id, [2] compaction cursor
+	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, st));
+	{
+		KernelTimer kt(st, K_PREP);
+		hipLaunchKernelGGL(k_chain_walk<T>, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, c->V, c->off, c->adj,
+		                   (const T *)c->w, (T *)d_out, d_ok, std::max(1, options().chain_cap), d_cnt);
+		kt.stop();
+	}
+	u32 h[2] = { 0, 0 };
+	PGQ_HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	if (h[1]) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+	const u32 nd = h[0];
+	tstats().s.meet_pairs += n - (int64_t)nd;
+	if (nd == 0) {
+		tstats().s.pairs += n;
+		return PGQ_OK;
+	}
+	PGQ_TRY(ws->def_src.reserve((size_t)nd * 8));
+	PGQ_TRY(ws->def_dst.reserve((size_t)nd * 8));
+	PGQ_TRY(ws->def_idx.reserve((size_t)nd * 4));
+	PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
+	PGQ_TRY(ws->def_off.reserve((size_t)nd));
+	hipLaunchKernelGGL(k_collect_open_rows, dim3(blocks_for(n)), dim3(256), 0, st, n, d_ok, d_src, d_dst,
+	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_cnt + 2);
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	{
+		WorkspaceLease inner;
+		PGQ_TRY(inner.acquire());
+		PGQ_TRY(cheapest_device<T>(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+		                           ws->def_len.as<int64_t>(), ws->def_off.as<uint8_t>(), false));
+		hipLaunchKernelGGL(k_apply_open_rows, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd, ws->def_idx.as<u32>(),
+		                   ws->def_len.as<int64_t>(), ws->def_off.as<uint8_t>(), d_out, d_ok);
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+	}
+	tstats().s.pairs += n - (int64_t)nd; // the rows of the inner call were counted there
+	return PGQ_OK;
+}
+
+template <typename T>
+static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                           int64_t *d_out, uint8_t *d_ok, bool chain) {
+	if (chain && options().chain && n > 0 && n < (1LL << 31)) return cheapest_with_chains<T>(c, ws, n, d_src, d_dst, d_out, d_ok);
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V;
 	const int64_t inf_bits = Inf<T>::bits;
@@ -365,8 +487,8 @@ int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_
 	WorkspaceLease lease;
 	PGQ_TRY(lease.acquire());
 	if (csr->w_type == PGQ_W_INT64)
-		return cheapest_device<int64_t>(csr, lease.ws, n, d_src, d_dst, (int64_t *)d_out, d_out_valid);
-	return cheapest_device<double>(csr, lease.ws, n, d_src, d_dst, (int64_t *)d_out, d_out_valid);
+		return cheapest_device<int64_t>(csr, lease.ws, n, d_src, d_dst, (int64_t *)d_out, d_out_valid, true);
+	return cheapest_device<double>(csr, lease.ws, n, d_src, d_dst, (int64_t *)d_out, d_out_valid, true);
 }
 
 int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, void *out,
@@ -392,10 +514,10 @@ int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src
 	int rc;
 	if (csr->w_type == PGQ_W_INT64)
 		rc = cheapest_device<int64_t>(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
-		                              ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>());
+		                              ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>(), true);
 	else
 		rc = cheapest_device<double>(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
-		                             ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>());
+		                             ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>(), true);
 	PGQ_TRY(rc);
 	std::vector<uint8_t> ok(n);
 	PGQ_HIP_TRY(hipMemcpy(out, ws->out_val.p, (size_t)n * 8, hipMemcpyDeviceToHost));

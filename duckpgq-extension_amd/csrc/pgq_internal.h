@@ -51,6 +51,8 @@ struct Options {
 	int force_mode = 0;     // 0 adaptive, 1 always push, 2 always pull (tests)
 	int force_pull = 0;     // 0 adaptive, 1 always k_pull_sparse, 2 always k_pull (tests)
 	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel
+	int chain = 1;          // cheapest_path_length: walk out-degree-1 chains per row before the batched relaxation
+	int chain_cap = 4096;   // steps after which a chain is taken for a cycle and left to the batched relaxation
 	int relax_small_limit = 2048; // changed vertices at or below which relaxation rounds loop on the device
 	int trace = 0;          // per-level line on stderr
 	int probe = 1;          // destination probe before each expansion

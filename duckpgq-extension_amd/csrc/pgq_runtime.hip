@@ -82,6 +82,7 @@ static int do_init(int device) {
 	env_int("PGQ_FORCE_PULL", g_opt.force_pull);
 	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
 	env_int("PGQ_RELAX_SMALL_LIMIT", g_opt.relax_small_limit);
+	env_int("PGQ_CHAIN", g_opt.chain);
 	env_int("PGQ_TRACE", g_opt.trace);
 	env_int("PGQ_PROBE", g_opt.probe);
 	env_int("PGQ_DEFER", g_opt.defer);
@@ -951,6 +952,8 @@ std::vector<OptRef> option_table() {
 		{ "force_pull", &o.force_pull, nullptr },
 		{ "blocks_per_cu", &o.blocks_per_cu, nullptr },
 		{ "relax_small_limit", &o.relax_small_limit, nullptr },
+		{ "chain", &o.chain, nullptr },
+		{ "chain_cap", &o.chain_cap, nullptr },
 		{ "trace", &o.trace, nullptr },
 		{ "probe", &o.probe, nullptr },
 		{ "defer", &o.defer, nullptr },

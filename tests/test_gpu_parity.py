@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _defaults():
     for k, v in (("words", 0), ("force_mode", 0), ("push_div", 12), ("hub_chunk", 4096), ("push_chunk", 256), ("probe", 1), ("defer", 8), ("force_pull", 0), ("sparse_lds", 1), ("streams", 2), ("sparse_pw", 1), ("sparse_unroll", 2), ("sparse_spill", 3),
-                 ("relax_small_limit", 2048), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
+                 ("relax_small_limit", 2048), ("chain", 1), ("chain_cap", 4096), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
                  ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 12), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20)):
@@ -680,3 +680,24 @@ def test_in_library_multi_gpu_shards_and_gathers():
             assert (got == want).all()
     finally:
         pgq.init_devices([0])
+
+
+def test_cheapest_chain_prepass_cycles_and_branches():
+    """k_chain_walk: rows whose source starts an out-degree-1 chain are answered by walking it; cycles (step cap) and
+    branching vertices fall back to the batched relaxation.  Same values with the pre-pass off."""
+    rng = np.random.default_rng(91)
+    V = 64
+    # ring 0->1->...->9->0, tail 20->21->22->3 (joins the ring), chain 30->31->32 (dead end), branch at 40: 40->41, 40->42->43
+    edges = [(i, (i + 1) % 10) for i in range(10)] + [(20, 21), (21, 22), (22, 3), (30, 31), (31, 32), (40, 41), (40, 42), (42, 43)]
+    s = np.array([e[0] for e in edges]); d = np.array([e[1] for e in edges])
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    for w in (rng.integers(1, 50, len(adj)), rng.random(len(adj)) + 0.5):
+        dev = pgq.DeviceCSR(V, off, adj, eid, w)
+        ora = OracleCSR.adopt(V, off, adj, eid, w)
+        ps, pd = np.repeat(np.arange(V), V), np.tile(np.arange(V), V)
+        want, wok = ora.lean_cheapest_path_length(V, ps, pd)
+        for chain, cap in ((1, 4096), (1, 3), (0, 4096)):
+            pgq.set_option("chain", chain)
+            pgq.set_option("chain_cap", cap)
+            out, ok = dev.cheapest_path_length(ps, pd)
+            assert (ok == wok).all() and (out[ok] == want[wok]).all()

@@ -79,6 +79,10 @@ def load_hip():
                                                C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.pgq_cheapest_path_length_bulk_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_void_p]
+    L.pgq_local_clustering_coefficient.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, C.c_void_p, C.c_void_p]
+    L.pgq_local_clustering_coefficient_bulk_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.pgq_pagerank.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, C.c_void_p, C.c_void_p]
+    L.pgq_pagerank_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.pgq_iterativelength_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pgq_init_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.pgq_init_mask.argtypes = [C.c_uint64]
@@ -116,6 +120,8 @@ def load_udf():
     L.pgq_udf_shortestpath.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, Vec, Vec, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pgq_udf_bind_cheapest.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int)]
+    for f in ("pgq_udf_local_clustering_coefficient", "pgq_udf_pagerank", "pgq_udf_weakly_connected_component"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_int32, C.c_int64, Vec, C.c_void_p, C.c_void_p]
     L.pgq_udf_delete_csr.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int)]
     L.pgq_udf_csr_get_w_type.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     for f in ("pgq_udf_scan_csr_v", "pgq_udf_scan_csr_e", "pgq_udf_scan_csr_w"):
@@ -343,6 +349,26 @@ class DeviceCSR:
         _check(self.L.pgq_iterativelength_bulk_device(self.h, n, C.c_void_p(d_src), C.c_void_p(d_dst),
                                                       C.c_void_p(d_out)))
 
+    def local_clustering_coefficient(self, src, src_valid=None):
+        keep = []
+        sv = make_vec(_i64(src), valid=src_valid, keep=keep)
+        n = len(src)
+        out = np.zeros(n, dtype=np.float32)
+        ov = np.zeros((n + 63) // 64 + 1, dtype=np.uint64)
+        _check(self.L.pgq_local_clustering_coefficient(self.h, self.V, n, sv, _p(out), _p(ov)))
+        return out, unpack_validity(ov, n)
+
+    def pagerank(self, src):
+        keep = []
+        sv = make_vec(_i64(src), keep=keep)
+        n = len(src)
+        out = np.zeros(n, dtype=np.float64)
+        ov = np.zeros((n + 63) // 64 + 1, dtype=np.uint64)
+        _check(self.L.pgq_pagerank(self.h, self.V, n, sv, _p(out), _p(ov)))
+        it = C.c_int(0)
+        _check(self.L.pgq_pagerank_device(self.h, None, C.byref(it)))
+        return out, unpack_validity(ov, n), it.value
+
     def iterativelength_multi(self, src, dst):
         """Host arrays answered by every enabled device (pgq_init_devices): shards + in-library gather."""
         src, dst = _i64(src), _i64(dst)
@@ -481,6 +507,24 @@ class PgqState:
         ok = self._search(self.U.pgq_udf_cheapest_path_length, csr_id, V, src, dst, src_valid, None, None, dst_valid,
                           out)
         return out, ok
+
+    def _analytics(self, fn, csr_id, src, dtype):
+        keep = []
+        sv = make_vec(_i64(src), keep=keep)
+        n = len(src)
+        out = np.zeros(n, dtype=dtype)
+        ov = np.zeros((n + 63) // 64 + 1, dtype=np.uint64)
+        self._ck(fn(self.s, csr_id, n, sv, _p(out), _p(ov)))
+        return out, unpack_validity(ov, n)
+
+    def local_clustering_coefficient(self, csr_id, src):
+        return self._analytics(self.U.pgq_udf_local_clustering_coefficient, csr_id, src, np.float32)
+
+    def pagerank(self, csr_id, src):
+        return self._analytics(self.U.pgq_udf_pagerank, csr_id, src, np.float64)
+
+    def weakly_connected_component(self, csr_id, src):
+        return self._analytics(self.U.pgq_udf_weakly_connected_component, csr_id, src, np.int64)
 
     def delete_csr(self, csr_id):
         f = C.c_int(0)

@@ -1,0 +1,412 @@
+// pgq_analytics.hip — the other consumers of the device CSR: local clustering coefficient and
+// PageRank.
+//
+//   local_clustering_coefficient   src/core/functions/scalar/local_clustering_coefficient.cpp:11-72
+//       count = sum over the SLOTS of src's adjacency of |{slots of that neighbour's adjacency whose vertex is a
+//       neighbour of src}|, result = float(count) / (deg_f * (deg_f - 1)), deg = number of slots.  Integer counting +
+//       three IEEE float operations: bit-identical to the reference.  It is the two-hop walk of pgq_meet.hip with a
+//       counter instead of a witness: one wavefront per row, the neighbour set in the LDS hash table + bit filter
+//       (lists up to 512); longer lists take one 1024-thread workgroup per row and a vertex bit map (LDS when it fits,
+//       a per-workgroup slice of global memory otherwise).
+//   pagerank                       src/core/functions/scalar/pagerank.cpp:11-111
+//       power iteration over v_size = V + 2 entries (the two trailing CSR offsets behave as dangling vertices), damping
+//       0.85, stop when the largest change is below 1e-6.  Pull form: in-lists sorted by (source, slot) — a stable radix
+//       sort of the forward slots by destination — and summed left to right by one thread per vertex, i.e. in exactly
+//       the order the reference's `temp_rank[neighbor] += rank_contrib` accumulates, so every partial sum matches bit
+//       for bit; only the dangling-rank total is a two-level sum (1024 ordered slices, then their ordered sum) instead
+//       of one sequential chain, hence a tolerance of 1e-12 relative in the tests.  Computed once per CSR handle.
+//
+// weakly_connected_component is NOT here: the reference's component id is the root its sequential union-find schedule
+// ends in (weakly_connected_component.cpp:14-34,83-90: goldens pin e.g. id 2 for the cycle 0-1-2-3), not a canonical
+// label; it is mirrored on the host in pgq_udf.cpp.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <mutex>
+
+#include "pgq_search.h"
+#include "pgq_walk.h"
+
+namespace pgq {
+
+// ---- local clustering coefficient ---------------------------------------------------------------------------------
+
+constexpr float kLccBig = -2.0f; // d_out marker: the row's list is too long for the hash table
+
+__device__ __forceinline__ float lcc_value(unsigned long long count, int deg) {
+	const float df = static_cast<float>(deg);
+	return static_cast<float>((long long)count) / (df * (df - 1.0f));
+}
+
+__global__ __launch_bounds__(64, 6) void k_lcc(int64_t n, const int64_t *__restrict__ src, int64_t V,
+                                               const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                               float *__restrict__ out, u32 *__restrict__ counters) {
+	__shared__ __attribute__((aligned(16))) u32 tab[kMeetSlots];
+	__shared__ __attribute__((aligned(16))) u32 bm[kMeetFilterWords];
+	const int lane = threadIdx.x & 63;
+	const int64_t nwaves = (int64_t)gridDim.x;
+	for (int64_t i = blockIdx.x; i < n; i += nwaves) {
+		const int64_t s = src[i];
+		if (s < 0) { // NULL row
+			if (lane == 0) out[i] = 0.0f;
+			continue;
+		}
+		if (s >= V) {
+			if (lane == 0) {
+				counters[1] = 1;
+				out[i] = 0.0f;
+			}
+			continue;
+		}
+		const int b = (int)off[s], deg = (int)off[s + 1] - b;
+		if (deg < 2) { // local_clustering_coefficient.cpp:44-47
+			if (lane == 0) out[i] = 0.0f;
+			continue;
+		}
+		if (deg > kMeetSetMax) {
+			if (lane == 0) {
+				out[i] = kLccBig;
+				atomicAdd(&counters[0], 1u);
+			}
+			continue;
+		}
+#pragma unroll
+		for (int k = 0; k < kMeetSlots / 256; k++)
+			reinterpret_cast<uint4_alias *>(tab)[k * 64 + lane] = make_uint4(kMeetEmpty, kMeetEmpty, kMeetEmpty, kMeetEmpty);
+#pragma unroll
+		for (int k = 0; k < kMeetFilterWords / 256; k++) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+		__builtin_amdgcn_wave_barrier();
+		for (int p = lane; p < deg; p += 64) {
+			const u32 x = (u32)adj[b + p];
+			const u32 fh = meet_fhash(x);
+			atomicOr(&bm[fh >> 5], 1u << (fh & 31));
+			u32 h = meet_hash(x);
+			for (;;) {
+				const u32 old = atomicCAS(&tab[h], kMeetEmpty, x);
+				if (old == kMeetEmpty || old == x) break;
+				h = (h + 1) & (kMeetSlots - 1);
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		unsigned long long count = 0;
+		(void)meet_walk(adj + b, deg, 0, 1, off, adj,
+		                [&](u32 x, u32) {
+			                const u32 fh = meet_fhash(x);
+			                if (((bm[fh >> 5] >> (fh & 31)) & 1u) && meet_lookup(tab, x)) count++;
+		                },
+		                []() { return false; });
+		for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+		if (lane == 0) out[i] = lcc_value(count, deg);
+	}
+}
+
+__global__ void k_lcc_collect_big(int64_t n, const float *__restrict__ out, u32 *__restrict__ rows, u32 *__restrict__ count) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && out[i] == kLccBig) rows[atomicAdd(count, 1u)] = (u32)i;
+}
+
+// one 1024-thread workgroup per long-list row; `gmap` != null: the vertex bit map lives in this workgroup's slice of
+// global memory (V too large for LDS)
+__global__ __launch_bounds__(1024) void k_lcc_big(u32 nrows, const u32 *__restrict__ rows, const int64_t *__restrict__ src,
+                                                  const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                  float *__restrict__ out, int bm_words, u32 *__restrict__ gmap) {
+	extern __shared__ u32 s_lmap[];
+	__shared__ unsigned long long s_count;
+	u32 *map = gmap ? gmap + (size_t)blockIdx.x * (size_t)bm_words : s_lmap;
+	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	for (u32 r = blockIdx.x; r < nrows; r += gridDim.x) {
+		__syncthreads();
+		const u32 i = rows[r];
+		const int64_t s = src[i];
+		const int b = (int)off[s], deg = (int)off[s + 1] - b;
+		for (int k = tid; k < bm_words; k += 1024) map[k] = 0;
+		if (tid == 0) s_count = 0;
+		__syncthreads();
+		for (int p = tid; p < deg; p += 1024) {
+			const u32 x = (u32)adj[b + p];
+			atomicOr(&map[x >> 5], 1u << (x & 31));
+		}
+		__syncthreads();
+		unsigned long long count = 0;
+		(void)meet_walk(adj + b, deg, wib, 16, off, adj, [&](u32 x, u32) { count += (map[x >> 5] >> (x & 31)) & 1u; },
+		                []() { return false; });
+		for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+		if (lane == 0 && count) atomicAdd(&s_count, count);
+		__syncthreads();
+		if (tid == 0) out[i] = lcc_value(s_count, deg);
+	}
+}
+
+static int lcc_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, float *d_out) {
+	hipStream_t st = ws->stream;
+	if (n == 0) return PGQ_OK;
+	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
+	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	u32 *d_cnt = reinterpret_cast<u32 *>(ws->counters.p); // [0] long-list rows, [1] bad id, [2] compaction cursor
+	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, st));
+	hipLaunchKernelGGL(k_lcc, dim3((unsigned)std::min<int64_t>(n, 256 * 24 * 4)), dim3(64), 0, st, n, d_src, c->V, c->off, c->adj,
+	                   d_out, d_cnt);
+	u32 h[2] = { 0, 0 };
+	PGQ_HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	if (h[1]) return fail(PGQ_ERR_INVALID_ARG, "vertex rowid out of range [0,V)");
+	if (h[0] > 0) {
+		const u32 nbig = h[0];
+		PGQ_TRY(ws->def_idx.reserve((size_t)nbig * 4));
+		hipLaunchKernelGGL(k_lcc_collect_big, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, ws->def_idx.as<u32>(), d_cnt + 2);
+		const int bm_words = (int)((c->V + 31) / 32);
+		const bool in_lds = (size_t)bm_words * 4 + 256 <= 150 * 1024;
+		const unsigned grid = std::min<u32>(nbig, 256);
+		u32 *gmap = nullptr;
+		if (!in_lds) {
+			PGQ_TRY(ws->lblk.reserve((size_t)grid * (size_t)bm_words * 4));
+			gmap = ws->lblk.as<u32>();
+		} else {
+			static std::atomic<int> attr_set { 0 };
+			if (!attr_set.load()) {
+				(void)hipFuncSetAttribute((const void *)k_lcc_big, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+				attr_set.store(1);
+			}
+		}
+		hipLaunchKernelGGL(k_lcc_big, dim3(grid), dim3(1024), in_lds ? (size_t)bm_words * 4 : 0, st, nbig, ws->def_idx.as<u32>(),
+		                   d_src, c->off, c->adj, d_out, bm_words, gmap);
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+	}
+	return PGQ_OK;
+}
+
+// ---- PageRank ---------------------------------------------------------------------------------------------------------
+
+__global__ void k_slot_sources(int64_t V, const int64_t *__restrict__ off, int32_t *__restrict__ slot_src) {
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = (int64_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
+	for (int64_t v = wave; v < V; v += nwaves)
+		for (int64_t e = off[v] + lane; e < off[v + 1]; e += 64) slot_src[e] = (int32_t)v;
+}
+__global__ void k_iota_keys(int64_t E, const int32_t *__restrict__ adj, u32 *__restrict__ key, u32 *__restrict__ val) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < E) {
+		key[i] = (u32)adj[i];
+		val[i] = (u32)i;
+	}
+}
+__global__ void k_gather_sources(int64_t E, const u32 *__restrict__ sorted_slot, const int32_t *__restrict__ slot_src,
+                                 int32_t *__restrict__ psrc) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < E) psrc[i] = slot_src[sorted_slot[i]];
+}
+__global__ void k_pr_init(int64_t vs, double *__restrict__ rank) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < vs) rank[i] = 1.0 / static_cast<double>(vs);
+}
+// contrib[i] = rank[i] / out-degree (pagerank.cpp:55); dangling vertices (and the two trailing entries) contribute 0 here
+__global__ void k_pr_contrib(int64_t V, int64_t vs, const int64_t *__restrict__ off, const double *__restrict__ rank,
+                             double *__restrict__ contrib) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= vs) return;
+	const int64_t deg = i < V ? off[i + 1] - off[i] : 0;
+	contrib[i] = deg > 0 ? rank[i] / static_cast<double>(deg) : 0.0;
+}
+// total rank of the dangling entries: 1024 ordered slices, then their ordered sum (one workgroup)
+__global__ __launch_bounds__(1024) void k_pr_dangling(int64_t V, int64_t vs, const int64_t *__restrict__ off,
+                                                      const double *__restrict__ rank, double *__restrict__ total) {
+	__shared__ double part[1024];
+	const int64_t per = (vs + 1023) / 1024;
+	const int64_t lo = (int64_t)threadIdx.x * per, hi = min(lo + per, vs);
+	double s = 0.0;
+	for (int64_t i = lo; i < hi; i++) {
+		const bool dangling = i >= V || off[i + 1] == off[i];
+		if (dangling) s += rank[i];
+	}
+	part[threadIdx.x] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double t = 0.0;
+		for (int k = 0; k < 1024; k++) t += part[k];
+		*total = t;
+	}
+}
+// new rank of vertex n: in-list summed left to right in (source, slot) order, then damping (pagerank.cpp:57-76)
+__global__ void k_pr_pull(int64_t V, int64_t vs, const int64_t *__restrict__ roff, const int32_t *__restrict__ psrc,
+                          const double *__restrict__ contrib, const double *__restrict__ rank,
+                          const double *__restrict__ dangling, double *__restrict__ next, unsigned long long *__restrict__ max_delta) {
+	const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	double delta = 0.0;
+	if (n < vs) {
+		double t = 0.0;
+		if (n < V)
+			for (int64_t k = roff[n]; k < roff[n + 1]; k++) t += contrib[psrc[k]];
+		const double corr = *dangling / static_cast<double>(vs);
+		const double r = (1 - 0.85) / static_cast<double>(vs) + 0.85 * (t + corr);
+		next[n] = r;
+		delta = fabs(r - rank[n]);
+	}
+	// non-negative doubles order like their bit patterns
+	unsigned long long bits = (unsigned long long)__double_as_longlong(delta);
+	for (int o = 32; o > 0; o >>= 1) {
+		const unsigned long long other = __shfl_xor(bits, o);
+		bits = other > bits ? other : bits;
+	}
+	if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_delta, bits);
+}
+
+static std::mutex g_pr_lock;
+
+static int pagerank_compute(pgq_csr *c, Workspace *ws) {
+	std::lock_guard<std::mutex> g(g_pr_lock);
+	if (c->pagerank) return PGQ_OK;
+	hipStream_t st = ws->stream;
+	const int64_t V = c->V, E = c->E, vs = V + 2;
+	const size_t En = (size_t)std::max<int64_t>(E, 1);
+	DevBuf key, val, skey, sval, slot_src, psrc, tmp, rank[2], contrib, scal;
+	auto cleanup = [&]() {
+		for (DevBuf *b : { &key, &val, &skey, &sval, &slot_src, &psrc, &tmp, &rank[1], &contrib, &scal }) b->release();
+	};
+	auto body = [&]() -> int {
+		for (DevBuf *b : { &key, &val, &skey, &sval, &slot_src, &psrc }) PGQ_TRY(b->reserve(En * 4));
+		for (DevBuf *b : { &rank[0], &rank[1], &contrib }) PGQ_TRY(b->reserve((size_t)vs * 8));
+		PGQ_TRY(scal.reserve(64));
+		if (E > 0) {
+			hipLaunchKernelGGL(k_slot_sources, dim3(256 * 8), dim3(256), 0, st, V, c->off, slot_src.as<int32_t>());
+			hipLaunchKernelGGL(k_iota_keys, dim3(blocks_for(E)), dim3(256), 0, st, E, c->adj, key.as<u32>(), val.as<u32>());
+			int end_bit = 1;
+			while ((1LL << end_bit) < V) end_bit++;
+			size_t sb = 0;
+			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, key.as<u32>(), skey.as<u32>(), val.as<u32>(), sval.as<u32>(),
+			                                               (int)E, 0, end_bit, st));
+			PGQ_TRY(tmp.reserve(sb + 16));
+			// stable: slots of one destination keep ascending slot order = (source, slot) order of the forward CSR
+			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, key.as<u32>(), skey.as<u32>(), val.as<u32>(), sval.as<u32>(),
+			                                               (int)E, 0, end_bit, st));
+			hipLaunchKernelGGL(k_gather_sources, dim3(blocks_for(E)), dim3(256), 0, st, E, sval.as<u32>(), slot_src.as<int32_t>(),
+			                   psrc.as<int32_t>());
+		}
+		hipLaunchKernelGGL(k_pr_init, dim3(blocks_for(vs)), dim3(256), 0, st, vs, rank[0].as<double>());
+		double *d_dang = scal.as<double>();
+		unsigned long long *d_max = reinterpret_cast<unsigned long long *>(scal.as<double>() + 1);
+		int cur = 0, it = 0;
+		for (;;) {
+			PGQ_HIP_TRY(hipMemsetAsync(d_max, 0, 8, st));
+			hipLaunchKernelGGL(k_pr_contrib, dim3(blocks_for(vs)), dim3(256), 0, st, V, vs, c->off, rank[cur].as<double>(),
+			                   contrib.as<double>());
+			hipLaunchKernelGGL(k_pr_dangling, dim3(1), dim3(1024), 0, st, V, vs, c->off, rank[cur].as<double>(), d_dang);
+			hipLaunchKernelGGL(k_pr_pull, dim3(blocks_for(vs)), dim3(256), 0, st, V, vs, c->roff, psrc.as<int32_t>(),
+			                   contrib.as<double>(), rank[cur].as<double>(), d_dang, rank[cur ^ 1].as<double>(), d_max);
+			unsigned long long bits = 0;
+			PGQ_HIP_TRY(hipMemcpyAsync(&bits, d_max, 8, hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			double max_delta;
+			memcpy(&max_delta, &bits, 8);
+			cur ^= 1;
+			it++;
+			if (max_delta < 1e-6 || it >= 10000) break;
+		}
+		c->pagerank_iterations = it;
+		if (cur == 1) std::swap(rank[0], rank[1]);
+		return PGQ_OK;
+	};
+	int rc = body();
+	(void)hipStreamSynchronize(st);
+	cleanup();
+	if (rc != PGQ_OK) {
+		rank[0].release();
+		return rc;
+	}
+	c->pagerank = rank[0].as<double>(); // ownership moves to the CSR handle (freed with it)
+	return PGQ_OK;
+}
+
+__global__ void k_pr_gather(int64_t n, const int64_t *__restrict__ src, int64_t vs, const double *__restrict__ rank,
+                            double *__restrict__ out, uint8_t *__restrict__ ok) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int64_t s = src[i];
+	const bool valid = s >= 0 && s < vs; // pagerank.cpp:99-103
+	ok[i] = valid ? 1 : 0;
+	out[i] = valid ? rank[s] : 0.0;
+}
+
+} // namespace pgq
+
+using namespace pgq;
+
+extern "C" {
+
+int pgq_local_clustering_coefficient_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, float *d_out) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (n < 0 || (n > 0 && (!d_src || !d_out))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	return lcc_device(csr, lease.ws, n, d_src, d_out);
+}
+
+int pgq_local_clustering_coefficient(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, float *out, uint64_t *out_valid) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
+	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");
+	if (n < 0 || (n > 0 && (!out || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
+	if (n == 0) return PGQ_OK;
+	FlatPairs fp;
+	PGQ_TRY(flatten_pairs(V, n, src, src, fp, false)); // NULL rows come back as -1; out-of-range ids are rejected
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	Workspace *ws = lease.ws;
+	PGQ_TRY(ws->in_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_val.reserve((size_t)n * 4));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, fp.src.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	PGQ_TRY(lcc_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->out_val.as<float>()));
+	PGQ_HIP_TRY(hipMemcpy(out, ws->out_val.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	mask_fill_valid(out_valid, n);
+	for (int64_t i = 0; i < n; i++)
+		if (fp.src[i] < 0) mask_set_invalid(out_valid, i); // local_clustering_coefficient.cpp:39-41
+	return PGQ_OK;
+}
+
+int pgq_pagerank_device(pgq_csr_t *csr, double *d_rank, int *iterations) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	PGQ_TRY(pagerank_compute(csr, lease.ws));
+	if (d_rank) PGQ_HIP_TRY(hipMemcpy(d_rank, csr->pagerank, (size_t)(csr->V + 2) * 8, hipMemcpyDeviceToDevice));
+	if (iterations) *iterations = csr->pagerank_iterations;
+	return PGQ_OK;
+}
+
+int pgq_pagerank(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, double *out, uint64_t *out_valid) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
+	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");
+	if (n < 0 || (n > 0 && (!out || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	Workspace *ws = lease.ws;
+	PGQ_TRY(pagerank_compute(csr, ws));
+	if (n == 0) return PGQ_OK;
+	// rows: NULL -> NULL; ids outside [0, V + 2) -> NULL (pagerank.cpp:93-104)
+	std::vector<int64_t> ids((size_t)n);
+	const int64_t *data = static_cast<const int64_t *>(src.data);
+	for (int64_t r = 0; r < n; r++) {
+		const int64_t p = src.sel ? (int64_t)src.sel[r] : r;
+		const bool valid = !src.validity || ((src.validity[p >> 6] >> (p & 63)) & 1ULL);
+		ids[(size_t)r] = valid ? data[p] : -1;
+	}
+	PGQ_TRY(ws->in_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_val.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_ok.reserve((size_t)n));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, ids.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	hipLaunchKernelGGL(k_pr_gather, dim3(blocks_for(n)), dim3(256), 0, ws->stream, n, ws->in_src.as<int64_t>(), V + 2,
+	                   csr->pagerank, ws->out_val.as<double>(), ws->out_ok.as<uint8_t>());
+	std::vector<uint8_t> ok((size_t)n);
+	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
+	PGQ_HIP_TRY(hipMemcpy(out, ws->out_val.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	PGQ_HIP_TRY(hipMemcpy(ok.data(), ws->out_ok.p, (size_t)n, hipMemcpyDeviceToHost));
+	mask_fill_valid(out_valid, n);
+	for (int64_t i = 0; i < n; i++)
+		if (!ok[(size_t)i]) mask_set_invalid(out_valid, i);
+	return PGQ_OK;
+}
+
+} // extern "C"

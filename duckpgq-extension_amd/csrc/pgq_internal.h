@@ -138,6 +138,9 @@ struct pgq_csr {
 	bool has_negative_weight = false;
 	// multi-GPU: copies of this CSR on the other enabled devices (pgq_csr_replicate), indexed like enabled_devices();
 	// entry = this object for its own device.  Owned by the primary.
+	// PageRank over this CSR (V + 2 doubles), computed once per handle like the reference's bind-data state
+	double *pagerank = nullptr;
+	int pagerank_iterations = 0;
 	std::vector<pgq_csr *> replicas;
 	bool is_replica = false;
 };

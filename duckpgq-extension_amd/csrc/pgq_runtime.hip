@@ -603,6 +603,7 @@ static void destroy_csr(pgq_csr *c) {
 	(void)hipFree(c->pull_parts);
 	(void)hipFree(c->rown);
 	(void)hipFree(c->rpk);
+	(void)hipFree(c->pagerank);
 	delete c;
 }
 

@@ -1,0 +1,131 @@
+// pgq_walk.h — device helpers shared by the pair-centric kernels (pgq_meet.hip) and the neighbourhood-counting kernels
+// (pgq_analytics.hip): a vertex set in LDS (open-addressing hash table + one-probe bit filter) and the segmented
+// adjacency walk.
+#pragma once
+#include "pgq_internal.h"
+
+namespace pgq {
+
+typedef uint4 __attribute__((may_alias)) uint4_alias; // 16-byte clears of u32 tables (no type-based reordering)
+constexpr int kMeetSlots = 1024;            // hash slots per wavefront
+constexpr int kMeetSetMax = kMeetSlots / 2; // longest one-hop list the table takes (load factor <= 1/2)
+constexpr u32 kMeetEmpty = 0xFFFFFFFFu;
+constexpr int64_t kMeetOpen = -9;           // d_out marker: not answered here
+
+__device__ __forceinline__ u32 meet_hash(u32 x) { return (x * 0x9E3779B1u) >> 22; } // 10 bits
+
+__device__ __forceinline__ bool meet_lookup(const u32 *tab, u32 x) {
+	u32 h = meet_hash(x);
+	for (;;) {
+		const u32 t = tab[h];
+		if (t == x) return true;
+		if (t == kMeetEmpty) return false;
+		h = (h + 1) & (kMeetSlots - 1);
+	}
+}
+
+// one-probe pre-filter: 8192-bit map of the set (a set of ~100 vertices leaves ~1 % of the bits on), so that the four
+// entries a lane holds cost four independent LDS reads instead of four dependent hash-table walks
+constexpr int kMeetFilterWords = 256;
+__device__ __forceinline__ u32 meet_fhash(u32 x) { return (x * 0x9E3779B1u) >> 19; } // 13 bits
+// `valid`: bit k set = entry k lies inside the segment.  Returns the entries that are in the set (bit k).  The four
+// filter reads are independent and branch-free; only lanes holding a filter hit (~1 % of the entries) walk the table.
+__device__ __forceinline__ u32 meet_probe4(const u32 *tab, const u32 *bm, const int4 v, u32 valid) {
+	const u32 h0 = meet_fhash((u32)v.x), h1 = meet_fhash((u32)v.y), h2 = meet_fhash((u32)v.z), h3 = meet_fhash((u32)v.w);
+	const u32 w0 = bm[h0 >> 5], w1 = bm[h1 >> 5], w2 = bm[h2 >> 5], w3 = bm[h3 >> 5];
+	u32 p = (((w0 >> (h0 & 31)) & 1u) | (((w1 >> (h1 & 31)) & 1u) << 1) | (((w2 >> (h2 & 31)) & 1u) << 2) |
+	         (((w3 >> (h3 & 31)) & 1u) << 3)) & valid;
+	u32 f = 0;
+	while (p) {
+		const u32 k = (u32)__ffs((int)p) - 1u;
+		p &= p - 1u;
+		const u32 x = k == 0 ? (u32)v.x : (k == 1 ? (u32)v.y : (k == 2 ? (u32)v.z : (u32)v.w));
+		if (meet_lookup(tab, x)) f |= 1u << k;
+	}
+	return f;
+}
+
+__device__ __forceinline__ u64 wave_min_u64(u64 x) {
+	for (int o = 32; o > 0; o >>= 1) {
+		const u64 y = __shfl_xor(x, o);
+		x = y < x ? y : x;
+	}
+	return x;
+}
+
+// Streams the adjacency segments of list[w], list[w + stride], ... (positions < list_n) and calls f(entry) for every
+// entry until stop() (wave-uniform) says so.  Returns the number of entries requested.
+template <typename F, typename Stop>
+__device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restrict__ list, int list_n, int w, int stride,
+                                                        const int64_t *__restrict__ xoff, const int32_t *__restrict__ xadj,
+                                                        F f, Stop stop) {
+	const int lane = threadIdx.x & 63;
+	unsigned long long entries = 0;
+	for (int pb = w; pb < list_n; pb += 64 * stride) {
+		int vb = 0, ve = 0;
+		u32 vid = 0;
+		const int p = pb + lane * stride;
+		if (p < list_n) {
+			vid = (u32)list[p];
+			vb = (int)xoff[vid];
+			ve = (int)xoff[vid + 1];
+		}
+		const int cnt = min(64, (list_n - pb + stride - 1) / stride);
+		int j = -1, q = 0, e = 0, b = 0;
+		u32 cv = 0;
+		auto seek = [&]() {
+			for (j++; j < cnt; j++) {
+				b = __builtin_amdgcn_readlane(vb, j);
+				e = __builtin_amdgcn_readlane(ve, j);
+				if (e > b) {
+					q = b & ~3;
+					cv = (u32)__builtin_amdgcn_readlane((int)vid, j);
+					return;
+				}
+			}
+		};
+		seek();
+		constexpr int DEPTH = 4;
+		int4 x[DEPTH];
+		int xb[DEPTH], xe[DEPTH], xq[DEPTH];
+		u32 xv[DEPTH];
+		auto fetch = [&](int u) {
+			xq[u] = -1;
+			if (j < cnt) {
+				const int t = q + 4 * lane;
+				x[u] = make_int4(-1, -1, -1, -1);
+				if (t < e) x[u] = *reinterpret_cast<const int4 *>(xadj + t);
+				xb[u] = b;
+				xe[u] = e;
+				xq[u] = q;
+				xv[u] = cv;
+				entries += (unsigned long long)(min(e, q + 256) - max(b, q));
+				q += 256;
+				if (q >= e) seek();
+			}
+		};
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++) fetch(u);
+		for (;;) {
+			bool any_chunk = false;
+#pragma unroll
+			for (int u = 0; u < DEPTH; u++) {
+				if (xq[u] < 0) continue;
+				any_chunk = true;
+				const int4 v = x[u];
+				const int t = xq[u] + 4 * lane, sb = xb[u], se = xe[u];
+				const u32 ev = xv[u];
+				fetch(u);
+				if (t >= sb && t < se) f((u32)v.x, ev);
+				if (t + 1 >= sb && t + 1 < se) f((u32)v.y, ev);
+				if (t + 2 >= sb && t + 2 < se) f((u32)v.z, ev);
+				if (t + 3 >= sb && t + 3 < se) f((u32)v.w, ev);
+			}
+			if (!any_chunk || stop()) break;
+		}
+		if (stop()) break;
+	}
+	return entries;
+}
+
+} // namespace pgq

@@ -152,6 +152,20 @@ int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src
 int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                          void *d_out, uint8_t *d_out_valid);
 
+/* ---- the other CSR consumers ------------------------------------------------------------- */
+
+/* local_clustering_coefficient(csr_id, id) -> FLOAT   src/core/functions/scalar/local_clustering_coefficient.cpp:11-72
+ * (bit-identical: integer counting + the reference's three float operations).  NULL rows -> NULL; ids outside [0,V)
+ * (undefined behaviour in the reference) -> PGQ_ERR_INVALID_ARG.  Bulk form: d_src[i] < 0 = NULL row (value 0). */
+int pgq_local_clustering_coefficient(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, float *out, uint64_t *out_valid);
+int pgq_local_clustering_coefficient_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, float *d_out);
+/* pagerank(csr_id, id) -> DOUBLE   src/core/functions/scalar/pagerank.cpp:11-111: power iteration over V + 2 entries,
+ * damping 0.85, threshold 1e-6, computed once per handle; rows outside [0, V + 2) or NULL -> NULL.  Partial sums follow
+ * the reference's accumulation order; the dangling total is a two-level sum (tests: 1e-12 relative).
+ * pgq_pagerank_device copies all V + 2 ranks into d_rank (may be NULL) and reports the iteration count. */
+int pgq_pagerank(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, double *out, uint64_t *out_valid);
+int pgq_pagerank_device(pgq_csr_t *csr, double *d_rank, int *iterations);
+
 /* ---- tuning & measurement --------------------------------------------------------------------------------- */
 
 /* Knobs (also readable from the environment at pgq_init: PGQ_WORDS, PGQ_PUSH_DIV, PGQ_PROFILE ...).

@@ -56,6 +56,9 @@ def lib():
         L.ora_cheapest_path_length.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, Vec, C.c_void_p, C.c_void_p]
         L.ora_lean_iterativelength.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_int]
+        L.ora_local_clustering_coefficient.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.ora_pagerank.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.ora_weakly_connected_component.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ora_lean_shortestpath.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
         L.ora_lean_cheapest_path_length.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
@@ -282,6 +285,28 @@ class OracleCSR:
         ov = np.zeros((n + 63) // 64 + 1, dtype=np.uint64)
         lib().ora_lean_cheapest_path_length(self.h, V, n, _ptr(src), _ptr(dst), _ptr(out), _ptr(ov))
         return out, unpack_validity(ov, n)
+
+    # -- the other CSR consumers (literal restatements) -------------------------
+    def local_clustering_coefficient(self, src):
+        src = _i64(src)
+        out = np.zeros(len(src), dtype=np.float32)
+        lib().ora_local_clustering_coefficient(self.h, len(src), _ptr(src), _ptr(out))
+        return out
+
+    def pagerank(self):
+        """(rank[V+2], iterations)"""
+        n = lib().ora_csr_vsize(self.h)
+        out = np.zeros(n, dtype=np.float64)
+        it = C.c_int(0)
+        lib().ora_pagerank(self.h, _ptr(out), C.byref(it))
+        return out, it.value
+
+    def weakly_connected_component(self, src):
+        src = _i64(src)
+        out = np.zeros(len(src), dtype=np.int64)
+        ov = np.zeros((len(src) + 63) // 64 + 1, dtype=np.uint64)
+        lib().ora_weakly_connected_component(self.h, len(src), _ptr(src), _ptr(out), _ptr(ov))
+        return out, unpack_validity(ov, len(src))
 
     # -- cpu_baseline driver ---------------------------------------------------
     def baseline_run(self, which, V, src, dst, nthreads=1, stats=False):

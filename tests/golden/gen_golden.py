@@ -182,7 +182,45 @@ def w_type():
                              "note": "weight literal 12 -> type 1 (int64), 1.2 -> type 2 (double), none -> 0"})
 
 
+def analytics():
+    """local_clustering_coefficient / pagerank / weakly_connected_component expectations."""
+    t = "test/sql/scalar/local_clustering_coefficient.test"
+    know = tuples_at(t, 57, "know")
+    rows, cite = block(t, 75)
+    person = pq.read_table(os.path.join(REF, "data/SNB0.003/person.parquet")).column("id").to_pylist()
+    rowid = {pid: i for i, pid in enumerate(person)}
+    srows, scite = block(t, 131)
+    dump("lcc.json", {
+        "student": {"source": cite, "V": 5, "edges": [[e[0], e[1]] for e in know],
+                    "rows": [[int(r[0]), r[1]] for r in rows]},
+        "snb003": {"source": scite, "graph": "snb003_knows.json (undirected feed)",
+                   "rows": [[rowid[int(r[0])], r[1]] for r in srows]},
+        "note": "FLOAT column: DuckDB prints the shortest decimal that round-trips a float32",
+    })
+    t = "test/sql/scalar/pagerank.test"
+    know = tuples_at(t, 11, "know")
+    rows, cite = block(t, 25)
+    txt = open(os.path.join(REF, t)).read().split("\n")
+    know2 = [[int(x) for x in re.findall(r"-?\d+", txt[i])][:2] for i in range(54, 68)]  # lines 55-68: (src, dst, edge)
+    rows2, cite2 = block(t, 82)
+    dump("pagerank.json", {
+        "g1": {"source": cite, "V": 5, "edges": [[e[0], e[1]] for e in know], "rows": [[int(r[0]), r[1]] for r in rows]},
+        "g2": {"source": cite2, "V": 5, "edges": know2, "rows": [[int(r[0]), r[1]] for r in rows2],
+               "graph_source": "%s:55-68" % t},
+        "note": "directed CSR feed; DOUBLE column printed with 17 significant digits",
+    })
+    t = "test/sql/scalar/weakly_connected_component.test"
+    cases = []
+    for vline, eline, sep, V in ((10, 13, 31, 5), (40, 44, 59, 5), (68, 72, 86, 6), (97, 101, 115, 5), (124, 128, 142, 5)):
+        rows, cite = block(t, sep)
+        cases.append({"source": cite, "V": V, "edges": [[e[0], e[1]] for e in tuples_at(t, eline, "know")],
+                      "rows": [[int(r[0]), int(r[1])] for r in rows]})
+    dump("wcc.json", {"cases": cases, "note": "undirected feed (CreateUndirectedCSRCTE); the component id is the root the "
+                                              "reference's sequential union-find ends in, not a canonical label"})
+
+
 if __name__ == "__main__":
+    analytics()
     student_directed()
     student_csr_layout()
     student_undirected()

@@ -701,3 +701,56 @@ def test_cheapest_chain_prepass_cycles_and_branches():
             pgq.set_option("chain_cap", cap)
             out, ok = dev.cheapest_path_length(ps, pd)
             assert (ok == wok).all() and (out[ok] == want[wok]).all()
+
+
+def test_local_clustering_coefficient_device_bit_exact():
+    """k_lcc / k_lcc_big against the reference's goldens (student graph, SNB SF0.003) and the literal restatement on a
+    skewed graph with adjacency lists beyond the 512-entry hash table (bit map path); float32 results bit for bit."""
+    from test_oracle_golden import repr_float32
+    lcc = load_golden("lcc.json")
+    g = lcc["student"]
+    st, _ = both(g["V"], undirected_rows(g["edges"]))
+    out, ok = st.local_clustering_coefficient(0, np.arange(g["V"]))
+    assert ok.all() and [repr_float32(x) for x in out] == [r[1] for r in g["rows"]]
+    snb = load_golden("snb003_knows.json")
+    st, _ = both(snb["V"], undirected_rows(snb["edges"]), csr_id=1)
+    ids = np.array([r[0] for r in lcc["snb003"]["rows"]])
+    out, ok = st.local_clustering_coefficient(1, ids)
+    assert [repr_float32(x) for x in out] == [r[1] for r in lcc["snb003"]["rows"]]
+    rng = np.random.default_rng(44)
+    V, E = 8000, 300000
+    s, d, e = random_graph(rng, V, E, skew=True)  # parallel edges, self loops, lists of several thousand entries
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    assert np.diff(off).max() > 600
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    ids = np.arange(V)
+    valid = rng.random(V) > 0.02
+    out, ok = dev.local_clustering_coefficient(ids, src_valid=valid)
+    want = ora.local_clustering_coefficient(ids)
+    assert (ok == valid).all() and (out[valid].view(np.uint32) == want[valid].view(np.uint32)).all()
+    with pytest.raises(pgq.PgqError, match="out of range"):
+        dev.local_clustering_coefficient(np.array([V + 3]))
+
+
+def test_pagerank_device_matches_reference():
+    """pgq_pagerank against the reference's goldens and the literal restatement (V + 2 entries, dangling vertices, the
+    same iteration count); tolerance 1e-12 relative: only the dangling-rank total is summed in a different order."""
+    pr = load_golden("pagerank.json")
+    for k, key in enumerate(("g1", "g2")):
+        g = pr[key]
+        st, ora = both(g["V"], directed_rows(g["edges"]), csr_id=k)
+        out, ok = st.pagerank(k, np.arange(g["V"]))
+        assert ok.all()
+        for vid, txt in g["rows"]:
+            assert abs(out[vid] - float(txt)) <= 1e-12 * float(txt), (key, vid, out[vid], txt)
+    rng = np.random.default_rng(45)
+    V, E = 20000, 150000
+    s, d, e = random_graph(rng, V, E, skew=True)  # many dangling vertices
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    want, wit = OracleCSR.adopt(V, off, adj, eid).pagerank()
+    ids = np.concatenate([np.arange(V + 2), [-1, V + 2]])
+    out, ok, it = dev.pagerank(ids)
+    assert ok[:V + 2].all() and not ok[V + 2:].any() and it == wit
+    assert np.max(np.abs(out[:V + 2] - want) / want) <= 1e-12

@@ -225,3 +225,35 @@ def test_fuzz_literal_vs_lean_multigraphs(seed):
     out, cok = cw.cheapest_path_length(V, ps[:300], pd[:300])
     lout, lcok = cw.lean_cheapest_path_length(V, ps[:300], pd[:300])
     assert (cok == lcok).all() and (out[cok] == lout[cok]).all()
+
+
+def test_analytics_goldens_lcc_pagerank_wcc():
+    """The other CSR consumers: literal restatements against the reference's goldens."""
+    lcc = load_golden("lcc.json")
+    g = lcc["student"]
+    ora = OracleCSR.from_edges(g["V"], *undirected_rows(g["edges"]))  # CreateUndirectedCSRCTE feed
+    got = ora.local_clustering_coefficient(np.arange(g["V"]))
+    assert [repr_float32(x) for x in got] == [r[1] for r in g["rows"]]
+    snb = load_golden("snb003_knows.json")
+    ora = OracleCSR.from_edges(snb["V"], *undirected_rows(snb["edges"]))
+    ids = [r[0] for r in lcc["snb003"]["rows"]]
+    got = ora.local_clustering_coefficient(np.array(ids))
+    assert [repr_float32(x) for x in got] == [r[1] for r in lcc["snb003"]["rows"]]
+    pr = load_golden("pagerank.json")
+    for key in ("g1", "g2"):
+        g = pr[key]
+        ora = OracleCSR.from_edges(g["V"], *directed_rows(g["edges"]))
+        rank, it = ora.pagerank()
+        assert len(rank) == g["V"] + 2 and it > 1
+        for vid, txt in g["rows"]:
+            assert abs(rank[vid] - float(txt)) <= 1e-15 * max(1.0, abs(float(txt))), (key, vid, rank[vid], txt)
+    for case in load_golden("wcc.json")["cases"]:
+        ora = OracleCSR.from_edges(case["V"], *undirected_rows(case["edges"]))
+        out, ok = ora.weakly_connected_component(np.arange(case["V"]))
+        assert ok.all() and [[i, int(c)] for i, c in enumerate(out)] == case["rows"], case["source"]
+
+
+def repr_float32(x):
+    """DuckDB's FLOAT rendering: the shortest decimal that round-trips the float32."""
+    s = np.format_float_positional(np.float32(x), unique=True, trim="0")
+    return s if "." in s else s + ".0"

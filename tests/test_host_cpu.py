@@ -220,3 +220,12 @@ def test_weakly_connected_component_host_mirror_matches_goldens_and_oracle():
     assert ok[:V].all() and not ok[V:].any() and (out[:V] == want).all()
     with pytest.raises(pgq.PgqError, match="CSR not found. Is the graph populated"):
         st.weakly_connected_component(9, [0])
+
+
+def test_duckdb_glue_type_checks_against_stub_headers():
+    """glue/pgq_glue.cpp (replacement bodies of the search UDFs + ~CSR patch + whole-relation entry point) compiles
+    against stubs of the DuckDB declarations it touches: DuckDB itself is not vendored here."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "duckpgq-extension_amd", "csrc"), "-B", "glue-check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

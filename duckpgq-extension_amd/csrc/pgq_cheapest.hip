@@ -237,38 +237,40 @@ __global__ void k_chain_walk(int64_t n, const int64_t *__restrict__ src, const i
                              const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const T *__restrict__ w,
                              T *__restrict__ out, uint8_t *__restrict__ ok, int cap, u32 *__restrict__ counters) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const int64_t s = src[i], d = dst[i];
-	out[i] = (T)0;
-	if (s < 0) {
-		ok[i] = 0;
-		return;
+	int step = 0;
+	if (i < n) {
+		const int64_t s = src[i], d = dst[i];
+		T acc = (T)0;
+		uint8_t state = 0; // 0 NULL, 1 found, 2 open
+		if (s >= V || (s >= 0 && (d < 0 || d >= V))) {
+			counters[1] = 1; // id out of range
+		} else if (s >= 0) {
+			int64_t x = s;
+			for (;; step++) {
+				if (x == d) {
+					state = 1;
+					break;
+				}
+				const int64_t b = off[x], deg = off[x + 1] - b;
+				if (deg == 0) break;
+				if (deg > 1 || step >= cap) {
+					state = 2;
+					break;
+				}
+				acc = acc + w[b];
+				x = adj[b];
+			}
+		}
+		out[i] = state == 1 ? acc : (T)0;
+		ok[i] = state;
 	}
-	if (s >= V || d < 0 || d >= V) {
-		counters[1] = 1; // id out of range
-		ok[i] = 0;
-		return;
-	}
-	int64_t x = s;
-	T acc = (T)0;
-	for (int step = 0;; step++) {
-		if (x == d) {
-			out[i] = acc;
-			ok[i] = 1;
-			return;
-		}
-		const int64_t b = off[x], deg = off[x + 1] - b;
-		if (deg == 0) {
-			ok[i] = 0;
-			return;
-		}
-		if (deg > 1 || step >= cap) {
-			ok[i] = 2;
-			atomicAdd(&counters[0], 1u);
-			return;
-		}
-		acc = acc + w[b];
-		x = adj[b];
+	// statistics: open rows and chain steps, one atomic each per wave
+	const u64 open = __ballot(i < n && ok[i] == 2);
+	int steps = step;
+	for (int sh = 32; sh; sh >>= 1) steps += __shfl_xor(steps, sh);
+	if ((threadIdx.x & 63) == 0) {
+		if (open) atomicAdd(&counters[0], (u32)__popcll(open));
+		if (steps) atomicAdd(&counters[3], (u32)steps);
 	}
 }
 __global__ void k_collect_open_rows(int64_t n, const uint8_t *__restrict__ ok, const int64_t *__restrict__ src,
@@ -309,15 +311,20 @@ static int cheapest_with_chains(pgq_csr *c, Workspace *ws, int64_t n, const int6
 	u32 *d_cnt = reinterpret_cast<u32 *>(ws->counters.p); // [0] open rows, [1] bad id, [2] compaction cursor
 	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, st));
 	{
-		KernelTimer kt(st, K_PREP);
+		KernelTimer kt(st, K_RELAX);
 		hipLaunchKernelGGL(k_chain_walk<T>, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, c->V, c->off, c->adj,
 		                   (const T *)c->w, (T *)d_out, d_ok, std::max(1, options().chain_cap), d_cnt);
 		kt.stop();
 	}
-	u32 h[2] = { 0, 0 };
+	u32 h[4] = { 0, 0, 0, 0 };
 	PGQ_HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	KernelTimer::flush();
+	{ // a chain step reads off[x], off[x+1], w[b], adj[b]; a row reads its pair and writes value + flag
+		pgq_stats_t &S = tstats().s;
+		S.edges_scanned += h[3];
+		S.algo_bytes[K_RELAX] += 28.0 * h[3] + 25.0 * (double)n;
+	}
 	if (h[1]) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
 	const u32 nd = h[0];
 	tstats().s.meet_pairs += n - (int64_t)nd;

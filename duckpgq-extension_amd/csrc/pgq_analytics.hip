@@ -177,25 +177,6 @@ static int lcc_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src
 
 // ---- PageRank ---------------------------------------------------------------------------------------------------------
 
-__global__ void k_slot_sources(int64_t V, const int64_t *__restrict__ off, int32_t *__restrict__ slot_src) {
-	const int lane = threadIdx.x & 63;
-	const int64_t wave = (int64_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
-	for (int64_t v = wave; v < V; v += nwaves)
-		for (int64_t e = off[v] + lane; e < off[v + 1]; e += 64) slot_src[e] = (int32_t)v;
-}
-__global__ void k_iota_keys(int64_t E, const int32_t *__restrict__ adj, u32 *__restrict__ key, u32 *__restrict__ val) {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < E) {
-		key[i] = (u32)adj[i];
-		val[i] = (u32)i;
-	}
-}
-__global__ void k_gather_sources(int64_t E, const u32 *__restrict__ sorted_slot, const int32_t *__restrict__ slot_src,
-                                 int32_t *__restrict__ psrc) {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < E) psrc[i] = slot_src[sorted_slot[i]];
-}
 __global__ void k_pr_init(int64_t vs, double *__restrict__ rank) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < vs) rank[i] = 1.0 / static_cast<double>(vs);
@@ -257,31 +238,16 @@ static int pagerank_compute(pgq_csr *c, Workspace *ws) {
 	std::lock_guard<std::mutex> g(g_pr_lock);
 	if (c->pagerank) return PGQ_OK;
 	hipStream_t st = ws->stream;
-	const int64_t V = c->V, E = c->E, vs = V + 2;
-	const size_t En = (size_t)std::max<int64_t>(E, 1);
-	DevBuf key, val, skey, sval, slot_src, psrc, tmp, rank[2], contrib, scal;
+	const int64_t V = c->V, vs = V + 2;
+	DevBuf rank[2], contrib, scal;
 	auto cleanup = [&]() {
-		for (DevBuf *b : { &key, &val, &skey, &sval, &slot_src, &psrc, &tmp, &rank[1], &contrib, &scal }) b->release();
+		for (DevBuf *b : { &rank[1], &contrib, &scal }) b->release();
 	};
+	// the reverse CSR lists the in-edges of a vertex by (source, forward slot): the order pagerank.cpp:60-66 adds in
+	const int32_t *psrc = c->radj;
 	auto body = [&]() -> int {
-		for (DevBuf *b : { &key, &val, &skey, &sval, &slot_src, &psrc }) PGQ_TRY(b->reserve(En * 4));
 		for (DevBuf *b : { &rank[0], &rank[1], &contrib }) PGQ_TRY(b->reserve((size_t)vs * 8));
 		PGQ_TRY(scal.reserve(64));
-		if (E > 0) {
-			hipLaunchKernelGGL(k_slot_sources, dim3(256 * 8), dim3(256), 0, st, V, c->off, slot_src.as<int32_t>());
-			hipLaunchKernelGGL(k_iota_keys, dim3(blocks_for(E)), dim3(256), 0, st, E, c->adj, key.as<u32>(), val.as<u32>());
-			int end_bit = 1;
-			while ((1LL << end_bit) < V) end_bit++;
-			size_t sb = 0;
-			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, key.as<u32>(), skey.as<u32>(), val.as<u32>(), sval.as<u32>(),
-			                                               (int)E, 0, end_bit, st));
-			PGQ_TRY(tmp.reserve(sb + 16));
-			// stable: slots of one destination keep ascending slot order = (source, slot) order of the forward CSR
-			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, key.as<u32>(), skey.as<u32>(), val.as<u32>(), sval.as<u32>(),
-			                                               (int)E, 0, end_bit, st));
-			hipLaunchKernelGGL(k_gather_sources, dim3(blocks_for(E)), dim3(256), 0, st, E, sval.as<u32>(), slot_src.as<int32_t>(),
-			                   psrc.as<int32_t>());
-		}
 		hipLaunchKernelGGL(k_pr_init, dim3(blocks_for(vs)), dim3(256), 0, st, vs, rank[0].as<double>());
 		double *d_dang = scal.as<double>();
 		unsigned long long *d_max = reinterpret_cast<unsigned long long *>(scal.as<double>() + 1);
@@ -291,7 +257,7 @@ static int pagerank_compute(pgq_csr *c, Workspace *ws) {
 			hipLaunchKernelGGL(k_pr_contrib, dim3(blocks_for(vs)), dim3(256), 0, st, V, vs, c->off, rank[cur].as<double>(),
 			                   contrib.as<double>());
 			hipLaunchKernelGGL(k_pr_dangling, dim3(1), dim3(1024), 0, st, V, vs, c->off, rank[cur].as<double>(), d_dang);
-			hipLaunchKernelGGL(k_pr_pull, dim3(blocks_for(vs)), dim3(256), 0, st, V, vs, c->roff, psrc.as<int32_t>(),
+			hipLaunchKernelGGL(k_pr_pull, dim3(blocks_for(vs)), dim3(256), 0, st, V, vs, c->roff, psrc,
 			                   contrib.as<double>(), rank[cur].as<double>(), d_dang, rank[cur ^ 1].as<double>(), d_max);
 			unsigned long long bits = 0;
 			PGQ_HIP_TRY(hipMemcpyAsync(&bits, d_max, 8, hipMemcpyDeviceToHost, st));

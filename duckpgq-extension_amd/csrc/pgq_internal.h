@@ -53,6 +53,7 @@ struct Options {
 	int blocks_per_cu = 8;  // persistent grid sizing for the pull kernel
 	int chain = 1;          // cheapest_path_length: walk out-degree-1 chains per row before the batched relaxation
 	int chain_cap = 4096;   // steps after which a chain is taken for a cycle and left to the batched relaxation
+	int alloc_cache_mb = 8192; // freed CSR / upload blocks kept for the next upload, per process (0: straight hipFree)
 	int relax_small_limit = 2048; // changed vertices at or below which relaxation rounds loop on the device
 	int trace = 0;          // per-level line on stderr
 	int probe = 1;          // destination probe before each expansion
@@ -63,6 +64,7 @@ struct Options {
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
 	int part_weight = 1024; // in-edges (+8 per vertex) per bottom-up work part
 	int upload_threads = 2;  // host threads staging a pageable CSR through pinned rings
+	int upload_narrow_host = 1; // 1: the staging threads narrow the adjacency to int32; 0: raw int64 over PCIe, narrowed on the device
 	int streams = 3;        // batches searched concurrently (one host thread + HIP stream each)
 	int sparse_lds = 1;     // keep the 1-bit frontier map in LDS when it fits (1024-thread workgroups)
 	int sparse_spill = 3;   // > 0: words beyond a record's inline ones go through the per-wave LDS queue; 0: per-lane trips (tests)
@@ -122,7 +124,6 @@ struct pgq_csr {
 	// reverse CSR (in-neighbours), built on device at upload
 	int64_t *roff = nullptr; // V+1
 	int32_t *radj = nullptr; // E  source vertex of the in-edge
-	int64_t *rslot = nullptr; // E  forward slot of the in-edge (path reconstruction)
 	// high in-degree vertices split into work items for the bottom-up kernel
 	pgq::HubItem *pull_hubs = nullptr; // device
 	int32_t *pull_hub_vertices = nullptr;
@@ -171,6 +172,17 @@ struct KernelTimer {
 };
 
 // scratch buffer that grows on demand, per workspace
+// cached device blocks for CSRs and upload temporaries (pgq_runtime.hip)
+int dev_alloc(void **out, size_t bytes);
+void dev_free(void *p);
+void dev_cache_trim();
+template <typename T> inline int dev_alloc_as(T **out, size_t count) {
+	void *p = nullptr;
+	int rc = dev_alloc(&p, count * sizeof(T));
+	*out = static_cast<T *>(p);
+	return rc;
+}
+
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;

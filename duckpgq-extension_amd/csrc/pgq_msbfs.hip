@@ -1114,8 +1114,9 @@ __global__ void k_scatter_te(int64_t n, const u32 *__restrict__ sidx, const int6
 }
 
 // ---- path reconstruction (shortest_path.cpp:149-204 with the :21-31 tie-break) ---------------------------------
-// One wavefront per resolved pair.  Walks back from dst: among the in-edges of x whose source has the lane's
-// bit in the previous level's frontier, take the one with the smallest forward slot.
+// One wavefront per resolved pair.  Walks back from dst: the in-edges of x are ordered by (source, forward slot), so
+// the first in-slot whose source has the lane's bit in the previous level's frontier names the smallest such source;
+// its first out-slot that points at x is the edge.
 template <int WD>
 __global__ __launch_bounds__(256) void k_reconstruct(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
                                                      const int32_t *__restrict__ sdst,
@@ -1124,7 +1125,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(int64_t lo, int64_t hi, con
                                                      const u64 *const *__restrict__ levels,
                                                      const int64_t *__restrict__ roff,
                                                      const int32_t *__restrict__ radj,
-                                                     const int64_t *__restrict__ rslot,
+                                                     const int64_t *__restrict__ off,
+                                                     const int32_t *__restrict__ adj,
                                                      const int64_t *__restrict__ edge_ids,
                                                      int64_t *__restrict__ child) {
 	const int lane = threadIdx.x & 63;
@@ -1140,28 +1142,23 @@ __global__ __launch_bounds__(256) void k_reconstruct(int64_t lo, int64_t hi, con
 	if (lane == 0) out[2 * k] = x;
 	for (int t = k - 1; t >= 0; t--) {
 		const u64 *F = levels[t];
-		u64 best = ~0ull;
-		int bv = -1;
-		for (int64_t j = roff[x] + lane; j < roff[x + 1]; j += 64) {
-			const int v = radj[j];
-			if (F[(size_t)v * WD + w] & bit) {
-				const u64 sl = (u64)rslot[j];
-				if (sl < best) {
-					best = sl;
-					bv = v;
-				}
-			}
+		int pv = -1;
+		const int64_t rb = roff[x], re = roff[x + 1];
+		for (int64_t j0 = rb; j0 < re && pv < 0; j0 += 64) {
+			const int64_t j = j0 + lane;
+			const int v = j < re ? radj[j] : -1;
+			const u64 hit = __ballot(v >= 0 && (F[(size_t)v * WD + w] & bit) != 0);
+			if (hit) pv = __shfl(v, __ffsll((long long)hit) - 1);
 		}
-		u64 m = best;
-		for (int o = 32; o > 0; o >>= 1) {
-			u64 other = __shfl_xor(m, o);
-			m = other < m ? other : m;
+		int64_t slot = -1;
+		const int64_t fb = off[pv], fe = off[pv + 1];
+		for (int64_t e0 = fb; e0 < fe && slot < 0; e0 += 64) {
+			const int64_t e = e0 + lane;
+			const u64 hit = __ballot(e < fe && adj[e] == x);
+			if (hit) slot = e0 + __ffsll((long long)hit) - 1;
 		}
-		const u64 who = __ballot(best == m);
-		const int src_lane = __ffsll((long long)who) - 1;
-		const int pv = __shfl(bv, src_lane);
 		if (lane == 0) {
-			out[2 * t + 1] = edge_ids ? edge_ids[m] : (int64_t)m;
+			out[2 * t + 1] = edge_ids ? edge_ids[slot] : slot;
 			out[2 * t] = pv;
 		}
 		x = pv;
@@ -1677,7 +1674,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				hipLaunchKernelGGL(k_reconstruct<WD>, dim3(blocks_for(cnt_pairs * 64)), dim3(256), 0, st, lo, hi,
 				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(),
 				                   sh->soff.as<int64_t>(), base_lane, (const u64 *const *)sh->levels_tab.p, c->roff,
-				                   c->radj, c->rslot, c->edge_ids, d_child);
+				                   c->radj, c->off, c->adj, c->edge_ids, d_child);
 				kt.stop();
 				PGQ_HIP_TRY(hipStreamSynchronize(st)); // tab is a stack vector
 				KernelTimer::flush();

@@ -13,7 +13,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
+#include <unordered_map>
 
 #include "pgq_internal.h"
 
@@ -105,7 +107,9 @@ static int do_init(int device) {
 	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
 	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
 	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
+	env_int("PGQ_ALLOC_CACHE_MB", g_opt.alloc_cache_mb);
 	env_int("PGQ_UPLOAD_THREADS", g_opt.upload_threads);
+	env_int("PGQ_UPLOAD_NARROW_HOST", g_opt.upload_narrow_host);
 	g_inited.store(1);
 	return PGQ_OK;
 }
@@ -158,6 +162,99 @@ void KernelTimer::flush() {
 		t_event_pool.push_back(p.b);
 	}
 	t_pending.clear();
+}
+
+// ---- device memory for CSRs and upload temporaries: freed blocks are kept for the next upload ------------------
+// DuckDB builds a CSR per query (CreateCsr*), so the same dozen block sizes come back every few milliseconds;
+// hipMalloc/hipFree of 100+ MB blocks cost more than the kernels that fill them.  Blocks are keyed by (device, rounded
+// size); at most `alloc_cache_mb` of free blocks are kept (0 disables the cache).  Callers free only memory no kernel
+// still uses (every upload and search ends with a stream synchronisation), which is what hipFree's implicit
+// synchronisation used to guarantee.
+namespace {
+struct BlockCache {
+	std::mutex lock;
+	std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;
+	std::unordered_map<void *, std::pair<int, size_t>> live;
+	size_t cached_bytes = 0;
+};
+BlockCache &block_cache() {
+	static BlockCache *c = new BlockCache(); // never destroyed: frees may run from static destructors
+	return *c;
+}
+size_t round_block(size_t bytes) {
+	const size_t g = bytes <= (1u << 20) ? 4096 : (2u << 20);
+	return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
+}
+} // namespace
+
+int dev_alloc(void **out, size_t bytes) {
+	*out = nullptr;
+	const size_t want = round_block(bytes);
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	BlockCache &bc = block_cache();
+	{
+		std::lock_guard<std::mutex> g(bc.lock);
+		auto it = bc.free_blocks.find({ dev, want });
+		if (it != bc.free_blocks.end() && !it->second.empty()) {
+			*out = it->second.back();
+			it->second.pop_back();
+			bc.cached_bytes -= want;
+			bc.live[*out] = { dev, want };
+			return PGQ_OK;
+		}
+	}
+	hipError_t e = hipMalloc(out, want);
+	if (e != hipSuccess) { // give the cached blocks back to the driver and try once more
+		dev_cache_trim();
+		e = hipMalloc(out, want);
+	}
+	if (e != hipSuccess) {
+		*out = nullptr;
+		return fail(PGQ_ERR_OOM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+	}
+	std::lock_guard<std::mutex> g(bc.lock);
+	bc.live[*out] = { dev, want };
+	return PGQ_OK;
+}
+
+void dev_free(void *p) {
+	if (!p) return;
+	BlockCache &bc = block_cache();
+	{
+		std::lock_guard<std::mutex> g(bc.lock);
+		auto it = bc.live.find(p);
+		if (it != bc.live.end()) {
+			const std::pair<int, size_t> key = it->second;
+			bc.live.erase(it);
+			const size_t cap = (size_t)std::max(0, options().alloc_cache_mb) << 20;
+			if (bc.cached_bytes + key.second <= cap) {
+				bc.free_blocks[key].push_back(p);
+				bc.cached_bytes += key.second;
+				return;
+			}
+		}
+	}
+	(void)hipFree(p);
+}
+
+void dev_cache_trim() {
+	BlockCache &bc = block_cache();
+	std::vector<std::pair<int, void *>> blocks;
+	{
+		std::lock_guard<std::mutex> g(bc.lock);
+		for (auto &kv : bc.free_blocks)
+			for (void *p : kv.second) blocks.push_back({ kv.first.first, p });
+		bc.free_blocks.clear();
+		bc.cached_bytes = 0;
+	}
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	for (auto &b : blocks) {
+		if (b.first != cur) (void)hipSetDevice(b.first);
+		(void)hipFree(b.second);
+		if (b.first != cur) (void)hipSetDevice(cur);
+	}
 }
 
 int DevBuf::reserve(size_t bytes) {
@@ -213,9 +310,9 @@ int flatten_pairs(int64_t V, int64_t n, const pgq_vec_t &src, const pgq_vec_t &d
 
 // ---- CSR upload kernels --------------------------------------------------------------------------------------
 
-// adjacency int64 -> int32, in-degree histogram, range check
-__global__ void k_narrow_adj(const int64_t *__restrict__ adj64, int32_t *__restrict__ adj32, int *__restrict__ rcnt,
-                             int64_t E, int64_t V, int *__restrict__ bad) {
+// adjacency int64 -> int32 with the range check
+__global__ void k_narrow_adj(const int64_t *__restrict__ adj64, int32_t *__restrict__ adj32, int64_t E, int64_t V,
+                             int *__restrict__ bad) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (; i < E; i += stride) {
@@ -225,33 +322,40 @@ __global__ void k_narrow_adj(const int64_t *__restrict__ adj64, int32_t *__restr
 			d = 0;
 		}
 		adj32[i] = (int32_t)d;
-		atomicAdd(&rcnt[d], 1);
 	}
 }
 
-__global__ void k_widen(const int *__restrict__ in, int64_t *__restrict__ out, int64_t n_in, int64_t n_out) {
-	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n_out) out[i] = i < n_in ? (int64_t)in[i] : 0;
-}
-
-// one thread per forward slot: find its source by binary search in the offsets, claim a reverse slot
-__global__ void k_scatter_reverse(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
-                                  const int64_t *__restrict__ roff, int *__restrict__ fill,
-                                  int32_t *__restrict__ radj, int64_t *__restrict__ rslot, int64_t E, int64_t V) {
-	int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; e < E; e += stride) {
-		int64_t lo = 0, hi = V; // largest v with off[v] <= e
-		while (lo < hi) {
-			int64_t mid = (lo + hi + 1) >> 1;
-			if (off[mid] <= e) lo = mid;
-			else hi = mid - 1;
+// The reverse CSR is the forward slot list sorted (stably) by destination: in-edges of a vertex come out ordered by
+// (source, forward slot).  That order is what the reference's tie-breaks are stated in (the parent of a path step is
+// the smallest vertex of the previous level, shortest_path.cpp:21-31; PageRank adds in-edge contributions in edge
+// order, pagerank.cpp:60-66), so nothing downstream needs the forward slot itself.
+// slot_src[e] = source vertex of forward slot e: a workgroup takes 256 consecutive rows and expands them
+__global__ __launch_bounds__(256) void k_slot_sources(int64_t V, const int64_t *__restrict__ off, u32 *__restrict__ slot_src) {
+	__shared__ int64_t s_off[257];
+	for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < V; r0 += (int64_t)gridDim.x * 256) {
+		const int rows = (int)std::min<int64_t>(256, V - r0);
+		__syncthreads();
+		for (int k = threadIdx.x; k <= rows; k += 256) s_off[k] = off[r0 + k];
+		__syncthreads();
+		const int64_t e0 = s_off[0], e1 = s_off[rows];
+		for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+			int lo = 0, hi = rows - 1; // largest k with s_off[k] <= e
+			while (lo < hi) {
+				const int mid = (lo + hi + 1) >> 1;
+				if (s_off[mid] <= e) lo = mid;
+				else hi = mid - 1;
+			}
+			slot_src[e] = (u32)(r0 + lo);
 		}
-		int32_t d = adj[e];
-		int64_t p = roff[d] + atomicAdd(&fill[d], 1);
-		radj[p] = (int32_t)lo;
-		rslot[p] = e;
 	}
+}
+// roff from the sorted destination keys: entry p closes every row in (key[p-1], key[p]]
+__global__ void k_row_bounds(const u32 *__restrict__ skey, int64_t E, int64_t V, int64_t *__restrict__ roff) {
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p > E) return;
+	const int64_t a = p ? (int64_t)skey[p - 1] : -1;
+	const int64_t b = p < E ? (int64_t)skey[p] : V;
+	for (int64_t v = a + 1; v <= b; v++) roff[v] = p;
 }
 
 __global__ void k_check_offsets(const int64_t *__restrict__ off, int64_t V, int *__restrict__ bad) {
@@ -270,7 +374,7 @@ template <typename T> __global__ void k_any_negative(const T *__restrict__ w, in
 
 // ---- CSR construction on the device (create_csr_vertex/create_csr_edge equivalent) -----------------------------
 __global__ void k_check_rows(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t n, int64_t V,
-                             u32 *__restrict__ key, u32 *__restrict__ idx, int *__restrict__ deg, int *__restrict__ bad) {
+                             u32 *__restrict__ key, u32 *__restrict__ idx, int *__restrict__ bad) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (; i < n; i += stride) {
@@ -281,23 +385,21 @@ __global__ void k_check_rows(const int64_t *__restrict__ src, const int64_t *__r
 		}
 		key[i] = (u32)s;
 		idx[i] = (u32)i;
-		atomicAdd(&deg[s], 1);
 	}
 }
 // slot i of the CSR holds row order[i]: gather dst / edge id / weight
 __global__ void k_gather_rows(const u32 *__restrict__ order, int64_t n, const int64_t *__restrict__ dst,
                               const int64_t *__restrict__ eid, const int64_t *__restrict__ w,
-                              int64_t *__restrict__ adj64, int64_t *__restrict__ eid_out, int64_t *__restrict__ w_out) {
+                              int32_t *__restrict__ adj, int64_t *__restrict__ eid_out, int64_t *__restrict__ w_out) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (; i < n; i += stride) {
 		const u32 r = order[i];
-		adj64[i] = dst[r];
+		adj[i] = (int32_t)dst[r]; // range-checked by k_check_rows
 		eid_out[i] = eid ? eid[r] : (int64_t)r;
 		if (w_out) w_out[i] = w[r];
 	}
 }
-
 
 // rown[e] = index of in-slot e's owner vertex inside its bottom-up work part (0..31): lets k_pull_sparse find the
 // owner of an in-edge with one coalesced byte load instead of a binary search.  One wavefront per part.
@@ -443,49 +545,146 @@ static int staged_download(void *h_dst, const void *d_src, size_t bytes, hipStre
 	return rc;
 }
 
-// in-degree histogram of an already narrowed adjacency
-__global__ void k_hist_adj32(const int32_t *__restrict__ adj32, int *__restrict__ rcnt, int64_t E) {
-	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; i < E; i += stride) atomicAdd(&rcnt[adj32[i]], 1);
+// ---- hub list, degree statistics and the bottom-up work partition, on the device -----------------------------------
+struct UploadStats {
+	unsigned long long two_hop_sum; // sum over v of in-degree x out-degree
+	int max_in, max_out, n_hubs, n_parts, negative_weight, pad;
+};
+struct HubRow {
+	int64_t vertex, begin, end;
+};
+__global__ __launch_bounds__(256) void k_degree_stats(int64_t V, const int64_t *__restrict__ off,
+                                                      const int64_t *__restrict__ roff, int64_t chunk, int hub_cap,
+                                                      UploadStats *__restrict__ st, HubRow *__restrict__ hubs) {
+	__shared__ unsigned long long s_sum[4];
+	__shared__ int s_in[4], s_out[4];
+	unsigned long long sum = 0;
+	int max_in = 0, max_out = 0;
+	for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+		const int64_t rb = roff[v], re = roff[v + 1];
+		const int64_t indeg = re - rb, outdeg = off[v + 1] - off[v];
+		sum += (unsigned long long)indeg * (unsigned long long)outdeg;
+		max_in = max(max_in, (int)indeg);
+		max_out = max(max_out, (int)outdeg);
+		if (indeg > chunk) { // rare: a few atomics per graph
+			const int k = atomicAdd(&st->n_hubs, 1);
+			if (k < hub_cap) hubs[k] = { v, rb, re };
+		}
+	}
+	for (int sh = 32; sh; sh >>= 1) {
+		sum += __shfl_xor(sum, sh);
+		max_in = max(max_in, __shfl_xor(max_in, sh));
+		max_out = max(max_out, __shfl_xor(max_out, sh));
+	}
+	const int w = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) {
+		s_sum[w] = sum;
+		s_in[w] = max_in;
+		s_out[w] = max_out;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicAdd(&st->two_hop_sum, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+		atomicMax(&st->max_in, max(max(s_in[0], s_in[1]), max(s_in[2], s_in[3])));
+		atomicMax(&st->max_out, max(max(s_out[0], s_out[1]), max(s_out[2], s_out[3])));
+	}
+}
+// Work partition for the bottom-up kernels: contiguous vertex ranges [begin,end) that never contain a hub, hold at most
+// 16 vertices (LDS accumulator rows of k_pull_sparse) and at most `wmax` of (in-degree + 8 per vertex).  A thread packs
+// one run of kPartRun consecutive vertices greedily; EMIT = false counts the parts of each run, EMIT = true writes
+// them at the scanned base.
+constexpr int kPartRun = 256;
+template <bool EMIT>
+__global__ void k_make_parts(int64_t V, const int64_t *__restrict__ roff, int64_t chunk, int64_t wmax,
+                             int *__restrict__ run_count, const int *__restrict__ run_base, int32_t *__restrict__ parts,
+                             UploadStats *__restrict__ st) {
+	const int64_t run = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t v0 = run * kPartRun;
+	if (v0 >= V) return;
+	const int64_t v1 = min(V, v0 + kPartRun);
+	int n = 0;
+	const int base = EMIT ? run_base[run] : 0;
+	int64_t begin = v0, acc = 0;
+	auto close = [&](int64_t end) {
+		if (end > begin) {
+			if (EMIT) {
+				parts[2 * (base + n)] = (int32_t)begin;
+				parts[2 * (base + n) + 1] = (int32_t)end;
+			}
+			n++;
+		}
+		begin = end;
+		acc = 0;
+	};
+	int64_t r = roff[v0];
+	for (int64_t v = v0; v < v1; v++) {
+		const int64_t rn = roff[v + 1], d = rn - r;
+		r = rn;
+		if (d > chunk) { // hub: handled by k_pull_hub, never inside a part
+			close(v);
+			begin = v + 1;
+			continue;
+		}
+		const int64_t wv = d + 8;
+		if (v > begin && (acc + wv > wmax || v - begin >= 16)) close(v);
+		acc += wv;
+	}
+	close(v1);
+	if (!EMIT) run_count[run] = n;
+	else if (v1 == V) st->n_parts = base + n;
 }
 
 // Builds everything derived from (off, adj64) that already sit in device memory.
 static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { // d_adj64 == nullptr: c->adj is set
 	const int64_t V = c->V, E = c->E;
+	const size_t En = (size_t)std::max<int64_t>(E, 1);
 	UploadTrace tr;
 	int *d_flag = nullptr;
-	PGQ_HIP_TRY(hipMalloc(&d_flag, 2 * sizeof(int)));
+	u32 *d_slot_src = nullptr, *d_skey = nullptr;
+	void *d_tmp = nullptr;
+	struct Temps {
+		int *&flag;
+		u32 *&a, *&b;
+		void *&t;
+		~Temps() {
+			dev_free(flag);
+			dev_free(a);
+			dev_free(b);
+			dev_free(t);
+		}
+	} temps { d_flag, d_slot_src, d_skey, d_tmp };
+	PGQ_TRY(dev_alloc_as(&d_flag, 2));
 	PGQ_HIP_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
 	if (V > 0) {
 		hipLaunchKernelGGL(k_check_offsets, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, c->off, V, d_flag);
 	}
-	int *d_cnt = nullptr;
-	PGQ_HIP_TRY(hipMalloc(&d_cnt, (size_t)(V + 1) * sizeof(int)));
-	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(V + 1) * sizeof(int), st));
-	if (!c->adj) PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)(std::max<int64_t>(E, 1) + 4) * sizeof(int32_t)));
-	// +4 entries: k_pull_sparse reads the in-adjacency as aligned 16-byte groups
-	PGQ_HIP_TRY(hipMalloc(&c->radj, (size_t)(std::max<int64_t>(E, 1) + 4) * sizeof(int32_t)));
-	PGQ_HIP_TRY(hipMalloc(&c->rslot, (size_t)std::max<int64_t>(E, 1) * sizeof(int64_t)));
-	PGQ_HIP_TRY(hipMalloc(&c->roff, (size_t)(V + 1) * sizeof(int64_t)));
-	if (E > 0) {
-		if (d_adj64) hipLaunchKernelGGL(k_narrow_adj, dim3(grid_for(E)), dim3(256), 0, st, d_adj64, c->adj, d_cnt, E, V, d_flag);
-		else hipLaunchKernelGGL(k_hist_adj32, dim3(grid_for(E)), dim3(256), 0, st, c->adj, d_cnt, E);
+	// +4 entries: k_meet3 / k_pull_sparse read the adjacencies as aligned 16-byte groups
+	if (!c->adj) PGQ_TRY(dev_alloc_as(&c->adj, En + 4));
+	PGQ_TRY(dev_alloc_as(&c->radj, En + 4));
+	PGQ_TRY(dev_alloc_as(&c->roff, (size_t)V + 1));
+	if (E > 0 && d_adj64) hipLaunchKernelGGL(k_narrow_adj, dim3(grid_for(E)), dim3(256), 0, st, d_adj64, c->adj, E, V, d_flag);
+	{ // the kernels below index by offsets and adjacency values: stop here if either is malformed
+		int h_bad = 0;
+		PGQ_HIP_TRY(hipMemcpyAsync(&h_bad, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		if (h_bad) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: offsets not monotone or adjacency out of [0,V)");
 	}
-	tr.mark("allocs + histogram");
-	// in-degree -> roff by exclusive scan
-	int64_t *d_deg64 = nullptr;
-	PGQ_HIP_TRY(hipMalloc(&d_deg64, (size_t)(V + 1) * sizeof(int64_t)));
-	hipLaunchKernelGGL(k_widen, dim3((unsigned)((V + 1 + 255) / 256)), dim3(256), 0, st, d_cnt, d_deg64, V, V + 1);
-	void *d_tmp = nullptr;
-	size_t tmp_bytes = 0;
-	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_deg64, c->roff, (int)(V + 1), st));
-	PGQ_HIP_TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
-	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_deg64, c->roff, (int)(V + 1), st));
-	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(V + 1) * sizeof(int), st));
+	tr.mark("allocs + narrow");
 	if (E > 0) {
-		hipLaunchKernelGGL(k_scatter_reverse, dim3(grid_for(E)), dim3(256), 0, st, c->off, c->adj, c->roff, d_cnt,
-		                   c->radj, c->rslot, E, V);
+		PGQ_TRY(dev_alloc_as(&d_slot_src, En));
+		PGQ_TRY(dev_alloc_as(&d_skey, En));
+		hipLaunchKernelGGL(k_slot_sources, dim3(grid_for(V, 256, 256 * 8)), dim3(256), 0, st, V, c->off, d_slot_src);
+		int end_bit = 1;
+		while ((1LL << end_bit) < V) end_bit++;
+		size_t sb = 0;
+		const u32 *keys = reinterpret_cast<const u32 *>(c->adj); // range-checked: every key is in [0,V)
+		u32 *vals = reinterpret_cast<u32 *>(c->radj);
+		PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, keys, d_skey, d_slot_src, vals, (int)E, 0, end_bit, st));
+		PGQ_TRY(dev_alloc(&d_tmp, sb + 16));
+		PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, sb, keys, d_skey, d_slot_src, vals, (int)E, 0, end_bit, st));
+		hipLaunchKernelGGL(k_row_bounds, dim3((unsigned)((E + 1 + 255) / 256)), dim3(256), 0, st, d_skey, E, V, c->roff);
+	} else {
+		PGQ_HIP_TRY(hipMemsetAsync(c->roff, 0, (size_t)(V + 1) * sizeof(int64_t), st));
 	}
 	if (c->w && E > 0) {
 		if (c->w_type == PGQ_W_INT64)
@@ -495,94 +694,95 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 			hipLaunchKernelGGL(k_any_negative<double>, dim3(grid_for(E)), dim3(256), 0, st, (const double *)c->w, E,
 			                   d_flag + 1);
 	}
-	tr.mark("scan + reverse scatter");
-	// degrees back to the host for the hub work lists
-	std::vector<int64_t> h_roff((size_t)V + 1), h_off((size_t)V + 1);
-	int h_flag[2] = { 0, 0 };
-	PGQ_TRY(staged_download(h_roff.data(), c->roff, (size_t)(V + 1) * sizeof(int64_t), st));
-	PGQ_TRY(staged_download(h_off.data(), c->off, (size_t)(V + 1) * sizeof(int64_t), st));
-	PGQ_HIP_TRY(hipMemcpyAsync(h_flag, d_flag, sizeof(h_flag), hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
-	(void)hipFree(d_flag);
-	(void)hipFree(d_cnt);
-	(void)hipFree(d_deg64);
-	(void)hipFree(d_tmp);
-	if (h_flag[0]) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: offsets not monotone or adjacency out of [0,V)");
-	c->has_negative_weight = h_flag[1] != 0;
-
-	tr.mark("degrees to host");
+	tr.mark("reverse CSR (sort by destination)");
+	// hubs, degree statistics and the work partition (device); only the counts and the hub rows come back
 	const int64_t chunk = std::max(64, options().hub_chunk);
 	c->hub_threshold = chunk;
-	std::vector<HubItem> items;
-	std::vector<int32_t> hubs;
-	for (int64_t v = 0; v < V; v++) {
-		int64_t indeg = h_roff[v + 1] - h_roff[v];
-		int64_t outdeg = h_off[v + 1] - h_off[v];
-		c->max_in_degree = std::max(c->max_in_degree, indeg);
-		c->max_out_degree = std::max(c->max_out_degree, outdeg);
-		c->two_hop_mean += (double)indeg * (double)outdeg / (double)std::max<int64_t>(V, 1);
-		if (indeg > chunk) {
-			hubs.push_back((int32_t)v);
-			// slices of a quarter chunk: a wavefront walks its slice 64 entries at a time (latency-bound), so more,
-			// shorter slices keep more of a hub's in-edges in flight
-			const int64_t slice = std::max<int64_t>(64, chunk / 4);
-			for (int64_t b = h_roff[v]; b < h_roff[v + 1]; b += slice)
-				items.push_back({ (int32_t)v, 0, b, std::min(b + slice, h_roff[v + 1]) });
+	const int hub_cap = (int)(E / chunk + 1); // a hub has more than `chunk` in-edges
+	const int64_t n_runs = (V + kPartRun - 1) / kPartRun;
+	UploadStats *d_us = nullptr;
+	HubRow *d_hub_rows = nullptr;
+	int *d_run = nullptr; // [0,n_runs] counts, [n_runs+1, 2 n_runs+1] bases
+	void *d_scan = nullptr;
+	struct Temps2 {
+		UploadStats *&a;
+		HubRow *&b;
+		int *&c;
+		void *&d;
+		~Temps2() {
+			dev_free(a);
+			dev_free(b);
+			dev_free(c);
+			dev_free(d);
 		}
+	} temps2 { d_us, d_hub_rows, d_run, d_scan };
+	PGQ_TRY(dev_alloc_as(&d_us, 1));
+	PGQ_TRY(dev_alloc_as(&d_hub_rows, (size_t)hub_cap));
+	PGQ_TRY(dev_alloc_as(&d_run, (size_t)(2 * n_runs + 2)));
+	PGQ_TRY(dev_alloc_as(&c->pull_parts, (size_t)std::max<int64_t>(2 * V, 2)));
+	PGQ_TRY(dev_alloc((void **)&c->rown, En + 8)); // read as aligned 4-byte groups
+	PGQ_HIP_TRY(hipMemsetAsync(d_us, 0, sizeof(UploadStats), st));
+	PGQ_HIP_TRY(hipMemsetAsync(c->rown, 0, En + 8, st));
+	if (V < (1ll << 28)) { // in-slots of hubs keep 0 (never read); padded for the 4 x 64-entry trips of k_pull_lanes
+		PGQ_TRY(dev_alloc_as(&c->rpk, En + 2048));
+		PGQ_HIP_TRY(hipMemsetAsync(c->rpk, 0, (En + 2048) * sizeof(uint32_t), st));
 	}
-	c->n_pull_hub_items = (int64_t)items.size();
-	c->n_pull_hub_vertices = (int64_t)hubs.size();
-	if (!items.empty()) {
-		PGQ_HIP_TRY(hipMalloc(&c->pull_hubs, items.size() * sizeof(HubItem)));
-		PGQ_HIP_TRY(hipMemcpy(c->pull_hubs, items.data(), items.size() * sizeof(HubItem), hipMemcpyHostToDevice));
-		PGQ_HIP_TRY(hipMalloc(&c->pull_hub_vertices, hubs.size() * sizeof(int32_t)));
-		PGQ_HIP_TRY(hipMemcpy(c->pull_hub_vertices, hubs.data(), hubs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	if (V > 0) {
+		const int64_t wmax = std::max(64, options().part_weight);
+		hipLaunchKernelGGL(k_degree_stats, dim3(grid_for(V, 256, 1024)), dim3(256), 0, st, V, c->off, c->roff, chunk, hub_cap,
+		                   d_us, d_hub_rows);
+		hipLaunchKernelGGL(k_make_parts<false>, dim3((unsigned)((n_runs + 63) / 64)), dim3(64), 0, st, V, c->roff, chunk,
+		                   wmax, d_run, (const int *)nullptr, (int32_t *)nullptr, d_us);
+		size_t sb = 0;
+		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, d_run, d_run + n_runs + 1, (int)n_runs, st));
+		PGQ_TRY(dev_alloc(&d_scan, sb + 16));
+		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, d_run, d_run + n_runs + 1, (int)n_runs, st));
+		hipLaunchKernelGGL(k_make_parts<true>, dim3((unsigned)((n_runs + 63) / 64)), dim3(64), 0, st, V, c->roff, chunk, wmax,
+		                   d_run, d_run + n_runs + 1, c->pull_parts, d_us);
 	}
-	// Work partition for the bottom-up kernels: contiguous vertex ranges [begin,end) that never contain a hub,
-	// hold at most 16 vertices (LDS accumulator rows of k_pull_sparse) and at most `part_weight` of
-	// (in-degree + 8 per vertex).  Dealt round-robin to the waves: many small equal parts balance skewed graphs.
-	{
-		const double wmax = (double)std::max(64, options().part_weight);
-		std::vector<int32_t> parts;
-		int64_t begin = 0;
-		double acc = 0;
-		auto close = [&](int64_t end) {
-			if (end > begin) {
-				parts.push_back((int32_t)begin);
-				parts.push_back((int32_t)end);
-			}
-			begin = end;
-			acc = 0;
-		};
-		for (int64_t v = 0; v < V; v++) {
-			int64_t d = h_roff[v + 1] - h_roff[v];
-			if (d > chunk) { // hub: handled by k_pull_hub, never inside a part
-				close(v);
-				begin = v + 1;
-				continue;
-			}
-			double wv = (double)d + 8.0;
-			if (v > begin && (acc + wv > wmax || v - begin >= 16)) close(v);
-			acc += wv;
+	UploadStats us;
+	int h_flag[2] = { 0, 0 };
+	PGQ_HIP_TRY(hipMemcpyAsync(&us, d_us, sizeof(us), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipMemcpyAsync(h_flag, d_flag, sizeof(h_flag), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	if (h_flag[0]) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: offsets not monotone or adjacency out of [0,V)");
+	c->has_negative_weight = h_flag[1] != 0;
+	c->max_in_degree = us.max_in;
+	c->max_out_degree = us.max_out;
+	c->two_hop_mean = (double)us.two_hop_sum / (double)std::max<int64_t>(V, 1);
+	c->n_pull_parts = us.n_parts;
+	if (us.n_parts > 0)
+		hipLaunchKernelGGL(k_fill_rown, dim3(256 * 8), dim3(256), 0, st, c->roff, c->pull_parts, c->n_pull_parts, c->radj,
+		                   c->rown, c->rpk);
+	tr.mark("degree statistics, parts, owner bytes");
+	int64_t n_items = 0;
+	if (us.n_hubs > 0) { // few rows: slice them on the host, in vertex order
+		std::vector<HubRow> rows((size_t)std::min(us.n_hubs, hub_cap));
+		PGQ_HIP_TRY(hipMemcpyAsync(rows.data(), d_hub_rows, rows.size() * sizeof(HubRow), hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		std::sort(rows.begin(), rows.end(), [](const HubRow &a, const HubRow &b) { return a.vertex < b.vertex; });
+		std::vector<HubItem> items;
+		std::vector<int32_t> hubs;
+		// slices of a quarter chunk: a wavefront walks its slice 64 entries at a time (latency-bound), so more, shorter
+		// slices keep more of a hub's in-edges in flight
+		const int64_t slice = std::max<int64_t>(64, chunk / 4);
+		for (const HubRow &h : rows) {
+			hubs.push_back((int32_t)h.vertex);
+			for (int64_t b = h.begin; b < h.end; b += slice) items.push_back({ (int32_t)h.vertex, 0, b, std::min(b + slice, h.end) });
 		}
-		close(V);
-		c->n_pull_parts = (int)(parts.size() / 2);
-		PGQ_HIP_TRY(hipMalloc(&c->rown, (size_t)std::max<int64_t>(E, 1) + 8)); // read as aligned 4-byte groups
-		PGQ_HIP_TRY(hipMemset(c->rown, 0, (size_t)std::max<int64_t>(E, 1) + 8));
-		if (V < (1ll << 28)) { // in-slots of hubs keep 0 (never read); padded for the 4 x 64-entry trips of k_pull_lanes
-			PGQ_HIP_TRY(hipMalloc(&c->rpk, (size_t)(std::max<int64_t>(E, 1) + 2048) * sizeof(uint32_t)));
-			PGQ_HIP_TRY(hipMemset(c->rpk, 0, (size_t)(std::max<int64_t>(E, 1) + 2048) * sizeof(uint32_t)));
-		}
-		if (!parts.empty()) {
-			PGQ_HIP_TRY(hipMalloc(&c->pull_parts, parts.size() * sizeof(int32_t)));
-			PGQ_HIP_TRY(hipMemcpy(c->pull_parts, parts.data(), parts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-			hipLaunchKernelGGL(k_fill_rown, dim3(256 * 8), dim3(256), 0, 0, c->roff, c->pull_parts, c->n_pull_parts, c->radj, c->rown, c->rpk);
-			PGQ_HIP_TRY(hipDeviceSynchronize());
-		}
+		c->n_pull_hub_items = (int64_t)items.size();
+		c->n_pull_hub_vertices = (int64_t)hubs.size();
+		n_items = (int64_t)items.size();
+		PGQ_TRY(dev_alloc((void **)&c->pull_hubs, items.size() * sizeof(HubItem)));
+		PGQ_HIP_TRY(hipMemcpyAsync(c->pull_hubs, items.data(), items.size() * sizeof(HubItem), hipMemcpyHostToDevice, st));
+		PGQ_TRY(dev_alloc((void **)&c->pull_hub_vertices, hubs.size() * sizeof(int32_t)));
+		PGQ_HIP_TRY(hipMemcpyAsync(c->pull_hub_vertices, hubs.data(), hubs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st)); // the host vectors go out of scope
 	}
-	tr.mark("hubs, parts, owner bytes");
-	c->bytes = (V + 1) * 16 + E * (4 + 4 + 8 + 1 + (c->rpk ? 4 : 0)) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
-	           (int64_t)items.size() * (int64_t)sizeof(HubItem);
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	tr.mark("hub slices");
+	c->bytes = (V + 1) * 16 + 8 * V + E * (4 + 4 + 1 + (c->rpk ? 4 : 0)) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
+	           n_items * (int64_t)sizeof(HubItem);
 	return PGQ_OK;
 }
 
@@ -591,19 +791,18 @@ static void destroy_csr(pgq_csr *c) {
 	if (!c->is_replica)
 		for (pgq_csr *r : c->replicas)
 			if (r && r != c) destroy_csr(r);
-	(void)hipFree(c->off);
-	(void)hipFree(c->adj);
-	(void)hipFree(c->edge_ids);
-	(void)hipFree(c->w);
-	(void)hipFree(c->roff);
-	(void)hipFree(c->radj);
-	(void)hipFree(c->rslot);
-	(void)hipFree(c->pull_hubs);
-	(void)hipFree(c->pull_hub_vertices);
-	(void)hipFree(c->pull_parts);
-	(void)hipFree(c->rown);
-	(void)hipFree(c->rpk);
-	(void)hipFree(c->pagerank);
+	dev_free(c->off);
+	dev_free(c->adj);
+	dev_free(c->edge_ids);
+	dev_free(c->w);
+	dev_free(c->roff);
+	dev_free(c->radj);
+	dev_free(c->pull_hubs);
+	dev_free(c->pull_hub_vertices);
+	dev_free(c->pull_parts);
+	dev_free(c->rown);
+	dev_free(c->rpk);
+	dev_free(c->pagerank);
 	delete c;
 }
 
@@ -631,33 +830,38 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 	int64_t *d_adj64 = nullptr;
 	auto body = [&]() -> int {
 		PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-		PGQ_HIP_TRY(hipMalloc(&c->off, (size_t)(V + 1) * sizeof(int64_t)));
+		PGQ_TRY(dev_alloc((void **)&c->off, (size_t)(V + 1) * sizeof(int64_t)));
 		PGQ_HIP_TRY(hipMemcpyAsync(c->off, offsets, (size_t)(V + 1) * sizeof(int64_t), kind, st));
 		if (E > 0 && on_device) {
 			d_adj64 = const_cast<int64_t *>(adj);
 			if (edge_ids) {
-				PGQ_HIP_TRY(hipMalloc(&c->edge_ids, (size_t)E * sizeof(int64_t)));
+				PGQ_TRY(dev_alloc((void **)&c->edge_ids, (size_t)E * sizeof(int64_t)));
 				PGQ_HIP_TRY(hipMemcpyAsync(c->edge_ids, edge_ids, (size_t)E * sizeof(int64_t), kind, st));
 			}
 			if (w_type != PGQ_W_NONE) {
-				PGQ_HIP_TRY(hipMalloc(&c->w, (size_t)E * 8));
+				PGQ_TRY(dev_alloc((void **)&c->w, (size_t)E * 8));
 				PGQ_HIP_TRY(hipMemcpyAsync(c->w, w, (size_t)E * 8, kind, st));
 			}
 		} else if (E > 0) {
 			// pageable host arrays: staged through pinned rings by several threads, adjacency narrowed on the way
 			std::atomic<int> oob { 0 };
 			UploadTrace tr;
-			PGQ_HIP_TRY(hipMalloc(&c->adj, (size_t)(E + 4) * sizeof(int32_t))); // +4: k_meet3 reads aligned 16-byte groups
-			PGQ_TRY(staged_upload(c->adj, adj, (size_t)E, 8, 1, V, &oob));
-			tr.mark("adjacency staged+narrowed");
-			if (oob.load()) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: adjacency out of [0,V)");
+			if (options().upload_narrow_host) { // half the PCIe bytes, but the staging threads do the narrowing
+				PGQ_TRY(dev_alloc((void **)&c->adj, (size_t)(E + 4) * sizeof(int32_t))); // +4: k_meet3 reads aligned 16-byte groups
+				PGQ_TRY(staged_upload(c->adj, adj, (size_t)E, 8, 1, V, &oob));
+				if (oob.load()) return fail(PGQ_ERR_INVALID_ARG, "CSR is malformed: adjacency out of [0,V)");
+			} else { // raw int64 over PCIe, narrowed and range-checked by k_narrow_adj
+				PGQ_TRY(dev_alloc((void **)&d_adj64, (size_t)E * sizeof(int64_t)));
+				PGQ_TRY(staged_upload(d_adj64, adj, (size_t)E, 8, 0, V, &oob));
+			}
+			tr.mark("adjacency staged");
 			if (edge_ids) {
-				PGQ_HIP_TRY(hipMalloc(&c->edge_ids, (size_t)E * sizeof(int64_t)));
+				PGQ_TRY(dev_alloc((void **)&c->edge_ids, (size_t)E * sizeof(int64_t)));
 				PGQ_TRY(staged_upload(c->edge_ids, edge_ids, (size_t)E, 8, 0, V, &oob));
 				tr.mark("edge ids staged");
 			}
 			if (w_type != PGQ_W_NONE) {
-				PGQ_HIP_TRY(hipMalloc(&c->w, (size_t)E * 8));
+				PGQ_TRY(dev_alloc((void **)&c->w, (size_t)E * 8));
 				PGQ_TRY(staged_upload(c->w, w, (size_t)E, 8, 0, V, &oob));
 			}
 		}
@@ -668,7 +872,7 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 		(void)hipStreamSynchronize(st);
 		(void)hipStreamDestroy(st);
 	}
-	if (!on_device && d_adj64) (void)hipFree(d_adj64);
+	if (!on_device && d_adj64) dev_free(d_adj64);
 	if (rc != PGQ_OK) {
 		destroy_csr(c);
 		return rc;
@@ -741,59 +945,56 @@ int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const 
 	c->w_type = w_type;
 	hipStream_t st = nullptr;
 	u32 *d_key = nullptr, *d_idx = nullptr, *d_skey = nullptr, *d_order = nullptr;
-	int *d_deg = nullptr, *d_bad = nullptr;
-	int64_t *d_deg64 = nullptr, *d_adj64 = nullptr;
+	int *d_bad = nullptr;
 	void *d_tmp = nullptr;
 	auto body = [&]() -> int {
 		PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 		const size_t En = (size_t)std::max<int64_t>(E, 1);
-		PGQ_HIP_TRY(hipMalloc(&d_key, En * 4));
-		PGQ_HIP_TRY(hipMalloc(&d_idx, En * 4));
-		PGQ_HIP_TRY(hipMalloc(&d_skey, En * 4));
-		PGQ_HIP_TRY(hipMalloc(&d_order, En * 4));
-		PGQ_HIP_TRY(hipMalloc(&d_deg, (size_t)(V + 1) * 4));
-		PGQ_HIP_TRY(hipMalloc(&d_bad, 4));
-		PGQ_HIP_TRY(hipMalloc(&d_deg64, (size_t)(V + 1) * 8));
-		PGQ_HIP_TRY(hipMalloc(&d_adj64, En * 8));
-		PGQ_HIP_TRY(hipMalloc(&c->off, (size_t)(V + 1) * 8));
-		PGQ_HIP_TRY(hipMalloc(&c->edge_ids, En * 8));
-		if (w_type != PGQ_W_NONE) PGQ_HIP_TRY(hipMalloc(&c->w, En * 8));
-		PGQ_HIP_TRY(hipMemsetAsync(d_deg, 0, (size_t)(V + 1) * 4, st));
+		PGQ_TRY(dev_alloc_as(&d_key, En));
+		PGQ_TRY(dev_alloc_as(&d_idx, En));
+		PGQ_TRY(dev_alloc_as(&d_skey, En));
+		PGQ_TRY(dev_alloc_as(&d_order, En));
+		PGQ_TRY(dev_alloc_as(&d_bad, 1));
+		PGQ_TRY(dev_alloc_as(&c->off, (size_t)V + 1));
+		PGQ_TRY(dev_alloc_as(&c->adj, En + 4));
+		PGQ_TRY(dev_alloc_as(&c->edge_ids, En));
+		if (w_type != PGQ_W_NONE) PGQ_TRY(dev_alloc(&c->w, En * 8));
 		PGQ_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
-		if (E > 0)
-			hipLaunchKernelGGL(k_check_rows, dim3(grid_for(E)), dim3(256), 0, st, d_src, d_dst, E, V, d_key, d_idx, d_deg, d_bad);
-		// out-degree -> offsets (CsrInitializeEdge's prefix sum, csr_creation.cpp:57-59)
-		hipLaunchKernelGGL(k_widen, dim3((unsigned)((V + 1 + 255) / 256)), dim3(256), 0, st, d_deg, d_deg64, V, V + 1);
-		size_t tb = 0;
-		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_deg64, c->off, (int)(V + 1), st));
-		size_t sb = 0;
-		int end_bit = 1;
-		while ((1LL << end_bit) < V) end_bit++;
-		if (E > 0)
-			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, d_key, d_skey, d_idx, d_order, (int)E, 0, end_bit, st));
-		PGQ_HIP_TRY(hipMalloc(&d_tmp, std::max(tb, sb) + 16));
-		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_deg64, c->off, (int)(V + 1), st));
 		if (E > 0) {
+			hipLaunchKernelGGL(k_check_rows, dim3(grid_for(E)), dim3(256), 0, st, d_src, d_dst, E, V, d_key, d_idx, d_bad);
+			int bad = 0;
+			PGQ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			if (bad) return fail(PGQ_ERR_INVALID_ARG, "edge endpoint out of range [0,V)");
+			size_t sb = 0;
+			int end_bit = 1;
+			while ((1LL << end_bit) < V) end_bit++;
+			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, d_key, d_skey, d_idx, d_order, (int)E, 0, end_bit, st));
+			PGQ_TRY(dev_alloc(&d_tmp, sb + 16));
 			// stable LSD radix sort by source == arrival order per vertex of the single-threaded reference
-			// (pos = ++v[src+1], csr_creation.cpp:132-138)
+			// (pos = ++v[src+1], csr_creation.cpp:132-138); the offsets (CsrInitializeEdge's prefix sum,
+			// csr_creation.cpp:57-59) are the row boundaries of the sorted keys
 			PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, sb, d_key, d_skey, d_idx, d_order, (int)E, 0, end_bit, st));
+			hipLaunchKernelGGL(k_row_bounds, dim3((unsigned)((E + 1 + 255) / 256)), dim3(256), 0, st, d_skey, E, V, c->off);
 			hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(E)), dim3(256), 0, st, d_order, E, d_dst, d_edge_id,
-			                   (const int64_t *)d_w, d_adj64, c->edge_ids, (int64_t *)c->w);
+			                   (const int64_t *)d_w, c->adj, c->edge_ids, (int64_t *)c->w);
+		} else {
+			PGQ_HIP_TRY(hipMemsetAsync(c->off, 0, (size_t)(V + 1) * sizeof(int64_t), st));
 		}
-		int bad = 0;
-		PGQ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+		// the temporaries go back to the block cache before finish_upload asks for its own (same sizes)
 		PGQ_HIP_TRY(hipStreamSynchronize(st));
-		if (bad) return fail(PGQ_ERR_INVALID_ARG, "edge endpoint out of range [0,V)");
-		return finish_upload(c, d_adj64, st);
+		for (void **p : { (void **)&d_key, (void **)&d_idx, (void **)&d_skey, (void **)&d_order, &d_tmp }) {
+			dev_free(*p);
+			*p = nullptr;
+		}
+		return finish_upload(c, nullptr, st);
 	};
 	int rc = body();
 	if (st) {
 		(void)hipStreamSynchronize(st);
 		(void)hipStreamDestroy(st);
 	}
-	for (void *p : { (void *)d_key, (void *)d_idx, (void *)d_skey, (void *)d_order, (void *)d_deg, (void *)d_bad,
-	                 (void *)d_deg64, (void *)d_adj64, d_tmp })
-		(void)hipFree(p);
+	for (void *p : { (void *)d_key, (void *)d_idx, (void *)d_skey, (void *)d_order, (void *)d_bad, d_tmp }) dev_free(p);
 	if (rc != PGQ_OK) {
 		destroy_csr(c);
 		return rc;
@@ -805,18 +1006,19 @@ int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const 
 int pgq_csr_download(const pgq_csr_t *c, int64_t *offsets, int64_t *adj, int64_t *edge_ids, void *w) {
 	PGQ_TRY(ensure_init());
 	if (!c) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
-	if (offsets) PGQ_HIP_TRY(hipMemcpy(offsets, c->off, (size_t)(c->V + 1) * 8, hipMemcpyDeviceToHost));
+	hipStream_t st = nullptr; // the null stream: downloads are rare (tests, CSR spill) and may serialise
+	if (offsets) PGQ_TRY(staged_download(offsets, c->off, (size_t)(c->V + 1) * 8, st));
 	if (adj && c->E > 0) {
 		std::vector<int32_t> a32((size_t)c->E);
-		PGQ_HIP_TRY(hipMemcpy(a32.data(), c->adj, (size_t)c->E * 4, hipMemcpyDeviceToHost));
+		PGQ_TRY(staged_download(a32.data(), c->adj, (size_t)c->E * 4, st));
 		for (int64_t i = 0; i < c->E; i++) adj[i] = a32[i];
 	}
 	if (edge_ids && c->E > 0) {
-		if (c->edge_ids) PGQ_HIP_TRY(hipMemcpy(edge_ids, c->edge_ids, (size_t)c->E * 8, hipMemcpyDeviceToHost));
+		if (c->edge_ids) PGQ_TRY(staged_download(edge_ids, c->edge_ids, (size_t)c->E * 8, st));
 		else
 			for (int64_t i = 0; i < c->E; i++) edge_ids[i] = i;
 	}
-	if (w && c->w && c->E > 0) PGQ_HIP_TRY(hipMemcpy(w, c->w, (size_t)c->E * 8, hipMemcpyDeviceToHost));
+	if (w && c->w && c->E > 0) PGQ_TRY(staged_download(w, c->w, (size_t)c->E * 8, st));
 	return PGQ_OK;
 }
 
@@ -880,7 +1082,7 @@ static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
 		*dst = nullptr;
 		if (!src || bytes == 0) return PGQ_OK;
 		PGQ_HIP_TRY(hipSetDevice(dev));
-		PGQ_HIP_TRY(hipMalloc(dst, bytes));
+		PGQ_TRY(dev_alloc(dst, bytes));
 		PGQ_HIP_TRY(hipMemcpyPeer(*dst, dev, src, c->device, bytes));
 		return PGQ_OK;
 	};
@@ -890,7 +1092,6 @@ static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
 	PGQ_TRY(copy((void **)&r->w, c->w, En * 8));
 	PGQ_TRY(copy((void **)&r->roff, c->roff, V1 * 8));
 	PGQ_TRY(copy((void **)&r->radj, c->radj, (En + 4) * 4));
-	PGQ_TRY(copy((void **)&r->rslot, c->rslot, En * 8));
 	PGQ_TRY(copy((void **)&r->pull_hubs, c->pull_hubs, (size_t)c->n_pull_hub_items * sizeof(HubItem)));
 	PGQ_TRY(copy((void **)&r->pull_hub_vertices, c->pull_hub_vertices, (size_t)c->n_pull_hub_vertices * 4));
 	PGQ_TRY(copy((void **)&r->pull_parts, c->pull_parts, (size_t)c->n_pull_parts * 2 * 4));
@@ -955,6 +1156,7 @@ std::vector<OptRef> option_table() {
 		{ "relax_small_limit", &o.relax_small_limit, nullptr },
 		{ "chain", &o.chain, nullptr },
 		{ "chain_cap", &o.chain_cap, nullptr },
+		{ "alloc_cache_mb", &o.alloc_cache_mb, nullptr },
 		{ "trace", &o.trace, nullptr },
 		{ "probe", &o.probe, nullptr },
 		{ "defer", &o.defer, nullptr },
@@ -978,6 +1180,7 @@ std::vector<OptRef> option_table() {
 		{ "meet_bias", nullptr, &o.meet_bias },
 		{ "lanes_unroll", &o.lanes_unroll, nullptr },
 		{ "upload_threads", &o.upload_threads, nullptr },
+		{ "upload_narrow_host", &o.upload_narrow_host, nullptr },
 	};
 }
 } // namespace
@@ -1024,8 +1227,8 @@ int pgq_measure_copy_bandwidth(int64_t bytes, int iters, double *out_gbps) {
 	PGQ_TRY(ensure_init());
 	if (bytes < 1024 || iters < 1 || !out_gbps) return fail(PGQ_ERR_INVALID_ARG, "bad bandwidth probe arguments");
 	void *a = nullptr, *b = nullptr;
-	PGQ_HIP_TRY(hipMalloc(&a, (size_t)bytes));
-	PGQ_HIP_TRY(hipMalloc(&b, (size_t)bytes));
+	PGQ_TRY(dev_alloc((void **)&a, (size_t)bytes));
+	PGQ_TRY(dev_alloc((void **)&b, (size_t)bytes));
 	PGQ_HIP_TRY(hipMemset(a, 1, (size_t)bytes));
 	int64_t n = bytes / 16;
 	hipEvent_t e0, e1;

@@ -27,6 +27,32 @@ up3 = time.perf_counter() - t0
 dev3.close()
 rng = np.random.default_rng(7)
 out = {"csr_upload_first_ms": up * 1e3, "csr_upload_host_arrays_ms": up2 * 1e3, "csr_upload_no_edge_ids_ms": up3 * 1e3}
+pgq.set_option("upload_narrow_host", 0)  # raw int64 adjacency over PCIe, narrowed on the device
+t0 = time.perf_counter()
+dev4 = pgq.DeviceCSR(V, off, adj, eid)
+out["csr_upload_host_arrays_raw_int64_ms"] = (time.perf_counter() - t0) * 1e3
+dev4.close()
+pgq.set_option("upload_narrow_host", 1)
+try:  # CSR / edge rows already in HBM (torch only holds the buffers)
+    import torch
+    t_off, t_adj, t_eid = (torch.from_numpy(x).cuda() for x in (off, adj, eid))
+    ts_, td_ = torch.from_numpy(s).cuda(), torch.from_numpy(d).cuda()
+    for key, make in (("csr_upload_device_arrays_ms",
+                       lambda: pgq.DeviceCSR.from_device_ptrs(V, t_off.data_ptr(), t_adj.data_ptr(), t_eid.data_ptr(), 0, 0)),
+                      ("csr_build_device_rows_ms",
+                       lambda: pgq.DeviceCSR.build_from_device_rows(V, len(s), ts_.data_ptr(), td_.data_ptr()))):
+        best = 1e9
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c = make()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+            c.close()
+        out[key] = best * 1e3
+    del t_off, t_adj, t_eid, ts_, td_
+except ImportError:
+    pass
 for n in (1, 64, 2048):
     ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
     for fn in ("iterativelength", "shortestpath"):

@@ -76,6 +76,8 @@ struct Options {
 	int meet_cap_paths = 1 << 12; // the same for shortestpath rows (their walks have no early exit; longer ones go to k_meet4)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
+	int meet4_lds_kb = 150;    // largest vertex bit map k_meet4 keeps in LDS (tests lower it to force the global-memory maps)
+	int meet4_global_mb = 256; // vertex bit maps of k_meet4 in global memory when V does not fit in LDS: total budget (0: off)
 	double meet_bias = 1.0; // pre-pass runs while its estimated bytes <= meet_bias x the MS-BFS estimate
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
 	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)

@@ -296,28 +296,45 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
 // The 16 wavefronts split the vertices of a one-hop list round-robin and stream their adjacency segments 16 bytes per
 // lane per request, four requests in flight each.  Rows whose two-hop walks exceed `cap` entries stay open.
 
-template <bool PATHS>
+template <bool PATHS, bool GM>
 __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                 int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                 const u32 *__restrict__ didx, int64_t *__restrict__ out_rows,
                                                 MeetPath *__restrict__ rec_rows, int64_t cap, int bm_words,
-                                                MeetCounters *__restrict__ mc) {
-	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex
+                                                MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
+	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
+	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
 	__shared__ int s_flag;
 	__shared__ unsigned long long s_work[2];
 	__shared__ unsigned long long s_best;
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 	unsigned long long entries = 0;
 	u32 vertices = 0;
-	auto bit = [&](u32 x) { return (s_map[x >> 5] >> (x & 31)) & 1u; };
+	// GM: bits are set by L2 atomics, so they are read with device-scope atomic loads (a plain load may hit a stale L1 line)
+	auto bit = [&](u32 x) {
+		const u32 w = GM ? __hip_atomic_load(&gmap[x >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_map[x >> 5];
+		return (w >> (x & 31)) & 1u;
+	};
+	auto mark = [&](u32 x) {
+		if constexpr (GM) atomicOr(&gmap[x >> 5], 1u << (x & 31));
+		else atomicOr(&s_map[x >> 5], 1u << (x & 31));
+	};
+	auto clear_map = [&]() {
+		if constexpr (GM) {
+			uint4 *m4 = reinterpret_cast<uint4 *>(gmap); // bm_words is a multiple of 4, slices are 16-byte aligned
+			for (int k = tid; k < bm_words / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
+		} else {
+			for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
+		}
+	};
 	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
 		__syncthreads(); // the previous row's flags and map are no longer read
 		const int64_t s = src[i], d = dst[i]; // rows left open by k_meet3: ids in range, src != dst, both have edges
 		const u32 row = didx[i];
 		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
 		const int degS = se - so, degD = de - di;
-		for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
+		clear_map();
 		if (tid == 0) {
 			s_flag = 0;
 			s_work[0] = s_work[1] = 0;
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 		unsigned long long wf = 0, wb = 0;
 		for (int p = tid; p < degS; p += 1024) {
 			const u32 v = (u32)adj[so + p];
-			atomicOr(&s_map[v >> 5], 1u << (v & 31));
+			mark(v);
 			wf += (unsigned long long)(off[v + 1] - off[v]);
 		}
 		for (int p = tid; p < degD; p += 1024) {
@@ -364,12 +381,12 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 		// PATHS: first inner vertex = smallest in-neighbour of `v` that src points at.  The map is rebuilt as N_out(src).
 		auto first_inner_vertex = [&](u32 v) -> u32 {
 			__syncthreads();
-			for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
+			clear_map();
 			if (tid == 0) s_best = ~0ull;
 			__syncthreads();
 			for (int p = tid; p < degS; p += 1024) {
 				const u32 x = (u32)adj[so + p];
-				atomicOr(&s_map[x >> 5], 1u << (x & 31));
+				mark(x);
 			}
 			__syncthreads();
 			u32 m = kMeetEmpty;
@@ -398,7 +415,7 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 		// B += N_out(N_out(src))
 		{
 			const unsigned long long e2 = meet_walk(adj + so, degS, wib, 16, off, adj,
-			                                        [&](u32 x, u32) { atomicOr(&s_map[x >> 5], 1u << (x & 31)); },
+			                                        [&](u32 x, u32) { mark(x); },
 			                                        []() { return false; });
 			if (lane == 0) entries += e2;
 		}
@@ -646,27 +663,40 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		entries += h.m.entries[k];
 		vertices += h.m.vertices[k];
 	}
-	// what is left (distance >= 4, or over k_meet3's caps): the LDS bit-map kernel, when the vertex bit map fits
-	const int bm_words = (int)((c->V + 31) / 32);
-	if (h.count > 0 && options().meet4 && (size_t)bm_words * 4 + 512 <= 150 * 1024) {
+	// what is left (distance >= 4, or over k_meet3's caps): the bit-map kernel.  The vertex bit map sits in LDS when it
+	// fits (V <= ~1.2 M); above that every workgroup gets a slice of a global buffer (L2-resident: 0.5 MB at V = 4 M).
+	const int bm_words = (int)((c->V + 127) / 128) * 4;
+	const bool lds_map = (size_t)bm_words * 4 + 512 <= (size_t)std::min(150, std::max(0, options().meet4_lds_kb)) * 1024;
+	const size_t gm_budget = (size_t)std::max(0, options().meet4_global_mb) << 20;
+	if (h.count > 0 && options().meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget)) {
 		static std::atomic<int> attr_set { 0 };
 		if (!attr_set.load()) {
-			(void)hipFuncSetAttribute((const void *)k_meet4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-			(void)hipFuncSetAttribute((const void *)k_meet4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			(void)hipFuncSetAttribute((const void *)k_meet4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			(void)hipFuncSetAttribute((const void *)k_meet4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 			attr_set.store(1);
 		}
 		const u32 nd = h.count;
+		u32 grid = std::min<u32>(nd, 256 * 4);
+		u32 *gmaps = nullptr;
+		if (!lds_map) {
+			grid = (u32)std::max<size_t>(1, std::min<size_t>(std::min<u32>(nd, 256), gm_budget / ((size_t)bm_words * 4)));
+			PGQ_TRY(ws->meet_maps.reserve((size_t)grid * bm_words * 4));
+			gmaps = ws->meet_maps.as<u32>();
+		}
+		const size_t lds = lds_map ? (size_t)bm_words * 4 : 0;
+		const int64_t cap4 = (int64_t)std::max(1, options().meet4_cap);
 		PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
 		{
 			KernelTimer kt(st, K_MEET);
-			if (paths)
-				hipLaunchKernelGGL(k_meet4<true>, dim3(std::min<u32>(nd, 256 * 4)), dim3(1024), (size_t)bm_words * 4, st,
-				                   (int64_t)nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff,
-				                   c->radj, ws->def_idx.as<u32>(), d_out, rec, (int64_t)std::max(1, options().meet4_cap), bm_words, mc);
-			else
-				hipLaunchKernelGGL(k_meet4<false>, dim3(std::min<u32>(nd, 256 * 4)), dim3(1024), (size_t)bm_words * 4, st,
-				                   (int64_t)nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff,
-				                   c->radj, ws->def_idx.as<u32>(), d_out, rec, (int64_t)std::max(1, options().meet4_cap), bm_words, mc);
+#define PGQ_MEET4(P, G)                                                                                                  \
+	hipLaunchKernelGGL((k_meet4<P, G>), dim3(grid), dim3(1024), lds, st, (int64_t)nd, ws->def_src.as<int64_t>(),          \
+	                   ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, rec, \
+	                   cap4, bm_words, mc, gmaps)
+			if (paths && lds_map) PGQ_MEET4(true, false);
+			else if (paths) PGQ_MEET4(true, true);
+			else if (lds_map) PGQ_MEET4(false, false);
+			else PGQ_MEET4(false, true);
+#undef PGQ_MEET4
 			kt.stop();
 		}
 		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,

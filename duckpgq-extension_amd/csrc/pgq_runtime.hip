@@ -105,6 +105,7 @@ static int do_init(int device) {
 	env_int("PGQ_MEET_CAP_PATHS", g_opt.meet_cap_paths);
 	env_int("PGQ_MEET4", g_opt.meet4);
 	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
+	env_int("PGQ_MEET4_GLOBAL_MB", g_opt.meet4_global_mb);
 	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
 	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
 	env_int("PGQ_ALLOC_CACHE_MB", g_opt.alloc_cache_mb);
@@ -1177,6 +1178,8 @@ std::vector<OptRef> option_table() {
 		{ "meet_cap_paths", &o.meet_cap_paths, nullptr },
 		{ "meet4", &o.meet4, nullptr },
 		{ "meet4_cap", &o.meet4_cap, nullptr },
+		{ "meet4_global_mb", &o.meet4_global_mb, nullptr },
+		{ "meet4_lds_kb", &o.meet4_lds_kb, nullptr },
 		{ "meet_bias", nullptr, &o.meet_bias },
 		{ "lanes_unroll", &o.lanes_unroll, nullptr },
 		{ "upload_threads", &o.upload_threads, nullptr },

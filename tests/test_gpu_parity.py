@@ -17,7 +17,7 @@ def _defaults():
                  ("relax_small_limit", 2048), ("chain", 1), ("chain_cap", 4096), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 12), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20)):
+                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 12), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150)):
         pgq.set_option(k, v)
     yield
 
@@ -159,8 +159,8 @@ def test_random_graph_all_variants(words, mode):
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
 
 
-@pytest.mark.parametrize("cap", [1 << 18, 3000, 1])
-def test_meet_prepass_matches_oracle(cap):
+@pytest.mark.parametrize("cap,lds_kb", [(1 << 18, 150), (3000, 150), (1, 150), (1 << 18, 0)])
+def test_meet_prepass_matches_oracle(cap, lds_kb):
     # k_meet3 (pgq_meet.hip): distances 1..3 from two-hop scans, everything else handed to the lane-batched search.
     # cap = adjacency entries a pair may scan: small caps leave most rows to the MS-BFS path (both paths mixed)
     rng = np.random.default_rng(77 + cap)
@@ -173,6 +173,7 @@ def test_meet_prepass_matches_oracle(cap):
     pgq.set_option("meet_bias", 1e9)  # always take the pre-pass
     pgq.set_option("meet4", 0 if cap == 1 else 1)  # k_meet4: LDS bit-map kernel for what k_meet3 leaves open
     pgq.set_option("meet4_cap", 1 << 20 if cap != 3000 else 2000)
+    pgq.set_option("meet4_lds_kb", lds_kb)  # 0: the vertex bit maps of k_meet4 live in global memory (graphs over ~1.2 M vertices)
     n = 3000
     ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
     ps[:50] = pd[:50]  # src == dst rows

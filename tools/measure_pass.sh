@@ -34,6 +34,7 @@ if [ "${1:-}" != "quick" ]; then
 	# HBM ceiling of this box (copy shapes) and the FETCH_SIZE calibration for 16/32-byte gathers
 	[ -x tools/membench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/membench tools/membench.hip 2>/dev/null
 	timeout 120 tools/membench copy > $O/membench_copy.jsonl 2>&1
+	timeout 120 tools/membench segments > $O/membench_segments.jsonl 2>&1
 	(cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/membench_gather -o p -- $R/tools/membench gather > $O/membench_gather.jsonl 2>&1; rm -f $O/membench_gather/*kernel_trace.csv)
 	timeout 200 python tools/chunk_latency.py > $O/chunk_latency.json 2> $O/chunk_latency.err
 fi

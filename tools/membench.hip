@@ -1,9 +1,11 @@
 // membench.hip — two measurements the roofline figures lean on (tools/, not part of the product):
 //   copy    16-byte copy kernels in several launch shapes: the box's own HBM ceiling (read + written bytes / time)
+//   segments  whole 1 KB / 4 KB segments at random starts, four requests per wavefront in flight: the ceiling for the
+//           list walks of k_meet3 / k_meet4
 //   gather  a 16- or 32-byte gather of known size with random indices: run under `rocprofv3 --pmc FETCH_SIZE` to
 //           calibrate the counter for the access pattern of k_pull_lanes / k_meet3 (MI355X_MICROARCH.md §HBM: the 2x
 //           correction is only calibrated for wide coalesced reads)
-// build: hipcc -O3 --offload-arch=gfx950 -o tools/membench tools/membench.hip      usage: tools/membench copy | gather
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/membench tools/membench.hip      usage: tools/membench copy | gather | segments
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -57,6 +59,30 @@ __global__ void k_gather(const unsigned *__restrict__ idx, long n, const uint4 *
 	if (a.x == 0x12345678u && a.y == 0x9abcdef0u) sink[0] = a; // never true: keeps the loads
 }
 
+// every wavefront reads whole segments (SEGW x 16 bytes per lane-row: 64 lanes x 16 B = 1 KB per request) at random
+// 16-byte-aligned starts, four requests in flight: the access pattern of k_meet3 / k_meet4 (adjacency lists of a few
+// hundred entries picked by a pair's one-hop list)
+__global__ __launch_bounds__(256) void k_seggather(const unsigned *__restrict__ starts, long nseg, int seg_lines,
+                                                   const uint4 *__restrict__ table, uint4 *__restrict__ sink) {
+	const int lane = threadIdx.x & 63;
+	const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+	uint4 acc = make_uint4(0, 0, 0, 0);
+	for (long i = wave; i < nseg; i += nwaves) {
+		const uint4 *p = table + starts[i] + lane;
+		for (int l = 0; l < seg_lines; l += 4) {
+			uint4 v[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) v[k] = l + k < seg_lines ? p[(l + k) * 64] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				acc.x ^= v[k].x;
+				acc.y ^= v[k].y;
+			}
+		}
+	}
+	if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
+}
+
 template <int UN, bool NT> static void run_copy(const char *name, void *a, void *b, long n, int grid, int block) {
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0));
@@ -88,6 +114,42 @@ int main(int argc, char **argv) {
 				run_copy<4, false>("copy16x4", a, b, n, grid, block);
 				run_copy<4, true>("copy16x4_nt", a, b, n, grid, block);
 			}
+		return 0;
+	}
+	if (!strcmp(mode, "segments")) {
+		// random 1 KB / 4 KB segments out of a 160 MB table (the SF100 adjacency) and a 1 GB table
+		const long nseg = 4l << 20;
+		std::vector<unsigned> h(nseg);
+		unsigned x = 777;
+		void *idx, *table, *sink;
+		CK(hipMalloc(&idx, nseg * 4));
+		CK(hipMalloc(&table, 1l << 30));
+		CK(hipMalloc(&sink, 64));
+		CK(hipMemset(table, 0, 1l << 30));
+		for (long table_bytes : { 160l << 20, 1l << 30 })
+			for (int seg_lines : { 1, 4 })
+				for (int waves_per_simd : { 4, 8 }) {
+					const unsigned n16 = (unsigned)((table_bytes - (long)seg_lines * 1024) / 16);
+					for (long i = 0; i < nseg; i++) {
+						x = x * 1664525u + 1013904223u;
+						h[i] = (x >> 3) % n16;
+					}
+					CK(hipMemcpy(idx, h.data(), nseg * 4, hipMemcpyHostToDevice));
+					hipEvent_t e0, e1;
+					CK(hipEventCreate(&e0));
+					CK(hipEventCreate(&e1));
+					const int grid = 256 * waves_per_simd; // 256 threads = one wave per SIMD per workgroup
+					hipLaunchKernelGGL(k_seggather, dim3(grid), dim3(256), 0, 0, (const unsigned *)idx, nseg / 16, seg_lines, (const uint4 *)table, (uint4 *)sink);
+					CK(hipEventRecord(e0, 0));
+					hipLaunchKernelGGL(k_seggather, dim3(grid), dim3(256), 0, 0, (const unsigned *)idx, nseg, seg_lines, (const uint4 *)table, (uint4 *)sink);
+					CK(hipEventRecord(e1, 0));
+					CK(hipEventSynchronize(e1));
+					float ms = 0;
+					CK(hipEventElapsedTime(&ms, e0, e1));
+					printf("{\"kernel\": \"seggather\", \"table_MB\": %ld, \"segment_bytes\": %d, \"waves_per_simd\": %d, "
+					       "\"segments\": %ld, \"ms\": %.3f, \"GBps\": %.0f}\n",
+					       table_bytes >> 20, seg_lines * 1024, waves_per_simd, nseg, ms, (double)nseg * seg_lines * 1024 / (ms * 1e-3) / 1e9);
+				}
 		return 0;
 	}
 	// gather: 64 M random reads of 16 / 32 bytes from tables of 4 MB (L2-resident) and 1 GB (HBM)

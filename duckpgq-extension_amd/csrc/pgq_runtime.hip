@@ -882,22 +882,12 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 	return PGQ_OK;
 }
 
-// 16-byte copy kernel for the measured HBM ceiling: four independent non-temporal requests per thread per round
-__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, int64_t n) {
+// 16-byte copy kernel for the measured HBM ceiling.  One request per thread per round in a grid of one 1024-thread
+// workgroup per CU (4 wavefronts per SIMD) was the fastest of the 36 shapes tools/membench tries on these boxes
+// (5.6 TB/s read + written; wider grids and deeper unrolling lose 10-25 % to DRAM page conflicts).
+__global__ __launch_bounds__(1024) void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, int64_t n) {
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	for (; i + 3 * stride < n; i += 4 * stride) {
-		uint4 v[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const unsigned long long *p = reinterpret_cast<const unsigned long long *>(in + i + k * stride);
-			const unsigned long long lo = __builtin_nontemporal_load(p), hi = __builtin_nontemporal_load(p + 1);
-			v[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-		}
-#pragma unroll
-		for (int k = 0; k < 4; k++) out[i + k * stride] = v[k];
-	}
-	for (; i < n; i += stride) out[i] = in[i];
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
 }
 
 } // namespace pgq
@@ -1237,10 +1227,10 @@ int pgq_measure_copy_bandwidth(int64_t bytes, int iters, double *out_gbps) {
 	hipEvent_t e0, e1;
 	PGQ_HIP_TRY(hipEventCreate(&e0));
 	PGQ_HIP_TRY(hipEventCreate(&e1));
-	hipLaunchKernelGGL(k_copy16, dim3(256 * 16), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, n);
+	hipLaunchKernelGGL(k_copy16, dim3(256), dim3(1024), 0, 0, (const uint4 *)a, (uint4 *)b, n);
 	PGQ_HIP_TRY(hipEventRecord(e0, 0));
 	for (int i = 0; i < iters; i++)
-		hipLaunchKernelGGL(k_copy16, dim3(256 * 16), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, n);
+		hipLaunchKernelGGL(k_copy16, dim3(256), dim3(1024), 0, 0, (const uint4 *)a, (uint4 *)b, n);
 	PGQ_HIP_TRY(hipEventRecord(e1, 0));
 	PGQ_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0.f;

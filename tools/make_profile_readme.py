@@ -111,6 +111,18 @@ if os.path.exists(mc):
               "8 TB/s is the denominator of every `frac` above; this is what a plain copy reaches on the same box." % (
                   best["kernel"], best["grid"], best["block"], best["GBps_read_plus_write"], len(rows),
                   min(r["GBps_read_plus_write"] for r in rows), best["GBps_read_plus_write"]), ""]
+ms_ = os.path.join(rdir, "membench_segments.jsonl")
+if os.path.exists(ms_):
+    rows = [json.loads(x) for x in open(ms_) if x.startswith("{")]
+    if rows:
+        L += ["## Ceiling for the list walks (`tools/membench segments`: whole segments at random 16-byte-aligned starts, "
+              "16 bytes per lane, four requests per wavefront in flight)", "",
+              "| table | segment | waves/SIMD | GB/s |", "|---|---|---|---|"]
+        for r in rows:
+            L.append("| %d MB | %d B | %d | %.0f |" % (r["table_MB"], r["segment_bytes"], r["waves_per_simd"], r["GBps"]))
+        L += ["", "`k_meet3` / `k_meet4` read adjacency lists of a few hundred entries (0.6 KB on average on the SF100-shaped "
+              "graph) picked by a pair's one-hop list out of the 160 MB adjacency: the 1 KB rows are the ceiling for that "
+              "pattern on this box.", ""]
 mg = os.path.join(rdir, "membench_gather.jsonl")
 if os.path.exists(mg):
     rows = [json.loads(x) for x in open(mg) if x.startswith("{")]
@@ -118,24 +130,26 @@ if os.path.exists(mg):
     for p in glob.glob(os.path.join(rdir, "membench_gather", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(p)):
             if r["Counter_Name"] == "FETCH_SIZE" and "k_gather" in r["Kernel_Name"]:
-                fetch.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+                fetch.setdefault(16 if "<16>" in r["Kernel_Name"] else 32, []).append(float(r["Counter_Value"]))
     if rows:
         L += ["## FETCH_SIZE against a gather of known size (`tools/membench gather` under `--pmc FETCH_SIZE`)", "",
-              "64 Mi random record reads; the index list (4 B per read) streams, the records are gathered.  "
-              "`expected` = index bytes + one 64-byte line per read for the 1 GB table (no reuse), index bytes + the "
-              "table once for the 4 MB table (L2-resident).", "",
-              "| kernel | table | G reads/s | raw FETCH_SIZE (KB) | 2× (MB) | expected (MB) | 2× ÷ expected |",
-              "|---|---|---|---|---|---|---|"]
-        seq = {16: sorted(fetch.get("void k_gather<16>", fetch.get("k_gather<16>", []))),
-               32: sorted(fetch.get("void k_gather<32>", fetch.get("k_gather<32>", [])))}
+              "64 Mi random record reads (16 or 32 bytes, records aligned to their size); the index list (4 B per read) "
+              "streams.  `raw` is the counter as rocprofv3 reports it (KB); the guide's correction doubles it.", "",
+              "| kernel | table | G reads/s | raw FETCH_SIZE (MB) | raw bytes per read (index bytes removed at 2x) | 2x (MB) |",
+              "|---|---|---|---|---|---|"]
         for r in rows:
             rec = int(r["kernel"].replace("gather", ""))
-            vals = seq.get(rec) or []
+            vals = sorted(fetch.get(rec) or [])
             raw = (vals[0] if r["table_MB"] <= 4 else vals[-1]) if vals else None
-            exp = r["index_bytes"] + (r["reads"] * max(64, rec) if r["table_MB"] > 4 else r["table_MB"] << 20)
-            L.append("| %s | %d MB | %.1f | %s | %s | %.0f | %s |" % (
-                r["kernel"], r["table_MB"], r["Greads_per_s"], fmt(raw), fmt(raw * 2 * 1024 / 1e6 if raw else None),
-                exp / 1e6, fmt(raw * 2 * 1024 / exp if raw else None, "{:.2f}")))
-        L.append("")
+            per = (raw * 1024 - r["index_bytes"] / 2) / r["reads"] if raw else None
+            L.append("| %s | %d MB | %.1f | %s | %s | %s |" % (
+                r["kernel"], r["table_MB"], r["Greads_per_s"], fmt(raw * 1024 / 1e6 if raw else None),
+                fmt(per, "{:.1f}"), fmt(raw * 2 * 1024 / 1e6 if raw else None)))
+        L += ["", "Reading: a random read of a 1 GB table costs one 64-byte request in the raw counter (the streamed index "
+              "list is counted at half its size, as the guide says of wide coalesced reads).  If the fabric moves 64 bytes "
+              "per such request, the doubled figure over-states gather traffic by up to 2x; if it moves 128, the doubled "
+              "figure is exact.  `roofline.traffic` and the PMC tables above use the guide's 2x throughout, so for the "
+              "gather-heavy kernels (`k_pull_lanes`, `k_pull`) they are upper bounds; for the list walks of `k_meet3` "
+              "(1 KB per wavefront request) the 2x figure is the calibrated one.", ""]
 open(os.path.join(root, "profiles", "README.md"), "w").write("\n".join(L) + "\n")
 print("wrote profiles/README.md (%d lines)" % len(L))

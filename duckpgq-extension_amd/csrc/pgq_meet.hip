@@ -218,8 +218,10 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
 				xq[u] = -1;
 				if (j < cnt) {
 					const int t = q + 4 * lane;
-					x[u] = make_int4(-1, -1, -1, -1);
-					if (t < e) x[u] = *reinterpret_cast<const int4 *>(xadj + t); // aligned; both adjacency arrays are padded
+					// unconditional: a load under a per-lane condition is waited for at the end of the branch, which
+					// serialises the requests.  Lanes past the segment re-read its first group (same line as lane 0: no
+					// extra request); their entries are masked by the range tests
+					x[u] = *reinterpret_cast<const int4 *>(xadj + (t < e ? t : q)); // aligned; the arrays are padded
 					xb[u] = b;
 					xe[u] = e;
 					xq[u] = q;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
 				rec[i].v1 = (int32_t)(u32)best;
 			}
 		}
-		if (lane == 0) out[i] = found ? 3 : kMeetOpen;
+		if (lane == 0) out[i] = found ? 3 : kMeetOpen4; // the walk ran to its end: the distance is at least 4
 	}
 	// one pair of atomics per workgroup, spread over the statistic slots
 	__shared__ unsigned long long s_stat[2];
@@ -334,6 +336,9 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 		const u32 row = didx[i];
 		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
 		const int degS = se - so, degD = de - di;
+		// rows k_meet3 walked to the end are known to be at distance >= 4: only the two two-hop walks remain (two
+		// dependent phases instead of six; their sizes passed k_meet3's cap, which is below this kernel's)
+		const bool known4 = out_rows[row] == kMeetOpen4;
 		clear_map();
 		if (tid == 0) {
 			s_flag = 0;
@@ -341,34 +346,6 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 			s_best = ~0ull;
 		}
 		__syncthreads();
-		// B = N_out(src); sizes of both two-hop walks
-		unsigned long long wf = 0, wb = 0;
-		for (int p = tid; p < degS; p += 1024) {
-			const u32 v = (u32)adj[so + p];
-			mark(v);
-			wf += (unsigned long long)(off[v + 1] - off[v]);
-		}
-		for (int p = tid; p < degD; p += 1024) {
-			const u32 u = (u32)radj[di + p];
-			wb += (unsigned long long)(roff[u + 1] - roff[u]);
-		}
-		for (int o = 32; o > 0; o >>= 1) {
-			wf += __shfl_xor(wf, o);
-			wb += __shfl_xor(wb, o);
-		}
-		if (lane == 0) {
-			if (wf) atomicAdd(&s_work[0], wf);
-			if (wb) atomicAdd(&s_work[1], wb);
-		}
-		__syncthreads();
-		if (tid == 0) {
-			entries += (unsigned long long)(degS + degD);
-			vertices += (u32)(degS + degD);
-		}
-		if (bit((u32)d)) { // dst in N_out(src)
-			if (tid == 0) out_rows[row] = 1;
-			continue;
-		}
 		// the smallest vertex of N_in(dst) whose bit is set (distance 2: the middle vertex; distance 3: the second one)
 		auto min_in_neighbour_of_dst = [&]() {
 			u32 m = kMeetEmpty;
@@ -399,18 +376,48 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 			__syncthreads();
 			return (u32)s_best;
 		};
-		min_in_neighbour_of_dst();
-		__syncthreads();
-		if (s_best != ~0ull) {
-			if (tid == 0) {
-				out_rows[row] = 2;
-				if constexpr (PATHS) rec_rows[row].v1 = (int32_t)(u32)s_best;
-			}
-			continue;
+		if (tid == 0) {
+			entries += (unsigned long long)(degS + degD);
+			vertices += (u32)(degS + degD);
 		}
-		if ((int64_t)s_work[0] > cap || (int64_t)s_work[1] > cap) {
-			if (tid == 0) out_rows[row] = kMeetOpen;
-			continue;
+		if (!known4) {
+			// B = N_out(src); sizes of both two-hop walks
+			unsigned long long wf = 0, wb = 0;
+			for (int p = tid; p < degS; p += 1024) {
+				const u32 v = (u32)adj[so + p];
+				mark(v);
+				wf += (unsigned long long)(off[v + 1] - off[v]);
+			}
+			for (int p = tid; p < degD; p += 1024) {
+				const u32 u = (u32)radj[di + p];
+				wb += (unsigned long long)(roff[u + 1] - roff[u]);
+			}
+			for (int o = 32; o > 0; o >>= 1) {
+				wf += __shfl_xor(wf, o);
+				wb += __shfl_xor(wb, o);
+			}
+			if (lane == 0) {
+				if (wf) atomicAdd(&s_work[0], wf);
+				if (wb) atomicAdd(&s_work[1], wb);
+			}
+			__syncthreads();
+			if (bit((u32)d)) { // dst in N_out(src)
+				if (tid == 0) out_rows[row] = 1;
+				continue;
+			}
+			min_in_neighbour_of_dst();
+			__syncthreads();
+			if (s_best != ~0ull) {
+				if (tid == 0) {
+					out_rows[row] = 2;
+					if constexpr (PATHS) rec_rows[row].v1 = (int32_t)(u32)s_best;
+				}
+				continue;
+			}
+			if ((int64_t)s_work[0] > cap || (int64_t)s_work[1] > cap) {
+				if (tid == 0) out_rows[row] = kMeetOpen;
+				continue;
+			}
 		}
 		// B += N_out(N_out(src))
 		{
@@ -420,19 +427,21 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 			if (lane == 0) entries += e2;
 		}
 		__syncthreads();
-		min_in_neighbour_of_dst(); // distance 3: N_in(dst) meets B
-		__syncthreads();
-		if (s_best != ~0ull) {
-			const u32 v2 = (u32)s_best;
-			if constexpr (PATHS) {
-				const u32 v1 = first_inner_vertex(v2);
-				if (tid == 0) {
-					rec_rows[row].v1 = (int32_t)v1;
-					rec_rows[row].v2 = (int32_t)v2;
+		if (!known4) {
+			min_in_neighbour_of_dst(); // distance 3: N_in(dst) meets B
+			__syncthreads();
+			if (s_best != ~0ull) {
+				const u32 v2 = (u32)s_best;
+				if constexpr (PATHS) {
+					const u32 v1 = first_inner_vertex(v2);
+					if (tid == 0) {
+						rec_rows[row].v1 = (int32_t)v1;
+						rec_rows[row].v2 = (int32_t)v2;
+					}
 				}
+				if (tid == 0) out_rows[row] = 3;
+				continue;
 			}
-			if (tid == 0) out_rows[row] = 3;
-			continue;
 		}
 		// distance 4: N_in(N_in(dst)) meets B.  PATHS: smallest (third vertex << 32 | second vertex) over all witnesses
 		{
@@ -489,12 +498,181 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 	}
 }
 
+// ---- distance only: k_meet4d -------------------------------------------------------------------------------------------
+// The rows that reach this kernel from `iterativelength` are of two kinds: rows whose cheaper two-hop walk is over
+// k_meet3's cap (heavy endpoints; nearly all of them at distance 2 or 3) and rows k_meet3 walked to the end (distance
+// >= 4 proven).  Marking a whole two-hop neighbourhood before testing anything, as the path variant above must (it needs
+// the smallest witness), would read a heavy row's 10^5..10^6 entries to answer what the first few thousand already
+// decide, so the distance-only flow tests in k_meet3's order with 16 wavefronts per row and the exact bit map as the set:
+//     sizes of both two-hop walks, distance 1                                  (the one-hop lists)
+//     map = one-hop list of the endpoint with the LARGER walk; distance 2      (the other endpoint's one-hop list)
+//     distance 3: two-hop walk of the cheaper endpoint against the map, ended by the first hit
+//     distance 4: map = two-hop set of the cheaper endpoint, two-hop walk of the other one, ended by the first hit
+// Rows with distance >= 4 proven start at the last step (cheaper endpoint: the shorter one-hop list).
+template <bool GM>
+__global__ __launch_bounds__(1024) void k_meet4d(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                 const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                 const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
+                                                 int bm_words, MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
+	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
+	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
+	__shared__ int s_flag;
+	__shared__ unsigned long long s_work[2];
+	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	unsigned long long entries = 0;
+	u32 vertices = 0;
+	auto bit = [&](u32 x) {
+		const u32 w = GM ? __hip_atomic_load(&gmap[x >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_map[x >> 5];
+		return (w >> (x & 31)) & 1u;
+	};
+	auto mark = [&](u32 x) {
+		if constexpr (GM) atomicOr(&gmap[x >> 5], 1u << (x & 31));
+		else atomicOr(&s_map[x >> 5], 1u << (x & 31));
+	};
+	auto clear_map = [&]() {
+		if constexpr (GM) {
+			uint4 *m4 = reinterpret_cast<uint4 *>(gmap);
+			for (int k = tid; k < bm_words / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
+		} else {
+			for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
+		}
+	};
+	auto flag_set = [&]() { return *(volatile int *)&s_flag != 0; };
+	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+		__syncthreads(); // the previous row's flag and map are no longer read
+		const int64_t s = src[i], d = dst[i]; // rows left open by k_meet3: ids in range, src != dst, both have edges
+		const u32 row = didx[i];
+		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
+		const int degS = se - so, degD = de - di;
+		const bool known4 = out_rows[row] == kMeetOpen4;
+		clear_map();
+		if (tid == 0) {
+			s_flag = 0;
+			s_work[0] = s_work[1] = 0;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			entries += (unsigned long long)(degS + degD);
+			vertices += (u32)(degS + degD);
+		}
+		bool walk_fwd = degS <= degD; // which endpoint's two-hop neighbourhood is walked / marked
+		if (!known4) {
+			unsigned long long wf = 0, wb = 0;
+			bool hit = false;
+			for (int p = tid; p < degS; p += 1024) {
+				const u32 v = (u32)adj[so + p];
+				hit |= v == (u32)d;
+				wf += (unsigned long long)(off[v + 1] - off[v]);
+			}
+			for (int p = tid; p < degD; p += 1024) {
+				const u32 u = (u32)radj[di + p];
+				wb += (unsigned long long)(roff[u + 1] - roff[u]);
+			}
+			for (int o = 32; o > 0; o >>= 1) {
+				wf += __shfl_xor(wf, o);
+				wb += __shfl_xor(wb, o);
+			}
+			if (lane == 0) {
+				if (wf) atomicAdd(&s_work[0], wf);
+				if (wb) atomicAdd(&s_work[1], wb);
+			}
+			if (__any(hit) && lane == 0) s_flag = 1;
+			__syncthreads();
+			if (s_flag) { // dst in N_out(src)
+				if (tid == 0) out_rows[row] = 1;
+				continue;
+			}
+			const int64_t work_f = (int64_t)s_work[0], work_b = (int64_t)s_work[1];
+			walk_fwd = work_f <= work_b;
+			{ // the set: one-hop list of the endpoint that is not walked
+				const int32_t *set_list = walk_fwd ? radj + di : adj + so;
+				const int set_n = walk_fwd ? degD : degS;
+				for (int p = tid; p < set_n; p += 1024) mark((u32)set_list[p]);
+			}
+			__syncthreads();
+			const int32_t *wl = walk_fwd ? adj + so : radj + di;
+			const int wn = walk_fwd ? degS : degD;
+			{ // distance 2: a common neighbour
+				bool f = false;
+				for (int p = tid; p < wn; p += 1024) f |= bit((u32)wl[p]) != 0;
+				if (__any(f) && lane == 0) s_flag = 1;
+			}
+			__syncthreads();
+			if (s_flag) {
+				if (tid == 0) out_rows[row] = 2;
+				continue;
+			}
+			if (min(work_f, work_b) > cap) {
+				if (tid == 0) out_rows[row] = kMeetOpen;
+				continue;
+			}
+			{ // distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
+				bool f = false;
+				const unsigned long long e2 = meet_walk(
+				    wl, wn, wib, 16, walk_fwd ? off : roff, walk_fwd ? adj : radj, [&](u32 x, u32) { f |= bit(x) != 0; },
+				    [&]() {
+					    if (__any(f)) s_flag = 1;
+					    return flag_set();
+				    });
+				if (lane == 0) entries += e2;
+				if (__any(f)) s_flag = 1;
+			}
+			__syncthreads();
+			if (s_flag) {
+				if (tid == 0) out_rows[row] = 3;
+				continue;
+			}
+			if (max(work_f, work_b) > cap) {
+				if (tid == 0) out_rows[row] = kMeetOpen;
+				continue;
+			}
+			clear_map(); // every wavefront is past its reads of the map (barrier above)
+			__syncthreads();
+		}
+		// distance 4: two-hop set of the walked endpoint, two-hop walk of the other one
+		{
+			const unsigned long long e2 = meet_walk(walk_fwd ? adj + so : radj + di, walk_fwd ? degS : degD, wib, 16,
+			                                        walk_fwd ? off : roff, walk_fwd ? adj : radj,
+			                                        [&](u32 x, u32) { mark(x); }, []() { return false; });
+			if (lane == 0) entries += e2;
+		}
+		__syncthreads();
+		{
+			bool f = false;
+			const unsigned long long e2 = meet_walk(
+			    walk_fwd ? radj + di : adj + so, walk_fwd ? degD : degS, wib, 16, walk_fwd ? roff : off,
+			    walk_fwd ? radj : adj, [&](u32 x, u32) { f |= bit(x) != 0; },
+			    [&]() {
+				    if (__any(f)) s_flag = 1;
+				    return flag_set();
+			    });
+			if (lane == 0) entries += e2;
+			if (__any(f)) s_flag = 1;
+		}
+		__syncthreads();
+		if (tid == 0) out_rows[row] = s_flag ? 4 : kMeetOpen;
+	}
+	__shared__ unsigned long long s_stat[2];
+	__syncthreads();
+	if (tid < 2) s_stat[tid] = 0;
+	__syncthreads();
+	for (int o = 32; o > 0; o >>= 1) entries += __shfl_xor(entries, o);
+	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
+	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
+	__syncthreads();
+	if (tid == 0) {
+		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
+		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
+	}
+}
+
 // ---- path emission -------------------------------------------------------------------------------------------------
 // [src, e1, v1, ..., ek, dst] for the rows the pre-pass answered (shortest_path.cpp:149-204): the edge of a hop is the
 // FIRST slot of the parent holding the child (shortest_path.cpp:23-30).  One wavefront per row.
 __global__ void k_path_counts(int64_t n, const int64_t *__restrict__ len, int64_t *__restrict__ cnt) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) cnt[i] = len[i] >= 0 ? 2 * len[i] + 1 : 0; // open (kMeetOpen) and NULL rows: nothing here
+	if (i < n) cnt[i] = len[i] >= 0 ? 2 * len[i] + 1 : 0; // open (kMeetOpen, kMeetOpen4) and NULL rows: nothing here
 }
 __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                     const int64_t *__restrict__ len, const MeetPath *__restrict__ rec,
@@ -598,7 +776,7 @@ __global__ void k_collect_open(int64_t n, const int64_t *__restrict__ out, const
                                const int64_t *__restrict__ dst, int64_t *__restrict__ dsrc, int64_t *__restrict__ ddst,
                                u32 *__restrict__ didx, u32 *__restrict__ count) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const bool open = i < n && out[i] == kMeetOpen;
+	const bool open = i < n && (out[i] == kMeetOpen || out[i] == kMeetOpen4);
 	const u64 m = __ballot(open);
 	if (!m) return;
 	const int lane = threadIdx.x & 63;
@@ -671,7 +849,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	if (h.count > 0 && options().meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget)) {
 		static std::atomic<int> attr_set { 0 };
 		if (!attr_set.load()) {
-			(void)hipFuncSetAttribute((const void *)k_meet4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			(void)hipFuncSetAttribute((const void *)k_meet4d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 			(void)hipFuncSetAttribute((const void *)k_meet4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 			attr_set.store(1);
 		}
@@ -688,14 +866,19 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
 		{
 			KernelTimer kt(st, K_MEET);
-#define PGQ_MEET4(P, G)                                                                                                  \
-	hipLaunchKernelGGL((k_meet4<P, G>), dim3(grid), dim3(1024), lds, st, (int64_t)nd, ws->def_src.as<int64_t>(),          \
+#define PGQ_MEET4(G)                                                                                                     \
+	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid), dim3(1024), lds, st, (int64_t)nd, ws->def_src.as<int64_t>(),       \
 	                   ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, rec, \
 	                   cap4, bm_words, mc, gmaps)
-			if (paths && lds_map) PGQ_MEET4(true, false);
-			else if (paths) PGQ_MEET4(true, true);
-			else if (lds_map) PGQ_MEET4(false, false);
-			else PGQ_MEET4(false, true);
+#define PGQ_MEET4D(G)                                                                                                    \
+	hipLaunchKernelGGL((k_meet4d<G>), dim3(grid), dim3(1024), lds, st, (int64_t)nd, ws->def_src.as<int64_t>(),            \
+	                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, cap4,    \
+	                   bm_words, mc, gmaps)
+			if (paths && lds_map) PGQ_MEET4(false);
+			else if (paths) PGQ_MEET4(true);
+			else if (lds_map) PGQ_MEET4D(false);
+			else PGQ_MEET4D(true);
+#undef PGQ_MEET4D
 #undef PGQ_MEET4
 			kt.stop();
 		}

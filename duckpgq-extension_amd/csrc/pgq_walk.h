@@ -11,6 +11,7 @@ constexpr int kMeetSlots = 1024;            // hash slots per wavefront
 constexpr int kMeetSetMax = kMeetSlots / 2; // longest one-hop list the table takes (load factor <= 1/2)
 constexpr u32 kMeetEmpty = 0xFFFFFFFFu;
 constexpr int64_t kMeetOpen = -9;           // d_out marker: not answered here
+constexpr int64_t kMeetOpen4 = -10;         // not answered, and distances 1..3 are excluded (k_meet3 finished its walk)
 
 __device__ __forceinline__ u32 meet_hash(u32 x) { return (x * 0x9E3779B1u) >> 22; } // 10 bits
 
@@ -27,7 +28,9 @@ __device__ __forceinline__ bool meet_lookup(const u32 *tab, u32 x) {
 // one-probe pre-filter: 8192-bit map of the set (a set of ~100 vertices leaves ~1 % of the bits on), so that the four
 // entries a lane holds cost four independent LDS reads instead of four dependent hash-table walks
 constexpr int kMeetFilterWords = 256;
-__device__ __forceinline__ u32 meet_fhash(u32 x) { return (x * 0x9E3779B1u) >> 19; } // 13 bits
+// the low 13 bits of the vertex id: one instruction; ids that differ by a multiple of 8192 share a bit, which costs a
+// (rare) table walk, never a wrong answer
+__device__ __forceinline__ u32 meet_fhash(u32 x) { return x & (kMeetFilterWords * 32 - 1); }
 // `valid`: bit k set = entry k lies inside the segment.  Returns the entries that are in the set (bit k).  The four
 // filter reads are independent and branch-free; only lanes holding a filter hit (~1 % of the entries) walk the table.
 __device__ __forceinline__ u32 meet_probe4(const u32 *tab, const u32 *bm, const int4 v, u32 valid) {
@@ -93,8 +96,9 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 			xq[u] = -1;
 			if (j < cnt) {
 				const int t = q + 4 * lane;
-				x[u] = make_int4(-1, -1, -1, -1);
-				if (t < e) x[u] = *reinterpret_cast<const int4 *>(xadj + t);
+				// unconditional (a load under a per-lane condition is waited for at the end of the branch): lanes past the
+				// segment re-read its first group, masked by the range tests below
+				x[u] = *reinterpret_cast<const int4 *>(xadj + (t < e ? t : q));
 				xb[u] = b;
 				xe[u] = e;
 				xq[u] = q;

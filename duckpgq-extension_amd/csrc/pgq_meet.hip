@@ -37,6 +37,15 @@ struct MeetPath {
 };
 
 constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so that a finished row frees its slot at once
+#ifndef PGQ_MEET3_WAVES
+#define PGQ_MEET3_WAVES 7 // wavefronts per SIMD k_meet3<false> is compiled for (72 VGPRs, no spills; 6..8 measure the same)
+#endif
+#ifndef PGQ_MEET3_NT
+#define PGQ_MEET3_NT 1 // non-temporal list loads: the lists are streamed once, the offset look-ups stay in L2 (-3 %)
+#endif
+#ifndef PGQ_MEET3_DEPTH
+#define PGQ_MEET3_DEPTH 2 // list requests in flight per wavefront (1..4 measure the same: the kernel runs at the traffic ceiling)
+#endif
 constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 atomics on one address take longer than the walks
 struct MeetCounters {
 	unsigned long long entries[kMeetStatSlots];  // adjacency entries scanned (both kinds of list)
@@ -53,7 +62,7 @@ struct MeetCounters {
 // PATHS: also record the path's inner vertices (MeetPath) — the walk then has to see every witness (the tie-break
 // needs the smallest, not the first), so it has no early exit.
 template <bool PATHS>
-__global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : PGQ_MEET3_WAVES) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                   int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
 			};
 			seek();
 			// PATHS walks every segment to the end: fewer wavefronts, more registers, four requests in flight
-			constexpr int DEPTH = PATHS ? 4 : 3;
+			constexpr int DEPTH = PATHS ? 4 : PGQ_MEET3_DEPTH;
 			int4 x[DEPTH];
 			int xb[DEPTH], xe[DEPTH], xq[DEPTH]; // the segment and position a chunk was requested from (wave-uniform)
 			u32 xv[DEPTH];                       // ... and the expanded vertex it belongs to
@@ -221,7 +230,15 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : 6) void k_meet3(int64_t 
 					// unconditional: a load under a per-lane condition is waited for at the end of the branch, which
 					// serialises the requests.  Lanes past the segment re-read its first group (same line as lane 0: no
 					// extra request); their entries are masked by the range tests
+#if PGQ_MEET3_NT
+					{ // streamed once: keep the lists out of L2 so that the offset look-ups stay in
+						typedef int v4i __attribute__((ext_vector_type(4)));
+						const v4i r = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(xadj + (t < e ? t : q)));
+						x[u] = make_int4(r.x, r.y, r.z, r.w);
+					}
+#else
 					x[u] = *reinterpret_cast<const int4 *>(xadj + (t < e ? t : q)); // aligned; the arrays are padded
+#endif
 					xb[u] = b;
 					xe[u] = e;
 					xq[u] = q;

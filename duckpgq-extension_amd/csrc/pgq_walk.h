@@ -98,7 +98,11 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 				const int t = q + 4 * lane;
 				// unconditional (a load under a per-lane condition is waited for at the end of the branch): lanes past the
 				// segment re-read its first group, masked by the range tests below
-				x[u] = *reinterpret_cast<const int4 *>(xadj + (t < e ? t : q));
+				{ // non-temporal: the lists are streamed once, the offset look-ups should stay in L2
+					typedef int v4i __attribute__((ext_vector_type(4)));
+					const v4i r = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(xadj + (t < e ? t : q)));
+					x[u] = make_int4(r.x, r.y, r.z, r.w);
+				}
 				xb[u] = b;
 				xe[u] = e;
 				xq[u] = q;

@@ -76,6 +76,9 @@ struct Options {
 	int meet_cap_paths = 1 << 12; // the same for shortestpath rows (their walks have no early exit; longer ones go to k_meet4)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
+	int bibfs_rows = 256;      // k_bibfs (one bidirectional search per row) runs when at most this many rows are still open (0: off)
+	int bibfs_cap = 8 << 20;   // adjacency entries one expansion of k_bibfs may read
+	int bibfs_queue = 1 << 17; // frontier vertices per side k_bibfs keeps
 	int meet4_lds_kb = 150;    // largest vertex bit map k_meet4 keeps in LDS (tests lower it to force the global-memory maps)
 	int meet4_global_mb = 256; // vertex bit maps of k_meet4 in global memory when V does not fit in LDS: total budget (0: off)
 	double meet_bias = 1.0; // pre-pass runs while its estimated bytes <= meet_bias x the MS-BFS estimate

@@ -684,6 +684,155 @@ __global__ __launch_bounds__(1024) void k_meet4d(int64_t n, const int64_t *__res
 	}
 }
 
+// ---- any distance, few rows: bidirectional BFS per row (k_bibfs) ---------------------------------------------------
+// What is still open after the kernels above is far apart (distance >= 5), unreachable, or over their caps.  On a graph
+// whose levels are expensive (R-MAT-22: ~1 ms per bottom-up level whatever the number of lanes) a handful of such rows
+// would drag the whole lane-batched search along, although each of them has a small side: an unreachable pair is
+// unreachable because one endpoint's closure is small, and a far pair's two frontiers stay far below the graph's
+// size until they meet.  One 1024-thread workgroup per row runs the textbook bidirectional search, level-synchronous:
+//     F = {src}, B = {dst} (visited bit maps, one per side; frontier vertex lists in global scratch), a = b = 0
+//     expand the side whose frontier has fewer adjacency entries by one level; a newly reached vertex that the other
+//     side has visited ends the search with distance a + b + 1
+// Exactness: before an expansion F and B are disjoint, so the distance exceeds a + b; a vertex x reached at forward
+// level a + 1 that B holds has backward level b exactly (a smaller one would put its forward predecessor into B as well,
+// and the search would have ended a round earlier), so the first meeting gives the BFS distance.  An empty new frontier
+// means that side's closure is complete: NULL, like the exhausted search of iterativelength.cpp:133-139.  A frontier over
+// `cap` entries or `qcap` vertices leaves the row open.
+template <bool GM>
+__global__ __launch_bounds__(1024) void k_bibfs(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
+                                                int bm_words, int qcap, MeetCounters *__restrict__ mc,
+                                                u32 *__restrict__ gmaps, u32 *__restrict__ queues) {
+	extern __shared__ u32 s_map[]; // !GM: both maps, (bm_words + 4) words each; the spare words take the masked lanes' bits
+	const int mw = bm_words + 4;
+	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * 2 * mw : nullptr;
+	u32 *const qbase = queues + (size_t)blockIdx.x * 4 * qcap; // [side][parity][qcap]
+	__shared__ int s_found;
+	__shared__ u32 s_cnt;
+	__shared__ unsigned long long s_work;
+	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	const u32 dummy = (u32)bm_words * 32u; // bit 0 of the first spare word
+	unsigned long long entries = 0;
+	u32 vertices = 0;
+	auto or_rtn = [&](int side, u32 x) -> u32 {
+		if constexpr (GM) return atomicOr(&gmap[side * mw + (x >> 5)], 1u << (x & 31));
+		else return atomicOr(&s_map[side * mw + (x >> 5)], 1u << (x & 31));
+	};
+	auto word_of = [&](int side, u32 x) -> u32 {
+		if constexpr (GM) return __hip_atomic_load(&gmap[side * mw + (x >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else return s_map[side * mw + (x >> 5)];
+	};
+	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+		__syncthreads();
+		const int64_t s = src[i], d = dst[i]; // open rows: ids in range, src != dst, both have edges
+		const u32 row = didx[i];
+		if constexpr (GM) {
+			uint4 *m4 = reinterpret_cast<uint4 *>(gmap); // mw is a multiple of 4, slices are 16-byte aligned
+			for (int k = tid; k < 2 * mw / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
+		} else {
+			for (int k = tid; k < 2 * mw; k += 1024) s_map[k] = 0;
+		}
+		if (tid == 0) s_found = 0;
+		__syncthreads();
+		if (tid == 0) {
+			(void)or_rtn(0, (u32)s);
+			(void)or_rtn(1, (u32)d);
+			qbase[0] = (u32)s;
+			qbase[2 * qcap] = (u32)d;
+		}
+		int nf[2] = { 1, 1 }, lvl[2] = { 0, 0 }, par[2] = { 0, 0 };
+		int64_t work[2] = { off[s + 1] - off[s], roff[d + 1] - roff[d] };
+		int64_t result = kMeetOpen;
+		__syncthreads();
+		for (;;) {
+			const int side = work[0] <= work[1] ? 0 : 1; // 0: forward from src, 1: backward from dst
+			if (work[side] > cap) break;
+			const int64_t *xoff = side ? roff : off;
+			const int32_t *xadj = side ? radj : adj;
+			const u32 *cur = qbase + (size_t)(side * 2 + par[side]) * qcap;
+			u32 *nxt = qbase + (size_t)(side * 2 + (par[side] ^ 1)) * qcap;
+			if (tid == 0) {
+				s_cnt = 0;
+				s_work = 0;
+				vertices += (u32)nf[side];
+			}
+			__syncthreads();
+			bool hit = false;
+			const unsigned long long e2 = meet_walk_chunks(
+			    reinterpret_cast<const int32_t *>(cur), nf[side], wib, 16, xoff, xadj,
+			    [&](const int4 &v, u32 valid, u32) {
+				    u32 xs[4] = { (u32)v.x, (u32)v.y, (u32)v.z, (u32)v.w };
+				    u32 old[4], oth[4];
+#pragma unroll
+				    for (int k = 0; k < 4; k++) xs[k] = ((valid >> k) & 1u) ? xs[k] : dummy; // no per-lane branches around memory operations
+#pragma unroll
+				    for (int k = 0; k < 4; k++) old[k] = or_rtn(side, xs[k]);
+#pragma unroll
+				    for (int k = 0; k < 4; k++) oth[k] = word_of(side ^ 1, xs[k]);
+#pragma unroll
+				    for (int k = 0; k < 4; k++) {
+					    const bool in = (valid >> k) & 1u;
+					    const bool fresh = in && !((old[k] >> (xs[k] & 31)) & 1u);
+					    hit |= in && ((oth[k] >> (xs[k] & 31)) & 1u);
+					    const u64 m = __ballot(fresh);
+					    if (m) {
+						    u32 base = 0;
+						    if (lane == 0) base = atomicAdd(&s_cnt, (u32)__popcll(m));
+						    base = (u32)__shfl((int)base, 0);
+						    const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+						    if (fresh && slot < (u32)qcap) nxt[slot] = xs[k];
+					    }
+				    }
+			    },
+			    [&]() {
+				    if (__any(hit)) s_found = 1;
+				    return *(volatile int *)&s_found != 0;
+			    });
+			if (lane == 0) entries += e2;
+			if (__any(hit)) s_found = 1;
+			__syncthreads();
+			if (s_found) {
+				result = lvl[0] + lvl[1] + 1;
+				break;
+			}
+			const u32 nn = s_cnt;
+			if (nn == 0) { // this side's closure is complete and never met the other one
+				result = -1;
+				break;
+			}
+			if (nn > (u32)qcap) break;
+			unsigned long long w = 0;
+			for (u32 p = tid; p < nn; p += 1024) {
+				const u32 v = nxt[p];
+				w += (unsigned long long)(xoff[v + 1] - xoff[v]);
+			}
+			for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+			if (lane == 0 && w) atomicAdd(&s_work, w);
+			__syncthreads();
+			work[side] = (int64_t)s_work;
+			nf[side] = (int)nn;
+			lvl[side]++;
+			par[side] ^= 1;
+			__syncthreads(); // s_cnt / s_work are reset by the next round
+		}
+		if (tid == 0) out_rows[row] = result;
+	}
+	__shared__ unsigned long long s_stat[2];
+	__syncthreads();
+	if (tid < 2) s_stat[tid] = 0;
+	__syncthreads();
+	for (int o = 32; o > 0; o >>= 1) entries += __shfl_xor(entries, o);
+	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
+	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
+	__syncthreads();
+	if (tid == 0) {
+		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
+		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
+	}
+}
+
 // ---- path emission -------------------------------------------------------------------------------------------------
 // [src, e1, v1, ..., ek, dst] for the rows the pre-pass answered (shortest_path.cpp:149-204): the edge of a hop is the
 // FIRST slot of the parent holding the child (shortest_path.cpp:23-30).  One wavefront per row.
@@ -897,6 +1046,47 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			else PGQ_MEET4D(true);
 #undef PGQ_MEET4D
 #undef PGQ_MEET4
+			kt.stop();
+		}
+		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
+		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
+		PGQ_HIP_TRY(hipMemcpyAsync(&h, mc, sizeof(h), hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		KernelTimer::flush();
+		for (int k = 0; k < kMeetStatSlots; k++) {
+			entries += h.m.entries[k];
+			vertices += h.m.vertices[k];
+		}
+	}
+	// a handful of rows still open (far apart, unreachable, over the caps): one bidirectional search each, so that the
+	// lane-batched search — whole-graph levels — only starts for what really needs it
+	if (!paths && h.count > 0 && (int64_t)h.count <= (int64_t)options().bibfs_rows) {
+		const int bmw = (int)((c->V + 127) / 128) * 4, mw = bmw + 4;
+		const bool lds_maps = (size_t)2 * mw * 4 + 512 <= (size_t)std::min(150, std::max(0, options().meet4_lds_kb)) * 1024;
+		const int qcap = std::max(1024, options().bibfs_queue);
+		const u32 nd = h.count;
+		const u32 grid = std::min<u32>(nd, 64);
+		static std::atomic<int> attr_set2 { 0 };
+		if (!attr_set2.load()) {
+			(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			attr_set2.store(1);
+		}
+		const size_t map_words = lds_maps ? 0 : (size_t)grid * 2 * mw;
+		PGQ_TRY(ws->meet_maps.reserve((map_words + (size_t)grid * 4 * qcap) * 4 + 64));
+		u32 *gmaps = ws->meet_maps.as<u32>();
+		u32 *queues = gmaps + map_words;
+		const int64_t capb = (int64_t)std::max(1, options().bibfs_cap);
+		PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
+		{
+			KernelTimer kt(st, K_MEET);
+			if (lds_maps)
+				hipLaunchKernelGGL(k_bibfs<false>, dim3(grid), dim3(1024), (size_t)2 * mw * 4, st, (int64_t)nd,
+				                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
+				                   ws->def_idx.as<u32>(), d_out, capb, bmw, qcap, mc, gmaps, queues);
+			else
+				hipLaunchKernelGGL(k_bibfs<true>, dim3(grid), dim3(1024), 0, st, (int64_t)nd, ws->def_src.as<int64_t>(),
+				                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out,
+				                   capb, bmw, qcap, mc, gmaps, queues);
 			kt.stop();
 		}
 		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,

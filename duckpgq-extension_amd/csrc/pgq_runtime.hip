@@ -106,6 +106,8 @@ static int do_init(int device) {
 	env_int("PGQ_MEET4", g_opt.meet4);
 	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
 	env_int("PGQ_MEET4_GLOBAL_MB", g_opt.meet4_global_mb);
+	env_int("PGQ_BIBFS_ROWS", g_opt.bibfs_rows);
+	env_int("PGQ_BIBFS_CAP", g_opt.bibfs_cap);
 	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
 	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
 	env_int("PGQ_ALLOC_CACHE_MB", g_opt.alloc_cache_mb);
@@ -1170,6 +1172,9 @@ std::vector<OptRef> option_table() {
 		{ "meet4_cap", &o.meet4_cap, nullptr },
 		{ "meet4_global_mb", &o.meet4_global_mb, nullptr },
 		{ "meet4_lds_kb", &o.meet4_lds_kb, nullptr },
+		{ "bibfs_rows", &o.bibfs_rows, nullptr },
+		{ "bibfs_cap", &o.bibfs_cap, nullptr },
+		{ "bibfs_queue", &o.bibfs_queue, nullptr },
 		{ "meet_bias", nullptr, &o.meet_bias },
 		{ "lanes_unroll", &o.lanes_unroll, nullptr },
 		{ "upload_threads", &o.upload_threads, nullptr },

@@ -136,4 +136,79 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 	return entries;
 }
 
+// The same walk with a per-chunk callback: g(v, valid, ev) gets the four entries a lane holds (bit k of `valid` set =
+// entry k lies inside its segment) so that it can issue its own memory operations four at a time.
+template <typename G, typename Stop>
+__device__ __forceinline__ unsigned long long meet_walk_chunks(const int32_t *__restrict__ list, int list_n, int w, int stride,
+                                                               const int64_t *__restrict__ xoff,
+                                                               const int32_t *__restrict__ xadj, G g, Stop stop) {
+	const int lane = threadIdx.x & 63;
+	unsigned long long entries = 0;
+	for (int pb = w; pb < list_n; pb += 64 * stride) {
+		int vb = 0, ve = 0;
+		u32 vid = 0;
+		const int p = pb + lane * stride;
+		if (p < list_n) {
+			vid = (u32)list[p];
+			vb = (int)xoff[vid];
+			ve = (int)xoff[vid + 1];
+		}
+		const int cnt = min(64, (list_n - pb + stride - 1) / stride);
+		int j = -1, q = 0, e = 0, b = 0;
+		u32 cv = 0;
+		auto seek = [&]() {
+			for (j++; j < cnt; j++) {
+				b = __builtin_amdgcn_readlane(vb, j);
+				e = __builtin_amdgcn_readlane(ve, j);
+				if (e > b) {
+					q = b & ~3;
+					cv = (u32)__builtin_amdgcn_readlane((int)vid, j);
+					return;
+				}
+			}
+		};
+		seek();
+		constexpr int DEPTH = 2;
+		int4 x[DEPTH];
+		int xb[DEPTH], xe[DEPTH], xq[DEPTH];
+		u32 xv[DEPTH];
+		auto fetch = [&](int u) {
+			xq[u] = -1;
+			if (j < cnt) {
+				const int t = q + 4 * lane;
+				typedef int v4i __attribute__((ext_vector_type(4)));
+				const v4i r = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(xadj + (t < e ? t : q)));
+				x[u] = make_int4(r.x, r.y, r.z, r.w);
+				xb[u] = b;
+				xe[u] = e;
+				xq[u] = q;
+				xv[u] = cv;
+				entries += (unsigned long long)(min(e, q + 256) - max(b, q));
+				q += 256;
+				if (q >= e) seek();
+			}
+		};
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++) fetch(u);
+		for (;;) {
+			bool any_chunk = false;
+#pragma unroll
+			for (int u = 0; u < DEPTH; u++) {
+				if (xq[u] < 0) continue;
+				any_chunk = true;
+				const int4 v = x[u];
+				const int t = xq[u] + 4 * lane, sb = xb[u], se = xe[u];
+				const u32 ev = xv[u];
+				fetch(u);
+				const u32 valid = (u32)(t >= sb && t < se) | ((u32)(t + 1 >= sb && t + 1 < se) << 1) |
+				                  ((u32)(t + 2 >= sb && t + 2 < se) << 2) | ((u32)(t + 3 >= sb && t + 3 < se) << 3);
+				g(v, valid, ev);
+			}
+			if (!any_chunk || stop()) break;
+		}
+		if (stop()) break;
+	}
+	return entries;
+}
+
 } // namespace pgq

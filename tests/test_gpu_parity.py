@@ -17,7 +17,8 @@ def _defaults():
                  ("relax_small_limit", 2048), ("chain", 1), ("chain_cap", 4096), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 12), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150)):
+                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 12), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
+                 ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17)):
         pgq.set_option(k, v)
     yield
 
@@ -203,6 +204,53 @@ def test_meet_prepass_matches_oracle(cap, lds_kb):
     ln, ok = st2.iterativelength(1, V2, ps, pd)
     assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
     assert st2.shortestpath(1, V2, ps, pd) == ora2.lean_shortestpath(V2, ps, pd)
+
+
+@pytest.mark.parametrize("lds_kb", [150, 0])
+def test_bibfs_few_open_rows_any_distance(lds_kb):
+    # k_bibfs (pgq_meet.hip): one bidirectional search per row for the few rows the two-hop kernels leave open — long
+    # distances, unreachable pairs (one side's closure is exhausted), caps that hand rows on to the lane-batched search
+    rng = np.random.default_rng(4242 + lds_kb)
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_bias", 1e9)
+    pgq.set_option("meet4_lds_kb", lds_kb)  # 0: visited maps in global memory (graphs whose maps do not fit in LDS)
+    # (a) a directed ring with a few chords: distances up to the hundreds, everything reachable
+    V = 3000
+    ring_s = np.arange(V, dtype=np.int64)
+    ring_d = (ring_s + 1) % V
+    ch_s, ch_d = rng.integers(0, V, 40), rng.integers(0, V, 40)
+    s, d = np.concatenate([ring_s, ch_s]), np.concatenate([ring_d, ch_d])
+    st, ora = both(V, (s, d, np.arange(len(s), dtype=np.int64)))
+    ps, pd = rng.integers(0, V, 150), rng.integers(0, V, 150)
+    oln, ook = ora.lean_iterativelength(V, ps, pd)
+    want = [int(v) if k else None for v, k in zip(oln, ook)]
+    assert max(v for v in want if v is not None) > 20
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    assert lens(ln, ok) == want
+    assert pgq.get_stats()["levels"] == 0  # every row was answered before the lane-batched search
+    # (b) sparse directed graph: dead ends, unreachable pairs with a small closure on one side
+    V2 = 5000
+    rows2 = random_graph(rng, V2, 6000)
+    st2, ora2 = both(V2, rows2, csr_id=1)
+    ps, pd = rng.integers(0, V2, 200), rng.integers(0, V2, 200)
+    oln, ook = ora2.lean_iterativelength(V2, ps, pd)
+    want2 = [int(v) if k else None for v, k in zip(oln, ook)]
+    assert None in want2
+    ln, ok = st2.iterativelength(1, V2, ps, pd)
+    assert lens(ln, ok) == want2
+    # (c) caps: expansions over `bibfs_cap` entries / frontiers over `bibfs_queue` vertices leave rows to the MS-BFS path
+    for cap, queue in ((40, 1 << 17), (8 << 20, 1024)):
+        pgq.set_option("bibfs_cap", cap)
+        pgq.set_option("bibfs_queue", queue)
+        rows3 = random_graph(rng, 4000, 40000, skew=True)
+        st3, ora3 = both(4000, rows3, csr_id=2)
+        pgq.set_option("meet_cap", 200)   # most rows pass the two-hop kernels unanswered ...
+        pgq.set_option("meet4_cap", 200)
+        ps, pd = rng.integers(0, 4000, 120), rng.integers(0, 4000, 120)
+        oln, ook = ora3.lean_iterativelength(4000, ps, pd)
+        ln, ok = st3.iterativelength(2, 4000, ps, pd)
+        assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
 
 
 def test_meet_prepass_large_inputs_cross_product_vs_distinct_sources():

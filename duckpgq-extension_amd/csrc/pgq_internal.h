@@ -73,7 +73,7 @@ struct Options {
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 	int meet = 1;           // iterativelength: answer pairs at distance <= 3 by the pair-centric pre-pass (k_meet3) when cheaper
 	int meet_cap = 1 << 16; // adjacency entries a pair's two-hop walk may scan; beyond: left to the MS-BFS path
-	int meet_cap_paths = 1 << 12; // the same for shortestpath rows (their walks have no early exit; longer ones go to k_meet4)
+	int meet_cap_paths = 1 << 16; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
 	int bibfs_rows = 256;      // k_bibfs (one bidirectional search per row) runs when at most this many rows are still open (0: off)

@@ -59,10 +59,9 @@ struct MeetCounters {
 // CU has in flight (registers permitting: 5 KB of LDS each) — the workgroup is a single wavefront so that a finished
 // row frees its slot at once.  Rows are dealt round-robin (one shared counter would serialise ~10^4 claims at 12-20 ns
 // each: more than the walks take).
-// PATHS: also record the path's inner vertices (MeetPath) — the walk then has to see every witness (the tie-break
-// needs the smallest, not the first), so it has no early exit.
+// PATHS: also record the path's inner vertices (MeetPath); the walk then runs from dst over the source-ordered in-lists.
 template <bool PATHS>
-__global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : PGQ_MEET3_WAVES) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                   int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
@@ -105,8 +104,11 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : PGQ_MEET3_WAVES) void k_
 		}
 		// expand from the endpoint with the shorter list (its two-hop walk is the cheaper one, nearly always); the
 		// other endpoint's list is the set.  fwd: walk N_out(N_out(s)) against the set N_in(d).
-		bool fwd = degS <= degD;
-		if ((fwd ? degD : degS) > kMeetSetMax) fwd = !fwd;
+		// PATHS always expands from dst against the set N_out(src): the in-lists are ordered by source (built so at
+		// upload), so the walk meets the witnesses in the order of the reference's tie-break (smallest second-to-last
+		// vertex first, then the smallest vertex before it) and may stop at the first one
+		bool fwd = PATHS ? false : degS <= degD;
+		if (!PATHS && (fwd ? degD : degS) > kMeetSetMax) fwd = !fwd;
 		const int set_n = fwd ? degD : degS;
 		const int exp_n = fwd ? degS : degD;
 		{
@@ -218,8 +220,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : PGQ_MEET3_WAVES) void k_
 				}
 			};
 			seek();
-			// PATHS walks every segment to the end: fewer wavefronts, more registers, four requests in flight
-			constexpr int DEPTH = PATHS ? 4 : PGQ_MEET3_DEPTH;
+			constexpr int DEPTH = PGQ_MEET3_DEPTH;
 			int4 x[DEPTH];
 			int xb[DEPTH], xe[DEPTH], xq[DEPTH]; // the segment and position a chunk was requested from (wave-uniform)
 			u32 xv[DEPTH];                       // ... and the expanded vertex it belongs to
@@ -276,7 +277,10 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : PGQ_MEET3_WAVES) void k_
 						if (m & 8u) best = min(best, key((u32)v.w));
 					}
 				}
-				if constexpr (!PATHS) found = __any(f != 0);
+				// the first chunk with a hit ends the walk; PATHS: chunks are processed in walk order and the lists ascend, so
+				// every later witness has a larger (second vertex, first vertex) key than the smallest one of this round
+				if constexpr (PATHS) found = __any(best != ~0ull);
+				else found = __any(f != 0);
 				if (found || !any_chunk) break;
 			}
 		}
@@ -305,15 +309,19 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 4 : PGQ_MEET3_WAVES) void k_
 	}
 }
 
-// ---- distance <= 4 with a vertex bit map in LDS (k_meet4) ---------------------------------------------------------
-// For the rows k_meet3 leaves open (distance 4, or lists / walks over its caps) on graphs whose vertex bit map fits in
-// LDS (V <= ~1.2 M): one 1024-thread workgroup per row marks the forward two-hop neighbourhood of src in the bit map
-// and tests the backward one- and two-hop neighbourhoods of dst against it:
-//     B = N_out(src)                    distance 1 iff dst in B;  distance 2 iff N_in(dst) meets B
-//     B += N_out(N_out(src))            distance 3 iff N_in(dst) meets B;  distance 4 iff N_in(N_in(dst)) meets B
+// ---- distance <= 4 with an exact vertex bit map, path variant (k_meet4) ---------------------------------------------
+// For the `shortestpath` rows k_meet3<true> leaves open (distance 4, or lists / walks over its caps): one 1024-thread
+// workgroup per row, the bit map in LDS when it fits (V <= ~1.2 M), else a slice of a global buffer (GM):
+//     B = N_out(src)                    distance 1 iff dst in B;  distance 2: smallest vertex of N_in(dst) in B
+//     distance 3: backward walk (in-lists of N_in(dst)) against B -> smallest (second vertex, first vertex)
+//     B += N_out(N_out(src))            distance 4: backward walk against B -> smallest (third, second); first vertex =
+//                                       smallest in-neighbour of the second that src points at
 // (each test only runs when the smaller distances have been excluded, so the first that holds is the BFS distance).
-// The 16 wavefronts split the vertices of a one-hop list round-robin and stream their adjacency segments 16 bytes per
-// lane per request, four requests in flight each.  Rows whose two-hop walks exceed `cap` entries stay open.
+// The in-lists are ordered by source, so a backward walk meets the witnesses in the order of the reference's tie-break
+// (shortest_path.cpp:21-31: the parent of a vertex is the smallest vertex of the previous level) and a wavefront stops
+// once its lists are past the best second-to-last vertex any wavefront has published.  The 16 wavefronts split a
+// one-hop list round-robin and stream the segments 16 bytes per lane per request.  Rows whose walks exceed `cap`
+// entries stay open.  Distance-only rows take k_meet4d below.
 
 template <bool PATHS, bool GM>
 __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
@@ -324,7 +332,6 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
                                                 MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
 	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
-	__shared__ int s_flag;
 	__shared__ unsigned long long s_work[2];
 	__shared__ unsigned long long s_best;
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -358,7 +365,6 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 		const bool known4 = out_rows[row] == kMeetOpen4;
 		clear_map();
 		if (tid == 0) {
-			s_flag = 0;
 			s_work[0] = s_work[1] = 0;
 			s_best = ~0ull;
 		}
@@ -431,7 +437,49 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 				}
 				continue;
 			}
-			if ((int64_t)s_work[0] > cap || (int64_t)s_work[1] > cap) {
+			if ((int64_t)s_work[1] > cap) {
+				if (tid == 0) out_rows[row] = kMeetOpen;
+				continue;
+			}
+		}
+		// The backward walk: in-lists of N_in(dst) in list order = ascending second-to-last vertex y, entries ascending, so
+		// the smallest key (y << 32 | x) over the entries x whose bit is set is the reference's choice (smallest parent at
+		// every step back from dst).  A wavefront stops once its lists are past the best y any wavefront has published.
+		auto backward_walk = [&]() {
+			unsigned long long best = ~0ull;
+			u32 last = 0;
+			const unsigned long long e2 = meet_walk(
+			    radj + di, degD, wib, 16, roff, radj,
+			    [&](u32 x, u32 ev) {
+				    last = ev;
+				    if (bit(x)) best = min(best, (unsigned long long)ev << 32 | x);
+			    },
+			    [&]() {
+				    if (__any(best != ~0ull)) {
+					    best = wave_min_u64(best);
+					    if (lane == 0) atomicMin(&s_best, best);
+				    }
+				    const u32 by = (u32)(*(volatile unsigned long long *)&s_best >> 32);
+				    return __any(last > by) != 0;
+			    });
+			if (lane == 0) entries += e2;
+			best = wave_min_u64(best);
+			if (lane == 0 && best != ~0ull) atomicMin(&s_best, best);
+		};
+		if (!known4) {
+			backward_walk(); // distance 3: against the map of N_out(src)
+			__syncthreads();
+			if (s_best != ~0ull) {
+				if (tid == 0) {
+					if constexpr (PATHS) {
+						rec_rows[row].v1 = (int32_t)(u32)s_best;
+						rec_rows[row].v2 = (int32_t)(u32)(s_best >> 32);
+					}
+					out_rows[row] = 3;
+				}
+				continue;
+			}
+			if ((int64_t)s_work[0] > cap) {
 				if (tid == 0) out_rows[row] = kMeetOpen;
 				continue;
 			}
@@ -444,52 +492,13 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 			if (lane == 0) entries += e2;
 		}
 		__syncthreads();
-		if (!known4) {
-			min_in_neighbour_of_dst(); // distance 3: N_in(dst) meets B
-			__syncthreads();
-			if (s_best != ~0ull) {
-				const u32 v2 = (u32)s_best;
-				if constexpr (PATHS) {
-					const u32 v1 = first_inner_vertex(v2);
-					if (tid == 0) {
-						rec_rows[row].v1 = (int32_t)v1;
-						rec_rows[row].v2 = (int32_t)v2;
-					}
-				}
-				if (tid == 0) out_rows[row] = 3;
-				continue;
-			}
-		}
-		// distance 4: N_in(N_in(dst)) meets B.  PATHS: smallest (third vertex << 32 | second vertex) over all witnesses
-		{
-			bool f = false;
-			unsigned long long best = ~0ull;
-			const unsigned long long e2 = meet_walk(
-			    radj + di, degD, wib, 16, roff, radj,
-			    [&](u32 x, u32 ev) {
-				    if (bit(x)) {
-					    f = true;
-					    if constexpr (PATHS) best = min(best, (unsigned long long)ev << 32 | x);
-				    }
-			    },
-			    [&]() {
-				    if constexpr (PATHS) return false;
-				    if (__any(f)) s_flag = 1;
-				    return *(volatile int *)&s_flag != 0;
-			    });
-			if (lane == 0) entries += e2;
-			if (__any(f)) s_flag = 1;
-			if constexpr (PATHS) {
-				best = wave_min_u64(best);
-				if (lane == 0 && best != ~0ull) atomicMin(&s_best, best);
-			}
-		}
+		backward_walk(); // distance 4: third vertex y, second vertex x
 		__syncthreads();
-		const bool found4 = s_flag != 0;
-		if constexpr (PATHS) {
-			if (found4) {
-				const unsigned long long key = s_best;
-				__syncthreads();
+		const bool found4 = s_best != ~0ull;
+		if (found4) {
+			const unsigned long long key = s_best;
+			__syncthreads();
+			if constexpr (PATHS) {
 				const u32 v3 = (u32)(key >> 32), v2 = (u32)key;
 				const u32 v1 = first_inner_vertex(v2);
 				if (tid == 0) {

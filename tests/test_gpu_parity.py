@@ -17,7 +17,7 @@ def _defaults():
                  ("relax_small_limit", 2048), ("chain", 1), ("chain_cap", 4096), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 12), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
+                 ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17)):
         pgq.set_option(k, v)
     yield

@@ -324,13 +324,14 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 // entries stay open.  Distance-only rows take k_meet4d below.
 
 template <bool PATHS, bool GM>
-__global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                 int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                 const u32 *__restrict__ didx, int64_t *__restrict__ out_rows,
                                                 MeetPath *__restrict__ rec_rows, int64_t cap, int bm_words,
                                                 MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
 	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
+	const int64_t n = (int64_t)*n_rows; // rows left open by the kernel before (counted on the device: no host round trip)
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
 	__shared__ unsigned long long s_work[2];
 	__shared__ unsigned long long s_best;
@@ -536,12 +537,13 @@ __global__ __launch_bounds__(1024) void k_meet4(int64_t n, const int64_t *__rest
 //     distance 4: map = two-hop set of the cheaper endpoint, two-hop walk of the other one, ended by the first hit
 // Rows with distance >= 4 proven start at the last step (cheaper endpoint: the shorter one-hop list).
 template <bool GM>
-__global__ __launch_bounds__(1024) void k_meet4d(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                  const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                  const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                  const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
                                                  int bm_words, MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
 	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
+	const int64_t n = (int64_t)*n_rows; // rows left open by the kernel before (counted on the device: no host round trip)
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
 	__shared__ int s_flag;
 	__shared__ unsigned long long s_work[2];
@@ -922,8 +924,8 @@ int estimate_distinct_sources(Workspace *ws, int64_t n, const int64_t *d_src, in
 	PGQ_TRY(ws->meet_cnt.reserve(sizeof(MeetCounters) + 16));
 	u32 *d_out = ws->meet_cnt.as<u32>();
 	hipLaunchKernelGGL(k_sample_sources, dim3(1), dim3(1024), 0, st, n, d_src, d_out);
-	u32 h[2] = { 0, 0 };
-	PGQ_HIP_TRY(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
+	u32 *h = static_cast<u32 *>(ws->h_meet); // pinned
+	PGQ_HIP_TRY(hipMemcpyAsync(h, d_out, 2 * sizeof(u32), hipMemcpyDeviceToHost, st));
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	const double d = h[0], s = h[1];
 	if (s < 1 || d < 1) {
@@ -985,7 +987,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
 	PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
 	MeetCounters *mc = ws->meet_cnt.as<MeetCounters>();
-	u32 *d_count = reinterpret_cast<u32 *>(mc + 1);
+	u32 *d_count = reinterpret_cast<u32 *>(mc + 1); // [0] rows open after k_meet3, [1] after k_meet4 / k_meet4d
 	PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
 	{
 		const int64_t cap = std::max(1, paths ? options().meet_cap_paths : options().meet_cap);
@@ -1002,51 +1004,37 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	}
 	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
 	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
-	struct Host {
-		MeetCounters m;
-		u32 count, pad[3];
-	};
-	static thread_local Host h;
-	PGQ_HIP_TRY(hipMemcpyAsync(&h, mc, sizeof(h), hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
-	KernelTimer::flush();
-	if (h.m.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
-	unsigned long long entries = 0, vertices = 0;
-	for (int k = 0; k < kMeetStatSlots; k++) {
-		entries += h.m.entries[k];
-		vertices += h.m.vertices[k];
-	}
-	// what is left (distance >= 4, or over k_meet3's caps): the bit-map kernel.  The vertex bit map sits in LDS when it
+	// what is left (distance >= 4, or over k_meet3's caps): the bit-map kernels, launched straight behind on a fixed grid —
+	// they read the row count from the device, so the host waits once for both.  The vertex bit map sits in LDS when it
 	// fits (V <= ~1.2 M); above that every workgroup gets a slice of a global buffer (L2-resident: 0.5 MB at V = 4 M).
 	const int bm_words = (int)((c->V + 127) / 128) * 4;
 	const bool lds_map = (size_t)bm_words * 4 + 512 <= (size_t)std::min(150, std::max(0, options().meet4_lds_kb)) * 1024;
 	const size_t gm_budget = (size_t)std::max(0, options().meet4_global_mb) << 20;
-	if (h.count > 0 && options().meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget)) {
+	const bool run4 = options().meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget);
+	if (run4) {
 		static std::atomic<int> attr_set { 0 };
 		if (!attr_set.load()) {
 			(void)hipFuncSetAttribute((const void *)k_meet4d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 			(void)hipFuncSetAttribute((const void *)k_meet4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 			attr_set.store(1);
 		}
-		const u32 nd = h.count;
-		u32 grid = std::min<u32>(nd, 256 * 4);
+		u32 grid = (u32)std::min<int64_t>(n, 256 * 4);
 		u32 *gmaps = nullptr;
 		if (!lds_map) {
-			grid = (u32)std::max<size_t>(1, std::min<size_t>(std::min<u32>(nd, 256), gm_budget / ((size_t)bm_words * 4)));
+			grid = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, 256), gm_budget / ((size_t)bm_words * 4)));
 			PGQ_TRY(ws->meet_maps.reserve((size_t)grid * bm_words * 4));
 			gmaps = ws->meet_maps.as<u32>();
 		}
 		const size_t lds = lds_map ? (size_t)bm_words * 4 : 0;
 		const int64_t cap4 = (int64_t)std::max(1, options().meet4_cap);
-		PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
 		{
 			KernelTimer kt(st, K_MEET);
 #define PGQ_MEET4(G)                                                                                                     \
-	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid), dim3(1024), lds, st, (int64_t)nd, ws->def_src.as<int64_t>(),       \
+	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid), dim3(1024), lds, st, (const u32 *)d_count, ws->def_src.as<int64_t>(), \
 	                   ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, rec, \
 	                   cap4, bm_words, mc, gmaps)
 #define PGQ_MEET4D(G)                                                                                                    \
-	hipLaunchKernelGGL((k_meet4d<G>), dim3(grid), dim3(1024), lds, st, (int64_t)nd, ws->def_src.as<int64_t>(),            \
+	hipLaunchKernelGGL((k_meet4d<G>), dim3(grid), dim3(1024), lds, st, (const u32 *)d_count, ws->def_src.as<int64_t>(),   \
 	                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, cap4,    \
 	                   bm_words, mc, gmaps)
 			if (paths && lds_map) PGQ_MEET4(false);
@@ -1058,14 +1046,24 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			kt.stop();
 		}
 		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
-		PGQ_HIP_TRY(hipMemcpyAsync(&h, mc, sizeof(h), hipMemcpyDeviceToHost, st));
-		PGQ_HIP_TRY(hipStreamSynchronize(st));
-		KernelTimer::flush();
-		for (int k = 0; k < kMeetStatSlots; k++) {
-			entries += h.m.entries[k];
-			vertices += h.m.vertices[k];
-		}
+		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count + 1);
+	}
+	struct Host {
+		MeetCounters m;
+		u32 count_after3, count_after4, pad[2];
+		u32 count;
+	};
+	static_assert(sizeof(Host) <= 8192, "pinned statistics block too small");
+	Host &h = *static_cast<Host *>(ws->h_meet);
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, mc, sizeof(MeetCounters) + 16, hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	if (h.m.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+	h.count = run4 ? h.count_after4 : h.count_after3;
+	unsigned long long entries = 0, vertices = 0;
+	for (int k = 0; k < kMeetStatSlots; k++) {
+		entries += h.m.entries[k];
+		vertices += h.m.vertices[k];
 	}
 	// a handful of rows still open (far apart, unreachable, over the caps): one bidirectional search each, so that the
 	// lane-batched search — whole-graph levels — only starts for what really needs it
@@ -1100,9 +1098,10 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		}
 		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
 		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
-		PGQ_HIP_TRY(hipMemcpyAsync(&h, mc, sizeof(h), hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, mc, sizeof(MeetCounters) + 16, hipMemcpyDeviceToHost, st));
 		PGQ_HIP_TRY(hipStreamSynchronize(st));
 		KernelTimer::flush();
+		h.count = h.count_after3; // the counter block was cleared: slot [0] now counts what k_bibfs left open
 		for (int k = 0; k < kMeetStatSlots; k++) {
 			entries += h.m.entries[k];
 			vertices += h.m.vertices[k];

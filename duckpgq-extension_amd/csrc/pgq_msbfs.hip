@@ -373,15 +373,26 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 			const int nb = lane < c64 ? radj[base + lane] : 0;
 			// which lane-words of that in-neighbour are non-empty (4-byte lookup, L2 resident) ...
 			const u32 nzb = lane < c64 ? nz_cur[nb] : 0u;
+			// gather only words that are non-empty there and still wanted here.  All WD loads of a chunk are issued before
+			// the first one is used, and they are unconditional (a load under a per-lane condition is waited for at the end
+			// of its branch): lanes with nothing to fetch read word `word` of row 0 — one cached line — and drop it
+			constexpr int GRP = WD < 8 ? WD : 8; // loads in flight per lane
 #pragma unroll
-			for (int r = 0; r < WD; r++) {
-				const int j = r * NS + slot;
-				const int nbj = __shfl(nb, j);
-				const u32 nzj = __shfl(nzb, j);
-				// ... gather only words that are non-empty there and still wanted here
-				if (want != 0 && ((nzj >> word) & 1u)) {
-					acc |= visit[(size_t)nbj * WD + word];
-					gath++;
+			for (int r0 = 0; r0 < WD; r0 += GRP) {
+				u64 w[GRP];
+				bool hot[GRP];
+#pragma unroll
+				for (int g = 0; g < GRP; g++) {
+					const int j = (r0 + g) * NS + slot;
+					const int nbj = __shfl(nb, j);
+					const u32 nzj = __shfl(nzb, j);
+					hot[g] = want != 0 && ((nzj >> word) & 1u);
+					w[g] = visit[hot[g] ? (size_t)nbj * WD + word : (size_t)word];
+				}
+#pragma unroll
+				for (int g = 0; g < GRP; g++) {
+					acc |= hot[g] ? w[g] : 0ull;
+					gath += hot[g] ? 1u : 0u;
 				}
 			}
 			scanned += (u64)c64;
@@ -835,14 +846,23 @@ __global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ it
 		const int c64 = (int)min((int64_t)64, it.end - base);
 		const int nb = lane < c64 ? radj[base + lane] : 0;
 		const u32 nzb = lane < c64 ? nz_cur[nb] : 0u;
+		constexpr int GRP = WD < 8 ? WD : 8; // unconditional loads, GRP in flight per lane (see k_pull)
 #pragma unroll
-		for (int r = 0; r < WD; r++) {
-			const int j = r * NS + slot;
-			const int nbj = __shfl(nb, j);
-			const u32 nzj = __shfl(nzb, j);
-			if (want != 0 && ((nzj >> word) & 1u)) {
-				acc |= visit[(size_t)nbj * WD + word];
-				gath++;
+		for (int r0 = 0; r0 < WD; r0 += GRP) {
+			u64 w[GRP];
+			bool hot[GRP];
+#pragma unroll
+			for (int g = 0; g < GRP; g++) {
+				const int j = (r0 + g) * NS + slot;
+				const int nbj = __shfl(nb, j);
+				const u32 nzj = __shfl(nzb, j);
+				hot[g] = want != 0 && ((nzj >> word) & 1u);
+				w[g] = visit[hot[g] ? (size_t)nbj * WD + word : (size_t)word];
+			}
+#pragma unroll
+			for (int g = 0; g < GRP; g++) {
+				acc |= hot[g] ? w[g] : 0ull;
+				gath += hot[g] ? 1u : 0u;
 			}
 		}
 		scanned += (u64)c64;
@@ -1178,6 +1198,7 @@ __global__ void k_trivial_paths(int64_t lo, int64_t hi, const int32_t *__restric
 Workspace::~Workspace() {
 	if (stream) (void)hipStreamDestroy(stream);
 	if (h_cnt) (void)hipHostFree(h_cnt);
+	if (h_meet) (void)hipHostFree(h_meet);
 	if (h_bstart) (void)hipHostFree(h_bstart);
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
@@ -1209,7 +1230,8 @@ int WorkspaceLease::acquire() {
 		ws->device = current_device();
 		// a half-built workspace never reaches the pool
 		if (hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess ||
-		    hipHostMalloc((void **)&ws->h_cnt, sizeof(Counters)) != hipSuccess) {
+		    hipHostMalloc((void **)&ws->h_cnt, sizeof(Counters)) != hipSuccess ||
+		    hipHostMalloc(&ws->h_meet, 8192) != hipSuccess) {
 			delete ws;
 			ws = nullptr;
 			return fail(PGQ_ERR_HIP, "cannot create a search workspace (stream / pinned counter block)");

@@ -38,6 +38,7 @@ struct Workspace {
 	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps;
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
+	void *h_meet = nullptr;    // pinned, 8 KB: the pre-pass statistics come back here (a pageable target is staged by the runtime)
 	int64_t *h_bstart = nullptr;
 	size_t h_bstart_cap = 0;
 	u32 epoch = 0;

@@ -321,7 +321,7 @@ class DeviceCSR:
         _check(self.L.pgq_iterativelength(self.h, self.V, n, sv, dv, _p(out), _p(ov)))
         return out, unpack_validity(ov, n)
 
-    def shortestpath(self, src, dst, src_valid=None, src_sel=None, dst_sel=None):
+    def shortestpath(self, src, dst, src_valid=None, src_sel=None, dst_sel=None, raw=False):
         keep = []
         sv, dv, n = self._vecs(src, dst, src_valid, src_sel, dst_sel, None, keep)
         off = np.zeros(n, dtype=np.uint64)
@@ -334,6 +334,8 @@ class DeviceCSR:
         ch = np.zeros(0, dtype=np.int64)
         if clen.value:
             ch = np.ctypeslib.as_array(C.cast(child, C.POINTER(C.c_int64)), shape=(clen.value,)).copy()
+        if raw:  # the LIST vector as DuckDB sees it: list_entry_t{offset,length} per row, validity words, child payload
+            return off, ln, ov, ch
         return _lists(off, ln, unpack_validity(ov, n), ch)
 
     def cheapest_path_length(self, src, dst, src_valid=None, dst_valid=None):

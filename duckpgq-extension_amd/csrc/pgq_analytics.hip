@@ -323,7 +323,7 @@ int pgq_local_clustering_coefficient(pgq_csr_t *csr, int64_t V, int64_t n, pgq_v
 	PGQ_TRY(ws->out_val.reserve((size_t)n * 4));
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, fp.src.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
 	PGQ_TRY(lcc_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->out_val.as<float>()));
-	PGQ_HIP_TRY(hipMemcpy(out, ws->out_val.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	PGQ_TRY(staged_download(out, ws->out_val.p, (size_t)n * 4, ws->stream));
 	mask_fill_valid(out_valid, n);
 	for (int64_t i = 0; i < n; i++)
 		if (fp.src[i] < 0) mask_set_invalid(out_valid, i); // local_clustering_coefficient.cpp:39-41
@@ -367,8 +367,8 @@ int pgq_pagerank(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, double *ou
 	                   csr->pagerank, ws->out_val.as<double>(), ws->out_ok.as<uint8_t>());
 	std::vector<uint8_t> ok((size_t)n);
 	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
-	PGQ_HIP_TRY(hipMemcpy(out, ws->out_val.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-	PGQ_HIP_TRY(hipMemcpy(ok.data(), ws->out_ok.p, (size_t)n, hipMemcpyDeviceToHost));
+	PGQ_TRY(staged_download(out, ws->out_val.p, (size_t)n * 8, ws->stream));
+	PGQ_TRY(staged_download(ok.data(), ws->out_ok.p, (size_t)n, ws->stream));
 	mask_fill_valid(out_valid, n);
 	for (int64_t i = 0; i < n; i++)
 		if (!ok[(size_t)i]) mask_set_invalid(out_valid, i);

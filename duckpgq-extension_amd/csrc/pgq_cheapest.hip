@@ -527,8 +527,8 @@ int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src
 		                             ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>(), true);
 	PGQ_TRY(rc);
 	std::vector<uint8_t> ok(n);
-	PGQ_HIP_TRY(hipMemcpy(out, ws->out_val.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-	PGQ_HIP_TRY(hipMemcpy(ok.data(), ws->out_ok.p, (size_t)n, hipMemcpyDeviceToHost));
+	PGQ_TRY(staged_download(out, ws->out_val.p, (size_t)n * 8, ws->stream));
+	PGQ_TRY(staged_download(ok.data(), ws->out_ok.p, (size_t)n, ws->stream));
 	mask_fill_valid(out_valid, n);
 	for (int64_t i = 0; i < n; i++)
 		if (!ok[i]) mask_set_invalid(out_valid, i);

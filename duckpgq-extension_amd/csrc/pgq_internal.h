@@ -188,6 +188,10 @@ template <typename T> inline int dev_alloc_as(T **out, size_t count) {
 	return rc;
 }
 
+// device -> pageable host memory through a pinned block (a pageable hipMemcpy D2H is staged by the runtime at well under
+// 1 GB/s on these boxes); waits for `st`
+int staged_download(void *h_dst, const void *d_src, size_t bytes, hipStream_t st);
+
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;

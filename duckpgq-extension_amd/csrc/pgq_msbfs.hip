@@ -2087,7 +2087,7 @@ int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, con
 		SearchOutput so;
 		PGQ_TRY(search_device(csr->replicas[(size_t)k], ws, hi - lo, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
 		                      ws->out_len.as<int64_t>(), false, nullptr, nullptr, 0, so));
-		PGQ_HIP_TRY(hipMemcpy(out_len + lo, ws->out_len.p, bytes, hipMemcpyDeviceToHost));
+		PGQ_TRY(staged_download(out_len + lo, ws->out_len.p, bytes, ws->stream));
 		return PGQ_OK;
 	};
 	std::vector<std::thread> pool;
@@ -2132,7 +2132,7 @@ int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq
 	SearchOutput so;
 	PGQ_TRY(search_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
 	                      false, nullptr, nullptr, 0, so));
-	PGQ_HIP_TRY(hipMemcpy(out_len, ws->out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	PGQ_TRY(staged_download(out_len, ws->out_len.p, (size_t)n * 8, ws->stream));
 	mask_fill_valid(out_valid, n);
 	for (int64_t i = 0; i < n; i++)
 		if (out_len[i] < 0) mask_set_invalid(out_valid, i); // payload stays -1 like iterativelength.cpp:100,137
@@ -2163,11 +2163,11 @@ int pgq_shortestpath(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_ve
 	PGQ_TRY(search_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
 	                      true, ws->out_off.as<int64_t>(), nullptr, 0, so));
 	std::vector<int64_t> len(n), off(n);
-	PGQ_HIP_TRY(hipMemcpy(len.data(), ws->out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-	PGQ_HIP_TRY(hipMemcpy(off.data(), ws->out_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	PGQ_TRY(staged_download(len.data(), ws->out_len.p, (size_t)n * 8, ws->stream));
+	PGQ_TRY(staged_download(off.data(), ws->out_off.p, (size_t)n * 8, ws->stream));
 	t_child.resize((size_t)so.child_used);
 	if (so.child_used > 0)
-		PGQ_HIP_TRY(hipMemcpy(t_child.data(), ws->child.p, (size_t)so.child_used * 8, hipMemcpyDeviceToHost));
+		PGQ_TRY(staged_download(t_child.data(), ws->child.p, (size_t)so.child_used * 8, ws->stream));
 	mask_fill_valid(out_valid, n);
 	for (int64_t i = 0; i < n; i++) {
 		if (len[i] < 0) {

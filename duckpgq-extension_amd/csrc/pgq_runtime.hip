@@ -533,7 +533,7 @@ static int staged_upload(void *d_dst, const void *h_src, size_t n_elems, size_t 
 }
 
 // device -> pageable host through one pinned block at a time (a pageable hipMemcpy D2H ran at ~0.6 GB/s here)
-static int staged_download(void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {
+int staged_download(void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {
 	void *blk = g_pinned.get();
 	if (!blk) return fail(PGQ_ERR_OOM, "hipHostMalloc of a staging block failed");
 	int rc = PGQ_OK;

@@ -56,11 +56,12 @@ except ImportError:
 for n in (1, 64, 2048):
     ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
     for fn in ("iterativelength", "shortestpath"):
-        getattr(dev, fn)(ps, pd)
+        kw = {"raw": True} if fn == "shortestpath" else {}  # the LIST vector's arrays, no Python lists
+        getattr(dev, fn)(ps, pd, **kw)
         ts = []
         for _ in range(5):
             t = time.perf_counter()
-            getattr(dev, fn)(ps, pd)
+            getattr(dev, fn)(ps, pd, **kw)
             ts.append(time.perf_counter() - t)
         out["%s_n%d_ms" % (fn, n)] = min(ts) * 1e3
 # the binder's shape: one source x all vertices (cross product), 2048-row chunks

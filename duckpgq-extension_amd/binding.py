@@ -84,6 +84,9 @@ def load_hip():
     L.pgq_pagerank.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, C.c_void_p, C.c_void_p]
     L.pgq_pagerank_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.pgq_iterativelength_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pgq_shortestpath_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.POINTER(C.c_int64)]
+    L.pgq_cheapest_path_length_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pgq_init_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.pgq_init_mask.argtypes = [C.c_uint64]
     L.pgq_csr_replicate.argtypes = [C.c_void_p]
@@ -377,6 +380,30 @@ class DeviceCSR:
         out = np.zeros(len(src), dtype=np.int64)
         _check(self.L.pgq_iterativelength_multi(self.h, len(src), _p(src), _p(dst), _p(out)))
         return out
+
+    def shortestpath_multi(self, src, dst):
+        """Paths of host rows by every enabled device; returns (lengths, offsets, child) like the bulk form."""
+        src, dst = _i64(src), _i64(dst)
+        n = len(src)
+        ln, off = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        used = C.c_int64(0)
+        cap = max(1024, 16 * n)
+        for _ in range(2):
+            child = np.zeros(cap, dtype=np.int64)
+            rc = self.L.pgq_shortestpath_multi(self.h, n, _p(src), _p(dst), _p(ln), _p(off), _p(child), cap, C.byref(used))
+            if rc == 0 or used.value <= cap:
+                break
+            cap = used.value  # too small: the call reported what it needs
+        _check(rc)
+        return ln, off, child[:used.value]
+
+    def cheapest_path_length_multi(self, src, dst):
+        src, dst = _i64(src), _i64(dst)
+        n = len(src)
+        out = np.zeros(n, dtype=np.int64 if self.w_type == 1 else np.float64)
+        ok = np.zeros(n, dtype=np.uint8)
+        _check(self.L.pgq_cheapest_path_length_multi(self.h, n, _p(src), _p(dst), _p(out), _p(ok)))
+        return out, ok.astype(bool)
 
     def replicate(self):
         _check(self.L.pgq_csr_replicate(self.h))

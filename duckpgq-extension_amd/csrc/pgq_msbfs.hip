@@ -1992,6 +1992,48 @@ using namespace pgq;
 // per-thread arena for list payloads returned by the chunk API
 static thread_local std::vector<int64_t> t_child;
 
+// body(k, lo, hi, replica, ws): shard k = rows [lo, hi) on device k's replica, called on a thread bound to that device
+template <typename Body>
+static int run_shards(pgq_csr_t *csr, int64_t n, Body body) {
+	PGQ_TRY(pgq_csr_replicate(csr));
+	const std::vector<int> devs = enabled_devices();
+	const int W = (int)devs.size();
+	const int64_t per = (n + W - 1) / W;
+	std::vector<int> rcs((size_t)W, PGQ_OK);
+	std::vector<std::string> errs((size_t)W);
+	std::vector<pgq_stats_t> wstats((size_t)W);
+	auto shard = [&](int k) -> int {
+		const int64_t lo = std::min<int64_t>((int64_t)k * per, n), hi = std::min<int64_t>(lo + per, n);
+		if (hi == lo) return PGQ_OK;
+		bind_thread_device(devs[(size_t)k]);
+		PGQ_TRY(ensure_init());
+		WorkspaceLease lease;
+		PGQ_TRY(lease.acquire());
+		return body(k, lo, hi, csr->replicas[(size_t)k], lease.ws);
+	};
+	std::vector<std::thread> pool;
+	for (int k = 1; k < W; k++)
+		pool.emplace_back([&, k]() {
+			(void)pgq_reset_stats();
+			rcs[(size_t)k] = shard(k);
+			if (rcs[(size_t)k] != PGQ_OK) errs[(size_t)k] = pgq_last_error();
+			wstats[(size_t)k] = tstats().s;
+		});
+	rcs[0] = shard(0);
+	bind_thread_device(-1);
+	(void)ensure_init();
+	for (auto &th : pool) th.join();
+	int rc = PGQ_OK;
+	for (int k = 0; k < W; k++) {
+		if (rcs[(size_t)k] != PGQ_OK && rc == PGQ_OK) {
+			rc = rcs[(size_t)k];
+			if (k > 0) set_error(errs[(size_t)k]);
+		}
+		if (k > 0) merge_stats(tstats().s, wstats[(size_t)k]);
+	}
+	return rc;
+}
+
 extern "C" {
 
 void pgq_thread_release(void) {
@@ -2063,21 +2105,7 @@ int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, con
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!src || !dst || !out_len))) return fail(PGQ_ERR_INVALID_ARG, "NULL array");
 	if (n == 0) return PGQ_OK;
-	PGQ_TRY(pgq_csr_replicate(csr));
-	const std::vector<int> devs = enabled_devices();
-	const int W = (int)devs.size();
-	const int64_t per = (n + W - 1) / W;
-	std::vector<int> rcs((size_t)W, PGQ_OK);
-	std::vector<std::string> errs((size_t)W);
-	std::vector<pgq_stats_t> wstats((size_t)W);
-	auto shard = [&](int k) -> int {
-		const int64_t lo = std::min<int64_t>((int64_t)k * per, n), hi = std::min<int64_t>(lo + per, n);
-		if (hi == lo) return PGQ_OK;
-		bind_thread_device(devs[(size_t)k]);
-		PGQ_TRY(ensure_init());
-		WorkspaceLease lease;
-		PGQ_TRY(lease.acquire());
-		Workspace *ws = lease.ws;
+	return run_shards(csr, n, [&](int, int64_t lo, int64_t hi, pgq_csr_t *replica, Workspace *ws) -> int {
 		const size_t bytes = (size_t)(hi - lo) * 8;
 		PGQ_TRY(ws->in_src.reserve(bytes));
 		PGQ_TRY(ws->in_dst.reserve(bytes));
@@ -2085,32 +2113,102 @@ int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, con
 		PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, src + lo, bytes, hipMemcpyHostToDevice, ws->stream));
 		PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, dst + lo, bytes, hipMemcpyHostToDevice, ws->stream));
 		SearchOutput so;
-		PGQ_TRY(search_device(csr->replicas[(size_t)k], ws, hi - lo, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
+		PGQ_TRY(search_device(replica, ws, hi - lo, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(),
 		                      ws->out_len.as<int64_t>(), false, nullptr, nullptr, 0, so));
-		PGQ_TRY(staged_download(out_len + lo, ws->out_len.p, bytes, ws->stream));
-		return PGQ_OK;
-	};
-	std::vector<std::thread> pool;
-	for (int k = 1; k < W; k++)
-		pool.emplace_back([&, k]() {
-			(void)pgq_reset_stats();
-			rcs[(size_t)k] = shard(k);
-			if (rcs[(size_t)k] != PGQ_OK) errs[(size_t)k] = pgq_last_error();
-			wstats[(size_t)k] = tstats().s;
-		});
-	rcs[0] = shard(0);
-	bind_thread_device(-1);
-	(void)ensure_init();
-	for (auto &th : pool) th.join();
-	int rc = PGQ_OK;
-	for (int k = 0; k < W; k++) {
-		if (rcs[(size_t)k] != PGQ_OK && rc == PGQ_OK) {
-			rc = rcs[(size_t)k];
-			if (k > 0) set_error(errs[(size_t)k]);
+		return staged_download(out_len + lo, ws->out_len.p, bytes, ws->stream);
+	});
+}
+
+// shortestpath on all enabled devices: every shard writes its lists into its own device buffer (grown once if the first
+// guess was too small), the payloads are then concatenated in shard order into `child` and the list offsets shifted by
+// the preceding shards' sizes — the gather of the ragged [v,e,v,...] lists.
+int pgq_shortestpath_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len,
+                           int64_t *out_offset, int64_t *child, int64_t child_cap, int64_t *child_used) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (n < 0 || (n > 0 && (!src || !dst || !out_len || !out_offset)) || child_cap < 0 || (child_cap > 0 && !child))
+		return fail(PGQ_ERR_INVALID_ARG, "NULL array");
+	if (child_used) *child_used = 0;
+	if (n == 0) return PGQ_OK;
+	const size_t W = enabled_devices().size();
+	std::vector<std::vector<int64_t>> payload(W);
+	std::vector<int64_t> shard_lo(W, 0), shard_hi(W, 0);
+	PGQ_TRY(run_shards(csr, n, [&](int k, int64_t lo, int64_t hi, pgq_csr_t *replica, Workspace *ws) -> int {
+		const int64_t m = hi - lo;
+		const size_t bytes = (size_t)m * 8;
+		PGQ_TRY(ws->in_src.reserve(bytes));
+		PGQ_TRY(ws->in_dst.reserve(bytes));
+		PGQ_TRY(ws->out_len.reserve(bytes));
+		PGQ_TRY(ws->out_off.reserve(bytes));
+		PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, src + lo, bytes, hipMemcpyHostToDevice, ws->stream));
+		PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, dst + lo, bytes, hipMemcpyHostToDevice, ws->stream));
+		DevBuf dchild; // not a workspace buffer: search_device uses ws->child for its own staging
+		int64_t cap = std::max<int64_t>(16 * m, 1024), used = 0;
+		int rc = PGQ_OK;
+		for (int attempt = 0; attempt < 2; attempt++) {
+			rc = dchild.reserve((size_t)cap * 8);
+			if (rc != PGQ_OK) break;
+			SearchOutput so;
+			rc = search_device(replica, ws, m, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
+			                   true, ws->out_off.as<int64_t>(), dchild.as<int64_t>(), cap, so);
+			used = so.child_used;
+			if (rc == PGQ_OK || used <= cap) break;
+			cap = used; // too small: the search reported what it needs
 		}
-		if (k > 0) merge_stats(tstats().s, wstats[(size_t)k]);
+		if (rc == PGQ_OK) rc = staged_download(out_len + lo, ws->out_len.p, bytes, ws->stream);
+		if (rc == PGQ_OK) rc = staged_download(out_offset + lo, ws->out_off.p, bytes, ws->stream);
+		if (rc == PGQ_OK) {
+			payload[(size_t)k].resize((size_t)used);
+			if (used > 0) rc = staged_download(payload[(size_t)k].data(), dchild.p, (size_t)used * 8, ws->stream);
+		}
+		shard_lo[(size_t)k] = lo;
+		shard_hi[(size_t)k] = hi;
+		dchild.release();
+		return rc;
+	}));
+	int64_t total = 0;
+	for (size_t k = 0; k < W; k++) total += (int64_t)payload[k].size();
+	if (child_used) *child_used = total;
+	if (total > child_cap) return fail(PGQ_ERR_INVALID_ARG, "child buffer too small for the path lists (see *child_used)");
+	int64_t base = 0;
+	for (size_t k = 0; k < W; k++) {
+		if (!payload[k].empty()) memcpy(child + base, payload[k].data(), payload[k].size() * 8);
+		if (base)
+			for (int64_t i = shard_lo[k]; i < shard_hi[k]; i++)
+				if (out_len[i] >= 0) out_offset[i] += base;
+		base += (int64_t)payload[k].size();
 	}
-	return rc;
+	return PGQ_OK;
+}
+
+// cheapest_path_length on all enabled devices: out = n values (int64 or double by the CSR's weight type), out_valid = n
+// bytes (1 = a path exists)
+int pgq_cheapest_path_length_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, void *out,
+                                   uint8_t *out_valid) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
+	if (n < 0 || (n > 0 && (!src || !dst || !out || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL array");
+	if (n == 0) return PGQ_OK;
+	return run_shards(csr, n, [&](int, int64_t lo, int64_t hi, pgq_csr_t *replica, Workspace *ws) -> int {
+		const int64_t m = hi - lo;
+		const size_t bytes = (size_t)m * 8;
+		DevBuf d_src, d_dst, d_val, d_ok; // the bulk entry point leases its own workspace
+		int rc = d_src.reserve(bytes);
+		if (rc == PGQ_OK) rc = d_dst.reserve(bytes);
+		if (rc == PGQ_OK) rc = d_val.reserve(bytes);
+		if (rc == PGQ_OK) rc = d_ok.reserve((size_t)m);
+		if (rc == PGQ_OK && (hipMemcpyAsync(d_src.p, src + lo, bytes, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
+		                     hipMemcpyAsync(d_dst.p, dst + lo, bytes, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
+		                     hipStreamSynchronize(ws->stream) != hipSuccess))
+			rc = fail(PGQ_ERR_HIP, "copying a shard's rows to its device failed");
+		if (rc == PGQ_OK)
+			rc = pgq_cheapest_path_length_bulk_device(replica, m, d_src.as<int64_t>(), d_dst.as<int64_t>(), d_val.p,
+			                                          d_ok.as<uint8_t>());
+		if (rc == PGQ_OK) rc = staged_download(static_cast<char *>(out) + (size_t)lo * 8, d_val.p, bytes, ws->stream);
+		if (rc == PGQ_OK) rc = staged_download(out_valid + lo, d_ok.p, (size_t)m, ws->stream);
+		for (DevBuf *b : { &d_src, &d_dst, &d_val, &d_ok }) b->release();
+		return rc;
+	});
 }
 
 int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,

@@ -714,6 +714,7 @@ def test_in_library_multi_gpu_shards_and_gathers():
     V, E = 40000, 600000
     s, d, e = random_graph(rng, V, E)
     off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    off_ = off
     dev = pgq.DeviceCSR(V, off, adj, eid)
     ora = OracleCSR.adopt(V, off, adj, eid)
     n = 9001
@@ -727,6 +728,27 @@ def test_in_library_multi_gpu_shards_and_gathers():
             pgq.set_option("meet", meet)
             got = dev.iterativelength_multi(ps, pd)
             assert (got == want).all()
+        # paths: every shard's ragged lists gathered behind each other, offsets shifted by the preceding shards' sizes
+        m = 3001
+        opaths = ora.lean_shortestpath(V, np.maximum(ps[:m], 0), pd[:m])
+        for meet in (1, 0):
+            pgq.set_option("meet", meet)
+            ln, off, child = dev.shortestpath_multi(ps[:m], pd[:m])
+            got = [None if ln[i] < 0 else child[off[i]:off[i] + 2 * ln[i] + 1].tolist() for i in range(m)]
+            assert got == [p if ps[i] >= 0 else None for i, p in enumerate(opaths)]
+            assert len(child) == sum(len(p) for p in got if p is not None)
+        # weighted: both weight types
+        for wt in (np.int64, np.float64):
+            w = rng.integers(1, 50, len(adj)).astype(wt)
+            if wt is np.float64:
+                w = w / 7.0
+            devw = pgq.DeviceCSR(V, off_, adj, eid, w)
+            oraw = OracleCSR.adopt(V, off_, adj, eid, w)
+            k = 600
+            want_w, want_ok = oraw.lean_cheapest_path_length(V, ps[5:5 + k], pd[5:5 + k])
+            got_w, got_ok = devw.cheapest_path_length_multi(ps[5:5 + k], pd[5:5 + k])
+            assert (got_ok == want_ok).all() and (got_w[want_ok] == want_w[want_ok]).all()
+            devw.close()
     finally:
         pgq.init_devices([0])
 

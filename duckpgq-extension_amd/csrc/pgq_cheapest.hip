@@ -17,7 +17,10 @@
 // dirty[parity][V] = 64-bit mask of lanes of v that improved in the previous round.  A lane is one distinct
 // source.  Rounds are kernel launches: improvements made in round r are consumed in round r+1, so no
 // intra-kernel visibility between XCDs is needed.
+#include <hipcub/hipcub.hpp>
+
 #include <cstddef>
+#include <mutex>
 #include <limits>
 #include <type_traits>
 
@@ -299,6 +302,403 @@ __global__ void k_apply_open_rows(int64_t nd, const u32 *__restrict__ didx, cons
 	ok[didx[j]] = dok[j];
 }
 
+// ---- weighted pairs on general graphs: bidirectional band-wise label correcting per row (k_wbibfs, int64 weights) ------
+// The batched relaxation below computes, per lane, the distances from the source to EVERY vertex it can reach: on the
+// weighted knows graph that is the whole graph per distinct source (8.6 visits per edge, 725 pairs/s in round 1).  A
+// single pair needs far less: the forward ball of src and the backward ball of dst, each of about half the distance.
+// One 1024-thread workgroup per row runs delta-stepping from both ends (a row-private distance array per side in global
+// memory, reset through the list of touched vertices; near / far vertex queues per side):
+//     expand the side with the smaller radius by one band [r, r + delta): relax the near queue to its fixpoint (a vertex
+//     improved to below r + delta goes back into the near queue, others into the far queue); every improvement of a vertex
+//     the other side has labelled offers  best = min(best, new label + other side's label)
+//     the band is complete: r += delta; stop when r_fwd + r_bwd >= best; refill the near queue from the far queue
+//     (skipping bands without vertices); an empty far queue means that side's closure is exhausted
+// Exactness (int64 sums, any order): when r_fwd + r_bwd >= best > D were to hold, take the last vertex x of an optimal path
+// with d_fwd(x) < r_fwd and its successor y: d_bwd(y) = D - d_fwd(y) <= D - r_fwd < r_bwd, so both are final, and the later
+// of "x relaxed forward" / "y relaxed backward" has offered d_fwd(x) + w + d_bwd(y) = D.  Checked against Dijkstra in a
+// Python model of exactly this schedule (zero weights, band skipping, duplicates in the queues) before it was written here.
+// A row whose queues or work exceed their caps stays open (ok = 2) and goes to the batched relaxation.
+constexpr long long kWbInf = 1LL << 62;
+struct WbCounters {
+	u32 open;
+	u32 pad;
+	unsigned long long relaxed;
+};
+
+__global__ void k_iota32(int64_t n, u32 *__restrict__ out) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (u32)i;
+}
+__global__ void k_gather_weights(int64_t n, const u32 *__restrict__ slot, const int64_t *__restrict__ w, int64_t *__restrict__ rw) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) rw[i] = w[slot[i]];
+}
+
+// adjacency walk of a vertex list with each vertex's 64-bit payload (its own label) and the slot position of a lane's four
+// entries (for the weights): g(v, valid, payload, t)
+template <typename G>
+__device__ __forceinline__ unsigned long long wb_walk(const u32 *__restrict__ list, int list_n, int w, int stride,
+                                                      const int64_t *__restrict__ xoff, const int32_t *__restrict__ xadj,
+                                                      const long long *__restrict__ pay, G g) {
+	const int lane = threadIdx.x & 63;
+	unsigned long long entries = 0;
+	for (int pb = w; pb < list_n; pb += 64 * stride) {
+		int vb = 0, ve = 0;
+		long long pv = 0;
+		const int p = pb + lane * stride;
+		if (p < list_n) {
+			const u32 vid = list[p];
+			vb = (int)xoff[vid];
+			ve = (int)xoff[vid + 1];
+			pv = __hip_atomic_load(&pay[vid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		const int cnt = min(64, (list_n - pb + stride - 1) / stride);
+		int j = -1, q = 0, e = 0, b = 0;
+		long long cp = 0;
+		auto seek = [&]() {
+			for (j++; j < cnt; j++) {
+				b = __builtin_amdgcn_readlane(vb, j);
+				e = __builtin_amdgcn_readlane(ve, j);
+				if (e > b) {
+					q = b & ~3;
+					const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)pv, j);
+					const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)((unsigned long long)pv >> 32), j);
+					cp = (long long)(((unsigned long long)hi << 32) | lo);
+					return;
+				}
+			}
+		};
+		seek();
+		while (j < cnt) { // one chunk at a time: the callback's own memory operations are the long part
+			const int t = q + 4 * lane;
+			typedef int v4i __attribute__((ext_vector_type(4)));
+			const v4i r = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(xadj + (t < e ? t : q)));
+			const u32 valid = (u32)(t >= b && t < e) | ((u32)(t + 1 >= b && t + 1 < e) << 1) |
+			                  ((u32)(t + 2 >= b && t + 2 < e) << 2) | ((u32)(t + 3 >= b && t + 3 < e) << 3);
+			entries += (unsigned long long)(min(e, q + 256) - max(b, q));
+			const long long cur = cp;
+			q += 256;
+			if (q >= e) seek();
+			g(make_int4(r.x, r.y, r.z, r.w), valid, cur, t);
+		}
+	}
+	return entries;
+}
+
+__global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                 const u32 *__restrict__ didx, const int64_t *__restrict__ off,
+                                                 const int32_t *__restrict__ adj, const int64_t *__restrict__ w,
+                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                 const int64_t *__restrict__ rw, int64_t V, long long delta,
+                                                 long long work_cap, int qcap, long long *__restrict__ dist_all,
+                                                 u32 *__restrict__ queues_all, int64_t *__restrict__ out,
+                                                 uint8_t *__restrict__ ok, WbCounters *__restrict__ wc) {
+	// per workgroup: dist[side][V + 1] (entry V takes the masked lanes), near[side][parity][qcap], far[side][qcap],
+	// touched[side][qcap]
+	long long *const dist0 = dist_all + (size_t)blockIdx.x * 2 * (size_t)(V + 1);
+	u32 *const qb = queues_all + (size_t)blockIdx.x * 8 * (size_t)qcap;
+	__shared__ u32 s_nn, s_nfar[2], s_nt[2], s_cnt2[2];
+	__shared__ unsigned long long s_best, s_min, s_work;
+	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	unsigned long long relaxed = 0;
+	u32 open_rows = 0;
+	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+		__syncthreads();
+		const int64_t s = src[i], d = dst[i]; // open rows of the chain pre-pass: ids in range, src != dst
+		const u32 row = didx[i];
+		if (tid == 0) {
+			s_nfar[0] = s_nfar[1] = 0;
+			s_nt[0] = s_nt[1] = 1;
+			s_best = (unsigned long long)kWbInf;
+			s_work = 0;
+			__hip_atomic_store(&dist0[s], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&dist0[(V + 1) + d], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			qb[6 * (size_t)qcap] = (u32)s;
+			qb[7 * (size_t)qcap] = (u32)d;
+			qb[0] = (u32)s;
+			qb[2 * (size_t)qcap] = (u32)d;
+		}
+		u32 nn0 = 1, nn1 = 1;      // near-queue fill per side
+		int par0 = 0, par1 = 0;    // which of a side's two near buffers is current
+		long long r0 = 0, r1 = 0;  // completed radius per side
+		int state = 2;             // 0 NULL, 1 found, 2 open
+		__threadfence_block();
+		__syncthreads();
+		if (s == d) state = 1, s_best = 0; // not expected here; kept for safety (every thread writes the same value)
+		while (state == 2 && s != d) {
+			const int side = r0 <= r1 ? 0 : 1;
+			const int64_t *xoff = side ? roff : off;
+			const int32_t *xadj = side ? radj : adj;
+			const int64_t *xw = side ? rw : w;
+			long long *mine = dist0 + (size_t)side * (size_t)(V + 1);
+			const long long *theirs = dist0 + (size_t)(side ^ 1) * (size_t)(V + 1);
+			u32 *far = qb + (size_t)(4 + side) * qcap;
+			u32 *touched = qb + (size_t)(6 + side) * qcap;
+			const long long rn = (side ? r1 : r0) + delta;
+			u32 nn = side ? nn1 : nn0;
+			int par = side ? par1 : par0;
+			bool over = false;
+			// -- the band [r, rn): relax the near queue to its fixpoint
+			while (nn > 0) {
+				const u32 *cur = qb + (size_t)(side * 2 + par) * qcap;
+				u32 *nxt = qb + (size_t)(side * 2 + (par ^ 1)) * qcap;
+				if (tid == 0) s_nn = 0;
+				__syncthreads();
+				unsigned long long lbest = (unsigned long long)kWbInf;
+				const unsigned long long e2 = wb_walk(cur, (int)nn, wib, 16, xoff, xadj, mine, [&](const int4 &v, u32 valid, long long dv, int t) {
+					const u32 xs[4] = { (u32)v.x, (u32)v.y, (u32)v.z, (u32)v.w };
+					u32 x[4];
+					long long nd[4], old[4], oth[4];
+					// no per-lane branches around memory operations: masked lanes use the spare entry V with an infinite label
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const bool in = (valid >> k) & 1u;
+						x[k] = in ? xs[k] : (u32)V;
+						const long long wt = xw[in ? (size_t)(t + k) : (size_t)0]; // masked lanes read slot 0
+						nd[k] = in ? dv + wt : kWbInf;
+					}
+#pragma unroll
+					for (int k = 0; k < 4; k++) old[k] = atomicMin(&mine[x[k]], nd[k]);
+#pragma unroll
+					for (int k = 0; k < 4; k++) oth[k] = __hip_atomic_load(&theirs[x[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const bool in = (valid >> k) & 1u;
+						const bool better = in && nd[k] < old[k];
+						const bool first = better && old[k] >= kWbInf;
+						if (better && oth[k] < kWbInf) lbest = min(lbest, (unsigned long long)(nd[k] + oth[k]));
+						const bool to_near = better && nd[k] < rn, to_far = better && !(nd[k] < rn);
+						const u64 mn = __ballot(to_near), mf = __ballot(to_far), mt = __ballot(first);
+						if (mn) {
+							u32 base = 0;
+							if (lane == 0) base = atomicAdd(&s_nn, (u32)__popcll(mn));
+							base = (u32)__shfl((int)base, 0);
+							const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(mn >> 32), __builtin_amdgcn_mbcnt_lo((u32)mn, 0u));
+							if (to_near && slot < (u32)qcap) nxt[slot] = x[k];
+						}
+						if (mf) {
+							u32 base = 0;
+							if (lane == 0) base = atomicAdd(&s_nfar[side], (u32)__popcll(mf));
+							base = (u32)__shfl((int)base, 0);
+							const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(mf >> 32), __builtin_amdgcn_mbcnt_lo((u32)mf, 0u));
+							if (to_far && slot < (u32)qcap) far[slot] = x[k];
+						}
+						if (mt) {
+							u32 base = 0;
+							if (lane == 0) base = atomicAdd(&s_nt[side], (u32)__popcll(mt));
+							base = (u32)__shfl((int)base, 0);
+							const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(mt >> 32), __builtin_amdgcn_mbcnt_lo((u32)mt, 0u));
+							if (first && slot < (u32)qcap) touched[slot] = x[k];
+						}
+					}
+				});
+				for (int o = 32; o > 0; o >>= 1) {
+					const unsigned long long y = __shfl_xor(lbest, o);
+					lbest = y < lbest ? y : lbest;
+				}
+				if (lane == 0) {
+					if (lbest < (unsigned long long)kWbInf) atomicMin(&s_best, lbest);
+					if (e2) atomicAdd(&s_work, e2);
+				}
+				__syncthreads();
+				nn = s_nn;
+				par ^= 1;
+				if (nn > (u32)qcap || s_nfar[side] > (u32)qcap || s_nt[side] > (u32)qcap || (long long)s_work > work_cap) {
+					over = true;
+					break;
+				}
+				__syncthreads(); // s_nn is reset by the next round
+			}
+			if (over) break; // state stays 2: the row is left to the batched relaxation
+			if (side) r1 = rn, nn1 = 0, par1 = par;
+			else r0 = rn, nn0 = 0, par0 = par;
+			if ((unsigned long long)(r0 + r1) >= s_best) {
+				state = 1;
+				break;
+			}
+			// -- refill the near queue from the far queue; bands without vertices are skipped
+			const u32 nf = s_nfar[side];
+			const long long rr = side ? r1 : r0;
+			if (tid == 0) s_min = (unsigned long long)kWbInf;
+			__syncthreads();
+			unsigned long long lm = (unsigned long long)kWbInf;
+			for (u32 p = tid; p < nf; p += 1024) {
+				const long long dv = __hip_atomic_load(&mine[far[p]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (dv >= rr) lm = min(lm, (unsigned long long)dv); // below rr: settled in an earlier band (a stale copy)
+			}
+			for (int o = 32; o > 0; o >>= 1) {
+				const unsigned long long y = __shfl_xor(lm, o);
+				lm = y < lm ? y : lm;
+			}
+			if (lane == 0 && lm < (unsigned long long)kWbInf) atomicMin(&s_min, lm);
+			__syncthreads();
+			const unsigned long long m = s_min;
+			if (m >= (unsigned long long)kWbInf) { // nothing left on this side: its closure is complete
+				state = s_best < (unsigned long long)kWbInf ? 1 : 0;
+				break;
+			}
+			long long base_r = rr;
+			if ((long long)m >= rr + delta) base_r = ((long long)m / delta) * delta;
+			if (side) r1 = base_r;
+			else r0 = base_r;
+			if ((unsigned long long)(r0 + r1) >= s_best) {
+				state = 1;
+				break;
+			}
+			// both near buffers of the side are free now: [par] becomes the new near queue, [par ^ 1] holds what stays far
+			u32 *newnear = qb + (size_t)(side * 2 + par) * qcap;
+			u32 *keep = qb + (size_t)(side * 2 + (par ^ 1)) * qcap;
+			if (tid == 0) s_cnt2[0] = s_cnt2[1] = 0;
+			__syncthreads();
+			for (u32 p0 = 0; p0 < nf; p0 += 1024) {
+				const u32 p = p0 + tid;
+				u32 u = 0;
+				long long dv = -1;
+				if (p < nf) {
+					u = far[p];
+					dv = __hip_atomic_load(&mine[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				const bool live = p < nf && dv >= base_r;
+				const bool tn = live && dv < base_r + delta, tk = live && !tn;
+				const u64 mn = __ballot(tn), mk = __ballot(tk);
+				if (mn) {
+					u32 b2 = 0;
+					if (lane == 0) b2 = atomicAdd(&s_cnt2[0], (u32)__popcll(mn));
+					b2 = (u32)__shfl((int)b2, 0);
+					if (tn) newnear[b2 + __builtin_amdgcn_mbcnt_hi((u32)(mn >> 32), __builtin_amdgcn_mbcnt_lo((u32)mn, 0u))] = u;
+				}
+				if (mk) {
+					u32 b2 = 0;
+					if (lane == 0) b2 = atomicAdd(&s_cnt2[1], (u32)__popcll(mk));
+					b2 = (u32)__shfl((int)b2, 0);
+					if (tk) keep[b2 + __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u))] = u;
+				}
+			}
+			__syncthreads();
+			const u32 nnew = s_cnt2[0], nkeep = s_cnt2[1];
+			for (u32 p = tid; p < nkeep; p += 1024) far[p] = keep[p];
+			if (tid == 0) s_nfar[side] = nkeep;
+			if (side) nn1 = nnew;
+			else nn0 = nnew;
+			__threadfence_block();
+			__syncthreads();
+		}
+		__syncthreads();
+		if (tid == 0) {
+			if (state == 2) open_rows++;
+			else {
+				out[row] = state == 1 ? (int64_t)s_best : 0;
+				ok[row] = (uint8_t)state;
+			}
+		}
+		// the labels go back to "infinite" through the touched lists (a list that overflowed: everything)
+		for (int sd = 0; sd < 2; sd++) {
+			long long *dd = dist0 + (size_t)sd * (size_t)(V + 1);
+			const u32 nt = s_nt[sd];
+			if (nt <= (u32)qcap) {
+				const u32 *tl = qb + (size_t)(6 + sd) * qcap;
+				for (u32 p = tid; p < nt; p += 1024) dd[tl[p]] = kWbInf;
+			} else {
+				for (int64_t v = tid; v < V; v += 1024) dd[v] = kWbInf;
+			}
+			if (tid == 0) dd[V] = kWbInf;
+		}
+		relaxed += tid == 0 ? s_work : 0ull;
+	}
+	if (tid == 0) {
+		if (open_rows) atomicAdd(&wc->open, open_rows);
+		if (relaxed) atomicAdd(&wc->relaxed, relaxed);
+	}
+}
+
+
+static std::mutex g_rw_lock;
+// in-edge weights in reverse-CSR order + the mean weight, built on first use (a stable sort of the forward slots by
+// destination: the permutation the upload used for radj)
+static int ensure_reverse_weights(pgq_csr *c, Workspace *ws) {
+	std::lock_guard<std::mutex> g(g_rw_lock);
+	if (c->rw || c->E == 0) return PGQ_OK;
+	hipStream_t st = ws->stream;
+	const int64_t E = c->E;
+	DevBuf iota, sslot, skey, tmp, sum;
+	auto body = [&]() -> int {
+		for (DevBuf *b : { &iota, &sslot, &skey }) PGQ_TRY(b->reserve((size_t)E * 4));
+		PGQ_TRY(sum.reserve(64));
+		hipLaunchKernelGGL(k_iota32, dim3(blocks_for(E)), dim3(256), 0, st, E, iota.as<u32>());
+		int end_bit = 1;
+		while ((1LL << end_bit) < c->V) end_bit++;
+		size_t sb = 0, rb = 0;
+		const u32 *keys = reinterpret_cast<const u32 *>(c->adj);
+		PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, keys, skey.as<u32>(), iota.as<u32>(), sslot.as<u32>(), (int)E, 0, end_bit, st));
+		PGQ_HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, rb, (const int64_t *)c->w, sum.as<int64_t>(), (int)E, st));
+		PGQ_TRY(tmp.reserve(std::max(sb, rb) + 16));
+		PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, keys, skey.as<u32>(), iota.as<u32>(), sslot.as<u32>(), (int)E, 0, end_bit, st));
+		void *rw = nullptr;
+		PGQ_TRY(dev_alloc(&rw, (size_t)E * 8));
+		hipLaunchKernelGGL(k_gather_weights, dim3(blocks_for(E)), dim3(256), 0, st, E, sslot.as<u32>(), (const int64_t *)c->w, (int64_t *)rw);
+		PGQ_HIP_TRY(hipcub::DeviceReduce::Sum(tmp.p, rb, (const int64_t *)c->w, sum.as<int64_t>(), (int)E, st));
+		int64_t total = 0;
+		hipError_t e1 = hipMemcpyAsync(&total, sum.p, 8, hipMemcpyDeviceToHost, st);
+		hipError_t e2 = hipStreamSynchronize(st);
+		if (e1 != hipSuccess || e2 != hipSuccess) {
+			dev_free(rw);
+			return fail(PGQ_ERR_HIP, "building the reverse weights failed");
+		}
+		c->w_mean = (double)total / (double)E;
+		c->rw = rw;
+		return PGQ_OK;
+	};
+	const int rc = body();
+	for (DevBuf *b : { &iota, &sslot, &skey, &tmp, &sum }) b->release();
+	return rc;
+}
+
+// rows [0, nd) in ws->def_src / def_dst / def_idx (the chain pre-pass's open rows): answered rows get their value and
+// flag written into d_out / d_ok, the others keep ok = 2.  *left = rows still open.
+static int weighted_pairs_prepass(pgq_csr *c, Workspace *ws, u32 nd, int64_t *d_out, uint8_t *d_ok, u32 *left) {
+	*left = nd;
+	const Options &opt = options();
+	if (!opt.wbibfs || c->w_type != PGQ_W_INT64 || (int64_t)nd > (int64_t)opt.wbibfs_rows) return PGQ_OK;
+	const int qcap = std::max(1024, opt.wbibfs_queue);
+	const size_t per_wg = (size_t)2 * (size_t)(c->V + 1) * 8 + (size_t)8 * qcap * 4;
+	const size_t budget = (size_t)std::max(0, opt.wbibfs_mem_mb) << 20;
+	const u32 grid = (u32)std::min<size_t>(std::min<u32>(nd, 256), budget / per_wg);
+	if (grid == 0) return PGQ_OK;
+	PGQ_TRY(ensure_reverse_weights(c, ws));
+	hipStream_t st = ws->stream;
+	const size_t dist_words = (size_t)grid * 2 * (size_t)(c->V + 1);
+	const bool fresh = ws->wb_scratch.cap < dist_words * 8 + (size_t)grid * 8 * qcap * 4 + 64 || ws->wb_V != c->V || ws->wb_grid != (int)grid;
+	PGQ_TRY(ws->wb_scratch.reserve(dist_words * 8 + (size_t)grid * 8 * qcap * 4 + 64));
+	long long *dist = ws->wb_scratch.as<long long>();
+	u32 *queues = reinterpret_cast<u32 *>(dist + dist_words);
+	if (fresh) { // every label infinite; the kernel restores what it touched
+		hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, (int64_t *)dist, (int64_t)dist_words, (int64_t)kWbInf);
+		ws->wb_V = c->V;
+		ws->wb_grid = (int)grid;
+	}
+	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	WbCounters *wc = reinterpret_cast<WbCounters *>(reinterpret_cast<char *>(ws->counters.p) + 32);
+	PGQ_HIP_TRY(hipMemsetAsync(wc, 0, sizeof(WbCounters), st));
+	const long long delta = std::max<long long>(1, (long long)(c->w_mean / std::max(1, opt.wbibfs_delta_div)));
+	{
+		KernelTimer kt(st, K_RELAX);
+		hipLaunchKernelGGL(k_wbibfs, dim3(grid), dim3(1024), 0, st, (int64_t)nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+		                   ws->def_idx.as<u32>(), c->off, c->adj, (const int64_t *)c->w, c->roff, c->radj, (const int64_t *)c->rw,
+		                   c->V, delta, (long long)std::max(1, opt.wbibfs_cap), qcap, dist, queues, d_out, d_ok, wc);
+		kt.stop();
+	}
+	WbCounters h;
+	PGQ_HIP_TRY(hipMemcpyAsync(&h, wc, sizeof(h), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	pgq_stats_t &S = tstats().s;
+	S.edges_scanned += (int64_t)h.relaxed;
+	S.algo_bytes[K_RELAX] += 28.0 * (double)h.relaxed; // adjacency entry, weight, label RMW, other side's label
+	S.meet_pairs += (int64_t)nd - (int64_t)h.open;
+	*left = h.open;
+	return PGQ_OK;
+}
+
 template <typename T>
 static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                            int64_t *d_out, uint8_t *d_ok, bool chain);
@@ -326,20 +726,36 @@ static int cheapest_with_chains(pgq_csr *c, Workspace *ws, int64_t n, const int6
 		S.algo_bytes[K_RELAX] += 28.0 * h[3] + 25.0 * (double)n;
 	}
 	if (h[1]) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
-	const u32 nd = h[0];
-	tstats().s.meet_pairs += n - (int64_t)nd;
-	if (nd == 0) {
+	const u32 nd_chain = h[0];
+	tstats().s.meet_pairs += n - (int64_t)nd_chain;
+	if (nd_chain == 0) {
 		tstats().s.pairs += n;
 		return PGQ_OK;
 	}
-	PGQ_TRY(ws->def_src.reserve((size_t)nd * 8));
-	PGQ_TRY(ws->def_dst.reserve((size_t)nd * 8));
-	PGQ_TRY(ws->def_idx.reserve((size_t)nd * 4));
-	PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
-	PGQ_TRY(ws->def_off.reserve((size_t)nd));
+	PGQ_TRY(ws->def_src.reserve((size_t)nd_chain * 8));
+	PGQ_TRY(ws->def_dst.reserve((size_t)nd_chain * 8));
+	PGQ_TRY(ws->def_idx.reserve((size_t)nd_chain * 4));
+	PGQ_TRY(ws->def_len.reserve((size_t)nd_chain * 8));
+	PGQ_TRY(ws->def_off.reserve((size_t)nd_chain));
 	hipLaunchKernelGGL(k_collect_open_rows, dim3(blocks_for(n)), dim3(256), 0, st, n, d_ok, d_src, d_dst,
 	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_cnt + 2);
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	u32 nd = nd_chain;
+	{ // general graphs: a bidirectional search per row; what it leaves open (caps) is collected again
+		u32 left = nd;
+		PGQ_TRY(weighted_pairs_prepass(c, ws, nd, d_out, d_ok, &left));
+		if (left != nd) {
+			nd = left;
+			if (nd == 0) {
+				tstats().s.pairs += n;
+				return PGQ_OK;
+			}
+			PGQ_HIP_TRY(hipMemsetAsync(d_cnt + 2, 0, 4, st));
+			hipLaunchKernelGGL(k_collect_open_rows, dim3(blocks_for(n)), dim3(256), 0, st, n, d_ok, d_src, d_dst,
+			                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_cnt + 2);
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+		}
+	}
 	{
 		WorkspaceLease inner;
 		PGQ_TRY(inner.acquire());

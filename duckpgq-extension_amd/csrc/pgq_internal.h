@@ -76,6 +76,12 @@ struct Options {
 	int meet_cap_paths = 1 << 16; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
+	int wbibfs = 1;            // cheapest_path_length, int64 weights: a bidirectional delta-stepping search per row before the batched relaxation
+	int wbibfs_rows = 1 << 20; // ... for at most this many rows per call
+	int wbibfs_cap = 64 << 20; // adjacency entries a row may relax before it is left to the batched relaxation
+	int wbibfs_queue = 1 << 17; // vertices per near / far / touched queue
+	int wbibfs_mem_mb = 2048;  // scratch budget (two label arrays of V entries per workgroup)
+	int wbibfs_delta_div = 8;  // band width = mean weight / this
 	int bibfs_rows = 256;      // k_bibfs (one bidirectional search per row) runs when at most this many rows are still open (0: off)
 	int bibfs_cap = 8 << 20;   // adjacency entries one expansion of k_bibfs may read
 	int bibfs_queue = 1 << 17; // frontier vertices per side k_bibfs keeps
@@ -145,6 +151,8 @@ struct pgq_csr {
 	// multi-GPU: copies of this CSR on the other enabled devices (pgq_csr_replicate), indexed like enabled_devices();
 	// entry = this object for its own device.  Owned by the primary.
 	// PageRank over this CSR (V + 2 doubles), computed once per handle like the reference's bind-data state
+	void *rw = nullptr;          // E x 8 B: in-edge weights in reverse-CSR order (built on first use by the weighted pair search)
+	double w_mean = 0;
 	double *pagerank = nullptr;
 	int pagerank_iterations = 0;
 	std::vector<pgq_csr *> replicas;

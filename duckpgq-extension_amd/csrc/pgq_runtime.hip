@@ -107,6 +107,8 @@ static int do_init(int device) {
 	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
 	env_int("PGQ_MEET4_GLOBAL_MB", g_opt.meet4_global_mb);
 	env_int("PGQ_BIBFS_ROWS", g_opt.bibfs_rows);
+	env_int("PGQ_WBIBFS", g_opt.wbibfs);
+	env_int("PGQ_WBIBFS_DELTA_DIV", g_opt.wbibfs_delta_div);
 	env_int("PGQ_BIBFS_CAP", g_opt.bibfs_cap);
 	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
 	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
@@ -806,6 +808,7 @@ static void destroy_csr(pgq_csr *c) {
 	dev_free(c->rown);
 	dev_free(c->rpk);
 	dev_free(c->pagerank);
+	dev_free(c->rw);
 	delete c;
 }
 
@@ -1173,6 +1176,12 @@ std::vector<OptRef> option_table() {
 		{ "meet4_global_mb", &o.meet4_global_mb, nullptr },
 		{ "meet4_lds_kb", &o.meet4_lds_kb, nullptr },
 		{ "bibfs_rows", &o.bibfs_rows, nullptr },
+		{ "wbibfs", &o.wbibfs, nullptr },
+		{ "wbibfs_rows", &o.wbibfs_rows, nullptr },
+		{ "wbibfs_cap", &o.wbibfs_cap, nullptr },
+		{ "wbibfs_queue", &o.wbibfs_queue, nullptr },
+		{ "wbibfs_mem_mb", &o.wbibfs_mem_mb, nullptr },
+		{ "wbibfs_delta_div", &o.wbibfs_delta_div, nullptr },
 		{ "bibfs_cap", &o.bibfs_cap, nullptr },
 		{ "bibfs_queue", &o.bibfs_queue, nullptr },
 		{ "meet_bias", nullptr, &o.meet_bias },

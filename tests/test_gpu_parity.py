@@ -18,7 +18,9 @@ def _defaults():
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
                  ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
-                 ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17)):
+                 ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
+                 # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
+                 ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_delta_div", 8), ("wbibfs_mem_mb", 2048)):
         pgq.set_option(k, v)
     yield
 
@@ -377,6 +379,51 @@ def test_cheapest_path_bit_exact(kind):
     dv[::7] = False
     out, ok = st.cheapest_path_length(0, V, ps, pd, dst_valid=dv)
     assert (ok == (rok & dv)).all()
+
+
+@pytest.mark.parametrize("delta_div", [8, 1, 100000])
+def test_weighted_pair_search_bit_exact(delta_div):
+    # k_wbibfs (pgq_cheapest.hip): bidirectional band-wise label correcting per row, int64 weights; delta_div sets the
+    # band width (mean weight / delta_div): wide bands (1), the default, and one-unit bands (100000)
+    rng = np.random.default_rng(500 + delta_div % 97)
+    pgq.set_option("wbibfs", 1)
+    pgq.set_option("wbibfs_delta_div", delta_div)
+    cases = []
+    V, E = 4000, 30000
+    s, d, e = random_graph(rng, V, E, skew=True)
+    cases.append((V, (s, d, e), rng.integers(1, 1000, E)))                      # skewed, hubs
+    cases.append((V, (s, d, e), rng.integers(0, 3, E)))                         # many zero-weight edges and ties
+    s2, d2, e2 = random_graph(rng, 6000, 7000)
+    cases.append((6000, (s2, d2, e2), rng.integers(1, 50, 7000)))               # sparse: unreachable pairs, small closures
+    s3 = np.concatenate([s[:5000], s[:5000]])
+    d3 = np.concatenate([d[:5000], d[:5000]])
+    cases.append((V, (s3, d3, np.arange(10000, dtype=np.int64)), rng.integers(1, 9, 10000)))  # parallel edges
+    for cid, (Vc, rows, w) in enumerate(cases):
+        st, ora = both(Vc, rows, w=w.astype(np.int64), csr_id=cid)
+        n = 700
+        ps, pd = rng.integers(0, Vc, n), rng.integers(0, Vc, n)
+        ps[:20] = pd[:20]
+        pgq.reset_stats()
+        out, ok = st.cheapest_path_length(cid, Vc, ps, pd)
+        lout, lok = ora.lean_cheapest_path_length(Vc, ps, pd)
+        assert (ok == lok).all() and (out[ok] == lout[ok]).all()
+        assert pgq.get_stats()["meet_pairs"] > 0
+    # caps: rows over the work / queue caps are left to the batched relaxation (mixed answers)
+    st, ora = both(cases[0][0], cases[0][1], w=cases[0][2].astype(np.int64), csr_id=9)
+    ps, pd = rng.integers(0, V, 300), rng.integers(0, V, 300)
+    lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
+    for cap, queue in ((2000, 1 << 17), (64 << 20, 1024)):
+        pgq.set_option("wbibfs_cap", cap)
+        pgq.set_option("wbibfs_queue", queue)
+        out, ok = st.cheapest_path_length(9, V, ps, pd)
+        assert (ok == lok).all() and (out[ok] == lout[ok]).all()
+    # double weights keep the batched relaxation (the two-sided sum is not the reference's left fold)
+    pgq.set_option("wbibfs_cap", 64 << 20)
+    pgq.set_option("wbibfs_queue", 1 << 17)
+    st, ora = both(V, cases[0][1], w=rng.random(E) + 0.01, csr_id=10)
+    out, ok = st.cheapest_path_length(10, V, ps[:100], pd[:100])
+    lout, lok = ora.lean_cheapest_path_length(V, ps[:100], pd[:100])
+    assert (ok == lok).all() and (out[ok] == lout[ok]).all()
 
 
 def test_cheapest_forest_and_zero_weights():

@@ -42,9 +42,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); the measured copy ceiling is reported beside it
 
 OPS = {"snb_sf100": "iterativelength", "rmat22": "iterativelength", "snb_paths": "shortestpath+reconstruction",
-       "forest_cheapest": "cheapest_path_length"}
-DEFAULT_PAIRS = {"snb_sf100": 65536, "rmat22": 1024, "snb_paths": 4096, "forest_cheapest": 4096}
-PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5}
+       "forest_cheapest": "cheapest_path_length", "snb_cheapest": "cheapest_path_length"}
+DEFAULT_PAIRS = {"snb_sf100": 65536, "rmat22": 1024, "snb_paths": 4096, "forest_cheapest": 4096, "snb_cheapest": 4096}
+PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5, "snb_cheapest": 6}
+CHEAPEST = ("forest_cheapest", "snb_cheapest")  # weighted workloads: value = pairs/s
 
 
 def parse():
@@ -61,7 +62,7 @@ def parse():
     ap.add_argument("--snb-friendships", type=int, default=19_940_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs timed on one CPU thread (0 = 8192 snb / 1024 rmat)")
-    ap.add_argument("--weights", default="int64", choices=["int64", "double"], help="forest_cheapest: weight type")
+    ap.add_argument("--weights", default="int64", choices=["int64", "double"], help="forest_cheapest / snb_cheapest: weight type")
     ap.add_argument("--backend", default="nccl")
     return ap.parse_args()
 
@@ -70,9 +71,14 @@ def build_graph(a):
     from duckpgq_extension_amd import graphgen
     t0 = time.time()
     w = None
-    if a.workload in ("snb_sf100", "snb_paths"):
+    if a.workload in ("snb_sf100", "snb_paths", "snb_cheapest"):
         V, s, d = graphgen.snb_knows_like(a.snb_vertices, a.snb_friendships, seed=100)
         name = "snb_sf100_knows(V=%d)" % V
+        if a.workload == "snb_cheapest":  # the general-graph case of cheapest_path_length: weights 1..999 on the knows graph
+            w = np.random.default_rng(6).integers(1, 1000, len(s))
+            if a.weights == "double":
+                w = w.astype(np.float64) / 7.0
+            name += ",%s w" % a.weights
     elif a.workload == "rmat22":
         V, s, d = graphgen.rmat(a.scale or 22, seed=22)
         name = "rmat%d_ef16" % (a.scale or 22)
@@ -163,7 +169,7 @@ def main():
     if a.workload == "snb_paths":
         d_off = torch.zeros(n, dtype=torch.int64, device=dev)
         d_child = torch.empty(child_cap, dtype=torch.int64, device=dev)
-    if a.workload == "forest_cheapest":
+    if a.workload in CHEAPEST:
         d_val = torch.zeros(n, dtype=torch.int64, device=dev)
         d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
     used_box = [0]
@@ -174,7 +180,7 @@ def main():
                                                  d_off.data_ptr(), d_child.data_ptr(), child_cap)
             assert rc == 0, pgq.load_hip().pgq_last_error()
             used_box[0] = used
-        elif a.workload == "forest_cheapest":
+        elif a.workload in CHEAPEST:
             csr.cheapest_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_val.data_ptr(), d_ok.data_ptr())
         else:
             csr.iterativelength_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr())
@@ -183,10 +189,10 @@ def main():
             if a.workload == "snb_paths":
                 sharding.gather_paths(d_len, d_off, d_child, used_box[0], per)
             else:
-                sharding.gather_rows(d_val if a.workload == "forest_cheapest" else d_len, total_pairs)
+                sharding.gather_rows(d_val if a.workload in CHEAPEST else d_len, total_pairs)
 
     # ---- work units (outside the timed region) -----------------------------------------------------------------
-    if a.workload != "forest_cheapest":
+    if a.workload not in CHEAPEST:
         csr.traversed_edges_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(), d_te.data_ptr())
     te_local = int(d_te.sum().item())
     ref_len = d_len.clone()
@@ -208,7 +214,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     stats = pgq.get_stats()
-    if a.workload == "forest_cheapest":
+    if a.workload in CHEAPEST:
         reach = int(d_ok.sum().item())
     else:
         assert bool((d_len == ref_len).all()), "results differ from the traversed-edge accounting pass"
@@ -248,7 +254,7 @@ def main():
         except Exception:
             copy_gbps = None
         pairs_per_s = total_pairs * a.steps / elapsed
-        if a.workload == "forest_cheapest":
+        if a.workload in CHEAPEST:
             metric, unit = "cheapest_path_pairs_per_s", "pairs/s"
             value = pairs_per_s
         else:
@@ -266,7 +272,7 @@ def main():
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-            "dtype": "u64" if a.workload != "forest_cheapest" else ("f64" if a.weights == "double" else "int64"),
+            "dtype": "u64" if a.workload not in CHEAPEST else ("f64" if a.weights == "double" else "int64"),
             "data": "synthetic",
             "config": {"workload": "%s %s, %d pairs %s, CSR replicated" % (
                 name, OPS[a.workload], pairs_per_gpu, "per GPU" if a.scaling == "weak" else "in total"),
@@ -306,9 +312,10 @@ def main():
         if not a.no_cpu_baseline and world == 1 and a.workload in ("snb_sf100", "rmat22"):  # rank 0, N=1 only
             mine = arrays["pairs"].view(-1, 2)[lo:hi].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, d_te, ref_len)
-        if not a.no_cpu_baseline and world == 1 and a.workload == "forest_cheapest":
+        if not a.no_cpu_baseline and world == 1 and a.workload in CHEAPEST:
             mine = arrays["pairs"].view(-1, 2)[lo:hi].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w, mine, d_val, d_ok)
+            ns = len(mine) if a.workload == "forest_cheapest" else min(len(mine), 128)  # a Dijkstra on the knows graph is ~0.1 s
+            out["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w, mine[:ns], d_val[:ns], d_ok[:ns])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -390,13 +390,15 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
                                                  const int32_t *__restrict__ adj, const int64_t *__restrict__ w,
                                                  const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                  const int64_t *__restrict__ rw, int64_t V, long long delta,
-                                                 long long work_cap, int qcap, long long *__restrict__ dist_all,
+                                                 long long work_cap, int qcap, int fcap, long long *__restrict__ dist_all,
                                                  u32 *__restrict__ queues_all, int64_t *__restrict__ out,
                                                  uint8_t *__restrict__ ok, WbCounters *__restrict__ wc) {
-	// per workgroup: dist[side][V + 1] (entry V takes the masked lanes), near[side][parity][qcap], far[side][qcap],
-	// touched[side][qcap]
+	// per workgroup: dist[side][V + 1] (entry V takes the masked lanes), near[side][parity][qcap] (vertices inside the
+	// current band, duplicates possible), far[side][parity][fcap] and touched[side][fcap] (every labelled vertex once)
 	long long *const dist0 = dist_all + (size_t)blockIdx.x * 2 * (size_t)(V + 1);
-	u32 *const qb = queues_all + (size_t)blockIdx.x * 8 * (size_t)qcap;
+	u32 *const qb = queues_all + (size_t)blockIdx.x * (4 * (size_t)qcap + 6 * (size_t)fcap);
+	u32 *const fb = qb + 4 * (size_t)qcap;  // far[side][parity]
+	u32 *const tb = fb + 4 * (size_t)fcap;  // touched[side]
 	__shared__ u32 s_nn, s_nfar[2], s_nt[2], s_cnt2[2];
 	__shared__ unsigned long long s_best, s_min, s_work;
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -413,13 +415,14 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 			s_work = 0;
 			__hip_atomic_store(&dist0[s], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__hip_atomic_store(&dist0[(V + 1) + d], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			qb[6 * (size_t)qcap] = (u32)s;
-			qb[7 * (size_t)qcap] = (u32)d;
+			tb[0] = (u32)s;
+			tb[(size_t)fcap] = (u32)d;
 			qb[0] = (u32)s;
 			qb[2 * (size_t)qcap] = (u32)d;
 		}
 		u32 nn0 = 1, nn1 = 1;      // near-queue fill per side
 		int par0 = 0, par1 = 0;    // which of a side's two near buffers is current
+		int fpar0 = 0, fpar1 = 0;  // ... and of its two far buffers
 		long long r0 = 0, r1 = 0;  // completed radius per side
 		int state = 2;             // 0 NULL, 1 found, 2 open
 		__threadfence_block();
@@ -432,8 +435,9 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 			const int64_t *xw = side ? rw : w;
 			long long *mine = dist0 + (size_t)side * (size_t)(V + 1);
 			const long long *theirs = dist0 + (size_t)(side ^ 1) * (size_t)(V + 1);
-			u32 *far = qb + (size_t)(4 + side) * qcap;
-			u32 *touched = qb + (size_t)(6 + side) * qcap;
+			const int fpar = side ? fpar1 : fpar0;
+			u32 *far = fb + (size_t)(side * 2 + fpar) * fcap;
+			u32 *touched = tb + (size_t)side * fcap;
 			const long long rn = (side ? r1 : r0) + delta;
 			u32 nn = side ? nn1 : nn0;
 			int par = side ? par1 : par0;
@@ -467,7 +471,9 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 						const bool better = in && nd[k] < old[k];
 						const bool first = better && old[k] >= kWbInf;
 						if (better && oth[k] < kWbInf) lbest = min(lbest, (unsigned long long)(nd[k] + oth[k]));
-						const bool to_near = better && nd[k] < rn, to_far = better && !(nd[k] < rn);
+						// a vertex enters the far queue once, when it is first labelled beyond the band: a later improvement either
+						// stays beyond the band (its entry is still there) or moves it into the near queue
+						const bool to_near = better && nd[k] < rn, to_far = first && !(nd[k] < rn);
 						const u64 mn = __ballot(to_near), mf = __ballot(to_far), mt = __ballot(first);
 						if (mn) {
 							u32 base = 0;
@@ -481,14 +487,14 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 							if (lane == 0) base = atomicAdd(&s_nfar[side], (u32)__popcll(mf));
 							base = (u32)__shfl((int)base, 0);
 							const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(mf >> 32), __builtin_amdgcn_mbcnt_lo((u32)mf, 0u));
-							if (to_far && slot < (u32)qcap) far[slot] = x[k];
+							if (to_far && slot < (u32)fcap) far[slot] = x[k];
 						}
 						if (mt) {
 							u32 base = 0;
 							if (lane == 0) base = atomicAdd(&s_nt[side], (u32)__popcll(mt));
 							base = (u32)__shfl((int)base, 0);
 							const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(mt >> 32), __builtin_amdgcn_mbcnt_lo((u32)mt, 0u));
-							if (first && slot < (u32)qcap) touched[slot] = x[k];
+							if (first && slot < (u32)fcap) touched[slot] = x[k];
 						}
 					}
 				});
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 				__syncthreads();
 				nn = s_nn;
 				par ^= 1;
-				if (nn > (u32)qcap || s_nfar[side] > (u32)qcap || s_nt[side] > (u32)qcap || (long long)s_work > work_cap) {
+				if (nn > (u32)qcap || s_nfar[side] > (u32)fcap || s_nt[side] > (u32)fcap || (long long)s_work > work_cap) {
 					over = true;
 					break;
 				}
@@ -545,9 +551,9 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 				state = 1;
 				break;
 			}
-			// both near buffers of the side are free now: [par] becomes the new near queue, [par ^ 1] holds what stays far
+			// the side's near buffers are free now: [par] becomes the new near queue; what stays far goes to the other far buffer
 			u32 *newnear = qb + (size_t)(side * 2 + par) * qcap;
-			u32 *keep = qb + (size_t)(side * 2 + (par ^ 1)) * qcap;
+			u32 *keep = fb + (size_t)(side * 2 + (fpar ^ 1)) * fcap;
 			if (tid == 0) s_cnt2[0] = s_cnt2[1] = 0;
 			__syncthreads();
 			for (u32 p0 = 0; p0 < nf; p0 += 1024) {
@@ -565,7 +571,8 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 					u32 b2 = 0;
 					if (lane == 0) b2 = atomicAdd(&s_cnt2[0], (u32)__popcll(mn));
 					b2 = (u32)__shfl((int)b2, 0);
-					if (tn) newnear[b2 + __builtin_amdgcn_mbcnt_hi((u32)(mn >> 32), __builtin_amdgcn_mbcnt_lo((u32)mn, 0u))] = u;
+					const u32 slot = b2 + __builtin_amdgcn_mbcnt_hi((u32)(mn >> 32), __builtin_amdgcn_mbcnt_lo((u32)mn, 0u));
+					if (tn && slot < (u32)qcap) newnear[slot] = u;
 				}
 				if (mk) {
 					u32 b2 = 0;
@@ -576,10 +583,10 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 			}
 			__syncthreads();
 			const u32 nnew = s_cnt2[0], nkeep = s_cnt2[1];
-			for (u32 p = tid; p < nkeep; p += 1024) far[p] = keep[p];
+			if (nnew > (u32)qcap) break; // more vertices in one band than the near queue holds: the row stays open
 			if (tid == 0) s_nfar[side] = nkeep;
-			if (side) nn1 = nnew;
-			else nn0 = nnew;
+			if (side) nn1 = nnew, fpar1 = fpar ^ 1;
+			else nn0 = nnew, fpar0 = fpar ^ 1;
 			__threadfence_block();
 			__syncthreads();
 		}
@@ -595,8 +602,8 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 		for (int sd = 0; sd < 2; sd++) {
 			long long *dd = dist0 + (size_t)sd * (size_t)(V + 1);
 			const u32 nt = s_nt[sd];
-			if (nt <= (u32)qcap) {
-				const u32 *tl = qb + (size_t)(6 + sd) * qcap;
+			if (nt <= (u32)fcap) {
+				const u32 *tl = tb + (size_t)sd * fcap;
 				for (u32 p = tid; p < nt; p += 1024) dd[tl[p]] = kWbInf;
 			} else {
 				for (int64_t v = tid; v < V; v += 1024) dd[v] = kWbInf;
@@ -660,15 +667,18 @@ static int weighted_pairs_prepass(pgq_csr *c, Workspace *ws, u32 nd, int64_t *d_
 	const Options &opt = options();
 	if (!opt.wbibfs || c->w_type != PGQ_W_INT64 || (int64_t)nd > (int64_t)opt.wbibfs_rows) return PGQ_OK;
 	const int qcap = std::max(1024, opt.wbibfs_queue);
-	const size_t per_wg = (size_t)2 * (size_t)(c->V + 1) * 8 + (size_t)8 * qcap * 4;
+	// far / touched hold every labelled vertex once: the boundary of a ball in a graph of degree ~90 is ~90 x the ball
+	const int fcap = (int)std::min<int64_t>(std::max<int64_t>(c->V, 1024), (int64_t)std::max(1024, opt.wbibfs_far));
+	const size_t q_words = (size_t)4 * qcap + (size_t)6 * fcap;
+	const size_t per_wg = (size_t)2 * (size_t)(c->V + 1) * 8 + q_words * 4;
 	const size_t budget = (size_t)std::max(0, opt.wbibfs_mem_mb) << 20;
 	const u32 grid = (u32)std::min<size_t>(std::min<u32>(nd, 256), budget / per_wg);
 	if (grid == 0) return PGQ_OK;
 	PGQ_TRY(ensure_reverse_weights(c, ws));
 	hipStream_t st = ws->stream;
 	const size_t dist_words = (size_t)grid * 2 * (size_t)(c->V + 1);
-	const bool fresh = ws->wb_scratch.cap < dist_words * 8 + (size_t)grid * 8 * qcap * 4 + 64 || ws->wb_V != c->V || ws->wb_grid != (int)grid;
-	PGQ_TRY(ws->wb_scratch.reserve(dist_words * 8 + (size_t)grid * 8 * qcap * 4 + 64));
+	const bool fresh = ws->wb_scratch.cap < dist_words * 8 + (size_t)grid * q_words * 4 + 64 || ws->wb_V != c->V || ws->wb_grid != (int)grid;
+	PGQ_TRY(ws->wb_scratch.reserve(dist_words * 8 + (size_t)grid * q_words * 4 + 64));
 	long long *dist = ws->wb_scratch.as<long long>();
 	u32 *queues = reinterpret_cast<u32 *>(dist + dist_words);
 	if (fresh) { // every label infinite; the kernel restores what it touched
@@ -684,7 +694,7 @@ static int weighted_pairs_prepass(pgq_csr *c, Workspace *ws, u32 nd, int64_t *d_
 		KernelTimer kt(st, K_RELAX);
 		hipLaunchKernelGGL(k_wbibfs, dim3(grid), dim3(1024), 0, st, (int64_t)nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
 		                   ws->def_idx.as<u32>(), c->off, c->adj, (const int64_t *)c->w, c->roff, c->radj, (const int64_t *)c->rw,
-		                   c->V, delta, (long long)std::max(1, opt.wbibfs_cap), qcap, dist, queues, d_out, d_ok, wc);
+		                   c->V, delta, (long long)std::max(1, opt.wbibfs_cap), qcap, fcap, dist, queues, d_out, d_ok, wc);
 		kt.stop();
 	}
 	WbCounters h;

@@ -76,10 +76,12 @@ struct Options {
 	int meet_cap_paths = 1 << 16; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
-	int wbibfs = 1;            // cheapest_path_length, int64 weights: a bidirectional delta-stepping search per row before the batched relaxation
+	int wbibfs = 0;            // cheapest_path_length, int64 weights: a bidirectional delta-stepping search per row before the batched
+	                           // relaxation (k_wbibfs).  Off by default: bit-exact in the tests, not yet measured at SF100 scale
 	int wbibfs_rows = 1 << 20; // ... for at most this many rows per call
 	int wbibfs_cap = 64 << 20; // adjacency entries a row may relax before it is left to the batched relaxation
-	int wbibfs_queue = 1 << 17; // vertices per near / far / touched queue
+	int wbibfs_queue = 1 << 17; // near-queue entries (vertices inside the current band, with duplicates)
+	int wbibfs_far = 1 << 21;   // far / touched entries (every labelled vertex once; at most V)
 	int wbibfs_mem_mb = 2048;  // scratch budget (two label arrays of V entries per workgroup)
 	int wbibfs_delta_div = 8;  // band width = mean weight / this
 	int bibfs_rows = 256;      // k_bibfs (one bidirectional search per row) runs when at most this many rows are still open (0: off)

@@ -1180,6 +1180,7 @@ std::vector<OptRef> option_table() {
 		{ "wbibfs_rows", &o.wbibfs_rows, nullptr },
 		{ "wbibfs_cap", &o.wbibfs_cap, nullptr },
 		{ "wbibfs_queue", &o.wbibfs_queue, nullptr },
+		{ "wbibfs_far", &o.wbibfs_far, nullptr },
 		{ "wbibfs_mem_mb", &o.wbibfs_mem_mb, nullptr },
 		{ "wbibfs_delta_div", &o.wbibfs_delta_div, nullptr },
 		{ "bibfs_cap", &o.bibfs_cap, nullptr },

@@ -20,7 +20,7 @@ def _defaults():
                  ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
-                 ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_delta_div", 8), ("wbibfs_mem_mb", 2048)):
+                 ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 8), ("wbibfs_mem_mb", 2048)):
         pgq.set_option(k, v)
     yield
 
@@ -412,11 +412,13 @@ def test_weighted_pair_search_bit_exact(delta_div):
     st, ora = both(cases[0][0], cases[0][1], w=cases[0][2].astype(np.int64), csr_id=9)
     ps, pd = rng.integers(0, V, 300), rng.integers(0, V, 300)
     lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
-    for cap, queue in ((2000, 1 << 17), (64 << 20, 1024)):
+    for cap, queue, far in ((2000, 1 << 17, 1 << 21), (64 << 20, 1024, 1 << 21), (64 << 20, 1 << 17, 1024)):
         pgq.set_option("wbibfs_cap", cap)
         pgq.set_option("wbibfs_queue", queue)
+        pgq.set_option("wbibfs_far", far)
         out, ok = st.cheapest_path_length(9, V, ps, pd)
         assert (ok == lok).all() and (out[ok] == lout[ok]).all()
+    pgq.set_option("wbibfs_far", 1 << 21)
     # double weights keep the batched relaxation (the two-sided sum is not the reference's left fold)
     pgq.set_option("wbibfs_cap", 64 << 20)
     pgq.set_option("wbibfs_queue", 1 << 17)

@@ -20,7 +20,7 @@ def _defaults():
                  ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
-                 ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 8), ("wbibfs_mem_mb", 2048)):
+                 ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048)):
         pgq.set_option(k, v)
     yield
 

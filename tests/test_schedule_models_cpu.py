@@ -1,0 +1,130 @@
+"""CPU models of two device schedules whose exactness rests on an argument rather than on the reference's loop order:
+k_bibfs (pgq_meet.hip: level-synchronous bidirectional BFS per row) and k_wbibfs (pgq_cheapest.hip: bidirectional
+band-wise label correcting per row).  The models follow the kernels' control flow (side selection, termination tests,
+far-queue refill with band skipping, duplicates in the near queue, arbitrary relaxation order) and are compared with the
+oracle's per-pair BFS / Dijkstra.  They exist to pin the *schedule*; the kernels themselves are checked on the GPU
+(tests/test_gpu_parity.py: test_bibfs_few_open_rows_any_distance, test_weighted_pair_search_bit_exact)."""
+import numpy as np
+
+from oracle.pgq_oracle import OracleCSR
+
+INF = 1 << 62
+
+
+def _csr(V, s, d, w=None):
+    order = np.argsort(s, kind="stable")
+    adj = d[order]
+    off = np.zeros(V + 1, dtype=np.int64)
+    np.add.at(off, s[order] + 1, 1)
+    off = np.cumsum(off)
+    ro = np.argsort(adj, kind="stable")  # the upload's permutation: in-edges by (source, slot)
+    radj = s[order][ro]
+    roff = np.zeros(V + 1, dtype=np.int64)
+    np.add.at(roff, adj[ro] + 1, 1)
+    roff = np.cumsum(roff)
+    ww = w[order] if w is not None else None
+    return off, adj, roff, radj, ww, (ww[ro] if w is not None else None), order
+
+
+def bibfs_model(off, adj, roff, radj, s, d):
+    """k_bibfs: expand the side whose frontier has fewer adjacency entries; first meeting = a + b + 1."""
+    if s == d:
+        return 0
+    seen = [{s}, {d}]
+    front = [[s], [d]]
+    lvl = [0, 0]
+    X = [(off, adj), (roff, radj)]
+    while True:
+        work = [sum(int(X[k][0][v + 1] - X[k][0][v]) for v in front[k]) for k in (0, 1)]
+        side = 0 if work[0] <= work[1] else 1
+        o, a = X[side]
+        nxt, hit = [], False
+        for v in front[side]:
+            for u in a[o[v]:o[v + 1]].tolist():
+                if u in seen[side ^ 1]:
+                    hit = True
+                if u not in seen[side]:
+                    seen[side].add(u)
+                    nxt.append(u)
+        if hit:
+            return lvl[0] + lvl[1] + 1
+        if not nxt:
+            return None  # this side's closure is complete
+        front[side] = nxt
+        lvl[side] += 1
+
+
+def wbibfs_model(off, adj, w, roff, radj, rw, s, d, delta, rng):
+    """k_wbibfs: bands of width delta, near queue relaxed to its fixpoint, far queue takes a vertex once."""
+    if s == d:
+        return 0
+    dist = [{s: 0}, {d: 0}]
+    near, far, r, best = [[s], [d]], [[], []], [0, 0], INF
+    X = [(off, adj, w), (roff, radj, rw)]
+    while True:
+        side = 0 if r[0] <= r[1] else 1
+        o, a, ww = X[side]
+        rn = r[side] + delta
+        while near[side]:
+            cur = near[side]
+            rng.shuffle(cur)
+            nxt = []
+            for v in cur:
+                dv = dist[side][v]
+                for e in range(int(o[v]), int(o[v + 1])):
+                    u, nd = int(a[e]), dv + int(ww[e])
+                    old = dist[side].get(u, INF)
+                    if nd < old:
+                        dist[side][u] = nd
+                        other = dist[side ^ 1].get(u, INF)
+                        if other != INF:
+                            best = min(best, nd + other)
+                        if nd < rn:
+                            nxt.append(u)
+                        elif old == INF:  # first labelling beyond the band: the only time a vertex enters the far queue
+                            far[side].append(u)
+            near[side] = nxt
+        r[side] = rn
+        if r[0] + r[1] >= best:
+            return best
+        live = [u for u in far[side] if dist[side][u] >= r[side]]
+        if not live:
+            return best if best != INF else None
+        m = min(dist[side][u] for u in live)
+        if m >= r[side] + delta:
+            r[side] = (m // delta) * delta
+            if r[0] + r[1] >= best:
+                return best
+        lo = r[side]
+        near[side] = [u for u in live if dist[side][u] < lo + delta]
+        far[side] = [u for u in live if dist[side][u] >= lo + delta]
+
+
+def test_bidirectional_bfs_schedule_matches_oracle():
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        V = int(rng.integers(4, 80))
+        E = int(rng.integers(V // 2, V * 4))
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        off, adj, roff, radj, _, _, order = _csr(V, s, d)
+        ora = OracleCSR.adopt(V, off, adj, np.arange(E, dtype=np.int64))
+        ps, pd = rng.integers(0, V, 40), rng.integers(0, V, 40)
+        ln, ok = ora.lean_iterativelength(V, ps, pd)
+        for a, b, want, k in zip(ps.tolist(), pd.tolist(), ln.tolist(), ok.tolist()):
+            assert bibfs_model(off, adj, roff, radj, a, b) == (want if k else None)
+
+
+def test_bidirectional_band_search_schedule_matches_dijkstra():
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        V = int(rng.integers(5, 60))
+        E = int(rng.integers(V, V * 6))
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        w = rng.integers(0 if trial % 3 == 0 else 1, 40, E)  # every third graph has zero-weight edges
+        off, adj, roff, radj, ww, rw, order = _csr(V, s, d, w)
+        ora = OracleCSR.adopt(V, off, adj, np.arange(E, dtype=np.int64), ww.astype(np.int64))
+        ps, pd = rng.integers(0, V, 30), rng.integers(0, V, 30)
+        out, ok = ora.lean_cheapest_path_length(V, ps, pd)
+        for a, b, want, k in zip(ps.tolist(), pd.tolist(), out.tolist(), ok.tolist()):
+            delta = int(rng.integers(1, 30))
+            assert wbibfs_model(off, adj, ww, roff, radj, rw, a, b, delta, rng) == (want if k else None)

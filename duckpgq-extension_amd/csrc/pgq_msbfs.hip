@@ -2049,6 +2049,7 @@ int pgq_release_cached_memory(void) {
 		drop.swap(g_ws_free);
 	}
 	for (Workspace *w : drop) delete w;
+	dev_cache_trim(); // and the freed CSR / upload blocks kept for the next upload
 	return PGQ_OK;
 }
 

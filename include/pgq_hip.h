@@ -125,7 +125,8 @@ int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src
                              uint64_t *out_valid);
 
 void pgq_thread_release(void); /* drop this thread's result arena */
-/* Frees the pooled per-call workspaces (search state sized by V x lanes is kept between calls for reuse). */
+/* Frees the pooled per-call workspaces (search state sized by V x lanes is kept between calls for reuse) and the
+ * freed CSR / upload blocks kept for the next upload (PGQ_ALLOC_CACHE_MB). */
 int pgq_release_cached_memory(void);
 
 /* ---- searches, bulk form (device memory, no chunk ceiling) ---------------------------------------------- */

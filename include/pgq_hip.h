@@ -137,12 +137,14 @@ int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_
 /* Rows in host memory, answered by all enabled devices: contiguous shards, one host thread and one CSR replica per
  * device, results gathered into out_len (same values as pgq_iterativelength_bulk_device: hop count, 0, or -1). */
 int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len);
-/* shortestpath by all enabled devices: out_len / out_offset as in the bulk form; the lists of all shards are gathered
+/* shortestpath (ShortestPathFunction, src/core/functions/scalar/shortest_path.cpp:43-207) by all enabled devices:
+ * out_len / out_offset as in the bulk form; the lists of all shards are gathered
  * into child (host memory, capacity child_cap int64) in row order of the shards.  *child_used = elements needed;
  * PGQ_ERR_INVALID_ARG when child_cap is too small (out_len is complete, the payload is not usable). */
 int pgq_shortestpath_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len,
                            int64_t *out_offset, int64_t *child, int64_t child_cap, int64_t *child_used);
-/* cheapest_path_length by all enabled devices: out = n int64 or double (by weight type), out_valid = n bytes. */
+/* cheapest_path_length (CheapestPathLengthFunction, cheapest_path_length.cpp:138-163) by all enabled devices:
+ * out = n int64 or double (by weight type), out_valid = n bytes. */
 int pgq_cheapest_path_length_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, void *out,
                                    uint8_t *out_valid);
 /* Measurement helper: same search, additionally d_out_te[i] = edges traversed by pair i's own level-synchronous BFS

@@ -203,12 +203,37 @@ PathFindingResult PathFindingRelation(DuckPGQState &state, int32_t csr_id, const
 	r.hops.assign(n, -1);
 	r.lists.assign(n, list_entry_t { 0, 0 });
 	r.valid.assign(n, false);
+	pgq_csr_t *device = DeviceCSR(state, csr, v_size);
+	if (pgq_num_enabled_devices() > 1 && n >= 4096) {
+		// several GPUs behind this process (pgq_init_devices at extension load): contiguous shards of the relation, one
+		// replica of the CSR per device, the ragged lists gathered behind each other
+		vector<int64_t> len(n), off(n);
+		int64_t used = 0;
+		r.child.resize(16 * n);
+		int rc = pgq_shortestpath_multi(device, (int64_t)n, src.data(), dst.data(), len.data(), off.data(), r.child.data(),
+		                                (int64_t)r.child.size(), &used);
+		if (rc != PGQ_OK && used > (int64_t)r.child.size()) { // the first guess was too small: the call said what it needs
+			r.child.resize((size_t)used);
+			rc = pgq_shortestpath_multi(device, (int64_t)n, src.data(), dst.data(), len.data(), off.data(), r.child.data(),
+			                            (int64_t)r.child.size(), &used);
+		}
+		if (rc != PGQ_OK) ThrowDevice();
+		r.child.resize((size_t)used);
+		for (idx_t i = 0; i < n; i++) {
+			if (len[i] < 0) continue; // NULL source or unreachable
+			r.hops[i] = len[i];
+			r.lists[i] = list_entry_t { (uint64_t)off[i], (uint64_t)(2 * len[i] + 1) };
+			r.valid[i] = len[i] >= lower && len[i] <= upper;
+		}
+		state.csr_to_delete.insert(csr_id);
+		return r;
+	}
 	vector<uint64_t> offsets(n), lengths(n), mask((n + 63) / 64 + 1);
 	pgq_vec_t s { src.data(), nullptr, nullptr }, d { dst.data(), nullptr, nullptr };
 	const int64_t *child = nullptr;
 	uint64_t child_len = 0;
-	if (pgq_shortestpath(DeviceCSR(state, csr, v_size), v_size, (int64_t)n, s, d, offsets.data(), lengths.data(), mask.data(),
-	                     &child, &child_len) != PGQ_OK)
+	if (pgq_shortestpath(device, v_size, (int64_t)n, s, d, offsets.data(), lengths.data(), mask.data(), &child, &child_len) !=
+	    PGQ_OK)
 		ThrowDevice();
 	r.child.assign(child, child + child_len);
 	for (idx_t i = 0; i < n; i++) {

@@ -28,12 +28,18 @@ for k, cs in agg.items():
     out[k] = d
 # bench.py looks kernels up by class name ("pull_sparse"): add aliases for the widest instantiation seen
 for cls, prefixes in (("pull_sparse", ("k_pull_lanes<", "k_pull_sparse<")), ("pull", ("k_pull<",)), ("push", ("k_push<",)),
-                      ("pull_hub", ("k_pull_hub<",)), ("relax", ("k_relax<",)), ("meet", ("k_meet3", "k_meet4"))):
+                      ("pull_hub", ("k_pull_hub<",)), ("relax", ("k_relax<",)), ("meet", ("k_meet3", "k_meet4", "k_bibfs"))):
     cands = [k for k in out if k.startswith(prefixes)]
     if cands:
-        # the kernel of the class that moves the most bytes per step (k_meet3 for "meet", the widest k_pull_lanes ...)
+        # bench.py's roofline figure for a class is the average over ALL launches of the class (k_meet3 and k_meet4d and
+        # k_bibfs for "meet"): the alias carries the launch-weighted average of the byte counters, plus the name of the
+        # kernel that moves the most bytes per step
         best = max(cands, key=lambda k: out[k].get("hbm_bytes_per_launch", 0) * out[k]["launches_profiled"])
-        out[cls] = dict(out[best], kernel=best)
+        launches = sum(out[k]["launches_profiled"] for k in cands)
+        alias = dict(out[best], kernel=best, kernels=sorted(cands), launches_profiled=launches)
+        for c in ("FETCH_SIZE", "WRITE_SIZE", "hbm_bytes_per_launch"):
+            alias[c] = sum(out[k].get(c, 0.0) * out[k]["launches_profiled"] for k in cands) / max(launches, 1)
+        out[cls] = alias
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", "pmc_%s.json" % wl), "w"), indent=1, sort_keys=True)
 for k in sorted(out, key=lambda k: -out[k].get("hbm_bytes_per_launch", 0)):

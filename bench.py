@@ -269,6 +269,12 @@ def main():
             except Exception:
                 traffic = None
         step_bytes = sum(stats["algo_bytes"].values())
+        traffic_gbps = None  # the PMC traffic (separate passes) over this run's launch duration: what the memory system moved
+        try:
+            if traffic and kms[dom] > 0:
+                traffic_gbps = float(traffic) / (kms[dom] / max(kl[dom], 1) * 1e-3) / 1e9
+        except Exception:
+            traffic_gbps = None
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
@@ -295,6 +301,8 @@ def main():
             # dominant kernel class of the one-batch-in-flight pass (no overlap: event time = kernel time)
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_GBps": traffic_gbps,
+                         "traffic_frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else None,
                          "launches": int(kl[dom]), "avg_launch_ms": kms[dom] / max(kl[dom], 1),
                          "algorithmic_bytes_per_launch": kb[dom] / max(kl[dom], 1),
                          "measured_copy_GBps": copy_gbps, "timing": "HIP events, one batch in flight, untimed pass",

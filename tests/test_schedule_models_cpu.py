@@ -128,3 +128,53 @@ def test_bidirectional_band_search_schedule_matches_dijkstra():
         for a, b, want, k in zip(ps.tolist(), pd.tolist(), out.tolist(), ok.tolist()):
             delta = int(rng.integers(1, 30))
             assert wbibfs_model(off, adj, ww, roff, radj, rw, a, b, delta, rng) == (want if k else None)
+
+
+def prepass_path_model(off, adj, roff, radj, s, d):
+    """Inner vertices the path variants of the pre-pass pick (k_meet3<true>, k_meet4<true>): distances 1..4 only.
+    Backward walks over in-lists ordered by source; the first hit in walk order is taken."""
+    outs = set(adj[off[s]:off[s + 1]].tolist())
+    if s == d:
+        return [s]
+    if d in outs:
+        return [s, d]
+    ind = radj[roff[d]:roff[d + 1]].tolist()  # ascending by source
+    for y in ind:  # distance 2: smallest common neighbour
+        if y in outs:
+            return [s, y, d]
+    for y in ind:  # distance 3: first in-list (ascending y) with a hit, first hit in it (ascending x)
+        for x in radj[roff[y]:roff[y + 1]].tolist():
+            if x in outs:
+                return [s, x, y, d]
+    two = set()
+    for x in outs:
+        two.update(adj[off[x]:off[x + 1]].tolist())
+    marked = outs | two  # k_meet4: B = N_out(src) + N_out(N_out(src))
+    for y in ind:  # distance 4: third vertex y, second vertex x; first vertex = smallest in-neighbour of x src points at
+        for x in radj[roff[y]:roff[y + 1]].tolist():
+            if x in marked:
+                v1 = next(z for z in radj[roff[x]:roff[x + 1]].tolist() if z in outs)
+                return [s, v1, x, y, d]
+    return None
+
+
+def test_ordered_backward_walk_picks_the_reference_path():
+    # the claim behind the early exit of the path kernels: with in-lists ordered by source, the first witness a backward
+    # walk meets is the path the reference's min-id-parent rule reconstructs (shortest_path.cpp:21-31)
+    rng = np.random.default_rng(23)
+    checked = {2: 0, 3: 0, 4: 0}
+    for trial in range(40):
+        V = int(rng.integers(8, 70))
+        E = int(rng.integers(V, V * 5))
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        off, adj, roff, radj, _, _, order = _csr(V, s, d)
+        eid = np.arange(E, dtype=np.int64)
+        ora = OracleCSR.adopt(V, off, adj, eid)
+        ps, pd = rng.integers(0, V, 60), rng.integers(0, V, 60)
+        for a, b, path in zip(ps.tolist(), pd.tolist(), ora.lean_shortestpath(V, ps, pd)):
+            if path is None or len(path) > 9:
+                continue
+            got = prepass_path_model(off, adj, roff, radj, a, b)
+            assert got == path[0::2]  # the vertices of [v, e, v, ...]
+            checked[(len(path) - 1) // 2] = checked.get((len(path) - 1) // 2, 0) + 1
+    assert checked[2] and checked[3] and checked[4]

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
                                                  const int32_t *__restrict__ adj, const int64_t *__restrict__ w,
                                                  const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                  const int64_t *__restrict__ rw, int64_t V, long long delta,
-                                                 long long work_cap, int qcap, int fcap, long long *__restrict__ dist_all,
+                                                 long long work_cap, int qcap, int fcap, int prune, long long *__restrict__ dist_all,
                                                  u32 *__restrict__ queues_all, int64_t *__restrict__ out,
                                                  uint8_t *__restrict__ ok, WbCounters *__restrict__ wc) {
 	// per workgroup: dist[side][V + 1] (entry V takes the masked lanes), near[side][parity][qcap] (vertices inside the
@@ -449,7 +449,12 @@ __global__ __launch_bounds__(1024) void k_wbibfs(int64_t n, const int64_t *__res
 				if (tid == 0) s_nn = 0;
 				__syncthreads();
 				unsigned long long lbest = (unsigned long long)kWbInf;
+				const long long r_other = side ? r0 : r1;
 				const unsigned long long e2 = wb_walk(cur, (int)nn, wib, 16, xoff, xadj, mine, [&](const int4 &v, u32 valid, long long dv, int t) {
+					// optional pruning (wbibfs_prune): a vertex whose label plus the other side's completed radius already
+					// reaches `best` cannot start a better path — an out-neighbour u the other side has settled with
+					// w + d_other(u) < r_other makes this vertex settled there too, and its own labelling offered that sum
+					if (prune && (unsigned long long)(dv + r_other) >= *(volatile unsigned long long *)&s_best) valid = 0;
 					const u32 xs[4] = { (u32)v.x, (u32)v.y, (u32)v.z, (u32)v.w };
 					u32 x[4];
 					long long nd[4], old[4], oth[4];
@@ -694,7 +699,7 @@ static int weighted_pairs_prepass(pgq_csr *c, Workspace *ws, u32 nd, int64_t *d_
 		KernelTimer kt(st, K_RELAX);
 		hipLaunchKernelGGL(k_wbibfs, dim3(grid), dim3(1024), 0, st, (int64_t)nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
 		                   ws->def_idx.as<u32>(), c->off, c->adj, (const int64_t *)c->w, c->roff, c->radj, (const int64_t *)c->rw,
-		                   c->V, delta, (long long)std::max(1, opt.wbibfs_cap), qcap, fcap, dist, queues, d_out, d_ok, wc);
+		                   c->V, delta, (long long)std::max(1, opt.wbibfs_cap), qcap, fcap, opt.wbibfs_prune, dist, queues, d_out, d_ok, wc);
 		kt.stop();
 	}
 	WbCounters h;

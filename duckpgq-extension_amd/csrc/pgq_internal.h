@@ -81,6 +81,7 @@ struct Options {
 	int wbibfs_rows = 1 << 20; // ... for at most this many rows per call
 	int wbibfs_cap = 64 << 20; // adjacency entries a row may relax before it is left to the batched relaxation
 	int wbibfs_queue = 1 << 17; // near-queue entries (vertices inside the current band, with duplicates)
+	int wbibfs_prune = 0;       // skip relaxing a vertex whose label + the other side's radius already reaches `best` (model: -28 % work; untimed)
 	int wbibfs_far = 1 << 21;   // far / touched entries (every labelled vertex once; at most V)
 	int wbibfs_mem_mb = 2048;  // scratch budget (two label arrays of V entries per workgroup)
 	int wbibfs_delta_div = 64; // band width = mean weight / this (a model run on the weighted knows graph: 3-10x fewer relaxations at 64 than at 8)

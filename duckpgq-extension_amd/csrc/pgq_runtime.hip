@@ -109,6 +109,7 @@ static int do_init(int device) {
 	env_int("PGQ_BIBFS_ROWS", g_opt.bibfs_rows);
 	env_int("PGQ_WBIBFS", g_opt.wbibfs);
 	env_int("PGQ_WBIBFS_DELTA_DIV", g_opt.wbibfs_delta_div);
+	env_int("PGQ_WBIBFS_PRUNE", g_opt.wbibfs_prune);
 	env_int("PGQ_BIBFS_CAP", g_opt.bibfs_cap);
 	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
 	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
@@ -1181,6 +1182,7 @@ std::vector<OptRef> option_table() {
 		{ "wbibfs_cap", &o.wbibfs_cap, nullptr },
 		{ "wbibfs_queue", &o.wbibfs_queue, nullptr },
 		{ "wbibfs_far", &o.wbibfs_far, nullptr },
+		{ "wbibfs_prune", &o.wbibfs_prune, nullptr },
 		{ "wbibfs_mem_mb", &o.wbibfs_mem_mb, nullptr },
 		{ "wbibfs_delta_div", &o.wbibfs_delta_div, nullptr },
 		{ "bibfs_cap", &o.bibfs_cap, nullptr },

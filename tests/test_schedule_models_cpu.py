@@ -54,7 +54,7 @@ def bibfs_model(off, adj, roff, radj, s, d):
         lvl[side] += 1
 
 
-def wbibfs_model(off, adj, w, roff, radj, rw, s, d, delta, rng):
+def wbibfs_model(off, adj, w, roff, radj, rw, s, d, delta, rng, prune=False):
     """k_wbibfs: bands of width delta, near queue relaxed to its fixpoint, far queue takes a vertex once."""
     if s == d:
         return 0
@@ -71,6 +71,8 @@ def wbibfs_model(off, adj, w, roff, radj, rw, s, d, delta, rng):
             nxt = []
             for v in cur:
                 dv = dist[side][v]
+                if prune and dv + r[side ^ 1] >= best:  # wbibfs_prune: cannot start a better path
+                    continue
                 for e in range(int(o[v]), int(o[v + 1])):
                     u, nd = int(a[e]), dv + int(ww[e])
                     old = dist[side].get(u, INF)
@@ -128,6 +130,7 @@ def test_bidirectional_band_search_schedule_matches_dijkstra():
         for a, b, want, k in zip(ps.tolist(), pd.tolist(), out.tolist(), ok.tolist()):
             delta = int(rng.integers(1, 30))
             assert wbibfs_model(off, adj, ww, roff, radj, rw, a, b, delta, rng) == (want if k else None)
+            assert wbibfs_model(off, adj, ww, roff, radj, rw, a, b, delta, rng, prune=True) == (want if k else None)
 
 
 def prepass_path_model(off, adj, roff, radj, s, d):

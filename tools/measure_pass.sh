@@ -38,6 +38,7 @@ if [ "${1:-}" != "quick" ]; then
 	(cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/membench_gather -o p -- $R/tools/membench gather > $O/membench_gather.jsonl 2>&1; rm -f $O/membench_gather/*kernel_trace.csv)
 	# the per-row weighted search (off by default until it has been timed here): weighted knows graph, 4096 pairs
 	PGQ_WBIBFS=1 timeout 150 python bench.py --workload snb_cheapest --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_snb_cheapest_wbibfs.json 2> $O/bench_snb_cheapest_wbibfs.err; cut -c1-160 $O/bench_snb_cheapest_wbibfs.json
+	PGQ_WBIBFS=1 PGQ_WBIBFS_PRUNE=1 timeout 150 python bench.py --workload snb_cheapest --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_snb_cheapest_wbibfs_prune.json 2>/dev/null; cut -c1-160 $O/bench_snb_cheapest_wbibfs_prune.json
 	timeout 200 python tools/chunk_latency.py > $O/chunk_latency.json 2> $O/chunk_latency.err
 fi
 ls $O

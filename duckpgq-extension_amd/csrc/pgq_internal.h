@@ -93,6 +93,8 @@ struct Options {
 	double meet_bias = 1.0; // pre-pass runs while its estimated bytes <= meet_bias x the MS-BFS estimate
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
 	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
+	int meet_layout = 1;    // build the padded adjacency + slot descriptors at upload (the pre-pass needs them)
+	int meet_align = 4;     // entries a padded list start is aligned to (4 = one 16-byte group; 16 / 32 = one 64 / 128-byte line)
 };
 Options &options();
 
@@ -146,6 +148,15 @@ struct pgq_csr {
 	int n_pull_parts = 0;
 	uint8_t *rown = nullptr; // E: owner vertex of every in-slot, as an index inside its part
 	uint32_t *rpk = nullptr; // E (+ padding): radj | rown << 28, one word per in-slot for k_pull_lanes (null if V >= 2^28)
+	// Layout of the pair-centric kernels (pgq_meet.hip; built at upload by build_meet_layout, null when meet_layout = 0):
+	// padded adjacencies whose lists start on a 16-byte group boundary (aligned to `meet_align` entries) and are filled
+	// up to whole groups with copies of their last entry; per vertex {first group, entries}; per adjacency slot a
+	// 16-byte descriptor {neighbour, the neighbour's first group, its entries, 0} in the slot's own direction, so that a
+	// two-hop walk needs no offset look-up
+	int32_t *padj = nullptr, *rpadj = nullptr; // 4 x padj_groups / rpadj_groups entries
+	uint2 *fseg = nullptr, *rseg = nullptr;    // V
+	uint4 *fdesc = nullptr, *rdesc = nullptr;  // E (+ 1): slot order of adj / radj
+	int64_t padj_groups = 0, rpadj_groups = 0;
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
 	double two_hop_mean = 0; // mean over vertices of in-degree x out-degree = expected two-hop walk of a random endpoint

@@ -44,7 +44,10 @@ constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so
 #define PGQ_MEET3_NT 1 // non-temporal list loads: the lists are streamed once, the offset look-ups stay in L2 (-3 %)
 #endif
 #ifndef PGQ_MEET3_DEPTH
-#define PGQ_MEET3_DEPTH 2 // list requests in flight per wavefront (1..4 measure the same: the kernel runs at the traffic ceiling)
+#define PGQ_MEET3_DEPTH 2 // list requests in flight per wavefront
+#endif
+#ifndef PGQ_MEET4_DEPTH
+#define PGQ_MEET4_DEPTH 2 // the same for each of the 16 wavefronts of a k_meet4d row (more only adds overshoot past the first hit)
 #endif
 constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 atomics on one address take longer than the walks
 struct MeetCounters {
@@ -54,20 +57,27 @@ struct MeetCounters {
 	u32 pad[3];
 };
 
-// One wavefront per row.  A row costs ~6 dependent memory round trips before its walk starts (row, offsets, one-hop
-// lists, their offsets) and a single wavefront streams only ~4 KB per round trip, so what counts is how many rows a
-// CU has in flight (registers permitting: 5 KB of LDS each) — the workgroup is a single wavefront so that a finished
-// row frees its slot at once.  Rows are dealt round-robin (one shared counter would serialise ~10^4 claims at 12-20 ns
-// each: more than the walks take).
+// One wavefront per row.  A row costs ~4 dependent memory round trips before its walk starts (row, offsets, the two
+// one-hop lists — the expanded side's arrives as slot descriptors, so the ranges of its vertices need no look-up) and a
+// single wavefront streams only a few KB per round trip, so what counts is how many rows a CU has in flight (registers
+// permitting: 5 KB of LDS each) — the workgroup is a single wavefront so that a finished row frees its slot at once.
+// Rows are dealt round-robin (one shared counter would serialise ~10^4 claims at 12-20 ns each: more than the walks
+// take).  The walk itself is seg_walk (pgq_walk.h): the padded lists of a round of 64 expanded vertices as one virtual
+// sequence of 16-byte groups, every lane of a request useful.  `cap` bounds the entries a row may WALK (nearly every
+// walk ends at its first hit long before): a row over it stays open for k_meet4d (16 wavefronts per row).
+// `go` (nullable): device flag written by k_meet_decide; 0 = the host will take the lane-batched path, do nothing.
 // PATHS: also record the path's inner vertices (MeetPath); the walk then runs from dst over the source-ordered in-lists.
 template <bool PATHS>
 __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                  const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
+                                                  const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
                                                   int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
-                                                  MeetCounters *__restrict__ mc) {
+                                                  const u32 *__restrict__ go, MeetCounters *__restrict__ mc) {
 	__shared__ __attribute__((aligned(16))) u32 s_tab[kMeetWPB][kMeetSlots];
 	__shared__ __attribute__((aligned(16))) u32 s_bm[kMeetWPB][kMeetFilterWords];
+	if (go && *go == 0) return;
 	const int lane = threadIdx.x & 63;
 	u32 *tab = s_tab[threadIdx.x >> 6];
 	u32 *bm = s_bm[threadIdx.x >> 6];
@@ -117,23 +127,18 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 				continue;
 			}
 		}
-		const int32_t *set_adj = fwd ? radj + di : adj + so;   // the set side's one-hop list
-		const int32_t *exp_adj = fwd ? adj + so : radj + di;   // the expanded side's one-hop list
-		const int64_t *xoff = fwd ? off : roff;                // adjacency of the expanded side's direction
-		const int32_t *xadj = fwd ? adj : radj;
-		const u32 other = (u32)(fwd ? s : d);                  // distance 1: the set list contains the other endpoint
-		// both one-hop lists are requested together; the expanded side's first 64 vertices then ask for their ranges
-		const u32 v0 = lane < exp_n ? (u32)exp_adj[lane] : 0u;
+		const int32_t *set_adj = fwd ? radj + di : adj + so;      // the set side's one-hop list (ids)
+		const uint4 *exp_desc = fwd ? fdesc + so : rdesc + di;    // the expanded side's one-hop list (slot descriptors)
+		const int32_t *xp = fwd ? padj : rpadj;                   // padded adjacency of the expanded side's direction
+		const u32 other = (u32)(fwd ? s : d);                     // distance 1: the set list contains the other endpoint
+		// both one-hop lists are requested together
+		uint4 d0 = make_uint4(0, 0, 0, 0);
+		if (lane < exp_n) d0 = exp_desc[lane];
 #pragma unroll
 		for (int k = 0; k < kMeetSlots / 256; k++)
 			reinterpret_cast<uint4_alias *>(tab)[k * 64 + lane] = make_uint4(kMeetEmpty, kMeetEmpty, kMeetEmpty, kMeetEmpty);
 #pragma unroll
 		for (int k = 0; k < kMeetFilterWords / 256; k++) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
-		int vb0 = 0, ve0 = 0;
-		if (lane < exp_n) {
-			vb0 = (int)xoff[v0];
-			ve0 = (int)xoff[v0 + 1];
-		}
 		__builtin_amdgcn_wave_barrier();
 		bool hit = false;
 		for (int pb = 0; pb < set_n; pb += 128) { // two rounds of 64 requested together
@@ -156,23 +161,20 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 			}
 		}
 		entries += (unsigned long long)set_n;
+		vertices += (u32)exp_n; // one 16-byte descriptor per expanded vertex
 		__builtin_amdgcn_wave_barrier();
 		{
 			if (__any(hit)) {
 				if (lane == 0) out[i] = 1;
 				continue;
 			}
-			// distance 2 (the middle vertex is the smallest common one) and the size of the two-hop walk
-			int64_t work = ve0 - vb0;
+			// distance 2: the middle vertex is the smallest common one
 			u32 mid = kMeetEmpty;
-			if (lane < exp_n && meet_lookup(tab, v0)) mid = v0;
+			if (lane < exp_n && meet_lookup(tab, d0.x)) mid = d0.x;
 			for (int p = 64 + lane; p < exp_n; p += 64) {
-				const u32 v = (u32)exp_adj[p];
+				const u32 v = exp_desc[p].x;
 				if (meet_lookup(tab, v)) mid = min(mid, v);
-				work += xoff[v + 1] - xoff[v];
 			}
-			entries += (unsigned long long)exp_n;
-			vertices += (u32)exp_n;
 			if (__any(mid != kMeetEmpty)) {
 				if constexpr (PATHS) {
 					const u32 m = (u32)wave_min_u64((u64)mid);
@@ -181,109 +183,28 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 				if (lane == 0) out[i] = 2;
 				continue;
 			}
-			for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
-			if (work > cap) {
-				if (lane == 0) out[i] = kMeetOpen;
-				continue;
-			}
 		}
-		// distance 3: stream the adjacency segment of every expanded-side vertex, 16 bytes per lane per request, one
-		// hash probe per entry.  The segments of a round of 64 vertices form one flat sequence of 256-entry chunks walked
-		// by a wave-uniform cursor; four chunk requests are always in flight (a chunk's registers are refilled as soon
-		// as it has been probed).
-		bool found = false;
-		u64 best = ~0ull; // PATHS: smallest (outer vertex << 32 | inner vertex) over all witnesses
-		for (int pb = 0; pb < exp_n && !found; pb += 64) {
-			const int cnt = min(64, exp_n - pb);
-			int vb = vb0, ve = ve0;
-			u32 vid = v0;
-			if (pb > 0) {
-				vb = ve = 0;
-				vid = 0;
-				if (lane < cnt) {
-					vid = (u32)exp_adj[pb + lane];
-					vb = (int)xoff[vid];
-					ve = (int)xoff[vid + 1];
-				}
-			}
-			int j = -1, q = 0, e = 0, b = 0; // cursor: vertex j of the round, aligned position q of its segment [b, e)
-			u32 cv = 0;                      // ... and that vertex's id
-			auto seek = [&]() { // next vertex with a non-empty segment
-				for (j++; j < cnt; j++) {
-					b = __builtin_amdgcn_readlane(vb, j); // wave-uniform: scalar registers
-					e = __builtin_amdgcn_readlane(ve, j);
-					if (e > b) {
-						q = b & ~3;
-						if constexpr (PATHS) cv = (u32)__builtin_amdgcn_readlane((int)vid, j);
-						return;
-					}
-				}
-			};
-			seek();
-			constexpr int DEPTH = PGQ_MEET3_DEPTH;
-			int4 x[DEPTH];
-			int xb[DEPTH], xe[DEPTH], xq[DEPTH]; // the segment and position a chunk was requested from (wave-uniform)
-			u32 xv[DEPTH];                       // ... and the expanded vertex it belongs to
-			auto fetch = [&](int u) {
-				xq[u] = -1;
-				if (j < cnt) {
-					const int t = q + 4 * lane;
-					// unconditional: a load under a per-lane condition is waited for at the end of the branch, which
-					// serialises the requests.  Lanes past the segment re-read its first group (same line as lane 0: no
-					// extra request); their entries are masked by the range tests
-#if PGQ_MEET3_NT
-					{ // streamed once: keep the lists out of L2 so that the offset look-ups stay in
-						typedef int v4i __attribute__((ext_vector_type(4)));
-						const v4i r = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(xadj + (t < e ? t : q)));
-						x[u] = make_int4(r.x, r.y, r.z, r.w);
-					}
-#else
-					x[u] = *reinterpret_cast<const int4 *>(xadj + (t < e ? t : q)); // aligned; the arrays are padded
-#endif
-					xb[u] = b;
-					xe[u] = e;
-					xq[u] = q;
-					xv[u] = cv;
-					entries += (unsigned long long)(min(e, q + 256) - max(b, q));
-					q += 256;
-					if (q >= e) seek();
-				}
-			};
-#pragma unroll
-			for (int u = 0; u < DEPTH; u++) fetch(u);
-			u32 f = 0;
-			for (;;) {
-				bool any_chunk = false;
-#pragma unroll
-				for (int u = 0; u < DEPTH; u++) {
-					if (xq[u] < 0) continue; // wave-uniform
-					any_chunk = true;
-					const int4 v = x[u];
-					const int cq = xq[u], t = cq + 4 * lane, sb = xb[u], se2 = xe[u];
-					const u32 ev = xv[u];
-					fetch(u); // refills x[u], xq[u], ...: everything about the current chunk was copied above
-					u32 valid = 0xFu; // a chunk inside its segment needs no per-entry range test (wave-uniform)
-					if (cq < sb || cq + 256 > se2)
-						valid = (u32)(t >= sb && t < se2) | ((u32)(t + 1 >= sb && t + 1 < se2) << 1) |
-						        ((u32)(t + 2 >= sb && t + 2 < se2) << 2) | ((u32)(t + 3 >= sb && t + 3 < se2) << 3);
-					const u32 m = meet_probe4(tab, bm, v, valid);
-					f |= m;
-					if constexpr (PATHS) {
-						// fwd: entry = second vertex, expanded = first; bwd: expanded = second vertex, entry = first
-						auto key = [&](u32 entry) { return fwd ? ((u64)entry << 32 | ev) : ((u64)ev << 32 | entry); };
-						if (m & 1u) best = min(best, key((u32)v.x));
-						if (m & 2u) best = min(best, key((u32)v.y));
-						if (m & 4u) best = min(best, key((u32)v.z));
-						if (m & 8u) best = min(best, key((u32)v.w));
-					}
-				}
-				// the first chunk with a hit ends the walk; PATHS: chunks are processed in walk order and the lists ascend, so
-				// every later witness has a larger (second vertex, first vertex) key than the smallest one of this round
-				if constexpr (PATHS) found = __any(best != ~0ull);
-				else found = __any(f != 0);
-				if (found || !any_chunk) break;
-			}
-		}
+		// distance 3: the padded lists of the expanded side's vertices, one hash probe per entry, ended by the first pass
+		// with a hit.  PATHS: requests are processed in walk order and the lists ascend, so every later witness has a
+		// larger (second vertex, first vertex) key than the smallest one of the pass that found the first
+		u32 f = 0;
+		u64 best = ~0ull; // PATHS: smallest (outer vertex << 32 | inner vertex) over the witnesses
+		bool capped = false;
+		entries += seg_walk<PGQ_MEET3_DEPTH, PATHS>(
+		    exp_desc, exp_n, 0, 1, xp, true, d0, (unsigned long long)cap, capped,
+		    [&](const int4 &v, bool ok, u32 ev) {
+			    const u32 m = meet_probe4(tab, bm, v, ok ? 0xFu : 0u);
+			    if constexpr (PATHS) { // backward walk: expanded vertex = second-to-last, entry = the one before it
+				    if (m & 1u) best = min(best, (u64)ev << 32 | (u32)v.x);
+				    if (m & 2u) best = min(best, (u64)ev << 32 | (u32)v.y);
+				    if (m & 4u) best = min(best, (u64)ev << 32 | (u32)v.z);
+				    if (m & 8u) best = min(best, (u64)ev << 32 | (u32)v.w);
+			    } else {
+				    f |= m;
+			    }
+		    },
+		    [&]() { return PATHS ? (__any(best != ~0ull) != 0) : (__any(f != 0) != 0); });
+		bool found;
 		if constexpr (PATHS) {
 			best = wave_min_u64(best);
 			found = best != ~0ull;
@@ -291,8 +212,11 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 				rec[i].v2 = (int32_t)(best >> 32);
 				rec[i].v1 = (int32_t)(u32)best;
 			}
+		} else {
+			found = __any(f != 0) != 0;
 		}
-		if (lane == 0) out[i] = found ? 3 : kMeetOpen4; // the walk ran to its end: the distance is at least 4
+		// the walk ran to its end without a witness: the distance is at least 4; it was cut short: nothing is known
+		if (lane == 0) out[i] = found ? 3 : (capped ? kMeetOpen : kMeetOpen4);
 	}
 	// one pair of atomics per workgroup, spread over the statistic slots
 	__shared__ unsigned long long s_stat[2];
@@ -540,6 +464,8 @@ template <bool GM>
 __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                  const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                  const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                 const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
+                                                 const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
                                                  const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
                                                  int bm_words, MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
 	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
@@ -567,6 +493,28 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 		}
 	};
 	auto flag_set = [&]() { return *(volatile int *)&s_flag != 0; };
+	// every wavefront reads the flag between two barriers, so that none of them can still be reading it when a later
+	// phase sets it again (a wavefront delayed between the barrier and its read would otherwise take another branch)
+	auto flag_snapshot = [&]() {
+		__syncthreads();
+		const int v = s_flag;
+		__syncthreads();
+		return v;
+	};
+	// the padded lists hold copies of a list's last entry and the lanes past a round's end re-read its last group:
+	// both repeat real entries, which neither a bit test nor a mark minds
+	auto walk_test = [&](const uint4 *list, int list_n, const int32_t *xp) {
+		bool f = false, capped = false;
+		const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
+		    list, list_n, wib, 16, xp, false, make_uint4(0, 0, 0, 0), ~0ull, capped,
+		    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
+		    [&]() {
+			    if (__any(f)) s_flag = 1;
+			    return flag_set();
+		    });
+		if (lane == 0) entries += e2;
+		if (__any(f)) s_flag = 1;
+	};
 	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
 		__syncthreads(); // the previous row's flag and map are no longer read
 		const int64_t s = src[i], d = dst[i]; // rows left open by k_meet3: ids in range, src != dst, both have edges
@@ -580,23 +528,17 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 			s_work[0] = s_work[1] = 0;
 		}
 		__syncthreads();
-		if (tid == 0) {
-			entries += (unsigned long long)(degS + degD);
-			vertices += (u32)(degS + degD);
-		}
+		if (tid == 0) vertices += (u32)(degS + degD); // both one-hop lists as descriptors
 		bool walk_fwd = degS <= degD; // which endpoint's two-hop neighbourhood is walked / marked
 		if (!known4) {
 			unsigned long long wf = 0, wb = 0;
 			bool hit = false;
 			for (int p = tid; p < degS; p += 1024) {
-				const u32 v = (u32)adj[so + p];
-				hit |= v == (u32)d;
-				wf += (unsigned long long)(off[v + 1] - off[v]);
+				const uint4 dd = fdesc[so + p];
+				hit |= dd.x == (u32)d;
+				wf += (unsigned long long)dd.z;
 			}
-			for (int p = tid; p < degD; p += 1024) {
-				const u32 u = (u32)radj[di + p];
-				wb += (unsigned long long)(roff[u + 1] - roff[u]);
-			}
+			for (int p = tid; p < degD; p += 1024) wb += (unsigned long long)rdesc[di + p].z;
 			for (int o = 32; o > 0; o >>= 1) {
 				wf += __shfl_xor(wf, o);
 				wb += __shfl_xor(wb, o);
@@ -606,8 +548,7 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 				if (wb) atomicAdd(&s_work[1], wb);
 			}
 			if (__any(hit) && lane == 0) s_flag = 1;
-			__syncthreads();
-			if (s_flag) { // dst in N_out(src)
+			if (flag_snapshot()) { // dst in N_out(src)
 				if (tid == 0) out_rows[row] = 1;
 				continue;
 			}
@@ -621,13 +562,13 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 			__syncthreads();
 			const int32_t *wl = walk_fwd ? adj + so : radj + di;
 			const int wn = walk_fwd ? degS : degD;
+			if (tid == 0) entries += (unsigned long long)(degS + degD);
 			{ // distance 2: a common neighbour
 				bool f = false;
 				for (int p = tid; p < wn; p += 1024) f |= bit((u32)wl[p]) != 0;
 				if (__any(f) && lane == 0) s_flag = 1;
 			}
-			__syncthreads();
-			if (s_flag) {
+			if (flag_snapshot()) {
 				if (tid == 0) out_rows[row] = 2;
 				continue;
 			}
@@ -635,19 +576,9 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 				if (tid == 0) out_rows[row] = kMeetOpen;
 				continue;
 			}
-			{ // distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
-				bool f = false;
-				const unsigned long long e2 = meet_walk(
-				    wl, wn, wib, 16, walk_fwd ? off : roff, walk_fwd ? adj : radj, [&](u32 x, u32) { f |= bit(x) != 0; },
-				    [&]() {
-					    if (__any(f)) s_flag = 1;
-					    return flag_set();
-				    });
-				if (lane == 0) entries += e2;
-				if (__any(f)) s_flag = 1;
-			}
-			__syncthreads();
-			if (s_flag) {
+			// distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
+			walk_test(walk_fwd ? fdesc + so : rdesc + di, wn, walk_fwd ? padj : rpadj);
+			if (flag_snapshot()) {
 				if (tid == 0) out_rows[row] = 3;
 				continue;
 			}
@@ -655,31 +586,28 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 				if (tid == 0) out_rows[row] = kMeetOpen;
 				continue;
 			}
-			clear_map(); // every wavefront is past its reads of the map (barrier above)
+			clear_map(); // every wavefront is past its reads of the map (barriers above)
 			__syncthreads();
 		}
 		// distance 4: two-hop set of the walked endpoint, two-hop walk of the other one
 		{
-			const unsigned long long e2 = meet_walk(walk_fwd ? adj + so : radj + di, walk_fwd ? degS : degD, wib, 16,
-			                                        walk_fwd ? off : roff, walk_fwd ? adj : radj,
-			                                        [&](u32 x, u32) { mark(x); }, []() { return false; });
+			bool capped = false;
+			const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
+			    walk_fwd ? fdesc + so : rdesc + di, walk_fwd ? degS : degD, wib, 16, walk_fwd ? padj : rpadj, false,
+			    make_uint4(0, 0, 0, 0), ~0ull, capped,
+			    [&](const int4 &v, bool, u32) {
+				    mark((u32)v.x);
+				    mark((u32)v.y);
+				    mark((u32)v.z);
+				    mark((u32)v.w);
+			    },
+			    []() { return false; });
 			if (lane == 0) entries += e2;
 		}
 		__syncthreads();
-		{
-			bool f = false;
-			const unsigned long long e2 = meet_walk(
-			    walk_fwd ? radj + di : adj + so, walk_fwd ? degD : degS, wib, 16, walk_fwd ? roff : off,
-			    walk_fwd ? radj : adj, [&](u32 x, u32) { f |= bit(x) != 0; },
-			    [&]() {
-				    if (__any(f)) s_flag = 1;
-				    return flag_set();
-			    });
-			if (lane == 0) entries += e2;
-			if (__any(f)) s_flag = 1;
-		}
-		__syncthreads();
-		if (tid == 0) out_rows[row] = s_flag ? 4 : kMeetOpen;
+		walk_test(walk_fwd ? rdesc + di : fdesc + so, walk_fwd ? degD : degS, walk_fwd ? rpadj : padj);
+		const int f4 = flag_snapshot();
+		if (tid == 0) out_rows[row] = f4 ? 4 : kMeetOpen;
 	}
 	__shared__ unsigned long long s_stat[2];
 	__syncthreads();
@@ -710,13 +638,17 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 // means that side's closure is complete: NULL, like the exhausted search of iterativelength.cpp:133-139.  A frontier over
 // `cap` entries or `qcap` vertices leaves the row open.
 template <bool GM>
-__global__ __launch_bounds__(1024) void k_bibfs(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(1024) void k_bibfs(const u32 *__restrict__ n_rows, u32 max_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                 const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                 const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
                                                 int bm_words, int qcap, MeetCounters *__restrict__ mc,
                                                 u32 *__restrict__ gmaps, u32 *__restrict__ queues) {
 	extern __shared__ u32 s_map[]; // !GM: both maps, (bm_words + 4) words each; the spare words take the masked lanes' bits
+	// rows still open, counted on the device (no host round trip before this launch); more than a handful: not this
+	// kernel's job, the lane-batched search takes them
+	const int64_t n = (int64_t)*n_rows;
+	if (n > (int64_t)max_rows) return;
 	const int mw = bm_words + 4;
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * 2 * mw : nullptr;
 	u32 *const qbase = queues + (size_t)blockIdx.x * 4 * qcap; // [side][parity][qcap]
@@ -890,9 +822,19 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // ---- how many distinct sources? ---------------------------------------------------------------------------------------
 // The pre-pass costs one two-hop walk per ROW, the lane-batched search one lane per distinct SOURCE: for cross-product
 // shaped inputs (few sources x many destinations, the binder's shape) the latter wins by orders of magnitude.  A
-// strided sample of the rows goes through an LDS hash set; the host inverts E[distinct] = U (1 - (1 - 1/U)^sample).
+// strided sample of the rows goes through an LDS hash set, thread 0 inverts E[distinct] = U (1 - (1 - 1/U)^sample) and
+// compares the two cost estimates ON THE DEVICE: the pre-pass kernels are launched straight behind and return at once
+// when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
 constexpr int kSampleRows = 4096, kSampleSlots = 16384;
-__global__ __launch_bounds__(1024) void k_sample_sources(int64_t n, const int64_t *__restrict__ src, u32 *__restrict__ out) {
+struct MeetDecision {
+	u32 go;           // 1: the pre-pass runs
+	u32 sample_rows;  // non-NULL rows sampled
+	u32 sample_fresh; // distinct sources among them
+	u32 pad;
+	double estimate;  // distinct sources of the whole input
+};
+__global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
+                                                     double batch_bytes, MeetDecision *__restrict__ out) {
 	__shared__ u32 s_set[kSampleSlots];
 	__shared__ u32 s_count[2];
 	for (int k = threadIdx.x; k < kSampleSlots; k += 1024) s_set[k] = kMeetEmpty;
@@ -916,42 +858,37 @@ __global__ __launch_bounds__(1024) void k_sample_sources(int64_t n, const int64_
 	if (fresh) atomicAdd(&s_count[0], fresh);
 	if (rows) atomicAdd(&s_count[1], rows);
 	__syncthreads();
-	if (threadIdx.x < 2) out[threadIdx.x] = s_count[threadIdx.x];
-}
-
-int estimate_distinct_sources(Workspace *ws, int64_t n, const int64_t *d_src, int64_t *estimate) {
-	hipStream_t st = ws->stream;
-	PGQ_TRY(ws->meet_cnt.reserve(sizeof(MeetCounters) + 16));
-	u32 *d_out = ws->meet_cnt.as<u32>();
-	hipLaunchKernelGGL(k_sample_sources, dim3(1), dim3(1024), 0, st, n, d_src, d_out);
-	u32 *h = static_cast<u32 *>(ws->h_meet); // pinned
-	PGQ_HIP_TRY(hipMemcpyAsync(h, d_out, 2 * sizeof(u32), hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
-	const double d = h[0], s = h[1];
-	if (s < 1 || d < 1) {
-		*estimate = 1;
-		return PGQ_OK;
+	if (threadIdx.x != 0) return;
+	const double d = s_count[0], sr = s_count[1];
+	double est;
+	if (sr < 1 || d < 1) {
+		est = 1;
+	} else if (d >= sr - 0.5) { // every sampled row had its own source
+		est = (double)n;
+	} else {
+		double lo = d, hi = (double)n; // E[distinct](U) is increasing in U
+		for (int it = 0; it < 60; it++) {
+			const double mid = 0.5 * (lo + hi);
+			const double e = mid * (1.0 - pow(1.0 - 1.0 / mid, sr));
+			if (e < d) lo = mid;
+			else hi = mid;
+		}
+		est = fmin((double)n, ceil(hi));
 	}
-	if (d >= s - 0.5) { // every sampled row had its own source
-		*estimate = n;
-		return PGQ_OK;
-	}
-	double lo = d, hi = (double)n; // E[distinct](U) is increasing in U
-	for (int it = 0; it < 60; it++) {
-		const double mid = 0.5 * (lo + hi);
-		const double e = mid * (1.0 - std::pow(1.0 - 1.0 / mid, s));
-		if (e < d) lo = mid;
-		else hi = mid;
-	}
-	*estimate = (int64_t)std::min<double>((double)n, std::ceil(hi));
-	return PGQ_OK;
+	const double distinct = fmin(est, (double)V);
+	const double batches = floor((distinct + 2047.0) / 2048.0);
+	out->go = meet_bytes <= batch_bytes * batches ? 1u : 0u;
+	out->sample_rows = s_count[1];
+	out->sample_fresh = s_count[0];
+	out->estimate = est;
 }
 
 // rows the pre-pass left open, compacted for the lane-batched search (order does not matter: results are scattered
 // back through didx)
 __global__ void k_collect_open(int64_t n, const int64_t *__restrict__ out, const int64_t *__restrict__ src,
                                const int64_t *__restrict__ dst, int64_t *__restrict__ dsrc, int64_t *__restrict__ ddst,
-                               u32 *__restrict__ didx, u32 *__restrict__ count) {
+                               u32 *__restrict__ didx, u32 *__restrict__ count, const u32 *__restrict__ go) {
+	if (go && *go == 0) return; // the pre-pass was called off: d_out holds nothing
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const bool open = i < n && (out[i] == kMeetOpen || out[i] == kMeetOpen4);
 	const u64 m = __ballot(open);
@@ -975,68 +912,97 @@ __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int
 }
 
 // Runs the pre-pass over n rows resident in HBM; rows it answers get their hop count (or -1 for NULL) in d_out, the
-// others are compacted into ws->def_src/def_dst/def_idx and counted in *n_open.
+// others are compacted into ws->def_src/def_dst/def_idx and counted in *n_open.  The whole chain — decision (large
+// inputs), k_meet3, the bit-map kernel, the bidirectional search for a handful of leftovers, the compactions between
+// them — is launched back to back; every kernel reads what it needs (the go flag, the number of rows still open) from
+// device memory, so the host waits ONCE per call.  decide: k_meet_decide compares `meet_bytes` with `batch_bytes` x
+// batches of distinct sources first; *ran = false when it said no (nothing was written to d_out).
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, bool paths) {
+                 u32 *n_open, bool paths, bool decide, double meet_bytes, double batch_bytes, bool *ran) {
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
-	PGQ_TRY(ws->meet_cnt.reserve(sizeof(MeetCounters) + 16));
+	const Options &opt = options();
+	if (ran) *ran = true;
+	struct DevBlock { // what comes back in one copy
+		MeetCounters m;
+		u32 count[4]; // rows open after k_meet3, after k_meet4 / k_meet4d, after k_bibfs
+		MeetDecision dec;
+	};
+	static_assert(sizeof(DevBlock) <= 8192, "pinned statistics block too small");
+	PGQ_TRY(ws->meet_cnt.reserve(sizeof(DevBlock)));
 	if (paths) PGQ_TRY(ws->meet_rec.reserve((size_t)n * sizeof(MeetPath)));
 	MeetPath *rec = paths ? ws->meet_rec.as<MeetPath>() : nullptr;
 	PGQ_TRY(ws->def_src.reserve((size_t)n * 8));
 	PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
 	PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
-	MeetCounters *mc = ws->meet_cnt.as<MeetCounters>();
-	u32 *d_count = reinterpret_cast<u32 *>(mc + 1); // [0] rows open after k_meet3, [1] after k_meet4 / k_meet4d
-	PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
+	DevBlock *db = ws->meet_cnt.as<DevBlock>();
+	MeetCounters *mc = &db->m;
+	u32 *d_count = db->count;
+	const u32 *d_go = decide ? &db->dec.go : nullptr;
+	PGQ_HIP_TRY(hipMemsetAsync(db, 0, sizeof(DevBlock), st));
+	if (decide)
+		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, batch_bytes, &db->dec);
 	{
-		const int64_t cap = std::max(1, paths ? options().meet_cap_paths : options().meet_cap);
+		const int64_t cap = std::max(1, paths ? opt.meet_cap_paths : opt.meet_cap);
 		KernelTimer kt(st, K_MEET);
 		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 4 rounds
 		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident));
 		if (paths)
 			hipLaunchKernelGGL(k_meet3<true>, grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,
-			                   c->radj, d_out, rec, cap, mc);
+			                   c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap, d_go, mc);
 		else
 			hipLaunchKernelGGL(k_meet3<false>, grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,
-			                   c->radj, d_out, rec, cap, mc);
+			                   c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap, d_go, mc);
 		kt.stop();
 	}
 	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
+	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count, d_go);
 	// what is left (distance >= 4, or over k_meet3's caps): the bit-map kernels, launched straight behind on a fixed grid —
-	// they read the row count from the device, so the host waits once for both.  The vertex bit map sits in LDS when it
-	// fits (V <= ~1.2 M); above that every workgroup gets a slice of a global buffer (L2-resident: 0.5 MB at V = 4 M).
+	// they read the row count from the device.  The vertex bit map sits in LDS when it fits (V <= ~1.2 M); above that
+	// every workgroup gets a slice of a global buffer (L2-resident: 0.5 MB at V = 4 M).
 	const int bm_words = (int)((c->V + 127) / 128) * 4;
-	const bool lds_map = (size_t)bm_words * 4 + 512 <= (size_t)std::min(150, std::max(0, options().meet4_lds_kb)) * 1024;
-	const size_t gm_budget = (size_t)std::max(0, options().meet4_global_mb) << 20;
-	const bool run4 = options().meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget);
+	const size_t lds_budget = (size_t)std::min(150, std::max(0, opt.meet4_lds_kb)) * 1024;
+	const bool lds_map = (size_t)bm_words * 4 + 512 <= lds_budget;
+	const size_t gm_budget = (size_t)std::max(0, opt.meet4_global_mb) << 20;
+	const bool run4 = opt.meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget);
+	// k_bibfs: both sides' maps in LDS when they fit, else in the global buffer behind the queues
+	const bool run_bi = !paths && opt.bibfs_rows > 0;
+	const int mwb = bm_words + 4;
+	const bool bi_lds = (size_t)2 * mwb * 4 + 512 <= lds_budget;
+	const int qcap = std::max(1024, opt.bibfs_queue);
+	const u32 bi_grid = (u32)std::min(64, std::max(1, opt.bibfs_rows));
+	u32 grid4 = (u32)std::min<int64_t>(n, 256 * 4);
+	size_t maps_bytes = 0;
+	if (run4 && !lds_map) {
+		grid4 = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, 256), gm_budget / ((size_t)bm_words * 4)));
+		maps_bytes = (size_t)grid4 * bm_words * 4;
+	}
+	const size_t bi_map_words = (run_bi && !bi_lds) ? (size_t)bi_grid * 2 * mwb : 0;
+	const size_t bi_bytes = run_bi ? (bi_map_words + (size_t)bi_grid * 4 * qcap) * 4 + 64 : 0;
+	if (maps_bytes + bi_bytes > 0) PGQ_TRY(ws->meet_maps.reserve(maps_bytes + bi_bytes + 64));
+	u32 *gmaps = ws->meet_maps.as<u32>();
+	u32 *bi_maps = gmaps ? gmaps + (maps_bytes + 15) / 16 * 4 : nullptr;
+	static std::atomic<int> attr_set { 0 };
+	if (!attr_set.load()) {
+		(void)hipFuncSetAttribute((const void *)k_meet4d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_meet4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+		attr_set.store(1);
+	}
+	const u32 *d_open = d_count; // the counter the next stage reads its row count from
 	if (run4) {
-		static std::atomic<int> attr_set { 0 };
-		if (!attr_set.load()) {
-			(void)hipFuncSetAttribute((const void *)k_meet4d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-			(void)hipFuncSetAttribute((const void *)k_meet4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-			attr_set.store(1);
-		}
-		u32 grid = (u32)std::min<int64_t>(n, 256 * 4);
-		u32 *gmaps = nullptr;
-		if (!lds_map) {
-			grid = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, 256), gm_budget / ((size_t)bm_words * 4)));
-			PGQ_TRY(ws->meet_maps.reserve((size_t)grid * bm_words * 4));
-			gmaps = ws->meet_maps.as<u32>();
-		}
 		const size_t lds = lds_map ? (size_t)bm_words * 4 : 0;
-		const int64_t cap4 = (int64_t)std::max(1, options().meet4_cap);
+		const int64_t cap4 = (int64_t)std::max(1, opt.meet4_cap);
 		{
 			KernelTimer kt(st, K_MEET);
 #define PGQ_MEET4(G)                                                                                                     \
-	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid), dim3(1024), lds, st, (const u32 *)d_count, ws->def_src.as<int64_t>(), \
+	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid4), dim3(1024), lds, st, d_open, ws->def_src.as<int64_t>(),          \
 	                   ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, rec, \
 	                   cap4, bm_words, mc, gmaps)
 #define PGQ_MEET4D(G)                                                                                                    \
-	hipLaunchKernelGGL((k_meet4d<G>), dim3(grid), dim3(1024), lds, st, (const u32 *)d_count, ws->def_src.as<int64_t>(),   \
-	                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, cap4,    \
-	                   bm_words, mc, gmaps)
+	hipLaunchKernelGGL((k_meet4d<G>), dim3(grid4), dim3(1024), lds, st, d_open, ws->def_src.as<int64_t>(),               \
+	                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj,   \
+	                   ws->def_idx.as<u32>(), d_out, cap4, bm_words, mc, gmaps)
 			if (paths && lds_map) PGQ_MEET4(false);
 			else if (paths) PGQ_MEET4(true);
 			else if (lds_map) PGQ_MEET4D(false);
@@ -1046,71 +1012,50 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			kt.stop();
 		}
 		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count + 1);
+		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count + 1, d_go);
+		d_open = d_count + 1;
 	}
-	struct Host {
-		MeetCounters m;
-		u32 count_after3, count_after4, pad[2];
-		u32 count;
-	};
-	static_assert(sizeof(Host) <= 8192, "pinned statistics block too small");
-	Host &h = *static_cast<Host *>(ws->h_meet);
-	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, mc, sizeof(MeetCounters) + 16, hipMemcpyDeviceToHost, st));
+	// a handful of rows still open (far apart, unreachable, over the caps): one bidirectional search each, so that the
+	// lane-batched search — whole-graph levels — only starts for what really needs it.  The kernel checks the count itself.
+	if (run_bi) {
+		u32 *queues = bi_maps + bi_map_words;
+		const int64_t capb = (int64_t)std::max(1, opt.bibfs_cap);
+		{
+			KernelTimer kt(st, K_MEET);
+			if (bi_lds)
+				hipLaunchKernelGGL(k_bibfs<false>, dim3(bi_grid), dim3(1024), (size_t)2 * mwb * 4, st, d_open, (u32)opt.bibfs_rows,
+				                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
+				                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, mc, bi_maps, queues);
+			else
+				hipLaunchKernelGGL(k_bibfs<true>, dim3(bi_grid), dim3(1024), 0, st, d_open, (u32)opt.bibfs_rows,
+				                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
+				                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, mc, bi_maps, queues);
+			kt.stop();
+		}
+		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
+		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count + 2, d_go);
+		d_open = d_count + 2;
+	}
+	DevBlock &h = *static_cast<DevBlock *>(ws->h_meet);
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, db, sizeof(DevBlock), hipMemcpyDeviceToHost, st));
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	KernelTimer::flush();
+	if (decide && !h.dec.go) {
+		if (ran) *ran = false;
+		*n_open = (u32)n;
+		return PGQ_OK;
+	}
 	if (h.m.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
-	h.count = run4 ? h.count_after4 : h.count_after3;
 	unsigned long long entries = 0, vertices = 0;
 	for (int k = 0; k < kMeetStatSlots; k++) {
 		entries += h.m.entries[k];
 		vertices += h.m.vertices[k];
 	}
-	// a handful of rows still open (far apart, unreachable, over the caps): one bidirectional search each, so that the
-	// lane-batched search — whole-graph levels — only starts for what really needs it
-	if (!paths && h.count > 0 && (int64_t)h.count <= (int64_t)options().bibfs_rows) {
-		const int bmw = (int)((c->V + 127) / 128) * 4, mw = bmw + 4;
-		const bool lds_maps = (size_t)2 * mw * 4 + 512 <= (size_t)std::min(150, std::max(0, options().meet4_lds_kb)) * 1024;
-		const int qcap = std::max(1024, options().bibfs_queue);
-		const u32 nd = h.count;
-		const u32 grid = std::min<u32>(nd, 64);
-		static std::atomic<int> attr_set2 { 0 };
-		if (!attr_set2.load()) {
-			(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-			attr_set2.store(1);
-		}
-		const size_t map_words = lds_maps ? 0 : (size_t)grid * 2 * mw;
-		PGQ_TRY(ws->meet_maps.reserve((map_words + (size_t)grid * 4 * qcap) * 4 + 64));
-		u32 *gmaps = ws->meet_maps.as<u32>();
-		u32 *queues = gmaps + map_words;
-		const int64_t capb = (int64_t)std::max(1, options().bibfs_cap);
-		PGQ_HIP_TRY(hipMemsetAsync(mc, 0, sizeof(MeetCounters) + 16, st));
-		{
-			KernelTimer kt(st, K_MEET);
-			if (lds_maps)
-				hipLaunchKernelGGL(k_bibfs<false>, dim3(grid), dim3(1024), (size_t)2 * mw * 4, st, (int64_t)nd,
-				                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
-				                   ws->def_idx.as<u32>(), d_out, capb, bmw, qcap, mc, gmaps, queues);
-			else
-				hipLaunchKernelGGL(k_bibfs<true>, dim3(grid), dim3(1024), 0, st, (int64_t)nd, ws->def_src.as<int64_t>(),
-				                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out,
-				                   capb, bmw, qcap, mc, gmaps, queues);
-			kt.stop();
-		}
-		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
-		PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, mc, sizeof(MeetCounters) + 16, hipMemcpyDeviceToHost, st));
-		PGQ_HIP_TRY(hipStreamSynchronize(st));
-		KernelTimer::flush();
-		h.count = h.count_after3; // the counter block was cleared: slot [0] now counts what k_bibfs left open
-		for (int k = 0; k < kMeetStatSlots; k++) {
-			entries += h.m.entries[k];
-			vertices += h.m.vertices[k];
-		}
-	}
-	S.meet_pairs += n - (int64_t)h.count;
+	const u32 open = h.count[d_open - d_count];
+	S.meet_pairs += n - (int64_t)open;
 	S.edges_scanned += (int64_t)entries;
 	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
-	*n_open = h.count;
+	*n_open = open;
 	return PGQ_OK;
 }
 

@@ -1770,17 +1770,22 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// cost less than the MS-BFS levels they replace: bytes ~ rows x E[in-degree x out-degree] x 4 (the cheaper
 	// endpoint is expanded: ~0.6 of that) against ~16 B per edge per 2048-lane batch.
 	const Options &mopt = options();
-	const bool may_meet = mopt.meet && !outp.want_te && outp.depth == 0 && c->E > 0;
+	const bool may_meet = mopt.meet && !outp.want_te && outp.depth == 0 && c->E > 0 && c->fdesc != nullptr;
+	const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
+	const double batch_bytes = mopt.meet_bias * (double)c->E * 16.0;
 	auto meet_pays = [&](int64_t distinct_sources) {
-		const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
 		const double batches = (double)((distinct_sources + 2047) / 2048);
-		return meet_bytes <= mopt.meet_bias * batches * (double)c->E * 16.0;
+		return meet_bytes <= batch_bytes * batches;
 	};
+	// few rows: every row is taken as a distinct source (the pessimistic case for the pre-pass); many rows: a sampled
+	// estimate of the distinct sources decides ON THE DEVICE, in the same launch chain (cross products share their lanes)
+	const bool decide = n > 16384;
 	// shortestpath: the pre-pass also records each answered row's inner vertices (reference tie-break); their lists are
 	// packed first, the lists of the rows left to the lane-batched search are appended behind them
-	auto run_meet_paths = [&]() -> int {
+	auto run_meet_paths = [&](bool *ran) -> int {
 		u32 nd = 0;
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, true));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, true, decide, meet_bytes, batch_bytes, ran));
+		if (!*ran) return PGQ_OK;
 		int64_t total = 0;
 		PGQ_TRY(meet_path_offsets(ws, n, d_out_len, &total));
 		WorkspaceLease inner;
@@ -1818,10 +1823,11 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			return fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(need) + " elements");
 		return PGQ_OK;
 	};
-	auto run_meet = [&]() -> int {
-		if (with_paths) return run_meet_paths();
+	auto run_meet = [&](bool *ran) -> int {
+		if (with_paths) return run_meet_paths(ran);
 		u32 nd = 0;
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, false, decide, meet_bytes, batch_bytes, ran));
+		if (!*ran) return PGQ_OK;
 		if (nd > 0) {
 			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
 			WorkspaceLease inner;
@@ -1836,13 +1842,10 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		}
 		return PGQ_OK;
 	};
-	// few rows: every row is taken as a distinct source (the pessimistic case for the pre-pass); many rows: a sampled
-	// estimate of the distinct sources decides (cross products share their lanes)
-	if (may_meet && n <= 16384 && meet_pays(std::min<int64_t>(n, c->V))) return run_meet();
-	if (may_meet && n > 16384 && meet_pays(std::min<int64_t>(n, c->V))) { // worth a look at the sharing
-		int64_t est = n;
-		PGQ_TRY(estimate_distinct_sources(ws, n, d_src, &est));
-		if (meet_pays(std::min<int64_t>(est, c->V))) return run_meet();
+	if (may_meet && meet_pays(std::min<int64_t>(n, c->V))) {
+		bool ran = true;
+		PGQ_TRY(run_meet(&ran));
+		if (ran) return PGQ_OK;
 	}
 	u32 U = 0;
 	// the accounting pass counts the full BFS of a pair even when dst has no in-edge, so it keeps those lanes

@@ -45,6 +45,70 @@ ThreadStats &tstats() {
 	return ts;
 }
 
+// one table for pgq_set_option / pgq_get_option
+struct OptRef {
+	const char *name;
+	int *i;
+	double *d;
+};
+static std::vector<OptRef> option_table() {
+	Options &o = options();
+	return {
+		{ "words", &o.words, nullptr },
+		{ "max_words", &o.max_words, nullptr },
+		{ "push_div", nullptr, &o.push_div },
+		{ "profile", &o.profile, nullptr },
+		{ "hub_chunk", &o.hub_chunk, nullptr },
+		{ "push_chunk", &o.push_chunk, nullptr },
+		{ "force_mode", &o.force_mode, nullptr },
+		{ "force_pull", &o.force_pull, nullptr },
+		{ "blocks_per_cu", &o.blocks_per_cu, nullptr },
+		{ "relax_small_limit", &o.relax_small_limit, nullptr },
+		{ "chain", &o.chain, nullptr },
+		{ "chain_cap", &o.chain_cap, nullptr },
+		{ "alloc_cache_mb", &o.alloc_cache_mb, nullptr },
+		{ "trace", &o.trace, nullptr },
+		{ "probe", &o.probe, nullptr },
+		{ "defer", &o.defer, nullptr },
+		{ "probe2", &o.probe2, nullptr },
+		{ "probe2_cap", &o.probe2_cap, nullptr },
+		{ "probe2_div", &o.probe2_div, nullptr },
+		{ "probe2_abs", &o.probe2_abs, nullptr },
+		{ "part_weight", &o.part_weight, nullptr },
+		{ "sparse_below", nullptr, &o.sparse_below },
+		{ "sparse_unroll", &o.sparse_unroll, nullptr },
+		{ "sparse_lds", &o.sparse_lds, nullptr },
+		{ "sparse_pw", &o.sparse_pw, nullptr },
+		{ "sparse_spill", &o.sparse_spill, nullptr },
+		{ "streams", &o.streams, nullptr },
+		{ "lanes", &o.lanes, nullptr },
+		{ "meet", &o.meet, nullptr },
+		{ "meet_cap", &o.meet_cap, nullptr },
+		{ "meet_cap_paths", &o.meet_cap_paths, nullptr },
+		{ "meet4", &o.meet4, nullptr },
+		{ "meet4_cap", &o.meet4_cap, nullptr },
+		{ "meet4_global_mb", &o.meet4_global_mb, nullptr },
+		{ "meet4_lds_kb", &o.meet4_lds_kb, nullptr },
+		{ "bibfs_rows", &o.bibfs_rows, nullptr },
+		{ "wbibfs", &o.wbibfs, nullptr },
+		{ "wbibfs_rows", &o.wbibfs_rows, nullptr },
+		{ "wbibfs_cap", &o.wbibfs_cap, nullptr },
+		{ "wbibfs_queue", &o.wbibfs_queue, nullptr },
+		{ "wbibfs_far", &o.wbibfs_far, nullptr },
+		{ "wbibfs_prune", &o.wbibfs_prune, nullptr },
+		{ "wbibfs_mem_mb", &o.wbibfs_mem_mb, nullptr },
+		{ "wbibfs_delta_div", &o.wbibfs_delta_div, nullptr },
+		{ "bibfs_cap", &o.bibfs_cap, nullptr },
+		{ "bibfs_queue", &o.bibfs_queue, nullptr },
+		{ "meet_bias", nullptr, &o.meet_bias },
+		{ "lanes_unroll", &o.lanes_unroll, nullptr },
+		{ "upload_threads", &o.upload_threads, nullptr },
+		{ "upload_narrow_host", &o.upload_narrow_host, nullptr },
+		{ "meet_layout", &o.meet_layout, nullptr },
+		{ "meet_align", &o.meet_align, nullptr },
+	};
+}
+
 static void env_int(const char *name, int &dst) {
 	const char *v = getenv(name);
 	if (v && *v) dst = atoi(v);
@@ -74,48 +138,13 @@ static int do_init(int device) {
 	if (e != hipSuccess) return fail(PGQ_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
 	g_device = device;
 	if (g_devices.empty()) g_devices.push_back(device);
-	env_int("PGQ_WORDS", g_opt.words);
-	env_int("PGQ_MAX_WORDS", g_opt.max_words);
-	env_double("PGQ_PUSH_DIV", g_opt.push_div);
-	env_int("PGQ_PROFILE", g_opt.profile);
-	env_int("PGQ_HUB_CHUNK", g_opt.hub_chunk);
-	env_int("PGQ_PUSH_CHUNK", g_opt.push_chunk);
-	env_int("PGQ_FORCE_MODE", g_opt.force_mode);
-	env_int("PGQ_FORCE_PULL", g_opt.force_pull);
-	env_int("PGQ_BLOCKS_PER_CU", g_opt.blocks_per_cu);
-	env_int("PGQ_RELAX_SMALL_LIMIT", g_opt.relax_small_limit);
-	env_int("PGQ_CHAIN", g_opt.chain);
-	env_int("PGQ_TRACE", g_opt.trace);
-	env_int("PGQ_PROBE", g_opt.probe);
-	env_int("PGQ_DEFER", g_opt.defer);
-	env_int("PGQ_PROBE2", g_opt.probe2);
-	env_int("PGQ_PROBE2_CAP", g_opt.probe2_cap);
-	env_int("PGQ_PROBE2_DIV", g_opt.probe2_div);
-	env_int("PGQ_PROBE2_ABS", g_opt.probe2_abs);
-	env_int("PGQ_PART_WEIGHT", g_opt.part_weight);
-	env_double("PGQ_SPARSE_BELOW", g_opt.sparse_below);
-	env_int("PGQ_SPARSE_UNROLL", g_opt.sparse_unroll);
-	env_int("PGQ_SPARSE_LDS", g_opt.sparse_lds);
-	env_int("PGQ_SPARSE_PW", g_opt.sparse_pw);
-	env_int("PGQ_SPARSE_SPILL", g_opt.sparse_spill);
-	env_int("PGQ_STREAMS", g_opt.streams);
-	env_int("PGQ_LANES", g_opt.lanes);
-	env_int("PGQ_MEET", g_opt.meet);
-	env_int("PGQ_MEET_CAP", g_opt.meet_cap);
-	env_int("PGQ_MEET_CAP_PATHS", g_opt.meet_cap_paths);
-	env_int("PGQ_MEET4", g_opt.meet4);
-	env_int("PGQ_MEET4_CAP", g_opt.meet4_cap);
-	env_int("PGQ_MEET4_GLOBAL_MB", g_opt.meet4_global_mb);
-	env_int("PGQ_BIBFS_ROWS", g_opt.bibfs_rows);
-	env_int("PGQ_WBIBFS", g_opt.wbibfs);
-	env_int("PGQ_WBIBFS_DELTA_DIV", g_opt.wbibfs_delta_div);
-	env_int("PGQ_WBIBFS_PRUNE", g_opt.wbibfs_prune);
-	env_int("PGQ_BIBFS_CAP", g_opt.bibfs_cap);
-	env_double("PGQ_MEET_BIAS", g_opt.meet_bias);
-	env_int("PGQ_LANES_UNROLL", g_opt.lanes_unroll);
-	env_int("PGQ_ALLOC_CACHE_MB", g_opt.alloc_cache_mb);
-	env_int("PGQ_UPLOAD_THREADS", g_opt.upload_threads);
-	env_int("PGQ_UPLOAD_NARROW_HOST", g_opt.upload_narrow_host);
+	// every option of the table can be preset from the environment: PGQ_<NAME IN CAPITALS>
+	for (const OptRef &r : option_table()) {
+		std::string name = "PGQ_";
+		for (const char *q = r.name; *q; q++) name += (char)toupper((unsigned char)*q);
+		if (r.i) env_int(name.c_str(), *r.i);
+		else env_double(name.c_str(), *r.d);
+	}
 	g_inited.store(1);
 	return PGQ_OK;
 }
@@ -640,6 +669,105 @@ __global__ void k_make_parts(int64_t V, const int64_t *__restrict__ roff, int64_
 	else if (v1 == V) st->n_parts = base + n;
 }
 
+// ---- layout of the pair-centric kernels: padded adjacency + slot descriptors (pgq_walk.h) ------------------------------
+// groups (16 bytes = 4 entries) a vertex's padded list occupies: its entries rounded up to `align` entries
+__global__ void k_seg_groups(int64_t V, const int64_t *__restrict__ off, u32 align, u32 *__restrict__ ng) {
+	const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= V) return;
+	const u32 len = (u32)(off[v + 1] - off[v]);
+	ng[v] = ((len + align - 1) / align) * (align >> 2);
+}
+__global__ void k_seg_fill(int64_t V, const int64_t *__restrict__ off, const u32 *__restrict__ gbeg, uint2 *__restrict__ seg) {
+	const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < V) seg[v] = make_uint2(gbeg[v], (u32)(off[v + 1] - off[v]));
+}
+// One workgroup copies the lists of 256 consecutive vertices: their padded groups are one contiguous range, a thread
+// writes whole groups (coalesced) and finds a group's vertex by binary search over the 257 group starts in LDS.
+// Positions past a list's end repeat its last entry.
+__global__ __launch_bounds__(256) void k_fill_padded(int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                     const uint2 *__restrict__ seg, u32 total_groups,
+                                                     int32_t *__restrict__ padj) {
+	__shared__ u32 s_beg[257];
+	__shared__ int64_t s_off[257];
+	const int64_t v0 = (int64_t)blockIdx.x * 256;
+	const int nv = (int)min((int64_t)256, V - v0);
+	for (int t = threadIdx.x; t <= nv; t += 256) {
+		s_beg[t] = (v0 + t < V) ? seg[v0 + t].x : total_groups;
+		s_off[t] = off[v0 + t];
+	}
+	__syncthreads();
+	const u32 g0 = s_beg[0], g1 = s_beg[nv];
+	for (u32 g = g0 + threadIdx.x; g < g1; g += 256) {
+		int lo = 0, hi = nv; // largest t with s_beg[t] <= g; lists without groups share their start with the next one
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (s_beg[mid] <= g) lo = mid;
+			else hi = mid;
+		}
+		const int64_t b = s_off[lo], len = s_off[lo + 1] - b;
+		const int64_t i0 = (int64_t)(g - s_beg[lo]) * 4;
+		int4 o;
+		o.x = adj[b + min(i0, len - 1)];
+		o.y = adj[b + min(i0 + 1, len - 1)];
+		o.z = adj[b + min(i0 + 2, len - 1)];
+		o.w = adj[b + min(i0 + 3, len - 1)];
+		reinterpret_cast<int4 *>(padj)[g] = o;
+	}
+}
+__global__ void k_fill_desc(int64_t E, const int32_t *__restrict__ adj, const uint2 *__restrict__ seg, uint4 *__restrict__ desc) {
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= E) return;
+	const u32 u = (u32)adj[e];
+	const uint2 s = seg[u];
+	desc[e] = make_uint4(u, s.x, s.y, 0u);
+}
+
+static int build_meet_layout_dir(pgq_csr *c, const int64_t *off, const int32_t *adj, int32_t **padj, uint2 **seg,
+                                 uint4 **desc, int64_t *groups_out, hipStream_t st) {
+	const int64_t V = c->V, E = c->E;
+	u32 align = (u32)std::max(4, options().meet_align) & ~3u;
+	// group indices are 32-bit: E / 4 + V x align / 4 bounds the padded size; one group per list start always fits
+	if ((double)E / 4.0 + (double)V * (align / 4.0) >= 4.0e9) align = 4;
+	u32 *d_ng = nullptr, *d_gb = nullptr;
+	void *d_tmp = nullptr;
+	struct Temps {
+		u32 *&a, *&b;
+		void *&t;
+		hipStream_t st;
+		~Temps() {
+			(void)hipStreamSynchronize(st); // the kernels below may still read them on an error return
+			dev_free(a);
+			dev_free(b);
+			dev_free(t);
+		}
+	} temps { d_ng, d_gb, d_tmp, st };
+	PGQ_TRY(dev_alloc_as(&d_ng, (size_t)V + 1));
+	PGQ_TRY(dev_alloc_as(&d_gb, (size_t)V + 1));
+	PGQ_HIP_TRY(hipMemsetAsync(d_ng + V, 0, sizeof(u32), st));
+	hipLaunchKernelGGL(k_seg_groups, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, off, align, d_ng);
+	size_t sb = 0;
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, d_ng, d_gb, (int)(V + 1), st));
+	PGQ_TRY(dev_alloc(&d_tmp, sb + 16));
+	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, sb, d_ng, d_gb, (int)(V + 1), st));
+	u32 total = 0;
+	PGQ_HIP_TRY(hipMemcpyAsync(&total, d_gb + V, sizeof(u32), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	PGQ_TRY(dev_alloc_as(seg, (size_t)V));
+	PGQ_TRY(dev_alloc_as(padj, (size_t)total * 4 + 4));
+	PGQ_TRY(dev_alloc_as(desc, (size_t)E + 1));
+	hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, off, d_gb, *seg);
+	hipLaunchKernelGGL(k_fill_padded, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, off, adj, *seg, total, *padj);
+	hipLaunchKernelGGL(k_fill_desc, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, E, adj, *seg, *desc);
+	*groups_out = (int64_t)total;
+	return PGQ_OK;
+}
+static int build_meet_layout(pgq_csr *c, hipStream_t st) {
+	if (!options().meet_layout || c->V <= 0 || c->E <= 0) return PGQ_OK;
+	PGQ_TRY(build_meet_layout_dir(c, c->off, c->adj, &c->padj, &c->fseg, &c->fdesc, &c->padj_groups, st));
+	PGQ_TRY(build_meet_layout_dir(c, c->roff, c->radj, &c->rpadj, &c->rseg, &c->rdesc, &c->rpadj_groups, st));
+	return PGQ_OK;
+}
+
 // Builds everything derived from (off, adj64) that already sit in device memory.
 static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { // d_adj64 == nullptr: c->adj is set
 	const int64_t V = c->V, E = c->E;
@@ -787,8 +915,12 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	}
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	tr.mark("hub slices");
+	PGQ_TRY(build_meet_layout(c, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	tr.mark("padded adjacency + slot descriptors");
 	c->bytes = (V + 1) * 16 + 8 * V + E * (4 + 4 + 1 + (c->rpk ? 4 : 0)) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
-	           n_items * (int64_t)sizeof(HubItem);
+	           n_items * (int64_t)sizeof(HubItem) +
+	           (c->fdesc ? 2 * E * 16 + 2 * V * 8 + (c->padj_groups + c->rpadj_groups) * 16 : 0);
 	return PGQ_OK;
 }
 
@@ -808,6 +940,12 @@ static void destroy_csr(pgq_csr *c) {
 	dev_free(c->pull_parts);
 	dev_free(c->rown);
 	dev_free(c->rpk);
+	dev_free(c->padj);
+	dev_free(c->rpadj);
+	dev_free(c->fseg);
+	dev_free(c->rseg);
+	dev_free(c->fdesc);
+	dev_free(c->rdesc);
 	dev_free(c->pagerank);
 	dev_free(c->rw);
 	delete c;
@@ -1094,6 +1232,14 @@ static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
 	PGQ_TRY(copy((void **)&r->pull_parts, c->pull_parts, (size_t)c->n_pull_parts * 2 * 4));
 	PGQ_TRY(copy((void **)&r->rown, c->rown, En + 8));
 	PGQ_TRY(copy((void **)&r->rpk, c->rpk, (En + 2048) * 4));
+	r->padj_groups = c->padj_groups;
+	r->rpadj_groups = c->rpadj_groups;
+	PGQ_TRY(copy((void **)&r->padj, c->padj, (size_t)c->padj_groups * 16 + 16));
+	PGQ_TRY(copy((void **)&r->rpadj, c->rpadj, (size_t)c->rpadj_groups * 16 + 16));
+	PGQ_TRY(copy((void **)&r->fseg, c->fseg, (size_t)c->V * 8));
+	PGQ_TRY(copy((void **)&r->rseg, c->rseg, (size_t)c->V * 8));
+	PGQ_TRY(copy((void **)&r->fdesc, c->fdesc, (En + 1) * 16));
+	PGQ_TRY(copy((void **)&r->rdesc, c->rdesc, (En + 1) * 16));
 	PGQ_HIP_TRY(hipDeviceSynchronize());
 	return PGQ_OK;
 }
@@ -1131,69 +1277,6 @@ int64_t pgq_csr_device_bytes(const pgq_csr_t *csr) { return csr ? csr->bytes : -
 
 } // extern "C"
 
-namespace {
-// one table for pgq_set_option / pgq_get_option
-struct OptRef {
-	const char *name;
-	int *i;
-	double *d;
-};
-std::vector<OptRef> option_table() {
-	Options &o = options();
-	return {
-		{ "words", &o.words, nullptr },
-		{ "max_words", &o.max_words, nullptr },
-		{ "push_div", nullptr, &o.push_div },
-		{ "profile", &o.profile, nullptr },
-		{ "hub_chunk", &o.hub_chunk, nullptr },
-		{ "push_chunk", &o.push_chunk, nullptr },
-		{ "force_mode", &o.force_mode, nullptr },
-		{ "force_pull", &o.force_pull, nullptr },
-		{ "blocks_per_cu", &o.blocks_per_cu, nullptr },
-		{ "relax_small_limit", &o.relax_small_limit, nullptr },
-		{ "chain", &o.chain, nullptr },
-		{ "chain_cap", &o.chain_cap, nullptr },
-		{ "alloc_cache_mb", &o.alloc_cache_mb, nullptr },
-		{ "trace", &o.trace, nullptr },
-		{ "probe", &o.probe, nullptr },
-		{ "defer", &o.defer, nullptr },
-		{ "probe2", &o.probe2, nullptr },
-		{ "probe2_cap", &o.probe2_cap, nullptr },
-		{ "probe2_div", &o.probe2_div, nullptr },
-		{ "probe2_abs", &o.probe2_abs, nullptr },
-		{ "part_weight", &o.part_weight, nullptr },
-		{ "sparse_below", nullptr, &o.sparse_below },
-		{ "sparse_unroll", &o.sparse_unroll, nullptr },
-		{ "sparse_lds", &o.sparse_lds, nullptr },
-		{ "sparse_pw", &o.sparse_pw, nullptr },
-		{ "sparse_spill", &o.sparse_spill, nullptr },
-		{ "streams", &o.streams, nullptr },
-		{ "lanes", &o.lanes, nullptr },
-		{ "meet", &o.meet, nullptr },
-		{ "meet_cap", &o.meet_cap, nullptr },
-		{ "meet_cap_paths", &o.meet_cap_paths, nullptr },
-		{ "meet4", &o.meet4, nullptr },
-		{ "meet4_cap", &o.meet4_cap, nullptr },
-		{ "meet4_global_mb", &o.meet4_global_mb, nullptr },
-		{ "meet4_lds_kb", &o.meet4_lds_kb, nullptr },
-		{ "bibfs_rows", &o.bibfs_rows, nullptr },
-		{ "wbibfs", &o.wbibfs, nullptr },
-		{ "wbibfs_rows", &o.wbibfs_rows, nullptr },
-		{ "wbibfs_cap", &o.wbibfs_cap, nullptr },
-		{ "wbibfs_queue", &o.wbibfs_queue, nullptr },
-		{ "wbibfs_far", &o.wbibfs_far, nullptr },
-		{ "wbibfs_prune", &o.wbibfs_prune, nullptr },
-		{ "wbibfs_mem_mb", &o.wbibfs_mem_mb, nullptr },
-		{ "wbibfs_delta_div", &o.wbibfs_delta_div, nullptr },
-		{ "bibfs_cap", &o.bibfs_cap, nullptr },
-		{ "bibfs_queue", &o.bibfs_queue, nullptr },
-		{ "meet_bias", nullptr, &o.meet_bias },
-		{ "lanes_unroll", &o.lanes_unroll, nullptr },
-		{ "upload_threads", &o.upload_threads, nullptr },
-		{ "upload_narrow_host", &o.upload_narrow_host, nullptr },
-	};
-}
-} // namespace
 
 extern "C" {
 

@@ -67,9 +67,10 @@ int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const 
                      u32 *nz_next, const u64 *active, int stop, Counters *d_cnt);
 
 // Pair-centric pre-pass (pgq_meet.hip): answers rows at distance <= 3 (and NULL / trivial / dead-end rows) into d_out,
-// compacts the others into ws->def_src/def_dst/def_idx; meet_apply scatters their lengths back.
+// compacts the others into ws->def_src/def_dst/def_idx; meet_apply scatters their lengths back.  decide: whether the
+// pre-pass pays (distinct sources, sampled) is settled on the device in the same launch chain; *ran = false: it did not run.
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, bool paths = false);
+                 u32 *n_open, bool paths, bool decide, double meet_bytes, double batch_bytes, bool *ran);
 // shortestpath through the pre-pass: element counts of the answered rows' lists -> offsets (ws->meet_poff) and *total;
 // the lists themselves ([src, e, v, ..., dst], first-slot edges); lengths + shifted offsets of the rows answered elsewhere
 int meet_path_offsets(Workspace *ws, int64_t n, const int64_t *d_len, int64_t *total);
@@ -78,9 +79,6 @@ int meet_emit_paths(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, 
 int meet_apply_paths(Workspace *ws, int64_t nd, const int64_t *d_len, const int64_t *d_off, int64_t base,
                      int64_t *d_out_len, int64_t *d_out_off);
 int meet_apply(Workspace *ws, int64_t nd, const int64_t *d_len, int64_t *d_out);
-// Distinct sources among n rows, estimated from a 4096-row sample (decides pre-pass vs lane batches for large inputs).
-int estimate_distinct_sources(Workspace *ws, int64_t n, const int64_t *d_src, int64_t *estimate);
-
 // Assigns one lane per distinct source: fills ws->usrc (lane -> vertex), the row arrays sorted by lane
 // (skey/sidx/ssrc/sdst/sres) and returns the number of distinct sources in *U.
 int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U,

@@ -56,6 +56,138 @@ __device__ __forceinline__ u64 wave_min_u64(u64 x) {
 	return x;
 }
 
+// ---- packed walk over the padded adjacency (round 3) ---------------------------------------------------------------
+// Device layout (pgq_runtime.hip, build_meet_layout): every vertex's list is copied into a padded adjacency whose lists
+// start on a 16-byte group boundary and are filled up to whole groups with copies of their last entry, and every
+// adjacency slot carries a 16-byte descriptor {neighbour, first group of the neighbour's padded list, its entries, 0}.
+// A two-hop walk therefore needs no offset look-ups (the expanded vertex's descriptor arrives with the one-hop list,
+// streamed) and a lane's 16-byte load never straddles two lists, so ONE 64-lane request can carry groups of SEVERAL
+// lists: the lists of a round of <= 64 expanded vertices form one virtual sequence of groups, lane l of request c reads
+// virtual group 64 c + l and finds its list by a 6-step search over the round's prefix sums (ds_bpermute).  A 1-KB
+// request then carries ~1 KB of list data whatever the list lengths (round 2: one request per list, ~35 % of the lanes
+// useful on the SF100-shaped graph).  Padding entries repeat a real entry of the same list: harmless for membership
+// tests, marking and minima; callers that count must use `ok` and the per-entry length (none does so far).
+struct SegRound {
+	u32 P;     // inclusive prefix sum of the round's group counts, per lane
+	u32 D;     // first group of this lane's list minus the groups before it: virtual group x of the list sits at D + x
+	u32 total; // groups in the round (wave-uniform)
+};
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const u32 t = (u32)__shfl_up((int)x, o);
+		if (lane >= o) x += t;
+	}
+	return x;
+}
+__device__ __forceinline__ SegRound seg_round(u32 gbeg, u32 len) {
+	const u32 ng = (len + 3u) >> 2;
+	SegRound r;
+	r.P = wave_incl_scan_u32(ng);
+	r.D = gbeg - (r.P - ng);
+	r.total = (u32)__builtin_amdgcn_readlane((int)r.P, 63);
+	return r;
+}
+// smallest lane j with P_j > x (x < total): the list virtual group x belongs to
+__device__ __forceinline__ int seg_find(u32 P, u32 x) {
+	int j = 0;
+#pragma unroll
+	for (int s = 32; s > 0; s >>= 1) {
+		const u32 p = (u32)__shfl((int)P, j + s - 1);
+		if (p <= x) j += s;
+	}
+	return j;
+}
+typedef int pgq_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 load_group_nt(const int32_t *__restrict__ xp, u32 group) {
+	// streamed once: non-temporal, so that the lists do not push the descriptors of hot vertices out of L2
+	const pgq_v4i r = __builtin_nontemporal_load(reinterpret_cast<const pgq_v4i *>(xp + (size_t)group * 4));
+	return make_int4(r.x, r.y, r.z, r.w);
+}
+
+// Walks the padded lists of the descriptors list[w], list[w + stride], ... (positions < list_n), DEPTH requests in
+// flight, and calls f(v, ok, ev) per lane and request: v = one 16-byte group (four entries of ONE list), ok = the lane
+// holds a group, ev = the expanded vertex the list belongs to (only when WANT_EV).  stop() is wave-uniform and is asked
+// after every DEPTH requests; `max_entries` bounds the entries requested (capped = true when it ended the walk).  `first`
+// (have_first): the caller already holds the descriptor of position w + lane * stride (requested early, to overlap its
+// latency).
+// Returns the entries of the requested groups (padding excluded; wave-uniform).
+template <int DEPTH, bool WANT_EV, typename F, typename Stop>
+__device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__ list, int list_n, int w, int stride,
+                                                       const int32_t *__restrict__ xp, bool have_first, uint4 first,
+                                                       unsigned long long max_entries, bool &capped, F f, Stop stop) {
+	const int lane = threadIdx.x & 63;
+	unsigned long long entries = 0, requested = 0; // requested: groups x 4, against max_entries
+	capped = false;
+	for (int pb = w; pb < list_n; pb += 64 * stride) {
+		const int p = pb + lane * stride;
+		uint4 d = make_uint4(0, 0, 0, 0);
+		if (pb == w && have_first) d = first;
+		else if (p < list_n) d = list[p];
+		if (p >= list_n) d = make_uint4(0, 0, 0, 0);
+		const SegRound r = seg_round(d.y, d.z);
+		if (r.total == 0) continue;
+		const int nchunk = (int)((r.total + 63u) >> 6);
+		int next = 0;
+		int4 x[DEPTH];
+		int xc[DEPTH];
+		bool xok[DEPTH];
+		u32 xv[DEPTH];
+		auto fetch = [&](int u) {
+			xc[u] = -1;
+			if (next < nchunk) { // wave-uniform
+				const u32 xx = (u32)next * 64u + (u32)lane;
+				const bool ok = xx < r.total;
+				const u32 xs = ok ? xx : r.total - 1u; // lanes past the end re-read the last group (same line, masked by ok)
+				const int j = seg_find(r.P, xs);
+				x[u] = load_group_nt(xp, (u32)__shfl((int)r.D, j) + xs);
+				xok[u] = ok;
+				if constexpr (WANT_EV) xv[u] = (u32)__shfl((int)d.x, j);
+				else xv[u] = 0;
+				xc[u] = next++;
+			}
+		};
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++) fetch(u);
+		bool halt = false;
+		for (;;) {
+			bool any_chunk = false;
+#pragma unroll
+			for (int u = 0; u < DEPTH; u++) {
+				if (xc[u] < 0) continue; // wave-uniform
+				any_chunk = true;
+				const int4 v = x[u];
+				const bool ok = xok[u];
+				const u32 ev = xv[u];
+				fetch(u); // refills slot u: everything about the current request was copied above
+				f(v, ok, ev);
+			}
+			if (!any_chunk) break;
+			if (stop()) {
+				halt = true;
+				break;
+			}
+			if (requested + (unsigned long long)next * 256ull > max_entries) {
+				capped = true;
+				halt = true;
+				break;
+			}
+		}
+		{ // real entries inside the groups requested so far: list j holds min(len, 4 x its groups below the cursor)
+			const u32 done = min((u32)next * 64u, r.total);
+			const u32 ng = (d.z + 3u) >> 2, start = r.P - ng;
+			const u32 g = done > start ? min(done - start, ng) : 0u;
+			u32 e = min(d.z, g * 4u);
+			for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
+			entries += e;
+			requested += (unsigned long long)done * 4ull;
+		}
+		if (halt) break;
+	}
+	return entries;
+}
+
 // Streams the adjacency segments of list[w], list[w + stride], ... (positions < list_n) and calls f(entry) for every
 // entry until stop() (wave-uniform) says so.  Returns the number of entries requested.
 template <typename F, typename Stop>

@@ -181,3 +181,107 @@ def test_ordered_backward_walk_picks_the_reference_path():
             assert got == path[0::2]  # the vertices of [v, e, v, ...]
             checked[(len(path) - 1) // 2] = checked.get((len(path) - 1) // 2, 0) + 1
     assert checked[2] and checked[3] and checked[4]
+
+
+# ---- padded adjacency + packed walk (pgq_runtime.hip build_meet_layout, pgq_walk.h seg_walk) -------------------------------
+
+def padded_layout_model(off, adj, align):
+    """k_seg_groups / k_seg_fill / k_fill_padded / k_fill_desc: per vertex {first group, entries}, lists padded to whole
+    16-byte groups (rounded up to `align` entries) with copies of their last entry, one descriptor per adjacency slot."""
+    V = len(off) - 1
+    ln = np.diff(off)
+    ng = ((ln + align - 1) // align) * (align // 4)
+    gbeg = np.concatenate([[0], np.cumsum(ng)])
+    padj = np.full(int(gbeg[-1]) * 4, -7, dtype=np.int64)
+    for v in range(V):
+        for g in range(int(gbeg[v]), int(gbeg[v + 1])):  # one thread per group, clamped to the last entry
+            i0 = (g - int(gbeg[v])) * 4
+            for k in range(4):
+                padj[4 * g + k] = adj[off[v] + min(i0 + k, ln[v] - 1)]
+    desc = [(int(u), int(gbeg[u]), int(ln[u])) for u in adj.tolist()]
+    return gbeg[:-1], ln, padj, desc
+
+
+def seg_find_model(P, x):
+    j = 0
+    for s in (32, 16, 8, 4, 2, 1):
+        if P[j + s - 1] <= x:
+            j += s
+    return j
+
+
+def seg_walk_model(desc_list, padj, w, stride, depth, stop_after=None):
+    """seg_walk: rounds of 64 descriptors (positions w, w + stride, ...), virtual groups 64 c + lane, the 6-step search,
+    lanes past the end re-reading the last group (ok = False).  Returns the (entry, ev, ok) stream and the entry count."""
+    seen, entries = [], 0
+    n = len(desc_list)
+    pb = w
+    while pb < n:
+        d = [desc_list[pb + l * stride] if pb + l * stride < n else (0, 0, 0) for l in range(64)]
+        ng = [(x[2] + 3) >> 2 for x in d]
+        P = np.cumsum(ng)
+        total = int(P[63])
+        D = [d[l][1] - (int(P[l]) - ng[l]) for l in range(64)]
+        nchunk = (total + 63) >> 6
+        nxt, halted = 0, False
+        while nxt < nchunk:
+            for _ in range(depth):
+                if nxt >= nchunk:
+                    break
+                for lane in range(64):
+                    xx = nxt * 64 + lane
+                    ok = xx < total
+                    xs = xx if ok else total - 1
+                    j = seg_find_model(P, xs)
+                    g = D[j] + xs
+                    for k in range(4):
+                        seen.append((int(padj[4 * g + k]), d[j][0], ok))
+                nxt += 1
+            if stop_after is not None and len(seen) >= stop_after:
+                halted = True
+                break
+        done = min(nxt * 64, total)
+        for l in range(64):
+            start = int(P[l]) - ng[l]
+            g = min(done - start, ng[l]) if done > start else 0
+            entries += min(d[l][2], g * 4)
+        if halted:
+            break
+        pb += 64 * stride
+    return seen, entries
+
+
+def test_padded_layout_and_packed_walk_visit_exactly_the_lists():
+    rng = np.random.default_rng(11)
+    for align in (4, 16, 32):
+        V = 90
+        deg = rng.integers(0, 12, V)
+        deg[rng.integers(0, V, 10)] = 0
+        deg[3] = 150  # a list longer than two requests
+        off = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        adj = rng.integers(0, V, int(off[-1]))
+        gbeg, ln, padj, desc = padded_layout_model(off, adj, align)
+        assert (padj >= 0).all()
+        for v in range(V):  # every padded list = the list, then copies of its last entry, start aligned
+            assert (gbeg[v] * 4) % align == 0
+            got = padj[4 * gbeg[v]:4 * gbeg[v] + ((ln[v] + 3) // 4) * 4]
+            assert got[:ln[v]].tolist() == adj[off[v]:off[v + 1]].tolist()
+            assert all(x == adj[off[v + 1] - 1] for x in got[ln[v]:])
+        for v in (3, 5, 17):  # two-hop walk of v: one wavefront, and 16 wavefronts with stride 16
+            lst = desc[off[v]:off[v + 1]]
+            want = sorted((int(x), u) for (u, _, _) in lst for x in adj[off[u]:off[u + 1]].tolist())
+            for waves, stride in ((1, 1), (16, 16)):
+                got, total = [], 0
+                for w in range(waves):
+                    seen, e = seg_walk_model(lst, padj, w, stride, depth=2)
+                    got += [(x, ev) for x, ev, ok in seen if ok]
+                    total += e
+                assert total == len(want)
+                # padding repeats real entries of the same list: the set of (entry, expanded vertex) pairs is exact,
+                # and every real entry is visited at least once
+                assert set(got) == set(want)
+                import collections
+                cg, cw = collections.Counter(got), collections.Counter(want)
+                assert all(cg[k] >= cw[k] for k in cw)
+            seen, e = seg_walk_model(lst, padj, 0, 1, depth=2, stop_after=1)  # early exit: entries = what was requested
+            assert 0 < e <= len(want)

@@ -6,27 +6,36 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over this rank's batch of (src,dst) pairs, inputs resident in HBM:
-pgq_iterativelength_bulk_device (pair-centric pre-pass for the pairs at distance <= 4, lane-batched MS-BFS for the
-rest), followed for N > 1 by the RCCL all_gather of the per-pair results (the only inter-GPU traffic; the CSR is
-replicated).
+pgq_iterativelength_bulk_device (pair-centric pre-pass for random pairs, lane-batched MS-BFS for cross products and
+for whatever the pre-pass leaves open), followed for N > 1 by the RCCL all_gather of the per-pair results (the only
+inter-GPU traffic; the CSR is replicated).
 
 Default workload = BASELINE.json configs[3] (the config the metric "MS-BFS MTEPS + src-dst pairs/sec, SNB SF100,
 1/2/4/8 GPU" is quoted on; it fits one GPU): synthetic LDBC-SNB-SF100-shaped Person-knows-Person graph (V=448,626,
-39.88 M symmetric CSR entries), iterativelength on 65,536 random pairs per GPU (`default_rng(4)`).  --scaling weak
-(default): every rank gets its own 65,536 pairs of one global list; --scaling strong: the 65,536 pairs are cut across
-the ranks.  Other BASELINE configs: --workload rmat22 (configs[1]), snb_paths (configs[2]), forest_cheapest (configs[4]).
+39.88 M symmetric CSR entries), iterativelength on 65,536 random pairs (`default_rng(4)`).
+  N = 1:  the top-level fields describe that workload; `legs` holds it ("prepass": every row is answered by the
+          pair-centric kernels) next to "msbfs_cross": the same graph and row count in the binder's call shape
+          (match.cpp:467-495: a cross product of endpoints — 2048 distinct sources x 32 destinations), which the library
+          routes to the lane-batched MS-BFS frontier expansion; each leg has its own ms/step, pairs/s, logical and
+          physical MTEPS, roofline of its dominant kernel class and a CPU-port comparison.
+  N > 1:  --scaling strong by default (configs[3] is 65,536 pairs in total, cut across the GPUs); the weak figure
+          (65,536 pairs on every GPU) is measured in the same run and reported under "weak".
+Other BASELINE configs: --workload rmat22 (configs[1]), snb_paths (configs[2]), forest_cheapest (configs[4]);
+snb_cross / snb_cross_allv run the cross-product shapes as the main workload; snb_cheapest = weighted knows graph.
 
-value    = MTEPS: traversed edges / second / 1e6, summed over ranks.  Traversed edges of a pair = out-degrees of all
-           vertices its own level-synchronous BFS expands up to the level that reaches dst (all levels if unreachable)
-           — a pure function of (graph, src, dst), counted once on the GPU outside the timed region
-           (pgq_traversed_edges_bulk_device) and pinned against the CPU oracle in tests/.
+value    = MTEPS, LOGICAL ("value_kind"): traversed edges / second / 1e6, summed over ranks.  Traversed edges of a
+           pair = out-degrees of all vertices its own level-synchronous BFS expands up to the level that reaches dst
+           (all levels if unreachable) — what the reference's per-pair lane traverses; a pure function of (graph, src,
+           dst), counted once on the GPU outside the timed region (pgq_traversed_edges_bulk_device) and pinned against
+           the CPU oracle in tests/.  It is NOT a hardware throughput: `mteps_physical` (adjacency entries the kernels
+           really scanned) and `pairs_per_s` are.
 roofline = the dominant kernel class of an untimed pass with one batch in flight and per-launch HIP events on the
            library's own stream (no overlap: a launch's event duration is its own duration); achieved = algorithmic
            bytes / that time (DESIGN.md has the formulas).  `step` = all kernel classes' algorithmic bytes over the
            wall time of the timed region.
 cpu_baseline = the literal restatement of the reference UDF (oracle/, 512-lane bitsets, 2048-row chunks) timed on this
-           box's host cores on a bounded sample of the same pairs, same MTEPS definition, one thread and one thread
-           per chunk.
+           box's host cores on a bounded sample of the same pairs, same MTEPS definition, compared row by row with
+           the output of the TIMED steps (the output buffer is poisoned before the timed loop).
 """
 import argparse
 import json
@@ -40,12 +49,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); the measured copy ceiling is reported beside it
+POISON = -7             # written into the result buffers before the timed loop: a step that writes nothing is caught
 
 OPS = {"snb_sf100": "iterativelength", "rmat22": "iterativelength", "snb_paths": "shortestpath+reconstruction",
-       "forest_cheapest": "cheapest_path_length", "snb_cheapest": "cheapest_path_length"}
-DEFAULT_PAIRS = {"snb_sf100": 65536, "rmat22": 1024, "snb_paths": 4096, "forest_cheapest": 4096, "snb_cheapest": 4096}
-PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5, "snb_cheapest": 6}
+       "forest_cheapest": "cheapest_path_length", "snb_cheapest": "cheapest_path_length",
+       "snb_cross": "iterativelength", "snb_cross_allv": "iterativelength"}
+DEFAULT_PAIRS = {"snb_sf100": 65536, "rmat22": 1024, "snb_paths": 4096, "forest_cheapest": 4096, "snb_cheapest": 4096,
+                 "snb_cross": 65536, "snb_cross_allv": 0}
+PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5, "snb_cheapest": 6, "snb_cross": 7,
+             "snb_cross_allv": 8}
 CHEAPEST = ("forest_cheapest", "snb_cheapest")  # weighted workloads: value = pairs/s
+SNB = ("snb_sf100", "snb_paths", "snb_cheapest", "snb_cross", "snb_cross_allv")
+EXPANSION = ("push", "pull", "pull_hub", "pull_sparse")  # the MS-BFS frontier-expansion kernel classes
 
 
 def parse():
@@ -55,12 +70,15 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="snb_sf100", choices=sorted(OPS))
     ap.add_argument("--pairs-per-gpu", type=int, default=0, help="0 = the BASELINE config's pair count")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: pairs-per-gpu rows on every rank; strong: pairs-per-gpu rows in total, cut across ranks")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: pairs-per-gpu rows on every rank; strong: pairs-per-gpu rows in total, cut across ranks "
+                         "(default: strong when more than one GPU runs — configs[3] is 65,536 pairs in total)")
     ap.add_argument("--scale", type=int, default=0, help="override graph scale (rmat scale / forest log2 V); tests")
     ap.add_argument("--snb-vertices", type=int, default=448626)
     ap.add_argument("--snb-friendships", type=int, default=19_940_000)
+    ap.add_argument("--cross-sources", type=int, default=2048, help="snb_cross: distinct sources (x pairs/sources destinations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="N = 1 default workload: skip the msbfs_cross leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs timed on one CPU thread (0 = 8192 snb / 1024 rmat)")
     ap.add_argument("--weights", default="int64", choices=["int64", "double"], help="forest_cheapest / snb_cheapest: weight type")
     ap.add_argument("--backend", default="nccl")
@@ -71,7 +89,7 @@ def build_graph(a):
     from duckpgq_extension_amd import graphgen
     t0 = time.time()
     w = None
-    if a.workload in ("snb_sf100", "snb_paths", "snb_cheapest"):
+    if a.workload in SNB:
         V, s, d = graphgen.snb_knows_like(a.snb_vertices, a.snb_friendships, seed=100)
         name = "snb_sf100_knows(V=%d)" % V
         if a.workload == "snb_cheapest":  # the general-graph case of cheapest_path_length: weights 1..999 on the knows graph
@@ -94,10 +112,26 @@ def build_graph(a):
     return name, V, off, adj, eid, w, time.time() - t0
 
 
+def cross_pairs(V, total, sources, seed):
+    """The binder's call shape (match.cpp:467-495): a cross product of endpoints.  `sources` distinct sources, each
+    with total / sources random destinations; rows grouped by source like a nested-loop join emits them."""
+    rng = np.random.default_rng(seed)
+    src = rng.choice(V, size=sources, replace=False)
+    per = max(1, total // sources)
+    s = np.repeat(src, per)
+    d = rng.integers(0, V, len(s))
+    return np.stack([s, d], axis=1).astype(np.int64)
+
+
 def make_pairs(a, V, total, off, adj):
     """One global, seeded pair list.  The reply forest gets destinations that are ancestors of their sources (uniform
     pairs are almost never connected there: the search would only measure the dead-end shortcut)."""
     rng = np.random.default_rng(PAIR_SEED[a.workload])
+    if a.workload == "snb_cross":
+        return cross_pairs(V, total, a.cross_sources, PAIR_SEED[a.workload])
+    if a.workload == "snb_cross_allv":  # 32 sources x every vertex as destination
+        src = rng.choice(V, size=32, replace=False)
+        return np.stack([np.repeat(src, V), np.tile(np.arange(V, dtype=np.int64), 32)], axis=1).astype(np.int64)
     if a.workload != "forest_cheapest":
         return rng.integers(0, V, size=(total, 2))
     deg = np.diff(off)
@@ -114,42 +148,234 @@ def make_pairs(a, V, total, off, adj):
     return np.stack([src, dst], axis=1)
 
 
+class Bench:
+    """One rank's state: the replicated CSR and the timing helpers."""
+
+    def __init__(self, a):
+        import torch
+        import torch.distributed as dist
+        import duckpgq_extension_amd as pgq
+        from duckpgq_extension_amd import sharding
+        self.a, self.torch, self.dist, self.pgq, self.sharding = a, torch, dist, pgq, sharding
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=a.backend, rank=self.rank, world_size=self.world)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local % ndev)
+        self.dev = torch.device("cuda", local % ndev)
+        pgq.load_hip().pgq_init(local % ndev)
+
+    def sync_all(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, wl, csr, mine_t, total_pairs, steps, warmup, paths=False, cheapest=False):
+        """Times `steps` passes over this rank's rows `mine_t` ([n, 2] device tensor) and returns the measurements:
+        wall time of the timed region, statistics of the timed region and of an isolated profiled pass, the output of
+        the timed steps and the traversed-edge counts."""
+        torch, dist, pgq, sharding = self.torch, self.dist, self.pgq, self.sharding
+        world, dev = self.world, self.dev
+        n = mine_t.shape[0]
+        d_src, d_dst = mine_t[:, 0].contiguous(), mine_t[:, 1].contiguous()
+        # two result buffers: the gather of step k (async, on RCCL's stream) overlaps the search of step k + 1
+        d_len = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(2)]
+        d_te = torch.zeros(n, dtype=torch.int64, device=dev)
+        child_cap = n * 64
+        d_off = d_child = d_val = d_ok = None
+        if paths:
+            d_off = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(2)]
+            d_child = [torch.empty(child_cap, dtype=torch.int64, device=dev) for _ in range(2)]
+        if cheapest:
+            d_val = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(2)]
+            d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+        pending = [None, None]
+        per = (total_pairs + world - 1) // world
+
+        def step(k):
+            b = k & 1
+            if pending[b] is not None:  # the gather that last read this buffer
+                pending[b].wait()
+                pending[b] = None
+            if paths:
+                rc, used = csr.shortestpath_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len[b].data_ptr(),
+                                                     d_off[b].data_ptr(), d_child[b].data_ptr(), child_cap)
+                assert rc == 0, pgq.load_hip().pgq_last_error()
+                if world > 1:
+                    sharding.gather_paths(d_len[b], d_off[b], d_child[b], used, per)
+            elif cheapest:
+                csr.cheapest_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_val[b].data_ptr(), d_ok.data_ptr())
+                if world > 1:
+                    pending[b] = sharding.gather_rows_async(d_val[b], total_pairs)
+            else:
+                csr.iterativelength_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len[b].data_ptr())
+                if world > 1:  # final RCCL gather of the per-pair results (xGMI)
+                    pending[b] = sharding.gather_rows_async(d_len[b], total_pairs)
+
+        def drain():
+            for b in (0, 1):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+
+        # ---- work units (outside the timed region) ----
+        ref_len = None
+        if not cheapest:
+            csr.traversed_edges_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len[0].data_ptr(), d_te.data_ptr())
+            ref_len = d_len[0].clone()
+        te_local = int(d_te.sum().item())
+        for k in range(warmup):
+            step(k)
+        drain()
+        pgq.set_option("profile", 0)
+        for b in (0, 1):  # poison: the comparison below only passes if the TIMED steps wrote every row
+            d_len[b].fill_(POISON)
+            if cheapest:
+                d_val[b].fill_(POISON)
+        pgq.reset_stats()
+        self.sync_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        drain()
+        self.sync_all()
+        elapsed = time.perf_counter() - t0
+        stats = pgq.get_stats()
+        last = (steps - 1) & 1
+        out_len = d_len[last].clone()
+        if cheapest:
+            reach = int(d_ok.sum().item())
+            out_val = d_val[last].clone()
+        else:
+            assert bool((out_len == ref_len).all()), "timed output differs from the traversed-edge accounting pass"
+            if steps > 1:
+                assert bool((d_len[last ^ 1] == ref_len).all()), "timed output differs from the accounting pass"
+            reach = int((out_len >= 0).sum().item())
+            out_val = None
+        # Untimed pass with one batch in flight and HIP events around every launch (recorded on the library's own stream):
+        # nothing overlaps, so a launch's event duration is that kernel's duration.
+        n_streams = int(pgq.get_option("streams"))
+        pgq.set_option("streams", 1)
+        pgq.set_option("profile", 1)
+        iso_steps = max(1, min(steps, 3))
+        step(0)
+        drain()
+        pgq.reset_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(iso_steps):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+        iso_elapsed = time.perf_counter() - t0
+        iso = pgq.get_stats()
+        pgq.set_option("profile", 0)
+        pgq.set_option("streams", n_streams)
+        return {"n": n, "elapsed": elapsed, "stats": stats, "iso": iso, "iso_steps": iso_steps, "iso_elapsed": iso_elapsed,
+                "te_local": te_local, "reach": reach, "out_len": out_len, "out_val": out_val, "d_ok": d_ok, "d_te": d_te,
+                "steps": steps}
+
+    def reduce(self, m):
+        """max over ranks of the timed region, sums of the work units."""
+        torch, dist = self.torch, self.dist
+        el = torch.tensor([m["elapsed"]], dtype=torch.float64, device=self.dev)
+        tot = torch.tensor([float(m["te_local"]), float(m["stats"]["edges_scanned"]), float(m["reach"])],
+                           dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        return float(el[0]), float(tot[0]), float(tot[1]), int(tot[2])
+
+
+def roofline_of(m, workload, copy_gbps, elapsed):
+    """Dominant kernel class of the isolated pass + the per-class table + the whole-step figure."""
+    iso, steps, iso_steps = m["iso"], m["steps"], m["iso_steps"]
+    kms, kb, kl = iso["kernel_ms"], iso["algo_bytes"], iso["launches"]
+    dom = max(kms, key=lambda k: kms[k])
+    ach = kb[dom] / 1e9 / (kms[dom] / 1e3) if kms[dom] > 0 else 0.0
+    traffic, traffic_src, traffic_gbps = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    if os.path.exists(pmc):  # written by tools/pmc_summary.py from separate rocprofv3 --pmc passes of this command
+        try:
+            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_%s.json (separate rocprofv3 --pmc passes, committed; not collected in this run)" % workload
+            if traffic and kms[dom] > 0:  # the PMC traffic over this run's launch duration: what the memory system moved
+                traffic_gbps = float(traffic) / (kms[dom] / max(kl[dom], 1) * 1e-3) / 1e9
+        except Exception:
+            traffic = None
+    step_bytes = sum(m["stats"]["algo_bytes"].values())
+    roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_GBps": traffic_gbps, "traffic_frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else None,
+            "launches": int(kl[dom]), "avg_launch_ms": kms[dom] / max(kl[dom], 1),
+            "algorithmic_bytes_per_launch": kb[dom] / max(kl[dom], 1),
+            "measured_copy_GBps": copy_gbps, "timing": "HIP events, one batch in flight, untimed pass",
+            "ms_per_step_of_that_pass": m["iso_elapsed"] / iso_steps * 1e3,
+            # all kernel classes' algorithmic bytes over the wall time of the timed region
+            "step": {"algorithmic_bytes": step_bytes / steps, "GBps": step_bytes / 1e9 / elapsed,
+                     "frac": step_bytes / 1e9 / elapsed / HBM_PEAK_GBPS}}
+    exp_ms = sum(kms.get(k, 0.0) for k in EXPANSION)
+    exp_b = sum(kb.get(k, 0.0) for k in EXPANSION)
+    if exp_ms > 0:  # the MS-BFS frontier-expansion kernels (top-down + bottom-up) together
+        roof["frontier_expansion"] = {"classes": [k for k in EXPANSION if kms.get(k, 0.0) > 0],
+                                      "ms_per_step": exp_ms / iso_steps, "GBps": exp_b / 1e9 / (exp_ms / 1e3),
+                                      "frac": exp_b / 1e9 / (exp_ms / 1e3) / HBM_PEAK_GBPS}
+    by_kernel = {k: {"ms_per_step": round(kms[k] / iso_steps, 4),
+                     "GBps": round(kb[k] / 1e9 / (kms[k] / 1e3), 1) if kb[k] > 0 else None,
+                     "launches_per_step": kl[k] / iso_steps} for k in kms if kms[k] > 0}
+    return roof, by_kernel
+
+
+def leg_summary(bench, m, workload, total_pairs, copy_gbps):
+    elapsed, te_total, scanned, reach = bench.reduce(m)
+    steps, stats = m["steps"], m["stats"]
+    roof, by_kernel = roofline_of(m, workload, copy_gbps, elapsed)
+    return {"ms_per_step": elapsed / steps * 1e3, "pairs_per_s": total_pairs * steps / elapsed,
+            "mteps_logical": te_total * steps / elapsed / 1e6, "mteps_physical": scanned / elapsed / 1e6,
+            "traversed_edges_per_step": te_total, "physical_edges_scanned_per_step": scanned / steps,
+            "reachable_pairs": reach,
+            "rows_answered_by_prepass_per_step": stats["meet_pairs"] / max(steps, 1),
+            "levels_per_step": stats["levels"] / max(steps, 1),
+            "push_pull_levels": [stats["push_levels"] // max(steps, 1), stats["pull_levels"] // max(steps, 1)],
+            "deferred_pairs_per_step": stats["deferred_pairs"] / max(steps, 1),
+            "roofline": roof, "roofline_by_kernel": by_kernel}, elapsed
+
+
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
+    bench = Bench(a)
+    torch, dist, pgq, sharding = bench.torch, bench.dist, bench.pgq, bench.sharding
+    world, rank, dev = bench.world, bench.rank, bench.dev
+    scaling = a.scaling or ("strong" if world > 1 else "weak")
+    cheapest = a.workload in CHEAPEST
+    paths = a.workload == "snb_paths"
 
-    import duckpgq_extension_amd as pgq
-    from duckpgq_extension_amd import sharding
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=a.backend, rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    torch.cuda.set_device(local % ndev)
-    dev = torch.device("cuda", local % ndev)
-    pgq.load_hip().pgq_init(local % ndev)
-
-    pairs_per_gpu = a.pairs_per_gpu or DEFAULT_PAIRS[a.workload]
-    total_pairs = pairs_per_gpu * world if a.scaling == "weak" else pairs_per_gpu
-    # ---- graph: rank 0 builds it (cached on disk), the others receive it over RCCL (CSR replicated on every GPU) ----
+    pairs_cfg = a.pairs_per_gpu or DEFAULT_PAIRS[a.workload]
+    # ---- graph: rank 0 builds it, the others receive it over RCCL (CSR replicated on every GPU) ----
     arrays, name, gen_s = None, "", 0.0
     if rank == 0:
         name, V, off, adj, eid, w, gen_s = build_graph(a)
         arrays = {"off": torch.from_numpy(off), "adj": torch.from_numpy(adj), "eid": torch.from_numpy(eid)}
         if w is not None:  # doubles travel as their bit patterns (the broadcast helper moves int64 tensors)
             arrays["w"] = torch.from_numpy(np.ascontiguousarray(w).view(np.int64))
-        allp = make_pairs(a, V, total_pairs, off, adj)
+        if a.workload == "snb_cross_allv":
+            pairs_cfg = 32 * V
+        # one global list: the first `pairs_cfg` rows are the strong-scaling set, all world x pairs_cfg the weak one
+        allp = make_pairs(a, V, pairs_cfg * world if a.workload != "snb_cross_allv" else pairs_cfg, off, adj)
         arrays["pairs"] = torch.from_numpy(np.ascontiguousarray(allp.reshape(-1)))
     arrays = sharding.broadcast_csr(arrays, dev)
     t_off, t_adj, t_eid, t_w = arrays["off"], arrays["adj"], arrays["eid"], arrays.get("w")
     has_w = t_w is not None
     V, E = t_off.numel() - 1, t_adj.numel()
+    allp_t = arrays["pairs"].view(-1, 2)
+    if a.workload == "snb_cross_allv":
+        pairs_cfg = allp_t.shape[0]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     csr = pgq.DeviceCSR.from_device_ptrs(V, t_off.data_ptr(), t_adj.data_ptr(), t_eid.data_ptr(),
@@ -157,194 +383,115 @@ def main():
                                          (2 if a.weights == "double" else 1) if has_w else 0)
     upload_s = time.perf_counter() - t0
 
-    # ---- pairs: one global list, contiguous shard per rank ------------------------------------------------------
-    lo, hi = sharding.shard_bounds(total_pairs, world, rank)
-    mine_t = arrays["pairs"].view(-1, 2)[lo:hi]
-    n = hi - lo
-    d_src, d_dst = mine_t[:, 0].contiguous(), mine_t[:, 1].contiguous()
-    d_len = torch.empty(n, dtype=torch.int64, device=dev)
-    d_te = torch.zeros(n, dtype=torch.int64, device=dev)
-    child_cap = n * 64
-    d_off = d_child = d_val = d_ok = None
-    if a.workload == "snb_paths":
-        d_off = torch.zeros(n, dtype=torch.int64, device=dev)
-        d_child = torch.empty(child_cap, dtype=torch.int64, device=dev)
-    if a.workload in CHEAPEST:
-        d_val = torch.zeros(n, dtype=torch.int64, device=dev)
-        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
-    used_box = [0]
+    def shard(mode):
+        total = min(allp_t.shape[0], pairs_cfg * world if mode == "weak" else pairs_cfg)
+        lo, hi = sharding.shard_bounds(total, world, rank)
+        return allp_t[lo:hi], total, lo, hi
 
-    def step():
-        if a.workload == "snb_paths":
-            rc, used = csr.shortestpath_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(),
-                                                 d_off.data_ptr(), d_child.data_ptr(), child_cap)
-            assert rc == 0, pgq.load_hip().pgq_last_error()
-            used_box[0] = used
-        elif a.workload in CHEAPEST:
-            csr.cheapest_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_val.data_ptr(), d_ok.data_ptr())
-        else:
-            csr.iterativelength_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr())
-        if world > 1:  # final RCCL gather of the per-pair results (xGMI): lengths, and the path lists for shortestpath
-            per = (total_pairs + world - 1) // world
-            if a.workload == "snb_paths":
-                sharding.gather_paths(d_len, d_off, d_child, used_box[0], per)
-            else:
-                sharding.gather_rows(d_val if a.workload in CHEAPEST else d_len, total_pairs)
-
-    # ---- work units (outside the timed region) -----------------------------------------------------------------
-    if a.workload not in CHEAPEST:
-        csr.traversed_edges_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(), d_te.data_ptr())
-    te_local = int(d_te.sum().item())
-    ref_len = d_len.clone()
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    pgq.set_option("profile", 0)
-    pgq.reset_stats()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    stats = pgq.get_stats()
-    if a.workload in CHEAPEST:
-        reach = int(d_ok.sum().item())
-    else:
-        assert bool((d_len == ref_len).all()), "results differ from the traversed-edge accounting pass"
-        reach = int((d_len >= 0).sum().item())
-    # Untimed pass with one batch in flight and HIP events around every launch (recorded on the library's own stream):
-    # nothing overlaps, so a launch's event duration is that kernel's duration.  `value` is the timed region above.
-    n_streams = int(pgq.get_option("streams"))
-    pgq.set_option("streams", 1)
-    pgq.set_option("profile", 1)
-    iso_steps = max(1, min(a.steps, 3))
-    step()
-    pgq.reset_stats()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iso_steps):
-        step()
-    torch.cuda.synchronize()
-    iso_elapsed = time.perf_counter() - t0
-    iso = pgq.get_stats()
-    pgq.set_option("profile", 0)
-    pgq.set_option("streams", n_streams)
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(te_local), float(stats["edges_scanned"]), float(reach)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(el[0])
-    te_total = float(tot[0])
+    mine_t, total_pairs, lo, hi = shard(scaling)
+    m = bench.run(a.workload, csr, mine_t, total_pairs, a.steps, a.warmup, paths=paths, cheapest=cheapest)
+    try:
+        copy_gbps = pgq.copy_bandwidth_gbps(1 << 30, 5) if rank == 0 else None
+    except Exception:
+        copy_gbps = None
+    main_leg, elapsed = leg_summary(bench, m, a.workload, total_pairs, copy_gbps)
+    other = None
+    if world > 1 and a.workload != "snb_cross_allv":  # the other scaling mode, measured in the same run
+        mode2 = "weak" if scaling == "strong" else "strong"
+        mine2, total2, _, _ = shard(mode2)
+        m2 = bench.run(a.workload, csr, mine2, total2, a.steps, a.warmup, paths=paths, cheapest=cheapest)
+        leg2, _ = leg_summary(bench, m2, a.workload, total2, copy_gbps)
+        other = (mode2, {k: leg2[k] for k in ("ms_per_step", "pairs_per_s", "mteps_logical", "mteps_physical")}, total2)
+    cross = None
+    if world == 1 and a.workload == "snb_sf100" and not a.no_legs:
+        # the binder's call shape on the same graph and row count: routed to the lane-batched MS-BFS
+        cp = cross_pairs(V, pairs_cfg, a.cross_sources, PAIR_SEED["snb_cross"])
+        cp_t = torch.from_numpy(cp).to(dev)
+        mc = bench.run("snb_cross", csr, cp_t, len(cp), max(2, min(a.steps, 5)), min(a.warmup, 2))
+        cross, _ = leg_summary(bench, mc, "snb_cross", len(cp), copy_gbps)
+        cross["workload"] = "%d distinct sources x %d destinations each = %d rows (match.cpp:467-495 shape)" % (
+            a.cross_sources, len(cp) // a.cross_sources, len(cp))
 
     if rank == 0:
-        kms, kb, kl = iso["kernel_ms"], iso["algo_bytes"], iso["launches"]
-        dom = max(kms, key=lambda k: kms[k])
-        ach = kb[dom] / 1e9 / (kms[dom] / 1e3) if kms[dom] > 0 else 0.0
-        try:
-            copy_gbps = pgq.copy_bandwidth_gbps(1 << 30, 5)
-        except Exception:
-            copy_gbps = None
-        pairs_per_s = total_pairs * a.steps / elapsed
-        if a.workload in CHEAPEST:
-            metric, unit = "cheapest_path_pairs_per_s", "pairs/s"
-            value = pairs_per_s
+        if cheapest:
+            metric, unit, value = "cheapest_path_pairs_per_s", "pairs/s", main_leg["pairs_per_s"]
         else:
-            metric, unit = "msbfs_mteps", "MTEPS"
-            value = te_total * a.steps / elapsed / 1e6
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % a.workload)
-        if os.path.exists(pmc):  # written by tools/pmc_summary.py from separate rocprofv3 --pmc passes of this command
-            try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_%s.json (separate rocprofv3 --pmc passes, committed; not collected in this run)" % a.workload
-            except Exception:
-                traffic = None
-        step_bytes = sum(stats["algo_bytes"].values())
-        traffic_gbps = None  # the PMC traffic (separate passes) over this run's launch duration: what the memory system moved
-        try:
-            if traffic and kms[dom] > 0:
-                traffic_gbps = float(traffic) / (kms[dom] / max(kl[dom], 1) * 1e-3) / 1e9
-        except Exception:
-            traffic_gbps = None
+            metric, unit, value = "msbfs_mteps", "MTEPS", main_leg["mteps_logical"]
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-            "dtype": "u64" if a.workload not in CHEAPEST else ("f64" if a.weights == "double" else "int64"),
+            "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "u64" if not cheapest else ("f64" if a.weights == "double" else "int64"),
             "data": "synthetic",
+            # value counts the edges the reference's per-pair BFS lanes would traverse, not adjacency entries read
+            "value_kind": "pairs/s" if cheapest else "logical (reference-lane traversed edges; see mteps_physical, pairs_per_s)",
             "config": {"workload": "%s %s, %d pairs %s, CSR replicated" % (
-                name, OPS[a.workload], pairs_per_gpu, "per GPU" if a.scaling == "weak" else "in total"),
+                name, OPS[a.workload], pairs_cfg, "per GPU" if scaling == "weak" else "in total"),
                 "V": V, "E": E, "pairs_total": total_pairs,
-                "parallelism": ("pairs sharded x%d, RCCL all_gather of %s" % (
-                    world, "lengths + path lists" if a.workload == "snb_paths" else "lengths")) if world > 1 else "1 GPU",
+                "parallelism": ("pairs sharded x%d, RCCL all_gather of %s (async, overlapped with the next step)" % (
+                    world, "lengths + path lists" if paths else "lengths")) if world > 1 else "1 GPU",
                 "graph_gen_s": round(gen_s, 1), "csr_upload_ms": round(upload_s * 1e3, 2)},
-            "pairs_per_s": pairs_per_s,
-            "reachable_pairs": int(tot[2]),
-            "traversed_edges_per_step": te_total,
+            "pairs_per_s": main_leg["pairs_per_s"],
+            "reachable_pairs": main_leg["reachable_pairs"],
+            "traversed_edges_per_step": main_leg["traversed_edges_per_step"],
             # logical edges (value) vs the adjacency entries the kernels physically scanned in the timed region
-            "mteps_physical": float(tot[1]) / elapsed / 1e6,
-            "physical_edges_scanned_per_step": float(tot[1]) / a.steps,
+            "mteps_physical": main_leg["mteps_physical"],
+            "physical_edges_scanned_per_step": main_leg["physical_edges_scanned_per_step"],
             # the CSR dies at QueryEnd: one query = one upload (device-resident arrays here) + the searches
-            "ms_per_step_incl_csr_upload": elapsed / a.steps * 1e3 + upload_s * 1e3,
-            "rows_answered_by_prepass_per_step": stats["meet_pairs"] / max(a.steps, 1),
-            "levels_per_step": stats["levels"] / max(a.steps, 1),
-            "push_pull_levels": [stats["push_levels"] // max(a.steps, 1), stats["pull_levels"] // max(a.steps, 1)],
-            "deferred_pairs_per_step": stats["deferred_pairs"] / max(a.steps, 1),
+            "ms_per_step_incl_csr_upload": main_leg["ms_per_step"] + upload_s * 1e3,
+            "rows_answered_by_prepass_per_step": main_leg["rows_answered_by_prepass_per_step"],
+            "levels_per_step": main_leg["levels_per_step"],
+            "push_pull_levels": main_leg["push_pull_levels"],
+            "deferred_pairs_per_step": main_leg["deferred_pairs_per_step"],
             # dominant kernel class of the one-batch-in-flight pass (no overlap: event time = kernel time)
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_GBps": traffic_gbps,
-                         "traffic_frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else None,
-                         "launches": int(kl[dom]), "avg_launch_ms": kms[dom] / max(kl[dom], 1),
-                         "algorithmic_bytes_per_launch": kb[dom] / max(kl[dom], 1),
-                         "measured_copy_GBps": copy_gbps, "timing": "HIP events, one batch in flight, untimed pass",
-                         "ms_per_step_of_that_pass": iso_elapsed / iso_steps * 1e3,
-                         # all kernel classes' algorithmic bytes over the wall time of the timed region
-                         "step": {"algorithmic_bytes": step_bytes / a.steps,
-                                  "GBps": step_bytes / 1e9 / elapsed, "frac": step_bytes / 1e9 / elapsed / HBM_PEAK_GBPS}},
+            "roofline": main_leg["roofline"],
             # every kernel class of that pass: event ms per step (they add up to less than its wall time: host round
             # trips and copies are not kernels), algorithmic GB/s, launches per step
-            "roofline_by_kernel": {k: {"ms_per_step": round(kms[k] / iso_steps, 4),
-                                       "GBps": round(kb[k] / 1e9 / (kms[k] / 1e3), 1) if kb[k] > 0 else None,
-                                       "launches_per_step": kl[k] / iso_steps}
-                                   for k in kms if kms[k] > 0},
+            "roofline_by_kernel": main_leg["roofline_by_kernel"],
         }
-        if not a.no_cpu_baseline and world == 1 and a.workload in ("snb_sf100", "rmat22"):  # rank 0, N=1 only
-            mine = arrays["pairs"].view(-1, 2)[lo:hi].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, d_te, ref_len)
-        if not a.no_cpu_baseline and world == 1 and a.workload in CHEAPEST:
-            mine = arrays["pairs"].view(-1, 2)[lo:hi].cpu().numpy()
+        if other is not None:
+            out[other[0]] = dict(other[1], pairs_total=other[2], scaling=other[0])
+        mine = allp_t[lo:hi].cpu().numpy()
+        if not a.no_cpu_baseline and world == 1 and a.workload in ("snb_sf100", "rmat22", "snb_cross"):  # rank 0, N=1 only
+            out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, m["d_te"], m["out_len"])
+        if not a.no_cpu_baseline and world == 1 and cheapest:
             ns = len(mine) if a.workload == "forest_cheapest" else min(len(mine), 128)  # a Dijkstra on the knows graph is ~0.1 s
-            out["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w, mine[:ns], d_val[:ns], d_ok[:ns])
+            out["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w, mine[:ns], m["out_val"][:ns], m["d_ok"][:ns])
+        if cross is not None:
+            if not a.no_cpu_baseline:
+                cross["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, cp, mc["d_te"], mc["out_len"], sample=8192)
+            legs = {"prepass": {k: main_leg[k] for k in main_leg if k != "roofline_by_kernel"}, "msbfs_cross": cross}
+            legs["prepass"]["workload"] = "%d random pairs (default_rng(4)): every row answered by the pair-centric kernels" % total_pairs
+            if "cpu_baseline" in out:
+                legs["prepass"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "pairs_per_s")}
+            out["legs"] = legs
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, V, off, adj, eid, mine, d_te, ref_len):
+def cpu_baseline(a, V, off, adj, eid, mine, d_te, out_len, sample=0):
     """The oracle's literal restatement of IterativeLengthFunction (reference memory layout and loops), driven in
     2048-row chunks like DuckDB drives the UDF.  Two bounded samples of this rank's pairs: one thread on the first
     `cpu_sample` pairs, and one thread per chunk (up to the host's cores) on as many chunks as there are cores.
-    Checker + baseline only — never on the product path."""
+    `out_len` is the output of the TIMED steps (the buffer was poisoned before them).  Checker + baseline only —
+    never on the product path."""
     from oracle.pgq_oracle import OracleCSR
     cores = os.cpu_count() or 1
     ora = OracleCSR.adopt(V, off, adj, eid)
-    ns1 = min(a.cpu_sample or (8192 if a.workload == "snb_sf100" else 1024), len(mine))
-    t0 = time.perf_counter()
-    ln, ok = ora.baseline_run("iterativelength", V, mine[:ns1, 0], mine[:ns1, 1], nthreads=1)
-    dt1 = time.perf_counter() - t0
-    gpu_len = ref_len[:ns1].cpu().numpy()
-    agree = bool(((gpu_len >= 0) == ok).all() and (gpu_len[ok] == ln[ok]).all())
-    te1 = float(d_te[:ns1].sum().item())
+    if sample:
+        mine = mine[:sample]
+    ns1 = min(a.cpu_sample or (8192 if a.workload in SNB else 1024), len(mine))
+    res = {}
+    if not sample:
+        t0 = time.perf_counter()
+        ln, ok = ora.baseline_run("iterativelength", V, mine[:ns1, 0], mine[:ns1, 1], nthreads=1)
+        dt1 = time.perf_counter() - t0
+        gpu_len = out_len[:ns1].cpu().numpy()
+        agree = bool(((gpu_len >= 0) == ok).all() and (gpu_len[ok] == ln[ok]).all())
+        te1 = float(d_te[:ns1].sum().item())
+        res["single_thread"] = {"value": te1 / dt1 / 1e6, "cores": 1, "pairs_per_s": ns1 / dt1,
+                                "sample": "first %d pairs, %.1f s; results equal the GPU's timed output: %s" % (ns1, dt1, agree)}
     # one worker per 2048-row chunk: the most threads DuckDB's chunking can use on these rows
     nchunks_all = max(1, (len(mine) + 2047) // 2048)
     threads = max(1, min(nchunks_all, cores))
@@ -352,22 +499,21 @@ def cpu_baseline(a, V, off, adj, eid, mine, d_te, ref_len):
     t0 = time.perf_counter()
     lnm, okm = ora.baseline_run("iterativelength", V, mine[:nsm, 0], mine[:nsm, 1], nthreads=threads)
     dtm = time.perf_counter() - t0
-    gpu_m = ref_len[:nsm].cpu().numpy()
+    gpu_m = out_len[:nsm].cpu().numpy()
     agree_m = bool(((gpu_m >= 0) == okm).all() and (gpu_m[okm] == lnm[okm]).all())
     tem = float(d_te[:nsm].sum().item())
-    return {"value": tem / dtm / 1e6, "unit": "MTEPS", "cores": threads, "kind": "port",
-            "sample": "first %d pairs of rank 0's shard in 2048-row chunks, one thread per chunk (%d threads), literal "
-                      "512-lane restatement (oracle/pgq_oracle.cpp), %.1f s; results equal the GPU's: %s" % (
-                          nsm, threads, dtm, agree_m),
-            "pairs_per_s": nsm / dtm, "host_cores_available": cores,
-            "single_thread": {"value": te1 / dt1 / 1e6, "cores": 1, "pairs_per_s": ns1 / dt1,
-                              "sample": "first %d pairs, %.1f s; results equal the GPU's: %s" % (ns1, dt1, agree)}}
+    res.update({"value": tem / dtm / 1e6, "unit": "MTEPS", "cores": threads, "kind": "port",
+                "sample": "first %d pairs of rank 0's shard in 2048-row chunks, one thread per chunk (%d threads), literal "
+                          "512-lane restatement (oracle/pgq_oracle.cpp), %.1f s; results equal the GPU's timed output: %s" % (
+                              nsm, threads, dtm, agree_m),
+                "pairs_per_s": nsm / dtm, "host_cores_available": cores})
+    return res
 
 
 def cpu_baseline_cheapest(V, off, adj, eid, w, mine, d_val, d_ok):
     """Per-pair Dijkstra of the oracle (lean restatement: same distances as the reference's batched Bellman-Ford, which
     needs 8 KiB per vertex per call and does not fit a 2^24-vertex graph) on this rank's pairs, one thread; every value
-    compared with the GPU's bit for bit."""
+    of the timed output compared bit for bit."""
     from oracle.pgq_oracle import OracleCSR
     ora = OracleCSR.adopt(V, off, adj, eid, w)
     t0 = time.perf_counter()
@@ -380,7 +526,7 @@ def cpu_baseline_cheapest(V, off, adj, eid, w, mine, d_val, d_ok):
     agree = bool((ok == wok).all() and (got[ok] == want[wok]).all())
     return {"value": len(mine) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
             "sample": "all %d pairs, per-pair Dijkstra (oracle/pgq_oracle.cpp lean restatement), %.1f s; results equal the "
-                      "GPU's: %s" % (len(mine), dt, agree)}
+                      "GPU's timed output: %s" % (len(mine), dt, agree)}
 
 
 if __name__ == "__main__":

@@ -29,7 +29,8 @@ class Stats(C.Structure):
 
 
 def lib_paths():
-    return os.path.join(_CSRC, "libpgq_hip.so"), os.path.join(_CSRC, "libpgq_udf.so")
+    # PGQ_HIP_LIB: another build of the device library (tuning sweeps compare compile-time variants); the product path is csrc/
+    return os.environ.get("PGQ_HIP_LIB") or os.path.join(_CSRC, "libpgq_hip.so"), os.path.join(_CSRC, "libpgq_udf.so")
 
 
 def build_native(force=False):

@@ -170,6 +170,9 @@ struct pgq_csr {
 	double *pagerank = nullptr;
 	int pagerank_iterations = 0;
 	std::vector<pgq_csr *> replicas;
+	std::vector<int> replica_devices;   // the device list `replicas` was built for (compared with enabled_devices())
+	std::vector<pgq_csr *> retired;     // replicas of an earlier device list: calls in flight may still read them; freed with the CSR
+	std::mutex replica_lock;            // guards the three vectors above
 	bool is_replica = false;
 };
 

@@ -354,11 +354,15 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 				continue;
 			}
 			min_in_neighbour_of_dst();
+			// every wavefront reads s_best between two barriers: the walks below publish into it again, and a wavefront
+			// delayed between a barrier and its read would otherwise take another branch than the rest
 			__syncthreads();
-			if (s_best != ~0ull) {
+			const unsigned long long best2 = s_best;
+			__syncthreads();
+			if (best2 != ~0ull) {
 				if (tid == 0) {
 					out_rows[row] = 2;
-					if constexpr (PATHS) rec_rows[row].v1 = (int32_t)(u32)s_best;
+					if constexpr (PATHS) rec_rows[row].v1 = (int32_t)(u32)best2;
 				}
 				continue;
 			}
@@ -394,11 +398,13 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 		if (!known4) {
 			backward_walk(); // distance 3: against the map of N_out(src)
 			__syncthreads();
-			if (s_best != ~0ull) {
+			const unsigned long long best3 = s_best;
+			__syncthreads();
+			if (best3 != ~0ull) {
 				if (tid == 0) {
 					if constexpr (PATHS) {
-						rec_rows[row].v1 = (int32_t)(u32)s_best;
-						rec_rows[row].v2 = (int32_t)(u32)(s_best >> 32);
+						rec_rows[row].v1 = (int32_t)(u32)best3;
+						rec_rows[row].v2 = (int32_t)(u32)(best3 >> 32);
 					}
 					out_rows[row] = 3;
 				}
@@ -789,7 +795,8 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
                                                     const int32_t *__restrict__ adj, const int64_t *__restrict__ edge_ids,
                                                     int64_t *__restrict__ child, int64_t *__restrict__ out_off) {
 	const int lane = threadIdx.x & 63;
-	const int64_t i = (int64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	// 64-bit row index: one wavefront per row, n may exceed 2^26 rows (the thread index would wrap in 32 bits)
+	const int64_t i = (int64_t)blockIdx.x * (int64_t)(blockDim.x >> 6) + (int64_t)(threadIdx.x >> 6);
 	if (i >= n) return;
 	const int64_t k = len[i];
 	if (k < 0) return;

@@ -1999,8 +1999,18 @@ static thread_local std::vector<int64_t> t_child;
 template <typename Body>
 static int run_shards(pgq_csr_t *csr, int64_t n, Body body) {
 	PGQ_TRY(pgq_csr_replicate(csr));
-	const std::vector<int> devs = enabled_devices();
+	std::vector<int> devs;
+	std::vector<pgq_csr *> replicas;
+	{ // a snapshot: another caller may rebuild the list for a new device set meanwhile (old replicas stay alive)
+		std::lock_guard<std::mutex> g(csr->replica_lock);
+		devs = csr->replica_devices;
+		replicas = csr->replicas;
+	}
 	const int W = (int)devs.size();
+	if (W == 0 || replicas.size() != (size_t)W) return fail(PGQ_ERR_INVALID_ARG, "CSR replicas do not match the enabled devices");
+	for (int k = 0; k < W; k++)
+		if (!replicas[(size_t)k] || replicas[(size_t)k]->device != devs[(size_t)k])
+			return fail(PGQ_ERR_INVALID_ARG, "CSR replica on the wrong device");
 	const int64_t per = (n + W - 1) / W;
 	std::vector<int> rcs((size_t)W, PGQ_OK);
 	std::vector<std::string> errs((size_t)W);
@@ -2012,7 +2022,7 @@ static int run_shards(pgq_csr_t *csr, int64_t n, Body body) {
 		PGQ_TRY(ensure_init());
 		WorkspaceLease lease;
 		PGQ_TRY(lease.acquire());
-		return body(k, lo, hi, csr->replicas[(size_t)k], lease.ws);
+		return body(k, lo, hi, replicas[(size_t)k], lease.ws);
 	};
 	std::vector<std::thread> pool;
 	for (int k = 1; k < W; k++)

@@ -299,6 +299,11 @@ int DevBuf::reserve(size_t bytes) {
 	cap = 0;
 	size_t want = bytes + bytes / 8 + 256;
 	hipError_t e = hipMalloc(&p, want);
+	if (e == hipErrorOutOfMemory) { // gigabytes of freed CSR blocks may sit in the block cache: give them back and retry
+		(void)hipGetLastError();
+		dev_cache_trim();
+		e = hipMalloc(&p, want);
+	}
 	if (e != hipSuccess) return fail(PGQ_ERR_OOM, std::string("hipMalloc(") + std::to_string(want) + "): " +
 	                                                  hipGetErrorString(e));
 	cap = want;
@@ -780,13 +785,15 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 		int *&flag;
 		u32 *&a, *&b;
 		void *&t;
+		hipStream_t st;
 		~Temps() {
+			(void)hipStreamSynchronize(st); // an error return may leave a sort writing them: not back to the cache before it is done
 			dev_free(flag);
 			dev_free(a);
 			dev_free(b);
 			dev_free(t);
 		}
-	} temps { d_flag, d_slot_src, d_skey, d_tmp };
+	} temps { d_flag, d_slot_src, d_skey, d_tmp, st };
 	PGQ_TRY(dev_alloc_as(&d_flag, 2));
 	PGQ_HIP_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
 	if (V > 0) {
@@ -843,13 +850,15 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 		HubRow *&b;
 		int *&c;
 		void *&d;
+		hipStream_t st;
 		~Temps2() {
+			(void)hipStreamSynchronize(st);
 			dev_free(a);
 			dev_free(b);
 			dev_free(c);
 			dev_free(d);
 		}
-	} temps2 { d_us, d_hub_rows, d_run, d_scan };
+	} temps2 { d_us, d_hub_rows, d_run, d_scan, st };
 	PGQ_TRY(dev_alloc_as(&d_us, 1));
 	PGQ_TRY(dev_alloc_as(&d_hub_rows, (size_t)hub_cap));
 	PGQ_TRY(dev_alloc_as(&d_run, (size_t)(2 * n_runs + 2)));
@@ -926,9 +935,12 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 
 static void destroy_csr(pgq_csr *c) {
 	if (!c) return;
-	if (!c->is_replica)
+	if (!c->is_replica) {
 		for (pgq_csr *r : c->replicas)
 			if (r && r != c) destroy_csr(r);
+		for (pgq_csr *r : c->retired)
+			if (r && r != c) destroy_csr(r);
+	}
 	dev_free(c->off);
 	dev_free(c->adj);
 	dev_free(c->edge_ids);
@@ -1247,8 +1259,11 @@ static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
 int pgq_csr_replicate(pgq_csr_t *c) {
 	PGQ_TRY(ensure_init());
 	if (!c || c->is_replica) return fail(PGQ_ERR_INVALID_ARG, "pgq_csr_replicate: NULL or replica handle");
-	const std::vector<int> &devs = enabled_devices();
-	if (!c->replicas.empty()) return PGQ_OK; // already done
+	const std::vector<int> devs = enabled_devices();
+	// one caller builds; a list built for another device set (a *_multi call before pgq_init_devices leaves a one-entry
+	// list) is rebuilt, the old replicas stay alive until the CSR is freed because calls in flight may still read them
+	std::lock_guard<std::mutex> g(c->replica_lock);
+	if (!c->replicas.empty() && c->replica_devices == devs) return PGQ_OK;
 	std::vector<pgq_csr *> reps(devs.size(), nullptr);
 	int rc = PGQ_OK;
 	bool self_used = false;
@@ -1258,15 +1273,29 @@ int pgq_csr_replicate(pgq_csr_t *c) {
 			self_used = true;
 			continue;
 		}
-		rc = clone_csr(c, devs[k], &reps[k]);
+		// reuse a replica of the previous list that sits on the right device
+		for (pgq_csr *&old : c->replicas)
+			if (old && old != c && old->device == devs[k]) {
+				reps[k] = old;
+				old = nullptr;
+				break;
+			}
+		if (!reps[k]) rc = clone_csr(c, devs[k], &reps[k]);
 	}
 	(void)hipSetDevice(current_device());
 	if (rc != PGQ_OK) {
 		for (pgq_csr *r : reps)
-			if (r && r != c) destroy_csr(r);
+			if (r && r != c) c->retired.push_back(r); // freed with the CSR (a reused one may still be in use)
+		for (pgq_csr *old : c->replicas)
+			if (old && old != c) c->retired.push_back(old);
+		c->replicas.clear();
+		c->replica_devices.clear();
 		return rc;
 	}
+	for (pgq_csr *old : c->replicas)
+		if (old && old != c) c->retired.push_back(old);
 	c->replicas = reps;
+	c->replica_devices = devs;
 	return PGQ_OK;
 }
 

@@ -53,31 +53,61 @@ def gather_rows(local, total):
     return torch.cat(parts)[:total]
 
 
+class _Pending:
+    """An all_gather in flight: keeps its buffers alive; wait() returns the gathered rows."""
+
+    def __init__(self, work, out, total, keep):
+        self.work, self.out, self.total, self.keep = work, out, total, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out[:self.total]
+
+
+def gather_rows_async(local, total):
+    """gather_rows without waiting: ONE all_gather_into_tensor issued with async_op (RCCL runs it on its own stream,
+    ordered behind the work already queued on the current stream), so that the next step's search overlaps it.  The
+    caller must not overwrite `local` before wait()."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return _Pending(None, local, total, None)
+    world = dist.get_world_size()
+    per = (total + world - 1) // world
+    pad = local
+    if local.numel() < per:
+        pad = torch.cat([local, torch.full((per - local.numel(),), -1, dtype=local.dtype, device=local.device)])
+    out = torch.empty(per * world, dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, pad, async_op=True)
+    return _Pending(work, out, total, pad)
+
+
 def gather_paths(d_len, d_off, d_child, used, per):
-    """all_gather of shortestpath results: per-pair hop counts and list offsets (equal blocks of `per` rows, the last
-    shard padded) and the packed [v,e,v,...] payloads (ragged: sizes first, then blocks padded to the largest).
-    Returns (lengths, offsets into the concatenated payload, payload); offsets of rank r are shifted by the payload
-    sizes of the ranks before it."""
+    """all_gather of shortestpath results in TWO collectives: a header block per rank — hop counts and list offsets of
+    its `per` rows (the last shard padded) and its payload size — then the packed [v,e,v,...] payloads, padded to the
+    largest (read from the gathered headers: 8 bytes per rank come back to the host).  Returns (lengths, offsets into
+    the concatenated payload, payload); offsets of rank r are shifted by the payload sizes of the ranks before it."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return d_len, d_off, d_child[:used]
     world = dist.get_world_size()
     dev = d_len.device
-
-    def pad_to(t, k, fill):
-        return t if t.numel() >= k else torch.cat([t, torch.full((k - t.numel(),), fill, dtype=t.dtype, device=dev)])
-
-    lens = [torch.empty(per, dtype=d_len.dtype, device=dev) for _ in range(world)]
-    offs = [torch.empty(per, dtype=d_off.dtype, device=dev) for _ in range(world)]
-    dist.all_gather(lens, pad_to(d_len, per, -1))
-    dist.all_gather(offs, pad_to(d_off, per, 0))
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([used], dtype=torch.int64, device=dev))
-    sizes = [int(x.item()) for x in sizes]
+    head = torch.empty(2 * per + 1, dtype=torch.int64, device=dev)
+    head[:per] = -1
+    head[per:2 * per] = 0
+    head[:d_len.numel()] = d_len
+    head[per:per + d_off.numel()] = d_off
+    head[2 * per] = used
+    heads = torch.empty(world * (2 * per + 1), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(heads, head)
+    heads = heads.view(world, 2 * per + 1)
+    sizes = heads[:, 2 * per].tolist()  # the one host read of the gather
     cap = max(max(sizes), 1)
-    blocks = [torch.empty(cap, dtype=d_child.dtype, device=dev) for _ in range(world)]
-    dist.all_gather(blocks, pad_to(d_child[:used], cap, 0))
-    base, shifted = 0, []
-    for r in range(world):
-        shifted.append(offs[r] + base)
-        base += sizes[r]
-    return torch.cat(lens), torch.cat(shifted), torch.cat([b[:k] for b, k in zip(blocks, sizes)])
+    block = torch.zeros(cap, dtype=d_child.dtype, device=dev)
+    block[:used] = d_child[:used]
+    blocks = torch.empty(world * cap, dtype=d_child.dtype, device=dev)
+    dist.all_gather_into_tensor(blocks, block)
+    blocks = blocks.view(world, cap)
+    base = torch.zeros(world, dtype=torch.int64)
+    base[1:] = torch.cumsum(torch.tensor(sizes[:-1], dtype=torch.int64), 0)
+    offs = heads[:, per:2 * per] + base.to(dev)[:, None]
+    return heads[:, :per].reshape(-1), offs.reshape(-1), torch.cat([blocks[r, :sizes[r]] for r in range(world)])

@@ -20,9 +20,27 @@ def _defaults():
                  ("meet", 0), ("meet_cap", 1 << 16), ("meet_cap_paths", 1 << 16), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
-                 ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048)):
+                 ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
+                 ("meet_layout", 1), ("meet_align", 4)):
         pgq.set_option(k, v)
     yield
+
+
+# The shipped configuration answers rows through the pair-centric pre-pass (and int64 weighted rows through the per-row
+# search) before the lane-batched kernels see them; on tiny graphs its cost model would decline, so `meet_bias` forces it.
+# Tests that replay the reference's golden vectors / fuzz tiny graphs run once per configuration.
+PRODUCT_CONFIGS = {
+    "lane_batches": {"meet": 0, "wbibfs": 0},
+    "prepass": {"meet": 1, "meet_bias": 1e9, "wbibfs": 0},
+    "prepass+wbibfs": {"meet": 1, "meet_bias": 1e9, "wbibfs": 1},
+}
+
+
+@pytest.fixture(params=sorted(PRODUCT_CONFIGS))
+def product_config(request):
+    for k, v in PRODUCT_CONFIGS[request.param].items():
+        pgq.set_option(k, v)
+    return request.param
 
 
 def both(V, rows, w=None, csr_id=0):
@@ -38,7 +56,7 @@ def lens(out, ok):
 
 # ---- golden vectors of the reference's own tests, replayed on the GPU ------------------------------------------
 
-def test_golden_student_directed():
+def test_golden_student_directed(product_config):
     g = load_golden("student_directed.json")  # shortest_path.test:59-82
     V = g["V"]
     st, _ = both(V, directed_rows(g["edges"]))
@@ -49,7 +67,7 @@ def test_golden_student_directed():
     assert got == {(p["src"], p["dst"]): (p["length"], p["path"]) for p in g["paths"]}
 
 
-def test_golden_student_undirected_and_edgeless():
+def test_golden_student_undirected_and_edgeless(product_config):
     g = load_golden("student_undirected.json")  # undirected_paths.test:91-123
     V = g["V"]
     st, _ = both(V, undirected_rows(g["edges"]))
@@ -66,7 +84,7 @@ def test_golden_student_undirected_and_edgeless():
     assert all(p is None for a, b, p in zip(s, d, paths) if a != b)
 
 
-def test_golden_snb003_paths():
+def test_golden_snb003_paths(product_config):
     g = load_golden("snb003_knows.json")  # complex_matching.test:329-360
     V = g["V"]
     st, ora = both(V, directed_rows(g["edges"]))
@@ -90,7 +108,7 @@ def test_golden_snb003_paths():
     assert ok[0] and ln[0] == ic["length"]
 
 
-def test_null_selection_and_reachability():
+def test_null_selection_and_reachability(product_config):
     g = load_golden("student_directed.json")
     V = g["V"]
     st, ora = both(V, directed_rows(g["edges"]))
@@ -162,13 +180,15 @@ def test_random_graph_all_variants(words, mode):
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
 
 
-@pytest.mark.parametrize("cap,lds_kb", [(1 << 18, 150), (3000, 150), (1, 150), (1 << 18, 0)])
-def test_meet_prepass_matches_oracle(cap, lds_kb):
+@pytest.mark.parametrize("cap,lds_kb,align", [(1 << 18, 150, 4), (3000, 150, 16), (1, 150, 4), (1 << 18, 0, 32), (300, 150, 4)])
+def test_meet_prepass_matches_oracle(cap, lds_kb, align):
     # k_meet3 (pgq_meet.hip): distances 1..3 from two-hop scans, everything else handed to the lane-batched search.
-    # cap = adjacency entries a pair may scan: small caps leave most rows to the MS-BFS path (both paths mixed)
+    # cap = adjacency entries a pair's walk may scan before it is handed on: small caps leave most rows to k_meet4d / the
+    # MS-BFS path (all paths mixed)
     rng = np.random.default_rng(77 + cap)
     V, E = 6000, 60000
     rows = random_graph(rng, V, E, skew=True)  # skewed: lists longer than the 512-entry hash table exist
+    pgq.set_option("meet_align", align)  # read at upload: padded lists start on 16 / 64 / 128-byte boundaries
     st, ora = both(V, rows)
     pgq.set_option("meet", 1)
     pgq.set_option("meet_cap", cap)
@@ -661,7 +681,7 @@ def test_device_csr_construction_matches_reference_layout():
         pgq.DeviceCSR.build_from_device_rows(V, 2, bad.data_ptr(), bad.data_ptr())
 
 
-def test_fuzz_tiny_graphs_against_literal_oracle():
+def test_fuzz_tiny_graphs_against_literal_oracle(product_config):
     """Many tiny graphs (self loops, duplicate and anti-parallel edges, isolated vertices, V=1, E=0, chains) through
     the UDF mirror, every function against the literal restatement of the reference."""
     rng = np.random.default_rng(2024)
@@ -874,3 +894,109 @@ def test_pagerank_device_matches_reference():
     out, ok, it = dev.pagerank(ids)
     assert ok[:V + 2].all() and not ok[V + 2:].any() and it == wit
     assert np.max(np.abs(out[:V + 2] - want) / want) <= 1e-12
+
+
+@pytest.mark.parametrize("cfg", ["lane_batches", "prepass"])
+def test_unpinned_variants_1500_rows_against_the_oracle(cfg):
+    """iterativelength2, iterativelengthbidirectional and reachability have no test in the reference (parity unpinned):
+    1500 random rows with NULL sources on a skewed graph and on a sparse one (dead ends, unreachable pairs) against the
+    oracle's restatement of iterativelength2.cpp:33-130 and the hop counts of iterativelength.cpp:34-143 — through the
+    lane batches and through the pre-pass."""
+    for k, v in PRODUCT_CONFIGS[cfg].items():
+        pgq.set_option(k, v)
+    rng = np.random.default_rng(808)
+    for V, E, skew in ((3000, 30000, True), (4000, 5000, False)):
+        st, ora = both(V, random_graph(rng, V, E, skew=skew))
+        n = 1500
+        ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        ps[:40] = pd[:40]
+        valid = rng.random(n) > 0.05
+        oln, ook = ora.iterativelength(V, ps, pd, src_valid=valid)
+        o2, o2k = ora.iterativelength(V, ps, pd, src_valid=valid, variant=2)
+        assert lens(o2, o2k) == lens(oln, ook)  # the two restatements agree with each other
+        for variant in (1, 2, 3):
+            ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid, variant=variant)
+            assert lens(ln, ok) == lens(oln, ook), variant
+        r, rok = st.reachability(0, V, ps, pd, src_valid=valid)
+        assert (rok == valid).all()  # NULL source -> NULL (INTEGRATION.md: intentional deviation from the reference)
+        assert (r[valid] == ook[valid]).all()
+
+
+@pytest.mark.slow
+def test_c5_forest_at_bench_scale_2_24():
+    """BASELINE configs[4] at the scale bench.py runs it (reply forest, V = 2^24): 4096 pairs with ancestor destinations
+    (and some unreachable ones), int64 and double weights, every value against the oracle's Dijkstra."""
+    rng = np.random.default_rng(56)
+    V, s, d = graphgen.reply_forest(1 << 24, seed=5)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    deg = np.diff(off)
+    cand = np.nonzero(deg > 0)[0]
+    src = cand[rng.integers(0, len(cand), 4096)]
+    dst = src.copy()
+    hops = rng.integers(1, 9, 4096)
+    for h in range(8):
+        move = (hops > h) & (deg[dst] > 0)
+        dst[move] = adj[off[dst[move]]]
+    dst[:512] = rng.integers(0, V, 512)
+    for w in (rng.integers(1, 1000, len(adj)), rng.random(len(adj)) + 0.01):
+        dev = pgq.DeviceCSR(V, off, adj, eid, w)
+        ora = OracleCSR.adopt(V, off, adj, eid, w)
+        out, ok = dev.cheapest_path_length(src, dst)
+        want, wok = ora.lean_cheapest_path_length(V, src, dst)
+        assert (ok == wok).all() and (out[ok] == want[wok]).all() and ok.sum() > 3000
+        dev.close()
+
+
+def test_eight_shards_on_one_gpu_65536_pairs():
+    """configs[3] as the in-library multi-GPU call sees it: 65,536 pairs cut into 8 shards (device 0 named eight times:
+    eight replicas, eight shard threads), every length against the single-shard answer and a sample against the oracle."""
+    import time
+    rng = np.random.default_rng(65)
+    V2, s2, d2 = graphgen.snb_knows_like(60000, 1500000, seed=9)
+    off, adj, eid = graphgen.csr_from_rows(V2, s2, d2)
+    dev = pgq.DeviceCSR(V2, off, adj, eid)
+    ora = OracleCSR.adopt(V2, off, adj, eid)
+    n = 65536
+    ps, pd = rng.integers(0, V2, n), rng.integers(0, V2, n)
+    pgq.set_option("meet", 1)
+    one = dev.iterativelength_multi(ps, pd)  # device list [0]: one shard
+    oln, ook = ora.lean_iterativelength(V2, ps[:2000], pd[:2000], nthreads=8)
+    assert (one[:2000] == np.where(ook, oln, -1)).all()
+    assert pgq.init_devices([0] * 8) == 8
+    try:
+        got = dev.iterativelength_multi(ps, pd)
+        assert (got == one).all()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            got = dev.iterativelength_multi(ps, pd)
+        dt8 = (time.perf_counter() - t0) / 5
+        assert (got == one).all()
+    finally:
+        pgq.init_devices([0])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dev.iterativelength_multi(ps, pd)
+    dt1 = (time.perf_counter() - t0) / 5
+    # eight shards on ONE device cannot be faster than one; what is checked is that sharding adds little fixed cost
+    print("65536 pairs: 1 shard %.3f ms, 8 shards on one GPU %.3f ms" % (dt1 * 1e3, dt8 * 1e3))
+    assert dt8 < dt1 + 0.004  # < 0.5 ms of fixed cost per shard, host copies included
+
+
+def test_replicas_follow_the_enabled_device_list():
+    """a *_multi call before pgq_init_devices leaves a one-entry replica list; the next call with more devices
+    enabled must rebuild it instead of indexing past its end."""
+    rng = np.random.default_rng(66)
+    V, E = 5000, 40000
+    s, d, e = random_graph(rng, V, E)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    ps, pd = rng.integers(0, V, 3000), rng.integers(0, V, 3000)
+    a = dev.iterativelength_multi(ps, pd)  # replicas built for [0]
+    assert pgq.init_devices([0, 0, 0]) == 3
+    try:
+        b = dev.iterativelength_multi(ps, pd)  # three shards: replicas must be extended
+        assert (a == b).all()
+    finally:
+        pgq.init_devices([0])
+    c = dev.iterativelength_multi(ps, pd)
+    assert (a == c).all()

@@ -42,6 +42,8 @@ def _worker(rank, world, port, total, q):
     ln, ok = ora.lean_iterativelength(V, pairs[lo:hi, 0], pairs[lo:hi, 1])
     ln[~ok] = -1
     allr = sharding.gather_rows(torch.from_numpy(ln), total)
+    pend = sharding.gather_rows_async(torch.from_numpy(ln), total)  # what bench.py overlaps with the next step
+    assert torch.equal(pend.wait(), allr)
     # path lists: packed per-rank payloads of different sizes, offsets relative to the rank's own buffer
     paths = ora.lean_shortestpath(V, pairs[lo:hi, 0], pairs[lo:hi, 1])
     offs, child = [], []

@@ -72,7 +72,7 @@ struct Options {
 	int sparse_unroll = 2;  // 64-entry chunks in flight per wave in k_pull_sparse (1, 2 or 4)
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 	int meet = 1;           // iterativelength: answer pairs at distance <= 3 by the pair-centric pre-pass (k_meet3) when cheaper
-	int meet_cap = 1 << 16; // adjacency entries a pair's two-hop walk may scan; beyond: left to the MS-BFS path
+	int meet_cap = 1 << 14; // adjacency entries a pair's two-hop walk may scan in k_meet3 (one wavefront); beyond: k_meet4d (16 wavefronts)
 	int meet_cap_paths = 1 << 16; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
@@ -93,8 +93,9 @@ struct Options {
 	double meet_bias = 1.0; // pre-pass runs while its estimated bytes <= meet_bias x the MS-BFS estimate
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
 	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
+	int meet_grid_mult = 8; // k_meet3 grid = this many times the 8192 one-wavefront workgroups the chip holds (rows per workgroup = n / grid)
 	int meet_layout = 1;    // build the padded adjacency + slot descriptors at upload (the pre-pass needs them)
-	int meet_align = 4;     // entries a padded list start is aligned to (4 = one 16-byte group; 16 / 32 = one 64 / 128-byte line)
+	int meet_align = 16;    // entries a padded list is aligned and padded to (4 = one 16-byte group; 16 / 32 = whole 64 / 128-byte lines: -4 % on k_meet3)
 };
 Options &options();
 

@@ -46,6 +46,9 @@ constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so
 #ifndef PGQ_MEET3_DEPTH
 #define PGQ_MEET3_DEPTH 2 // list requests in flight per wavefront
 #endif
+#ifndef PGQ_MEET4_MARK_DEPTH
+#define PGQ_MEET4_MARK_DEPTH 2 // the marking walk of k_meet4d never stops early: deeper costs nothing but registers
+#endif
 #ifndef PGQ_MEET4_DEPTH
 #define PGQ_MEET4_DEPTH 2 // the same for each of the 16 wavefronts of a k_meet4d row (more only adds overshoot past the first hit)
 #endif
@@ -75,12 +78,13 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
                                                   const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
                                                   int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
                                                   const u32 *__restrict__ go, MeetCounters *__restrict__ mc) {
-	__shared__ __attribute__((aligned(16))) u32 s_tab[kMeetWPB][kMeetSlots];
-	__shared__ __attribute__((aligned(16))) u32 s_bm[kMeetWPB][kMeetFilterWords];
+	static_assert(kMeetWPB == 1, "one wavefront per workgroup: the LDS arrays are addressed statically");
+	__shared__ __attribute__((aligned(16))) u32 tab[kMeetSlots];
+	__shared__ __attribute__((aligned(16))) u32 bm[kMeetFilter2Words];
+	__shared__ __attribute__((aligned(16))) unsigned char win[64];
 	if (go && *go == 0) return;
 	const int lane = threadIdx.x & 63;
-	u32 *tab = s_tab[threadIdx.x >> 6];
-	u32 *bm = s_bm[threadIdx.x >> 6];
+	win[lane] = 0;
 	unsigned long long entries = 0; // wave-uniform
 	u32 vertices = 0;
 	const int64_t wave0 = (int64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 		for (int k = 0; k < kMeetSlots / 256; k++)
 			reinterpret_cast<uint4_alias *>(tab)[k * 64 + lane] = make_uint4(kMeetEmpty, kMeetEmpty, kMeetEmpty, kMeetEmpty);
 #pragma unroll
-		for (int k = 0; k < kMeetFilterWords / 256; k++) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+		for (int k = 0; k < kMeetFilter2Words / 256; k++) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
 		__builtin_amdgcn_wave_barrier();
 		bool hit = false;
 		for (int pb = 0; pb < set_n; pb += 128) { // two rounds of 64 requested together
@@ -149,8 +153,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 				const u32 x = r ? x1 : x0;
 				if (x != kMeetEmpty) {
 					hit |= x == other;
-					const u32 fh = meet_fhash(x);
-					atomicOr(&bm[fh >> 5], 1u << (fh & 31));
+					atomicOr(&bm[meet_f2_word(x)], meet_f2_mask(x));
 					u32 h = meet_hash(x);
 					for (;;) {
 						const u32 old = atomicCAS(&tab[h], kMeetEmpty, x);
@@ -187,23 +190,23 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 		// distance 3: the padded lists of the expanded side's vertices, one hash probe per entry, ended by the first pass
 		// with a hit.  PATHS: requests are processed in walk order and the lists ascend, so every later witness has a
 		// larger (second vertex, first vertex) key than the smallest one of the pass that found the first
-		u32 f = 0;
+		bool f = false;
 		u64 best = ~0ull; // PATHS: smallest (outer vertex << 32 | inner vertex) over the witnesses
 		bool capped = false;
 		entries += seg_walk<PGQ_MEET3_DEPTH, PATHS>(
-		    exp_desc, exp_n, 0, 1, xp, true, d0, (unsigned long long)cap, capped,
+		    exp_desc, exp_n, 0, 1, xp, win, true, d0, (unsigned long long)cap, capped,
 		    [&](const int4 &v, bool ok, u32 ev) {
-			    const u32 m = meet_probe4(tab, bm, v, ok ? 0xFu : 0u);
 			    if constexpr (PATHS) { // backward walk: expanded vertex = second-to-last, entry = the one before it
+				    const u32 m = ok ? meet_which4(tab, bm, v) : 0u;
 				    if (m & 1u) best = min(best, (u64)ev << 32 | (u32)v.x);
 				    if (m & 2u) best = min(best, (u64)ev << 32 | (u32)v.y);
 				    if (m & 4u) best = min(best, (u64)ev << 32 | (u32)v.z);
 				    if (m & 8u) best = min(best, (u64)ev << 32 | (u32)v.w);
-			    } else {
-				    f |= m;
+			    } else { // a lane past the round's end re-reads real entries of the last list: no mask needed
+				    f |= meet_any4(tab, bm, v);
 			    }
 		    },
-		    [&]() { return PATHS ? (__any(best != ~0ull) != 0) : (__any(f != 0) != 0); });
+		    [&]() { return PATHS ? (__any(best != ~0ull) != 0) : (__any(f) != 0); });
 		bool found;
 		if constexpr (PATHS) {
 			best = wave_min_u64(best);
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 				rec[i].v1 = (int32_t)(u32)best;
 			}
 		} else {
-			found = __any(f != 0) != 0;
+			found = __any(f) != 0;
 		}
 		// the walk ran to its end without a witness: the distance is at least 4; it was cut short: nothing is known
 		if (lane == 0) out[i] = found ? 3 : (capped ? kMeetOpen : kMeetOpen4);
@@ -479,7 +482,10 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
 	__shared__ int s_flag;
 	__shared__ unsigned long long s_work[2];
+	__shared__ __attribute__((aligned(16))) unsigned char s_win[16][64];
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	unsigned char *win = s_win[wib]; // seg_owner's window of this wavefront
+	win[lane] = 0;
 	unsigned long long entries = 0;
 	u32 vertices = 0;
 	auto bit = [&](u32 x) {
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 	auto walk_test = [&](const uint4 *list, int list_n, const int32_t *xp) {
 		bool f = false, capped = false;
 		const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
-		    list, list_n, wib, 16, xp, false, make_uint4(0, 0, 0, 0), ~0ull, capped,
+		    list, list_n, wib, 16, xp, win, false, make_uint4(0, 0, 0, 0), ~0ull, capped,
 		    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
 		    [&]() {
 			    if (__any(f)) s_flag = 1;
@@ -598,8 +604,8 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 		// distance 4: two-hop set of the walked endpoint, two-hop walk of the other one
 		{
 			bool capped = false;
-			const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
-			    walk_fwd ? fdesc + so : rdesc + di, walk_fwd ? degS : degD, wib, 16, walk_fwd ? padj : rpadj, false,
+			const unsigned long long e2 = seg_walk<PGQ_MEET4_MARK_DEPTH, false>(
+			    walk_fwd ? fdesc + so : rdesc + di, walk_fwd ? degS : degD, wib, 16, walk_fwd ? padj : rpadj, win, false,
 			    make_uint4(0, 0, 0, 0), ~0ull, capped,
 			    [&](const int4 &v, bool, u32) {
 				    mark((u32)v.x);
@@ -953,8 +959,8 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		const int64_t cap = std::max(1, paths ? opt.meet_cap_paths : opt.meet_cap);
 		KernelTimer kt(st, K_MEET);
 		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 4 rounds
-		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, 4 * resident));
-		if (paths)
+		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, (int64_t)std::max(1, opt.meet_grid_mult) * resident));
+if (paths)
 			hipLaunchKernelGGL(k_meet3<true>, grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,
 			                   c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap, d_go, mc);
 		else
@@ -1063,6 +1069,94 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	S.edges_scanned += (int64_t)entries;
 	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
 	*n_open = open;
+	return PGQ_OK;
+}
+
+// ---- iterativelengthbidirectional: every row through the bidirectional search ---------------------------------------------
+// The reference's IterativeLengthBidirectionalFunction (iterativelength_bidirectional.cpp:43-153) is meant to search
+// forward from src and backward from dst over the transposed CSR until the two meet (it is unreachable from the binder
+// and indexes its backward CSR wrongly).  Here that is k_bibfs for EVERY row: k_bidir_classify answers
+// what needs no search (NULL -> NULL, src == dst -> 0, an endpoint without edges in its direction -> NULL) and marks
+// the rest open; k_bibfs takes them one 1024-thread workgroup per row; rows over its caps stay open for the caller
+// (the lane-batched search).  Same answers as iterativelength (the BFS distance), different schedule.
+__global__ void k_bidir_classify(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t V,
+                                 const int64_t *__restrict__ off, const int64_t *__restrict__ roff, int64_t *__restrict__ out,
+                                 MeetCounters *__restrict__ mc) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int64_t s = src[i], d = dst[i];
+	int64_t r = kMeetOpen;
+	if (s < 0) r = -1; // NULL row
+	else if (s >= V || d < 0 || d >= V) {
+		mc->bad = 1;
+		r = -1;
+	} else if (s == d) r = 0;
+	else if (off[s + 1] == off[s] || roff[d + 1] == roff[d]) r = -1; // no path can exist
+	out[i] = r;
+}
+
+int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
+                       u32 *n_open) {
+	hipStream_t st = ws->stream;
+	pgq_stats_t &S = tstats().s;
+	const Options &opt = options();
+	struct DevBlock {
+		MeetCounters m;
+		u32 count[4];
+	};
+	PGQ_TRY(ws->meet_cnt.reserve(sizeof(DevBlock) + 64));
+	PGQ_TRY(ws->def_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
+	PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
+	DevBlock *db = ws->meet_cnt.as<DevBlock>();
+	PGQ_HIP_TRY(hipMemsetAsync(db, 0, sizeof(DevBlock), st));
+	hipLaunchKernelGGL(k_bidir_classify, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, c->V, c->off, c->roff, d_out, &db->m);
+	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
+	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), db->count, (const u32 *)nullptr);
+	const int bm_words = (int)((c->V + 127) / 128) * 4, mwb = bm_words + 4;
+	const size_t lds_budget = (size_t)std::min(150, std::max(0, opt.meet4_lds_kb)) * 1024;
+	const bool bi_lds = (size_t)2 * mwb * 4 + 512 <= lds_budget;
+	const int qcap = std::max(1024, opt.bibfs_queue);
+	const u32 grid = (u32)std::min<int64_t>(n, 256);
+	const size_t map_words = bi_lds ? 0 : (size_t)grid * 2 * mwb;
+	PGQ_TRY(ws->meet_maps.reserve((map_words + (size_t)grid * 4 * qcap) * 4 + 64));
+	u32 *maps = ws->meet_maps.as<u32>();
+	u32 *queues = maps + map_words;
+	static std::atomic<int> attr_set { 0 };
+	if (!attr_set.load()) {
+		(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+		attr_set.store(1);
+	}
+	const int64_t capb = (int64_t)std::max(1, opt.bibfs_cap);
+	{
+		KernelTimer kt(st, K_MEET);
+		if (bi_lds)
+			hipLaunchKernelGGL(k_bibfs<false>, dim3(grid), dim3(1024), (size_t)2 * mwb * 4, st, (const u32 *)db->count, 0xFFFFFFFFu,
+			                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
+			                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, &db->m, maps, queues);
+		else
+			hipLaunchKernelGGL(k_bibfs<true>, dim3(grid), dim3(1024), 0, st, (const u32 *)db->count, 0xFFFFFFFFu,
+			                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
+			                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, &db->m, maps, queues);
+		kt.stop();
+	}
+	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
+	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), db->count + 1, (const u32 *)nullptr);
+	DevBlock &h = *static_cast<DevBlock *>(ws->h_meet);
+	static_assert(sizeof(DevBlock) <= 8192, "pinned statistics block too small");
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, db, sizeof(DevBlock), hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	if (h.m.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+	unsigned long long entries = 0, vertices = 0;
+	for (int k = 0; k < kMeetStatSlots; k++) {
+		entries += h.m.entries[k];
+		vertices += h.m.vertices[k];
+	}
+	S.meet_pairs += n - (int64_t)h.count[1];
+	S.edges_scanned += (int64_t)entries;
+	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
+	*n_open = h.count[1];
 	return PGQ_OK;
 }
 

@@ -1327,6 +1327,7 @@ struct SearchOutput {
 	int depth = 0;        // nesting level of the straggler pass
 	bool deferred = false;
 	bool overflow = false; // the caller's child buffer was too small (lengths are still complete)
+	bool bidir = false;    // iterativelengthbidirectional: every row through the per-row bidirectional search first
 };
 static constexpr int kMaxTeLevels = 1024;
 
@@ -1842,6 +1843,23 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		}
 		return PGQ_OK;
 	};
+	if (outp.bidir && !with_paths && !outp.want_te && outp.depth == 0 && c->E > 0) {
+		u32 nd = 0;
+		PGQ_TRY(meet_bidirectional(c, ws, n, d_src, d_dst, d_out_len, &nd));
+		if (nd > 0) { // over k_bibfs's caps: the lane-batched search
+			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
+			WorkspaceLease inner;
+			PGQ_TRY(inner.acquire());
+			SearchOutput so2;
+			so2.depth = outp.depth + 1;
+			S.pairs -= nd; // counted once
+			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
+			PGQ_TRY(meet_apply(ws, nd, ws->def_len.as<int64_t>(), d_out_len));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+		}
+		return PGQ_OK;
+	}
 	if (may_meet && meet_pays(std::min<int64_t>(n, c->V))) {
 		bool ran = true;
 		PGQ_TRY(run_meet(&ran));
@@ -2066,17 +2084,25 @@ int pgq_release_cached_memory(void) {
 	return PGQ_OK;
 }
 
-int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
-                                    int64_t *d_out_len) {
+static int iterativelength_bulk(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out_len,
+                                bool bidir) {
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out_len))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
 	WorkspaceLease lease;
 	PGQ_TRY(lease.acquire());
 	SearchOutput so;
+	so.bidir = bidir;
 	return search_device(csr, lease.ws, n, d_src, d_dst, d_out_len, false, nullptr, nullptr, 0, so);
 }
-
+int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                    int64_t *d_out_len) {
+	return iterativelength_bulk(csr, n, d_src, d_dst, d_out_len, false);
+}
+int pgq_iterativelength_bidirectional_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                                  int64_t *d_out_len) {
+	return iterativelength_bulk(csr, n, d_src, d_dst, d_out_len, true);
+}
 int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t *d_out_len, int64_t *d_out_te) {
 	PGQ_TRY(ensure_init());
@@ -2225,8 +2251,8 @@ int pgq_cheapest_path_length_multi(pgq_csr_t *csr, int64_t n, const int64_t *src
 	});
 }
 
-int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
-                        uint64_t *out_valid) {
+static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
+                                 uint64_t *out_valid, bool bidir) {
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_csr(csr, V));
 	if (n < 0 || (n > 0 && (!out_len || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
@@ -2242,6 +2268,7 @@ int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, fp.src.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, fp.dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
 	SearchOutput so;
+	so.bidir = bidir;
 	PGQ_TRY(search_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
 	                      false, nullptr, nullptr, 0, so));
 	PGQ_TRY(staged_download(out_len, ws->out_len.p, (size_t)n * 8, ws->stream));
@@ -2249,6 +2276,14 @@ int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq
 	for (int64_t i = 0; i < n; i++)
 		if (out_len[i] < 0) mask_set_invalid(out_valid, i); // payload stays -1 like iterativelength.cpp:100,137
 	return PGQ_OK;
+}
+int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
+                        uint64_t *out_valid) {
+	return iterativelength_chunk(csr, V, n, src, dst, out_len, out_valid, false);
+}
+int pgq_iterativelength_bidirectional(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
+                                      uint64_t *out_valid) {
+	return iterativelength_chunk(csr, V, n, src, dst, out_len, out_valid, true);
 }
 
 int pgq_shortestpath(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, uint64_t *out_offset,

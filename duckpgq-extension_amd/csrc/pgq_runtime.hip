@@ -104,6 +104,7 @@ static std::vector<OptRef> option_table() {
 		{ "lanes_unroll", &o.lanes_unroll, nullptr },
 		{ "upload_threads", &o.upload_threads, nullptr },
 		{ "upload_narrow_host", &o.upload_narrow_host, nullptr },
+		{ "meet_grid_mult", &o.meet_grid_mult, nullptr },
 		{ "meet_layout", &o.meet_layout, nullptr },
 		{ "meet_align", &o.meet_align, nullptr },
 	};

@@ -71,6 +71,10 @@ int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const 
 // pre-pass pays (distinct sources, sampled) is settled on the device in the same launch chain; *ran = false: it did not run.
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, bool paths, bool decide, double meet_bytes, double batch_bytes, bool *ran);
+// iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its
+// caps are compacted like the pre-pass's open rows
+int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
+                       u32 *n_open);
 // shortestpath through the pre-pass: element counts of the answered rows' lists -> offsets (ws->meet_poff) and *total;
 // the lists themselves ([src, e, v, ..., dst], first-slot edges); lengths + shifted offsets of the rows answered elsewhere
 int meet_path_offsets(Workspace *ws, int64_t n, const int64_t *d_len, int64_t *total);

@@ -293,7 +293,14 @@ int pgq_udf_iterativelength2(pgq_state_t *s, int32_t id, int64_t V, int64_t n, p
 
 int pgq_udf_iterativelengthbidirectional(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
                                          int64_t *out, uint64_t *out_valid) {
-	return pgq_udf_iterativelength(s, id, V, n, src, dst, out, out_valid);
+	// the bidirectional schedule (forward CSR from src, transposed CSR from dst): its own device entry point
+	CsrRef c;
+	pgq_csr_t *d;
+	if (search_prologue(s, id, V, &c, &d, "shortest path")) return -1;
+	if (pgq_iterativelength_bidirectional(d, V, n, src, dst, out, out_valid) != PGQ_OK) return device_fail();
+	std::lock_guard<std::mutex> g(s->csr_lock);
+	s->csr_to_delete.insert(id); // iterativelength_bidirectional.cpp:152
+	return 0;
 }
 
 int pgq_udf_shortestpath(pgq_state_t *s, int32_t id, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,

@@ -58,46 +58,70 @@ __device__ __forceinline__ u64 wave_min_u64(u64 x) {
 
 // ---- packed walk over the padded adjacency (round 3) ---------------------------------------------------------------
 // Device layout (pgq_runtime.hip, build_meet_layout): every vertex's list is copied into a padded adjacency whose lists
-// start on a 16-byte group boundary and are filled up to whole groups with copies of their last entry, and every
-// adjacency slot carries a 16-byte descriptor {neighbour, first group of the neighbour's padded list, its entries, 0}.
-// A two-hop walk therefore needs no offset look-ups (the expanded vertex's descriptor arrives with the one-hop list,
-// streamed) and a lane's 16-byte load never straddles two lists, so ONE 64-lane request can carry groups of SEVERAL
-// lists: the lists of a round of <= 64 expanded vertices form one virtual sequence of groups, lane l of request c reads
-// virtual group 64 c + l and finds its list by a 6-step search over the round's prefix sums (ds_bpermute).  A 1-KB
-// request then carries ~1 KB of list data whatever the list lengths (round 2: one request per list, ~35 % of the lanes
-// useful on the SF100-shaped graph).  Padding entries repeat a real entry of the same list: harmless for membership
-// tests, marking and minima; callers that count must use `ok` and the per-entry length (none does so far).
+// start on a 16-byte group boundary (aligned to `meet_align` entries) and are filled up to whole groups with copies of
+// their last entry, and every adjacency slot carries a 16-byte descriptor {neighbour, first group of the neighbour's
+// padded list, its entries, 0}.  A two-hop walk therefore needs no offset look-ups (the expanded vertex's descriptor
+// arrives with the one-hop list, streamed) and a lane's 16-byte load never straddles two lists, so ONE 64-lane request
+// can carry groups of SEVERAL lists: the lists of a round of <= 64 expanded vertices form one virtual sequence of
+// groups, lane l of request c reads virtual group 64 c + l; the lists drop their ids into a 64-byte LDS window at the
+// positions where they begin and a DPP max-scan spreads them (seg_owner).  A 1-KB request then carries ~1 KB of list data whatever the list lengths (round 2: one request
+// per list, ~35 % of the lanes useful on the SF100-shaped graph).  Measured alternatives that lost: a 6-step binary search per
+// lane over the prefix sums with ds_bpermute (34 VALU + 7 dependent LDS round trips per request), a wave-uniform cursor
+// over the list ends with one readlane + compare per boundary inside the request (k_meet3 0.267 vs 0.222 ms: a serial
+// SALU/VALU chain with hazards), and 32-byte units per lane (one search per 2 KB, but 25 %
+// more entries requested past the first hit and no less time).  Padding entries repeat a real entry of the same list:
+// harmless for membership tests, marking and minima; callers that count must use `ok` and the per-entry length.
 struct SegRound {
 	u32 P;     // inclusive prefix sum of the round's group counts, per lane
 	u32 D;     // first group of this lane's list minus the groups before it: virtual group x of the list sits at D + x
+	u32 ng;    // groups of this lane's list
 	u32 total; // groups in the round (wave-uniform)
 };
+// Inclusive scans over the 64 lanes with DPP (pure VALU: row shifts inside the rows of 16, then the two row
+// broadcasts of gfx9): 7 instructions instead of 6 ds_bpermute round trips.  bound_ctrl reads 0 for lanes outside the
+// row and lanes disabled by a row / bank mask keep `old` = 0, the identity of both operators (unsigned values).
+#define PGQ_DPP(old, src, ctrl, rmask, bmask) (u32) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, bmask, true)
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
-	const int lane = threadIdx.x & 63;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const u32 t = (u32)__shfl_up((int)x, o);
-		if (lane >= o) x += t;
-	}
-	return x;
+	u32 r = x + PGQ_DPP(0u, x, 0x111, 0xf, 0xf);  // row_shr:1
+	r += PGQ_DPP(0u, x, 0x112, 0xf, 0xf);         // row_shr:2
+	r += PGQ_DPP(0u, x, 0x113, 0xf, 0xf);         // row_shr:3
+	r += PGQ_DPP(0u, r, 0x114, 0xf, 0xe);         // row_shr:4, lanes 4..15 of a row
+	r += PGQ_DPP(0u, r, 0x118, 0xf, 0xc);         // row_shr:8, lanes 8..15 of a row
+	r += PGQ_DPP(0u, r, 0x142, 0xa, 0xf);         // row_bcast:15 into rows 1 and 3
+	r += PGQ_DPP(0u, r, 0x143, 0xc, 0xf);         // row_bcast:31 into rows 2 and 3
+	return r;
+}
+__device__ __forceinline__ u32 wave_incl_max_u32(u32 x) {
+	u32 r = max(x, PGQ_DPP(0u, x, 0x111, 0xf, 0xf));
+	r = max(r, PGQ_DPP(0u, x, 0x112, 0xf, 0xf));
+	r = max(r, PGQ_DPP(0u, x, 0x113, 0xf, 0xf));
+	r = max(r, PGQ_DPP(0u, r, 0x114, 0xf, 0xe));
+	r = max(r, PGQ_DPP(0u, r, 0x118, 0xf, 0xc));
+	r = max(r, PGQ_DPP(0u, r, 0x142, 0xa, 0xf));
+	r = max(r, PGQ_DPP(0u, r, 0x143, 0xc, 0xf));
+	return r;
 }
 __device__ __forceinline__ SegRound seg_round(u32 gbeg, u32 len) {
-	const u32 ng = (len + 3u) >> 2;
 	SegRound r;
-	r.P = wave_incl_scan_u32(ng);
-	r.D = gbeg - (r.P - ng);
+	r.ng = (len + 3u) >> 2;
+	r.P = wave_incl_scan_u32(r.ng);
+	r.D = gbeg - (r.P - r.ng);
 	r.total = (u32)__builtin_amdgcn_readlane((int)r.P, 63);
 	return r;
 }
-// smallest lane j with P_j > x (x < total): the list virtual group x belongs to
-__device__ __forceinline__ int seg_find(u32 P, u32 x) {
-	int j = 0;
-#pragma unroll
-	for (int s = 32; s > 0; s >>= 1) {
-		const u32 p = (u32)__shfl((int)P, j + s - 1);
-		if (p <= x) j += s;
-	}
-	return j;
+// The list virtual group x0 + lane belongs to, for all 64 lanes of a request at once: every list that overlaps the
+// window [x0, x0 + 64) drops its lane id (+1) at the window position where it begins (position 0 if it began earlier)
+// into a 64-byte LDS window, and an inclusive max-scan over the positions spreads the ids to the right — two LDS
+// operations and 7 DPP instructions instead of the 6 dependent ds_bpermute steps of a binary search per lane.  `win`:
+// 64 zeroed bytes of this wavefront; they are zero again on return.  Lanes past the round's end get the last list.
+__device__ __forceinline__ int seg_owner(const SegRound &r, u32 x0, unsigned char *win) {
+	const int lane = threadIdx.x & 63;
+	const u32 start = r.P - r.ng;
+	if (r.ng != 0 && start < x0 + 64u && r.P > x0) win[start > x0 ? start - x0 : 0u] = (unsigned char)(lane + 1);
+	__builtin_amdgcn_wave_barrier();
+	const u32 own = win[lane];
+	win[lane] = 0;
+	return (int)wave_incl_max_u32(own) - 1;
 }
 typedef int pgq_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int4 load_group_nt(const int32_t *__restrict__ xp, u32 group) {
@@ -108,15 +132,15 @@ __device__ __forceinline__ int4 load_group_nt(const int32_t *__restrict__ xp, u3
 
 // Walks the padded lists of the descriptors list[w], list[w + stride], ... (positions < list_n), DEPTH requests in
 // flight, and calls f(v, ok, ev) per lane and request: v = one 16-byte group (four entries of ONE list), ok = the lane
-// holds a group, ev = the expanded vertex the list belongs to (only when WANT_EV).  stop() is wave-uniform and is asked
+// holds a group, ev = the expanded vertex the list belongs to (only when WANT_EV).  `win`: 64 zeroed bytes of LDS owned
+// by this wavefront (seg_owner).  stop() is wave-uniform and is asked
 // after every DEPTH requests; `max_entries` bounds the entries requested (capped = true when it ended the walk).  `first`
 // (have_first): the caller already holds the descriptor of position w + lane * stride (requested early, to overlap its
-// latency).
-// Returns the entries of the requested groups (padding excluded; wave-uniform).
+// latency).  Returns the entries of the requested groups (padding excluded; wave-uniform).
 template <int DEPTH, bool WANT_EV, typename F, typename Stop>
 __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__ list, int list_n, int w, int stride,
-                                                       const int32_t *__restrict__ xp, bool have_first, uint4 first,
-                                                       unsigned long long max_entries, bool &capped, F f, Stop stop) {
+                                                       const int32_t *__restrict__ xp, unsigned char *win, bool have_first,
+                                                       uint4 first, unsigned long long max_entries, bool &capped, F f, Stop stop) {
 	const int lane = threadIdx.x & 63;
 	unsigned long long entries = 0, requested = 0; // requested: groups x 4, against max_entries
 	capped = false;
@@ -140,7 +164,7 @@ __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__
 				const u32 xx = (u32)next * 64u + (u32)lane;
 				const bool ok = xx < r.total;
 				const u32 xs = ok ? xx : r.total - 1u; // lanes past the end re-read the last group (same line, masked by ok)
-				const int j = seg_find(r.P, xs);
+				const int j = seg_owner(r, (u32)next * 64u, win); // lanes past the end: the last list, like xs
 				x[u] = load_group_nt(xp, (u32)__shfl((int)r.D, j) + xs);
 				xok[u] = ok;
 				if constexpr (WANT_EV) xv[u] = (u32)__shfl((int)d.x, j);
@@ -176,8 +200,8 @@ __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__
 		}
 		{ // real entries inside the groups requested so far: list j holds min(len, 4 x its groups below the cursor)
 			const u32 done = min((u32)next * 64u, r.total);
-			const u32 ng = (d.z + 3u) >> 2, start = r.P - ng;
-			const u32 g = done > start ? min(done - start, ng) : 0u;
+			const u32 start = r.P - r.ng;
+			const u32 g = done > start ? min(done - start, r.ng) : 0u;
 			u32 e = min(d.z, g * 4u);
 			for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
 			entries += e;
@@ -186,6 +210,46 @@ __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__
 		if (halt) break;
 	}
 	return entries;
+}
+
+// ---- the set side of a pair-centric walk: blocked two-bit filter + exact table ---------------------------------------------
+// A request holds 256 entries; with the one-bit filter of round 2 (8192 bits, ~1 % of them set by a 100-vertex set) 92 %
+// of the REQUESTS had some lane with a filter hit, so nearly every request ran the divergent table walk (it showed as
+// 59 SALU + 76 VALU wave-instructions per request, half of the kernel's issue slots).  Two bits per entry inside ONE
+// 32-bit word of a 16384-bit filter cost the same single LDS read and bring a 100-vertex set's false positives to
+// ~0.07 % per entry (~16 % of the requests); word = bits 5..13 of the id, bits = its bits 0..4 and 14..18.
+constexpr int kMeetFilter2Words = 512;
+__device__ __forceinline__ u32 meet_f2_word(u32 x) { return (x >> 5) & (kMeetFilter2Words - 1); }
+__device__ __forceinline__ u32 meet_f2_mask(u32 x) { return (1u << (x & 31)) | (1u << ((x >> 14) & 31)); }
+__device__ __forceinline__ bool meet_f2_hit(const u32 *bm2, u32 x) {
+	const u32 w = bm2[meet_f2_word(x)];
+	return ((w >> (x & 31)) & (w >> ((x >> 14) & 31)) & 1u) != 0;
+}
+// any of the four entries of `v` in the set?  The four filter reads are independent and branch-free; only a lane holding
+// a filter hit walks the table
+__device__ __forceinline__ bool meet_any4(const u32 *tab, const u32 *bm2, const int4 v) {
+	const u32 w0 = bm2[meet_f2_word((u32)v.x)], w1 = bm2[meet_f2_word((u32)v.y)];
+	const u32 w2 = bm2[meet_f2_word((u32)v.z)], w3 = bm2[meet_f2_word((u32)v.w)];
+	const u32 t0 = (w0 >> ((u32)v.x & 31)) & (w0 >> (((u32)v.x >> 14) & 31));
+	const u32 t1 = (w1 >> ((u32)v.y & 31)) & (w1 >> (((u32)v.y >> 14) & 31));
+	const u32 t2 = (w2 >> ((u32)v.z & 31)) & (w2 >> (((u32)v.z >> 14) & 31));
+	const u32 t3 = (w3 >> ((u32)v.w & 31)) & (w3 >> (((u32)v.w >> 14) & 31));
+	if (!((t0 | t1 | t2 | t3) & 1u)) return false;
+	return ((t0 & 1u) && meet_lookup(tab, (u32)v.x)) || ((t1 & 1u) && meet_lookup(tab, (u32)v.y)) ||
+	       ((t2 & 1u) && meet_lookup(tab, (u32)v.z)) || ((t3 & 1u) && meet_lookup(tab, (u32)v.w));
+}
+// which of the four entries are in the set (bit k = entry k), for callers that need the witnesses
+__device__ __forceinline__ u32 meet_which4(const u32 *tab, const u32 *bm2, const int4 v) {
+	u32 p = (u32)meet_f2_hit(bm2, (u32)v.x) | ((u32)meet_f2_hit(bm2, (u32)v.y) << 1) | ((u32)meet_f2_hit(bm2, (u32)v.z) << 2) |
+	        ((u32)meet_f2_hit(bm2, (u32)v.w) << 3);
+	u32 f = 0;
+	while (p) {
+		const u32 k = (u32)__ffs((int)p) - 1u;
+		p &= p - 1u;
+		const u32 x = k == 0 ? (u32)v.x : (k == 1 ? (u32)v.y : (k == 2 ? (u32)v.z : (u32)v.w));
+		if (meet_lookup(tab, x)) f |= 1u << k;
+	}
+	return f;
 }
 
 // Streams the adjacency segments of list[w], list[w + stride], ... (positions < list_n) and calls f(entry) for every

@@ -113,6 +113,13 @@ int64_t pgq_csr_device_bytes(const pgq_csr_t *csr);
 int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
                         uint64_t *out_valid);
 
+/* iterativelengthbidirectional(csr_id, V, src, dst) -> BIGINT (src/core/functions/scalar/iterativelength_bidirectional.cpp:43-153,
+ * intended semantics: the reference's version is unreachable from the binder and indexes its backward CSR wrongly).
+ * The same hop counts as pgq_iterativelength, found by one bidirectional BFS per row: forward over the CSR from src,
+ * backward over the transposed CSR (built at upload) from dst, always expanding the cheaper side. */
+int pgq_iterativelength_bidirectional(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst,
+                                      int64_t *out_len, uint64_t *out_valid);
+
 /* shortestpath(csr_id, V, src, dst) -> LIST(BIGINT) [src, e1, v1, ..., ek, dst].  list entries go to
  * out_offset/out_length (list_entry_t fields), the child payload to *out_child (owned by the library, valid
  * until the next pgq_shortestpath call on the same thread or pgq_thread_release).  NULL rows keep entry {0,0}. */

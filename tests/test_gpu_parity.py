@@ -762,7 +762,8 @@ def test_two_ranks_on_one_gpu_product_path():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in (["--workload", "snb_sf100", "--scaling", "strong"], ["--workload", "snb_paths"]):
+    for extra in (["--workload", "snb_sf100", "--scaling", "strong"], ["--workload", "snb_paths", "--scaling", "weak"],
+                  ["--workload", "snb_sf100"]):  # the default for N > 1 is strong (configs[3]: 65,536 pairs in total)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
                "--warmup", "1", "--backend", "gloo", "--pairs-per-gpu", "3000", "--snb-vertices", "20000",
@@ -772,7 +773,10 @@ def test_two_ranks_on_one_gpu_product_path():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         out = json.loads(line)
         assert out["n_gpus"] == 2 and out["value"] > 0
-        assert out["config"]["pairs_total"] == (3000 if "strong" in extra else 6000)
+        assert out["config"]["pairs_total"] == (6000 if "weak" in extra else 3000)
+        assert out["scaling"] == ("weak" if "weak" in extra else "strong")
+        if "weak" not in extra:  # the other mode is measured in the same run
+            assert out["weak"]["pairs_total"] == 6000 and out["weak"]["pairs_per_s"] > 0
 
 
 def test_in_library_multi_gpu_shards_and_gathers():

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -93,9 +94,11 @@ struct Options {
 	double meet_bias = 1.0; // pre-pass runs while its estimated bytes <= meet_bias x the MS-BFS estimate
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
 	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
+	int meet_trace = 0;      // debugging: per-workgroup timestamps of k_meet4d, summarised on stderr
+	int meet4_grid_mult = 4; // k_meet4 / k_meet4d grid = this many 1024-thread workgroups per CU (2 fit beside their LDS bit maps)
 	int meet_grid_mult = 8; // k_meet3 grid = this many times the 8192 one-wavefront workgroups the chip holds (rows per workgroup = n / grid)
 	int meet_layout = 1;    // build the padded adjacency + slot descriptors at upload (the pre-pass needs them)
-	int meet_align = 16;    // entries a padded list is aligned and padded to (4 = one 16-byte group; 16 / 32 = whole 64 / 128-byte lines: -4 % on k_meet3)
+	int meet_align = 32;    // entries a padded list is aligned and padded to (4 = one 16-byte group; 16 / 32 = whole 64 / 128-byte lines: -4 % / -6 % on the pre-pass)
 };
 Options &options();
 
@@ -158,6 +161,7 @@ struct pgq_csr {
 	uint2 *fseg = nullptr, *rseg = nullptr;    // V
 	uint4 *fdesc = nullptr, *rdesc = nullptr;  // E (+ 1): slot order of adj / radj
 	int64_t padj_groups = 0, rpadj_groups = 0;
+	std::atomic<int> meet_far_rows { 1 }; // the last pre-pass call left rows for k_bibfs (it is launched only then; pgq_meet.hip)
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
 	double two_hop_mean = 0; // mean over vertices of in-degree x out-degree = expected two-hop walk of a random endpoint

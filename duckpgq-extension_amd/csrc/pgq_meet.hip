@@ -46,12 +46,16 @@ constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so
 #ifndef PGQ_MEET3_DEPTH
 #define PGQ_MEET3_DEPTH 2 // list requests in flight per wavefront
 #endif
+#ifndef PGQ_MEET4_BLOCKS
+#define PGQ_MEET4_BLOCKS 8 // wavefronts per SIMD k_meet4d is compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs); at 84 VGPRs only one fits
+#endif
 #ifndef PGQ_MEET4_MARK_DEPTH
 #define PGQ_MEET4_MARK_DEPTH 2 // the marking walk of k_meet4d never stops early: deeper costs nothing but registers
 #endif
 #ifndef PGQ_MEET4_DEPTH
 #define PGQ_MEET4_DEPTH 2 // the same for each of the 16 wavefronts of a k_meet4d row (more only adds overshoot past the first hit)
 #endif
+constexpr u32 kMeetKnown4Bit = 0x80000000u; // in the compacted row indices (k_collect_open): the row is known to be at distance >= 4
 constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 atomics on one address take longer than the walks
 struct MeetCounters {
 	unsigned long long entries[kMeetStatSlots];  // adjacency entries scanned (both kinds of list)
@@ -285,12 +289,12 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
 		__syncthreads(); // the previous row's flags and map are no longer read
 		const int64_t s = src[i], d = dst[i]; // rows left open by k_meet3: ids in range, src != dst, both have edges
-		const u32 row = didx[i];
+		const u32 row = didx[i] & ~kMeetKnown4Bit;
 		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
 		const int degS = se - so, degD = de - di;
 		// rows k_meet3 walked to the end are known to be at distance >= 4: only the two two-hop walks remain (two
 		// dependent phases instead of six; their sizes passed k_meet3's cap, which is below this kernel's)
-		const bool known4 = out_rows[row] == kMeetOpen4;
+		const bool known4 = (didx[i] & kMeetKnown4Bit) != 0;
 		clear_map();
 		if (tid == 0) {
 			s_work[0] = s_work[1] = 0;
@@ -470,14 +474,15 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 //     distance 4: map = two-hop set of the cheaper endpoint, two-hop walk of the other one, ended by the first hit
 // Rows with distance >= 4 proven start at the last step (cheaper endpoint: the shorter one-hop list).
 template <bool GM>
-__global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(const u32 *__restrict__ n_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                  const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                  const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                  const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
                                                  const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
                                                  const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
-                                                 int bm_words, MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
-	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
+                                                 int bm_words, MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps,
+                                                 unsigned long long *__restrict__ trace) {
+	extern __shared__ __attribute__((aligned(16))) u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
 	const int64_t n = (int64_t)*n_rows; // rows left open by the kernel before (counted on the device: no host round trip)
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
 	__shared__ int s_flag;
@@ -501,7 +506,8 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 			uint4 *m4 = reinterpret_cast<uint4 *>(gmap);
 			for (int k = tid; k < bm_words / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
 		} else {
-			for (int k = tid; k < bm_words; k += 1024) s_map[k] = 0;
+			uint4_alias *m4 = reinterpret_cast<uint4_alias *>(s_map);
+			for (int k = tid; k < bm_words / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
 		}
 	};
 	auto flag_set = [&]() { return *(volatile int *)&s_flag != 0; };
@@ -515,10 +521,10 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 	};
 	// the padded lists hold copies of a list's last entry and the lanes past a round's end re-read its last group:
 	// both repeat real entries, which neither a bit test nor a mark minds
-	auto walk_test = [&](const uint4 *list, int list_n, const int32_t *xp) {
+	auto walk_test = [&](const uint4 *list, int list_n, const int32_t *xp, bool have_first, uint4 first) {
 		bool f = false, capped = false;
 		const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
-		    list, list_n, wib, 16, xp, win, false, make_uint4(0, 0, 0, 0), ~0ull, capped,
+		    list, list_n, wib, 16, xp, win, have_first, first, ~0ull, capped,
 		    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
 		    [&]() {
 			    if (__any(f)) s_flag = 1;
@@ -527,99 +533,170 @@ __global__ __launch_bounds__(1024) void k_meet4d(const u32 *__restrict__ n_rows,
 		if (lane == 0) entries += e2;
 		if (__any(f)) s_flag = 1;
 	};
+	// A row is ~8 dependent memory round trips (row -> offsets -> descriptors -> lists, twice) and only two rows fit a CU
+	// (the bit map), so the kernel is bound by that chain: the NEXT row's header is requested while the current row
+	// walks (volatile loads: the compiler must not sink them to their first use), and both walks' first descriptors are
+	// requested together.
+	struct Hdr {
+		int64_t s, d;
+		u32 code;
+		int so, se, di, de;
+	};
+	auto load_ids = [&](int64_t i, Hdr &h) {
+		h.s = *(const volatile int64_t *)&src[i];
+		h.d = *(const volatile int64_t *)&dst[i];
+		h.code = *(const volatile u32 *)&didx[i];
+	};
+	auto load_offsets = [&](Hdr &h) {
+		h.so = (int)*(const volatile int64_t *)&off[h.s];
+		h.se = (int)*(const volatile int64_t *)&off[h.s + 1];
+		h.di = (int)*(const volatile int64_t *)&roff[h.d];
+		h.de = (int)*(const volatile int64_t *)&roff[h.d + 1];
+	};
+	// option meet_trace: per-workgroup {start, end, rows, longest row} in 10-ns ticks of the constant clock
+	const unsigned long long t_begin = trace ? wall_clock64() : 0ull;
+	unsigned long long t_row_max = 0, n_rows_done = 0, t_ph[3] = { 0, 0, 0 }; // phases: header + clear, marking walk, testing walk
+	Hdr cur = { 0, 0, 0, 0, 0, 0, 0 }, nxt = { 0, 0, 0, 0, 0, 0, 0 };
+	if ((int64_t)blockIdx.x < n) {
+		load_ids(blockIdx.x, cur);
+		load_offsets(cur);
+	}
 	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
 		__syncthreads(); // the previous row's flag and map are no longer read
-		const int64_t s = src[i], d = dst[i]; // rows left open by k_meet3: ids in range, src != dst, both have edges
-		const u32 row = didx[i];
-		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
+		const bool have_next = i + gridDim.x < n;
+		bool next_offsets = false;
+		if (have_next) load_ids(i + gridDim.x, nxt);
+		auto prefetch_next_offsets = [&]() { // second level of the next row's header: its ids have arrived by now
+			if (have_next && !next_offsets) {
+				load_offsets(nxt);
+				next_offsets = true;
+			}
+		};
+		const int64_t d = cur.d; // rows left open by k_meet3: ids in range, src != dst, both have edges
+		const u32 row = cur.code & ~kMeetKnown4Bit;
+		const int so = cur.so, se = cur.se, di = cur.di, de = cur.de;
 		const int degS = se - so, degD = de - di;
-		const bool known4 = out_rows[row] == kMeetOpen4;
-		clear_map();
-		if (tid == 0) {
-			s_flag = 0;
-			s_work[0] = s_work[1] = 0;
-		}
-		__syncthreads();
-		if (tid == 0) vertices += (u32)(degS + degD); // both one-hop lists as descriptors
-		bool walk_fwd = degS <= degD; // which endpoint's two-hop neighbourhood is walked / marked
-		if (!known4) {
-			unsigned long long wf = 0, wb = 0;
-			bool hit = false;
-			for (int p = tid; p < degS; p += 1024) {
-				const uint4 dd = fdesc[so + p];
-				hit |= dd.x == (u32)d;
-				wf += (unsigned long long)dd.z;
-			}
-			for (int p = tid; p < degD; p += 1024) wb += (unsigned long long)rdesc[di + p].z;
-			for (int o = 32; o > 0; o >>= 1) {
-				wf += __shfl_xor(wf, o);
-				wb += __shfl_xor(wb, o);
-			}
-			if (lane == 0) {
-				if (wf) atomicAdd(&s_work[0], wf);
-				if (wb) atomicAdd(&s_work[1], wb);
-			}
-			if (__any(hit) && lane == 0) s_flag = 1;
-			if (flag_snapshot()) { // dst in N_out(src)
-				if (tid == 0) out_rows[row] = 1;
-				continue;
-			}
-			const int64_t work_f = (int64_t)s_work[0], work_b = (int64_t)s_work[1];
-			walk_fwd = work_f <= work_b;
-			{ // the set: one-hop list of the endpoint that is not walked
-				const int32_t *set_list = walk_fwd ? radj + di : adj + so;
-				const int set_n = walk_fwd ? degD : degS;
-				for (int p = tid; p < set_n; p += 1024) mark((u32)set_list[p]);
+		const bool known4 = (cur.code & kMeetKnown4Bit) != 0;
+		const unsigned long long t_row0 = trace ? wall_clock64() : 0ull;
+		auto process_row = [&]() {
+			clear_map();
+			if (tid == 0) {
+				s_flag = 0;
+				s_work[0] = s_work[1] = 0;
 			}
 			__syncthreads();
-			const int32_t *wl = walk_fwd ? adj + so : radj + di;
-			const int wn = walk_fwd ? degS : degD;
-			if (tid == 0) entries += (unsigned long long)(degS + degD);
-			{ // distance 2: a common neighbour
-				bool f = false;
-				for (int p = tid; p < wn; p += 1024) f |= bit((u32)wl[p]) != 0;
-				if (__any(f) && lane == 0) s_flag = 1;
+			if (tid == 0) vertices += (u32)(degS + degD); // both one-hop lists as descriptors
+			bool walk_fwd = degS <= degD; // which endpoint's two-hop neighbourhood is walked / marked
+			if (!known4) {
+				unsigned long long wf = 0, wb = 0;
+				bool hit = false;
+				for (int p = tid; p < degS; p += 1024) {
+					const uint4 dd = fdesc[so + p];
+					hit |= dd.x == (u32)d;
+					wf += (unsigned long long)dd.z;
+				}
+				for (int p = tid; p < degD; p += 1024) wb += (unsigned long long)rdesc[di + p].z;
+				for (int o = 32; o > 0; o >>= 1) {
+					wf += __shfl_xor(wf, o);
+					wb += __shfl_xor(wb, o);
+				}
+				if (lane == 0) {
+					if (wf) atomicAdd(&s_work[0], wf);
+					if (wb) atomicAdd(&s_work[1], wb);
+				}
+				if (__any(hit) && lane == 0) s_flag = 1;
+				if (flag_snapshot()) { // dst in N_out(src)
+					if (tid == 0) out_rows[row] = 1;
+					return;
+				}
+				const int64_t work_f = (int64_t)s_work[0], work_b = (int64_t)s_work[1];
+				walk_fwd = work_f <= work_b;
+				{ // the set: one-hop list of the endpoint that is not walked
+					const int32_t *set_list = walk_fwd ? radj + di : adj + so;
+					const int set_n = walk_fwd ? degD : degS;
+					for (int p = tid; p < set_n; p += 1024) mark((u32)set_list[p]);
+				}
+				__syncthreads();
+				const int32_t *wl = walk_fwd ? adj + so : radj + di;
+				const int wn = walk_fwd ? degS : degD;
+				if (tid == 0) entries += (unsigned long long)(degS + degD);
+				{ // distance 2: a common neighbour
+					bool f = false;
+					for (int p = tid; p < wn; p += 1024) f |= bit((u32)wl[p]) != 0;
+					if (__any(f) && lane == 0) s_flag = 1;
+				}
+				if (flag_snapshot()) {
+					if (tid == 0) out_rows[row] = 2;
+					return;
+				}
+				if (min(work_f, work_b) > cap) {
+					if (tid == 0) out_rows[row] = kMeetOpen;
+					return;
+				}
+				prefetch_next_offsets();
+				// distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
+				walk_test(walk_fwd ? fdesc + so : rdesc + di, wn, walk_fwd ? padj : rpadj, false, make_uint4(0, 0, 0, 0));
+				if (flag_snapshot()) {
+					if (tid == 0) out_rows[row] = 3;
+					return;
+				}
+				if (max(work_f, work_b) > cap) {
+					if (tid == 0) out_rows[row] = kMeetOpen;
+					return;
+				}
+				clear_map(); // every wavefront is past its reads of the map (barriers above)
+				__syncthreads();
 			}
-			if (flag_snapshot()) {
-				if (tid == 0) out_rows[row] = 2;
-				continue;
+			// distance 4: two-hop set of the walked endpoint, two-hop walk of the other one.  Both walks' first
+			// descriptors are requested together (one round trip instead of two)
+			const uint4 *mark_list = walk_fwd ? fdesc + so : rdesc + di, *test_list = walk_fwd ? rdesc + di : fdesc + so;
+			const int mark_n = walk_fwd ? degS : degD, test_n = walk_fwd ? degD : degS;
+			uint4 d_mark = make_uint4(0, 0, 0, 0), d_test = make_uint4(0, 0, 0, 0);
+			if (lane < mark_n) d_mark = mark_list[lane]; // every wavefront holds the round's 64 descriptors (it takes every 16th request)
+			if (lane < test_n) d_test = test_list[lane];
+			prefetch_next_offsets();
+			const unsigned long long t_p1 = trace ? wall_clock64() : 0ull;
+			{
+				bool capped = false;
+				const unsigned long long e2 = seg_walk<PGQ_MEET4_MARK_DEPTH, false>(
+				    mark_list, mark_n, wib, 16, walk_fwd ? padj : rpadj, win, true, d_mark, ~0ull, capped,
+				    [&](const int4 &v, bool, u32) {
+					    mark((u32)v.x);
+					    mark((u32)v.y);
+					    mark((u32)v.z);
+					    mark((u32)v.w);
+				    },
+				    []() { return false; });
+				if (lane == 0) entries += e2;
 			}
-			if (min(work_f, work_b) > cap) {
-				if (tid == 0) out_rows[row] = kMeetOpen;
-				continue;
-			}
-			// distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
-			walk_test(walk_fwd ? fdesc + so : rdesc + di, wn, walk_fwd ? padj : rpadj);
-			if (flag_snapshot()) {
-				if (tid == 0) out_rows[row] = 3;
-				continue;
-			}
-			if (max(work_f, work_b) > cap) {
-				if (tid == 0) out_rows[row] = kMeetOpen;
-				continue;
-			}
-			clear_map(); // every wavefront is past its reads of the map (barriers above)
 			__syncthreads();
+			const unsigned long long t_p2 = trace ? wall_clock64() : 0ull;
+			walk_test(test_list, test_n, walk_fwd ? rpadj : padj, true, d_test);
+			const int f4 = flag_snapshot();
+			if (trace) {
+				t_ph[0] += t_p1 - t_row0;
+				t_ph[1] += t_p2 - t_p1;
+				t_ph[2] += wall_clock64() - t_p2;
+			}
+			if (tid == 0) out_rows[row] = f4 ? 4 : kMeetOpen;
+		};
+		const unsigned long long t_row = trace ? wall_clock64() : 0ull;
+		process_row();
+		if (trace) {
+			t_row_max = max(t_row_max, wall_clock64() - t_row);
+			n_rows_done++;
 		}
-		// distance 4: two-hop set of the walked endpoint, two-hop walk of the other one
-		{
-			bool capped = false;
-			const unsigned long long e2 = seg_walk<PGQ_MEET4_MARK_DEPTH, false>(
-			    walk_fwd ? fdesc + so : rdesc + di, walk_fwd ? degS : degD, wib, 16, walk_fwd ? padj : rpadj, win, false,
-			    make_uint4(0, 0, 0, 0), ~0ull, capped,
-			    [&](const int4 &v, bool, u32) {
-				    mark((u32)v.x);
-				    mark((u32)v.y);
-				    mark((u32)v.z);
-				    mark((u32)v.w);
-			    },
-			    []() { return false; });
-			if (lane == 0) entries += e2;
-		}
-		__syncthreads();
-		walk_test(walk_fwd ? rdesc + di : fdesc + so, walk_fwd ? degD : degS, walk_fwd ? rpadj : padj);
-		const int f4 = flag_snapshot();
-		if (tid == 0) out_rows[row] = f4 ? 4 : kMeetOpen;
+		prefetch_next_offsets();
+		cur = nxt;
+	}
+	if (trace && tid == 0) {
+		trace[8 * blockIdx.x] = t_begin;
+		trace[8 * blockIdx.x + 1] = wall_clock64();
+		trace[8 * blockIdx.x + 2] = n_rows_done;
+		trace[8 * blockIdx.x + 3] = t_row_max;
+		trace[8 * blockIdx.x + 4] = t_ph[0];
+		trace[8 * blockIdx.x + 5] = t_ph[1];
+		trace[8 * blockIdx.x + 6] = t_ph[2];
 	}
 	__shared__ unsigned long long s_stat[2];
 	__syncthreads();
@@ -682,7 +759,7 @@ __global__ __launch_bounds__(1024) void k_bibfs(const u32 *__restrict__ n_rows, 
 	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
 		__syncthreads();
 		const int64_t s = src[i], d = dst[i]; // open rows: ids in range, src != dst, both have edges
-		const u32 row = didx[i];
+		const u32 row = didx[i] & ~kMeetKnown4Bit;
 		if constexpr (GM) {
 			uint4 *m4 = reinterpret_cast<uint4 *>(gmap); // mw is a multiple of 4, slices are 16-byte aligned
 			for (int k = tid; k < 2 * mw / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
@@ -879,14 +956,17 @@ __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *
 	} else if (d >= sr - 0.5) { // every sampled row had its own source
 		est = (double)n;
 	} else {
-		double lo = d, hi = (double)n; // E[distinct](U) is increasing in U
-		for (int it = 0; it < 60; it++) {
-			const double mid = 0.5 * (lo + hi);
-			const double e = mid * (1.0 - pow(1.0 - 1.0 / mid, sr));
-			if (e < d) lo = mid;
+		// E[distinct](U) is increasing in U: bisection in single precision ((1 - 1/U)^s as exp(s log1p(-1/U)); a double
+		// pow() per step made this one-thread tail 35 us of a 42-us kernel that sits in front of every large call)
+		float lo = (float)d, hi = (float)n;
+		const float fs = (float)sr, fd = (float)d;
+		for (int it = 0; it < 32; it++) {
+			const float mid = 0.5f * (lo + hi);
+			const float e = mid * (1.0f - __expf(fs * log1pf(-1.0f / mid)));
+			if (e < fd) lo = mid;
 			else hi = mid;
 		}
-		est = fmin((double)n, ceil(hi));
+		est = fmin((double)n, ceil((double)hi));
 	}
 	const double distinct = fmin(est, (double)V);
 	const double batches = floor((distinct + 2047.0) / 2048.0);
@@ -914,14 +994,14 @@ __global__ void k_collect_open(int64_t n, const int64_t *__restrict__ out, const
 		const u32 p = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
 		dsrc[p] = src[i];
 		ddst[p] = dst[i];
-		didx[p] = (u32)i;
+		didx[p] = (u32)i | (out[i] == kMeetOpen4 ? kMeetKnown4Bit : 0u); // bit 31: distances 1..3 are excluded (k_meet4d needs no look-up)
 	}
 }
 
 __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
                              int64_t *__restrict__ out) {
 	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j < nd) out[didx[j]] = dlen[j];
+	if (j < nd) out[didx[j] & ~kMeetKnown4Bit] = dlen[j];
 }
 
 // Runs the pre-pass over n rows resident in HBM; rows it answers get their hop count (or -1 for NULL) in d_out, the
@@ -979,12 +1059,18 @@ if (paths)
 	const size_t gm_budget = (size_t)std::max(0, opt.meet4_global_mb) << 20;
 	const bool run4 = opt.meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget);
 	// k_bibfs: both sides' maps in LDS when they fit, else in the global buffer behind the queues
-	const bool run_bi = !paths && opt.bibfs_rows > 0;
+	// k_bibfs serves the few rows the two-hop kernels leave open (far apart, unreachable, over the caps).  Launching it
+	// costs ~12 us of stream time even when no row is open, so it stays in the chain only while this CSR has shown such
+	// rows: the first call runs it; a call that ends with every row answered before it switches it off, and any later
+	// call that leaves rows open (they go to the lane-batched search, same answers) switches it on again.
+	const bool run_bi = !paths && opt.bibfs_rows > 0 && c->meet_far_rows.load(std::memory_order_relaxed) != 0;
 	const int mwb = bm_words + 4;
 	const bool bi_lds = (size_t)2 * mwb * 4 + 512 <= lds_budget;
 	const int qcap = std::max(1024, opt.bibfs_queue);
 	const u32 bi_grid = (u32)std::min(64, std::max(1, opt.bibfs_rows));
-	u32 grid4 = (u32)std::min<int64_t>(n, 256 * 4);
+	// two 1024-thread workgroups fit a CU beside their bit maps: a grid of exactly the resident count, so that every
+	// workgroup streams through its rows (next row's header prefetched) instead of a second generation starting cold
+	u32 grid4 = (u32)std::min<int64_t>(n, 256 * std::max(1, opt.meet4_grid_mult));
 	size_t maps_bytes = 0;
 	if (run4 && !lds_map) {
 		grid4 = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, 256), gm_budget / ((size_t)bm_words * 4)));
@@ -1002,6 +1088,12 @@ if (paths)
 		(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 		attr_set.store(1);
 	}
+	unsigned long long *d_trace = nullptr;
+	if (opt.meet_trace && run4 && !paths) {
+		PGQ_TRY(ws->meet_trace.reserve((size_t)grid4 * 64));
+		d_trace = ws->meet_trace.as<unsigned long long>();
+		PGQ_HIP_TRY(hipMemsetAsync(d_trace, 0, (size_t)grid4 * 64, st));
+	}
 	const u32 *d_open = d_count; // the counter the next stage reads its row count from
 	if (run4) {
 		const size_t lds = lds_map ? (size_t)bm_words * 4 : 0;
@@ -1015,7 +1107,7 @@ if (paths)
 #define PGQ_MEET4D(G)                                                                                                    \
 	hipLaunchKernelGGL((k_meet4d<G>), dim3(grid4), dim3(1024), lds, st, d_open, ws->def_src.as<int64_t>(),               \
 	                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj,   \
-	                   ws->def_idx.as<u32>(), d_out, cap4, bm_words, mc, gmaps)
+	                   ws->def_idx.as<u32>(), d_out, cap4, bm_words, mc, gmaps, d_trace)
 			if (paths && lds_map) PGQ_MEET4(false);
 			else if (paths) PGQ_MEET4(true);
 			else if (lds_map) PGQ_MEET4D(false);
@@ -1053,6 +1145,26 @@ if (paths)
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, db, sizeof(DevBlock), hipMemcpyDeviceToHost, st));
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	KernelTimer::flush();
+	if (d_trace) { // debugging aid: where k_meet4d's time goes
+		std::vector<unsigned long long> t((size_t)grid4 * 8);
+		PGQ_HIP_TRY(hipMemcpy(t.data(), d_trace, t.size() * 8, hipMemcpyDeviceToHost));
+		unsigned long long t0 = ~0ull, t1 = 0, rows = 0, longest = 0, first_end = ~0ull, last_start = 0, ph[3] = { 0, 0, 0 };
+		for (u32 b = 0; b < grid4; b++) {
+			if (!t[8 * b + 1]) continue;
+			t0 = std::min(t0, t[8 * b]);
+			t1 = std::max(t1, t[8 * b + 1]);
+			first_end = std::min(first_end, t[8 * b + 1]);
+			last_start = std::max(last_start, t[8 * b]);
+			rows += t[8 * b + 2];
+			longest = std::max(longest, t[8 * b + 3]);
+			for (int k = 0; k < 3; k++) ph[k] += t[8 * b + 4 + k];
+		}
+		const double nr = (double)std::max<unsigned long long>(rows, 1);
+		fprintf(stderr, "[pgq] k_meet4d trace: %u workgroups, %llu rows, span %.1f us, last start +%.1f us, first end +%.1f us, longest row %.1f us; "
+		        "mean per row: header+clear %.2f us, marking walk %.2f us, testing walk %.2f us\n",
+		        grid4, rows, (double)(t1 - t0) * 0.01, (double)(last_start - t0) * 0.01, (double)(first_end - t0) * 0.01,
+		        (double)longest * 0.01, (double)ph[0] * 0.01 / nr, (double)ph[1] * 0.01 / nr, (double)ph[2] * 0.01 / nr);
+	}
 	if (decide && !h.dec.go) {
 		if (ran) *ran = false;
 		*n_open = (u32)n;
@@ -1065,6 +1177,10 @@ if (paths)
 		vertices += h.m.vertices[k];
 	}
 	const u32 open = h.count[d_open - d_count];
+	if (!paths && opt.bibfs_rows > 0) {
+		const u32 before_bi = h.count[run4 ? 1 : 0]; // rows open when k_bibfs was (or would have been) launched
+		c->meet_far_rows.store(before_bi > 0 ? 1 : 0, std::memory_order_relaxed);
+	}
 	S.meet_pairs += n - (int64_t)open;
 	S.edges_scanned += (int64_t)entries;
 	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
@@ -1191,8 +1307,9 @@ __global__ void k_apply_open_paths(int64_t nd, const u32 *__restrict__ didx, con
                                    int64_t *__restrict__ out_off) {
 	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= nd) return;
-	out_len[didx[j]] = dlen[j];
-	if (dlen[j] >= 0) out_off[didx[j]] = base + doff[j];
+	const u32 row = didx[j] & ~kMeetKnown4Bit;
+	out_len[row] = dlen[j];
+	if (dlen[j] >= 0) out_off[row] = base + doff[j];
 }
 int meet_apply_paths(Workspace *ws, int64_t nd, const int64_t *d_len, const int64_t *d_off, int64_t base,
                      int64_t *d_out_len, int64_t *d_out_off) {

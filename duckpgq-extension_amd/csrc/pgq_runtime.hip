@@ -105,6 +105,8 @@ static std::vector<OptRef> option_table() {
 		{ "upload_threads", &o.upload_threads, nullptr },
 		{ "upload_narrow_host", &o.upload_narrow_host, nullptr },
 		{ "meet_grid_mult", &o.meet_grid_mult, nullptr },
+		{ "meet4_grid_mult", &o.meet4_grid_mult, nullptr },
+		{ "meet_trace", &o.meet_trace, nullptr },
 		{ "meet_layout", &o.meet_layout, nullptr },
 		{ "meet_align", &o.meet_align, nullptr },
 	};

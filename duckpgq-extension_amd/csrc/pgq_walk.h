@@ -130,30 +130,34 @@ __device__ __forceinline__ int4 load_group_nt(const int32_t *__restrict__ xp, u3
 	return make_int4(r.x, r.y, r.z, r.w);
 }
 
-// Walks the padded lists of the descriptors list[w], list[w + stride], ... (positions < list_n), DEPTH requests in
-// flight, and calls f(v, ok, ev) per lane and request: v = one 16-byte group (four entries of ONE list), ok = the lane
-// holds a group, ev = the expanded vertex the list belongs to (only when WANT_EV).  `win`: 64 zeroed bytes of LDS owned
-// by this wavefront (seg_owner).  stop() is wave-uniform and is asked
-// after every DEPTH requests; `max_entries` bounds the entries requested (capped = true when it ended the walk).  `first`
-// (have_first): the caller already holds the descriptor of position w + lane * stride (requested early, to overlap its
-// latency).  Returns the entries of the requested groups (padding excluded; wave-uniform).
+// Walks the padded lists of the descriptors list[0 .. list_n), DEPTH requests in flight, and calls f(v, ok, ev) per lane
+// and request: v = one 16-byte group (four entries of ONE list), ok = the lane holds a group, ev = the expanded vertex
+// the list belongs to (only when WANT_EV).  The descriptors are taken in rounds of 64 (lane j = descriptor j of the
+// round); wavefront `w` of `nw` cooperating ones takes the requests w, w + nw, ... of every round, so the wavefronts of a
+// workgroup share a round's groups evenly whatever the list lengths (a hub neighbour's list used to land on ONE of
+// k_meet4d's 16 wavefronts: its phase took as long as that list).  `win`: 64 zeroed bytes of LDS owned by this wavefront
+// (seg_owner).  stop() is wave-uniform and is asked after every DEPTH requests; `max_entries` bounds the entries
+// requested (capped = true when it ended the walk).  `first` (have_first): the caller already holds descriptor `lane` of
+// the first round (requested early, to overlap its latency).  Returns the entries of the requested groups (padding
+// removed pro rata of the round; wave-uniform).
 template <int DEPTH, bool WANT_EV, typename F, typename Stop>
-__device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__ list, int list_n, int w, int stride,
+__device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__ list, int list_n, int w, int nw,
                                                        const int32_t *__restrict__ xp, unsigned char *win, bool have_first,
                                                        uint4 first, unsigned long long max_entries, bool &capped, F f, Stop stop) {
 	const int lane = threadIdx.x & 63;
 	unsigned long long entries = 0, requested = 0; // requested: groups x 4, against max_entries
 	capped = false;
-	for (int pb = w; pb < list_n; pb += 64 * stride) {
-		const int p = pb + lane * stride;
+	for (int pb = 0; pb < list_n; pb += 64) {
+		const int p = pb + lane;
 		uint4 d = make_uint4(0, 0, 0, 0);
-		if (pb == w && have_first) d = first;
+		if (pb == 0 && have_first) d = first;
 		else if (p < list_n) d = list[p];
 		if (p >= list_n) d = make_uint4(0, 0, 0, 0);
 		const SegRound r = seg_round(d.y, d.z);
 		if (r.total == 0) continue;
 		const int nchunk = (int)((r.total + 63u) >> 6);
-		int next = 0;
+		int next = w; // this wavefront's next request of the round
+		int issued = 0;
 		int4 x[DEPTH];
 		int xc[DEPTH];
 		bool xok[DEPTH];
@@ -169,7 +173,9 @@ __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__
 				xok[u] = ok;
 				if constexpr (WANT_EV) xv[u] = (u32)__shfl((int)d.x, j);
 				else xv[u] = 0;
-				xc[u] = next++;
+				xc[u] = next;
+				next += nw;
+				issued++;
 			}
 		};
 #pragma unroll
@@ -192,20 +198,18 @@ __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__
 				halt = true;
 				break;
 			}
-			if (requested + (unsigned long long)next * 256ull > max_entries) {
+			if (requested + (unsigned long long)issued * 256ull > max_entries) {
 				capped = true;
 				halt = true;
 				break;
 			}
 		}
-		{ // real entries inside the groups requested so far: list j holds min(len, 4 x its groups below the cursor)
-			const u32 done = min((u32)next * 64u, r.total);
-			const u32 start = r.P - r.ng;
-			const u32 g = done > start ? min(done - start, r.ng) : 0u;
-			u32 e = min(d.z, g * 4u);
+		{ // entries of the groups requested in this round: the round's entries pro rata of its groups
+			u32 e = d.z;
 			for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
-			entries += e;
-			requested += (unsigned long long)done * 4ull;
+			const unsigned long long groups = min((unsigned long long)issued * 64ull, (unsigned long long)r.total);
+			entries += (unsigned long long)e * groups / r.total;
+			requested += groups * 4ull;
 		}
 		if (halt) break;
 	}

@@ -237,21 +237,22 @@ def seg_owner_model(P, ng, x0):
     return [v - 1 for v in dpp_incl_scan_model(win, max)]
 
 
-def seg_walk_model(desc_list, padj, w, stride, depth, stop_after=None):
-    """seg_walk: rounds of 64 descriptors (positions w, w + stride, ...), virtual groups 64 c + lane, the 6-step search,
-    lanes past the end re-reading the last group (ok = False).  Returns the (entry, ev, ok) stream and the entry count."""
-    seen, entries = [], 0
+def seg_walk_model(desc_list, padj, w, nw, depth, stop_after=None):
+    """seg_walk: rounds of 64 descriptors (lane j = descriptor j of the round); wavefront w of nw takes the requests
+    w, w + nw, ... of every round; virtual groups 64 c + lane, owners by the window scan, lanes past the end re-reading
+    the last group (ok = False).  Returns the (entry, ev, ok) stream and the number of groups requested."""
+    seen, groups = [], 0
     n = len(desc_list)
-    pb = w
+    pb = 0
     while pb < n:
-        d = [desc_list[pb + l * stride] if pb + l * stride < n else (0, 0, 0) for l in range(64)]
+        d = [desc_list[pb + l] if pb + l < n else (0, 0, 0) for l in range(64)]
         ng = [(x[2] + 3) >> 2 for x in d]
         P = np.cumsum(ng)
         assert dpp_incl_scan_model(ng, lambda a, b: a + b) == [int(v) for v in P]
         total = int(P[63])
         D = [d[l][1] - (int(P[l]) - ng[l]) for l in range(64)]
         nchunk = (total + 63) >> 6
-        nxt, halted = 0, False
+        nxt, issued, halted = w, 0, False
         while nxt < nchunk:
             for _ in range(depth):
                 if nxt >= nchunk:
@@ -266,19 +267,16 @@ def seg_walk_model(desc_list, padj, w, stride, depth, stop_after=None):
                     g = D[j] + xs
                     for k in range(4):
                         seen.append((int(padj[4 * g + k]), d[j][0], ok))
-                nxt += 1
+                nxt += nw
+                issued += 1
             if stop_after is not None and len(seen) >= stop_after:
                 halted = True
                 break
-        done = min(nxt * 64, total)
-        for l in range(64):
-            start = int(P[l]) - ng[l]
-            g = min(done - start, ng[l]) if done > start else 0
-            entries += min(d[l][2], g * 4)
+        groups += min(issued * 64, total)
         if halted:
             break
-        pb += 64 * stride
-    return seen, entries
+        pb += 64
+    return seen, groups
 
 
 def test_padded_layout_and_packed_walk_visit_exactly_the_lists():
@@ -300,18 +298,19 @@ def test_padded_layout_and_packed_walk_visit_exactly_the_lists():
         for v in (3, 5, 17):  # two-hop walk of v: one wavefront, and 16 wavefronts with stride 16
             lst = desc[off[v]:off[v + 1]]
             want = sorted((int(x), u) for (u, _, _) in lst for x in adj[off[u]:off[u + 1]].tolist())
-            for waves, stride in ((1, 1), (16, 16)):
+            for nw in (1, 16):
                 got, total = [], 0
-                for w in range(waves):
-                    seen, e = seg_walk_model(lst, padj, w, stride, depth=2)
+                for w in range(nw):
+                    seen, g = seg_walk_model(lst, padj, w, nw, depth=2)
                     got += [(x, ev) for x, ev, ok in seen if ok]
-                    total += e
-                assert total == len(want)
+                    total += g
+                # the wavefronts' requests partition the rounds' groups
+                assert total == sum((ln_u + 3) // 4 for (_, _, ln_u) in lst)
                 # padding repeats real entries of the same list: the set of (entry, expanded vertex) pairs is exact,
                 # and every real entry is visited at least once
                 assert set(got) == set(want)
                 import collections
                 cg, cw = collections.Counter(got), collections.Counter(want)
                 assert all(cg[k] >= cw[k] for k in cw)
-            seen, e = seg_walk_model(lst, padj, 0, 1, depth=2, stop_after=1)  # early exit: entries = what was requested
-            assert (0 < e <= len(want)) if want else e == 0
+            seen, g = seg_walk_model(lst, padj, 0, 1, depth=2, stop_after=1)  # early exit after the first pass
+            assert (0 < g <= 128) if want else g == 0

@@ -15,9 +15,10 @@ Default workload = BASELINE.json configs[3] (the config the metric "MS-BFS MTEPS
 39.88 M symmetric CSR entries), iterativelength on 65,536 random pairs (`default_rng(4)`).
   N = 1:  the top-level fields describe that workload; `legs` holds it ("prepass": every row is answered by the
           pair-centric kernels) next to "msbfs_cross": the same graph and row count in the binder's call shape
-          (match.cpp:467-495: a cross product of endpoints — 2048 distinct sources x 32 destinations), which the library
-          routes to the lane-batched MS-BFS frontier expansion; each leg has its own ms/step, pairs/s, logical and
-          physical MTEPS, roofline of its dominant kernel class and a CPU-port comparison.
+          (match.cpp:467-495: a cross product of endpoints — 2048 distinct sources x 1024 destinations each = 2.1 M
+          rows), which the library routes to the lane-batched MS-BFS frontier expansion (one lane per distinct source);
+          each leg has its own ms/step, pairs/s, logical and physical MTEPS, roofline of its dominant kernel class and a
+          CPU-port comparison.
   N > 1:  --scaling strong by default (configs[3] is 65,536 pairs in total, cut across the GPUs); the weak figure
           (65,536 pairs on every GPU) is measured in the same run and reported under "weak".
 Other BASELINE configs: --workload rmat22 (configs[1]), snb_paths (configs[2]), forest_cheapest (configs[4]);
@@ -55,7 +56,7 @@ OPS = {"snb_sf100": "iterativelength", "rmat22": "iterativelength", "snb_paths":
        "forest_cheapest": "cheapest_path_length", "snb_cheapest": "cheapest_path_length",
        "snb_cross": "iterativelength", "snb_cross_allv": "iterativelength"}
 DEFAULT_PAIRS = {"snb_sf100": 65536, "rmat22": 1024, "snb_paths": 4096, "forest_cheapest": 4096, "snb_cheapest": 4096,
-                 "snb_cross": 65536, "snb_cross_allv": 0}
+                 "snb_cross": 2048 * 1024, "snb_cross_allv": 0}
 PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5, "snb_cheapest": 6, "snb_cross": 7,
              "snb_cross_allv": 8}
 CHEAPEST = ("forest_cheapest", "snb_cheapest")  # weighted workloads: value = pairs/s
@@ -76,7 +77,8 @@ def parse():
     ap.add_argument("--scale", type=int, default=0, help="override graph scale (rmat scale / forest log2 V); tests")
     ap.add_argument("--snb-vertices", type=int, default=448626)
     ap.add_argument("--snb-friendships", type=int, default=19_940_000)
-    ap.add_argument("--cross-sources", type=int, default=2048, help="snb_cross: distinct sources (x pairs/sources destinations)")
+    ap.add_argument("--cross-sources", type=int, default=2048, help="snb_cross / msbfs_cross leg: distinct sources")
+    ap.add_argument("--cross-dests", type=int, default=1024, help="snb_cross / msbfs_cross leg: destinations per source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="N = 1 default workload: skip the msbfs_cross leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs timed on one CPU thread (0 = 8192 snb / 1024 rmat)")
@@ -128,7 +130,7 @@ def make_pairs(a, V, total, off, adj):
     pairs are almost never connected there: the search would only measure the dead-end shortcut)."""
     rng = np.random.default_rng(PAIR_SEED[a.workload])
     if a.workload == "snb_cross":
-        return cross_pairs(V, total, a.cross_sources, PAIR_SEED[a.workload])
+        return cross_pairs(V, total, a.cross_sources * max(1, total // (a.cross_sources * a.cross_dests)), PAIR_SEED[a.workload])
     if a.workload == "snb_cross_allv":  # 32 sources x every vertex as destination
         src = rng.choice(V, size=32, replace=False)
         return np.stack([np.repeat(src, V), np.tile(np.arange(V, dtype=np.int64), 32)], axis=1).astype(np.int64)
@@ -405,7 +407,7 @@ def main():
     cross = None
     if world == 1 and a.workload == "snb_sf100" and not a.no_legs:
         # the binder's call shape on the same graph and row count: routed to the lane-batched MS-BFS
-        cp = cross_pairs(V, pairs_cfg, a.cross_sources, PAIR_SEED["snb_cross"])
+        cp = cross_pairs(V, a.cross_sources * a.cross_dests, a.cross_sources, PAIR_SEED["snb_cross"])
         cp_t = torch.from_numpy(cp).to(dev)
         mc = bench.run("snb_cross", csr, cp_t, len(cp), max(2, min(a.steps, 5)), min(a.warmup, 2))
         cross, _ = leg_summary(bench, mc, "snb_cross", len(cp), copy_gbps)

@@ -922,24 +922,41 @@ __global__ void k_pull_hub_fold(const int32_t *__restrict__ hubs, int64_t nh, co
 }
 
 // ---- per-pair detection (iterativelength.cpp:119-129) ------------------------------------------------------------
+// Grid-stride over the batch's rows.  A cross product has thousands of rows per lane: one atomic per open row on the
+// same few words of the active-lane mask cost 3 ns each (14 M rows of 32 sources: 80 ms per level), and even a read of
+// the mask per row through L2 is a hot spot on one channel (2 ms per level).  So the open rows' lane bits are collected
+// in a workgroup-local mask in LDS and every workgroup ORs its non-empty words into the global mask once (checking
+// first whether they are already there), with one counter update per workgroup.
 template <int WD>
-__global__ void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const int32_t *__restrict__ sdst,
-                         int32_t *__restrict__ sres, u32 base_lane, const u64 *__restrict__ seen, int level,
-                         u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
-	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	bool open = false;
-	if (i < hi && sres[i] == -1) {
+__global__ __launch_bounds__(256) void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const int32_t *__restrict__ sdst,
+                                                int32_t *__restrict__ sres, u32 base_lane, const u64 *__restrict__ seen, int level,
+                                                u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
+	__shared__ u32 s_open;
+	__shared__ u64 s_act[WD];
+	if (threadIdx.x == 0) s_open = 0;
+	if (threadIdx.x < WD) s_act[threadIdx.x] = 0;
+	__syncthreads();
+	u32 n_open = 0;
+	for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+		if (sres[i] != -1) continue;
 		const u32 l = skey[i] - base_lane;
 		const u64 bit = 1ull << (l & 63);
 		if (seen[(size_t)sdst[i] * WD + (l >> 6)] & bit) {
 			sres[i] = level;
 		} else {
-			open = true;
-			atomicOr(&active_next[l >> 6], bit);
+			n_open++;
+			if (!(s_act[l >> 6] & bit)) atomicOr(&s_act[l >> 6], bit); // rows are sorted by lane: nearly always set already
 		}
 	}
-	const u64 m = __ballot(open);
-	if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt->unresolved, (u32)__popcll(m));
+	for (int o = 32; o > 0; o >>= 1) n_open += __shfl_xor(n_open, o);
+	if ((threadIdx.x & 63) == 0 && n_open) atomicAdd(&s_open, n_open);
+	__syncthreads();
+	if (threadIdx.x < WD) {
+		const u64 m = s_act[threadIdx.x];
+		if (m && (__hip_atomic_load(&active_next[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m)
+			atomicOr(&active_next[threadIdx.x], m);
+	}
+	if (threadIdx.x == 0 && s_open) atomicAdd(&cnt->unresolved, s_open);
 }
 
 
@@ -955,43 +972,76 @@ __global__ __launch_bounds__(256) void k_probe(int64_t lo, int64_t hi, const u32
                                                const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
                                                const int32_t *__restrict__ radj, int level,
                                                u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
-	__shared__ u32 open_in_block;
-	if (threadIdx.x == 0) open_in_block = 0;
+	// Persistent wavefronts over 64-row chunks: a chunk's result words are read coalesced, and only the rows still open
+	// (a ballot) get the wave-wide in-list scan — late levels of a cross product have millions of answered rows and a
+	// few thousand open ones (a wavefront per ROW cost 2.4 ms of launches for 2 M rows).  Active-lane bits and the
+	// open count are collected per workgroup like in k_detect.
+	__shared__ u32 s_open;
+	__shared__ u64 s_act[WD];
+	if (threadIdx.x == 0) s_open = 0;
+	if (threadIdx.x < WD) s_act[threadIdx.x] = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const int64_t i = lo + (int64_t)__builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-	if (i < hi && sres[i] == -1) {
-		const u32 l = skey[i] - base_lane;
-		const int w = (int)(l >> 6);
-		const u64 bit = 1ull << (l & 63);
-		const int d = sdst[i];
-		bool found = false;
-		const int64_t b = roff[d], e = roff[d + 1];
-		if (b == e) { // nothing points at dst: unreachable, no search needed (reported as NULL like :133-139)
-			if (lane == 0) sres[i] = -2;
-			goto done;
+	const int64_t n = hi - lo;
+	const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+	// few rows: G wavefronts share a chunk (each takes every G-th open row of it), so that a wavefront scans the in-lists
+	// of a handful of rows, not of 64
+	const int64_t nchunks = (n + 63) >> 6;
+	const int G = (int)max((int64_t)1, min((int64_t)64, nwaves / max(nchunks, (int64_t)1)));
+	const int g = (int)(gw % G);
+	u32 n_open = 0; // lane 0 counts
+	for (int64_t chunk = gw / G; chunk * 64 < n; chunk += nwaves / G) {
+		const int64_t i = lo + chunk * 64 + lane;
+		const bool mine_open = i < hi && sres[i] == -1;
+		u32 my_l = 0;
+		int my_d = 0;
+		if (mine_open) {
+			my_l = skey[i] - base_lane;
+			my_d = sdst[i];
 		}
-		for (int64_t base = b; base < e && !found; base += 64) {
-			const int64_t j = base + lane;
-			bool hit = false;
-			if (j < e) {
-				const int v = radj[j];
-				if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
+		u64 todo = __ballot(mine_open);
+		int rank = 0;
+		while (todo) {
+			const int k = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			if (rank++ % G != g) continue;
+			const u32 l = (u32)__builtin_amdgcn_readlane((int)my_l, k);
+			const int d = __builtin_amdgcn_readlane(my_d, k);
+			const int w = (int)(l >> 6);
+			const u64 bit = 1ull << (l & 63);
+			const int64_t b = roff[d], e = roff[d + 1];
+			if (b == e) { // nothing points at dst: unreachable, no search needed (reported as NULL like :133-139)
+				if (lane == 0) sres[lo + chunk * 64 + k] = -2;
+				continue;
 			}
-			found = __any(hit);
-		}
-		if (lane == 0) {
-			if (found) {
-				sres[i] = level;
-			} else {
-				atomicOr(&active_next[w], bit);
-				atomicAdd(&open_in_block, 1u);
+			bool found = false;
+			for (int64_t base = b; base < e && !found; base += 64) {
+				const int64_t j = base + lane;
+				bool hit = false;
+				if (j < e) {
+					const int v = radj[j];
+					if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
+				}
+				found = __any(hit);
+			}
+			if (lane == 0) {
+				if (found) {
+					sres[lo + chunk * 64 + k] = level;
+				} else {
+					n_open++;
+					if (!(s_act[w] & bit)) atomicOr(&s_act[w], bit);
+				}
 			}
 		}
 	}
-done:
+	if (lane == 0 && n_open) atomicAdd(&s_open, n_open);
 	__syncthreads();
-	if (threadIdx.x == 0 && open_in_block) atomicAdd(&cnt->unresolved, open_in_block);
+	if (threadIdx.x < WD) {
+		const u64 m = s_act[threadIdx.x];
+		if (m && (__hip_atomic_load(&active_next[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m)
+			atomicOr(&active_next[threadIdx.x], m);
+	}
+	if (threadIdx.x == 0 && s_open) atomicAdd(&cnt->unresolved, s_open);
 }
 
 // Two-hop destination probe: a pair still open after k_probe(level) has hop count level+1 iff some in-neighbour u of
@@ -999,7 +1049,8 @@ done:
 // it first sums the in-degrees of N_in(dst); if the walk N_in(dst) x N_in(u) would exceed `work_cap` in-edges (hub
 // destinations) the pair is left open for the regular expansion / deferral, otherwise the 16 wavefronts split the
 // u's and stop as soon as one finds a hit.  Runs only when few pairs are left (it replaces a full-width
-// expansion that would serve only them).
+// expansion that would serve only them).  Persistent workgroups: each scans 64-row chunks of the batch for the rows
+// still open (a workgroup per ROW meant millions of empty launches on a cross product).
 template <int WD>
 __global__ __launch_bounds__(1024) void k_probe2(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
                                                  const int32_t *__restrict__ sdst, int32_t *__restrict__ sres,
@@ -1009,55 +1060,72 @@ __global__ __launch_bounds__(1024) void k_probe2(int64_t lo, int64_t hi, const u
                                                  int64_t work_cap, Counters *__restrict__ cnt) {
 	__shared__ unsigned long long s_work;
 	__shared__ int s_found;
+	__shared__ u32 s_list[64], s_n, s_answered;
 	const u32 open_now = cnt->unresolved;
 	if (open_now == 0 || open_now > run_below) return;
-	const int64_t i = lo + blockIdx.x;
-	if (i >= hi || sres[i] != -1) return;
 	const int lane = threadIdx.x & 63;
 	const int wib = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	if (threadIdx.x == 0) {
-		s_work = 0;
-		s_found = 0;
-	}
-	__syncthreads();
-	const u32 l = skey[i] - base_lane;
-	const int w = (int)(l >> 6);
-	const u64 bit = 1ull << (l & 63);
-	const int d = sdst[i];
-	const int64_t b = roff[d], e = roff[d + 1];
-	unsigned long long mine = 0;
-	for (int64_t k = b + threadIdx.x; k < e; k += blockDim.x) {
-		const int u = radj[k];
-		mine += (unsigned long long)(roff[u + 1] - roff[u]);
-	}
-	for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-	if (lane == 0 && mine) atomicAdd(&s_work, mine);
-	__syncthreads();
-	if ((int64_t)s_work > work_cap) return; // too expensive here: the pair stays open
-	for (int64_t k = b + wib; k < e; k += nw) {
-		if (*(volatile int *)&s_found) break;
-		const int u = radj[k]; // wave-uniform
-		const int64_t ub = roff[u], ue = roff[u + 1];
-		bool found = false;
-		for (int64_t base = ub; base < ue && !found; base += 64) {
-			const int64_t j = base + lane;
-			bool hit = false;
-			if (j < ue) {
-				const int v = radj[j];
-				if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
+	if (threadIdx.x == 0) s_answered = 0;
+	for (int64_t c0 = lo + (int64_t)blockIdx.x * 64; c0 < hi; c0 += (int64_t)gridDim.x * 64) {
+		__syncthreads();
+		if (threadIdx.x == 0) s_n = 0;
+		__syncthreads();
+		if (threadIdx.x < 64) {
+			const int64_t i = c0 + threadIdx.x;
+			if (i < hi && sres[i] == -1) s_list[atomicAdd(&s_n, 1u)] = (u32)(i - c0);
+		}
+		__syncthreads();
+		const u32 cnt_open = s_n;
+		for (u32 q = 0; q < cnt_open; q++) {
+			__syncthreads(); // the previous pair's flags are no longer read
+			const int64_t i = c0 + s_list[q];
+			if (threadIdx.x == 0) {
+				s_work = 0;
+				s_found = 0;
 			}
-			found = __any(hit);
-		}
-		if (found) {
-			if (lane == 0) s_found = 1;
-			break;
+			__syncthreads();
+			const u32 l = skey[i] - base_lane;
+			const int w = (int)(l >> 6);
+			const u64 bit = 1ull << (l & 63);
+			const int d = sdst[i];
+			const int64_t b = roff[d], e = roff[d + 1];
+			unsigned long long mine = 0;
+			for (int64_t k = b + threadIdx.x; k < e; k += blockDim.x) {
+				const int u = radj[k];
+				mine += (unsigned long long)(roff[u + 1] - roff[u]);
+			}
+			for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+			if (lane == 0 && mine) atomicAdd(&s_work, mine);
+			__syncthreads();
+			if ((int64_t)s_work > work_cap) continue; // too expensive here: the pair stays open (uniform: s_work is shared)
+			for (int64_t k = b + wib; k < e; k += nw) {
+				if (*(volatile int *)&s_found) break;
+				const int u = radj[k]; // wave-uniform
+				const int64_t ub = roff[u], ue = roff[u + 1];
+				bool found = false;
+				for (int64_t base = ub; base < ue && !found; base += 64) {
+					const int64_t j = base + lane;
+					bool hit = false;
+					if (j < ue) {
+						const int v = radj[j];
+						if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
+					}
+					found = __any(hit);
+				}
+				if (found) {
+					if (lane == 0) s_found = 1;
+					break;
+				}
+			}
+			__syncthreads();
+			if (threadIdx.x == 0 && s_found) {
+				sres[i] = level + 1;
+				s_answered++;
+			}
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x == 0 && s_found) {
-		sres[i] = level + 1;
-		atomicSub(&cnt->unresolved, 1u);
-	}
+	if (threadIdx.x == 0 && s_answered) atomicSub(&cnt->unresolved, s_answered);
 }
 
 // ---- straggler deferral ------------------------------------------------------------------------------------------------
@@ -1328,6 +1396,7 @@ struct SearchOutput {
 	bool deferred = false;
 	bool overflow = false; // the caller's child buffer was too small (lengths are still complete)
 	bool bidir = false;    // iterativelengthbidirectional: every row through the per-row bidirectional search first
+	bool from_meet = false; // these rows are what the pair-centric pre-pass left open: do not run it on them again
 };
 static constexpr int kMaxTeLevels = 1024;
 
@@ -1428,7 +1497,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		// The destination probe answers a pair one expansion early; it costs one in-neighbour scan per open pair,
 		// so it is used while the batch has few pairs relative to the graph (not for cross products) and never in
 		// the traversed-edge accounting pass (which needs every level of every lane).
-		const bool use_probe = opt.probe && !outp.want_te && (hi - lo) * 4 <= std::max<int64_t>(V, 1);
+		const bool use_probe = opt.probe && !outp.want_te; // whether a level is probed is decided per level (below)
 		// open pairs at or below this count stop the batch: 0 = everything answered, > 0 = defer the stragglers
 		int stop = -1;
 		if (use_probe) {
@@ -1449,13 +1518,32 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				                   (int)((push && q_nxt == 0) || (zq_cur && q_cur == 0)),
 				                   (int)((push && q_nxt == 1) || (zq_cur && q_cur == 1)));
 			}
+			// The probe answers the pairs at distance t from frontier t-1 (one in-list scan per open pair) BEFORE level t
+			// is expanded.  That only pays when it can spare an expensive expansion: before a top-down level (tiny) or a
+			// sparse bottom-up level it costs more than it saves (cross product of 2048 sources x 32 destinations on the
+			// SF100-shaped graph: the probes of levels 1 and 2 took 0.6 ms and spared nothing), before a DENSE bottom-up
+			// level (1.5 ms at WD = 32) it answers what that level would have been run for.  Few open pairs: always.
+			bool probe_now = false;
 			if (use_probe) {
+				const double wpn = (double)front_edges / (double)std::max<int64_t>(E, 1) *
+				                   ((double)front_words / (double)std::max<u32>(front_vertices, 1u)) * active_frac;
+				const bool dense_next = !push && !(opt.force_pull == 1 || (opt.force_pull == 0 && wpn < opt.sparse_below));
+				// in bytes at the rate the expansion kernels stream: a probe is one latency-bound wavefront per open pair
+				// (measured 4.7 ns per pair at mean in-degree 89: ~256 B per in-edge); a dense level moves ~E (8 + 6 WD),
+				// a sparse one ~4 E + 16 per frontier out-edge + V (4 + 24 WD), a top-down one ~20 per frontier out-edge
+				const double probe_bytes = (double)unresolved * ((double)E / (double)std::max<int64_t>(V, 1)) * 256.0;
+				const double level_bytes = push ? (double)front_edges * 20.0
+				                                : (dense_next ? (double)E * (8.0 + 6.0 * WD)
+				                                              : (double)E * 4.0 + (double)front_edges * 16.0 + (double)V * (4.0 + 24.0 * WD));
+				probe_now = opt.probe_always || probe_bytes <= level_bytes;
+			}
+			if (probe_now) {
 				KernelTimer kt(st, K_DETECT);
-				hipLaunchKernelGGL(k_probe<WD>, dim3(blocks_for((hi - lo) * 64)), dim3(256), 0, st, lo, hi,
+				hipLaunchKernelGGL(k_probe<WD>, dim3(std::min(blocks_for(hi - lo), 8u * ncu)), dim3(256), 0, st, lo, hi,
 				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
 				if (opt.probe2 && !with_paths)
-					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)(hi - lo)), dim3(1024), 0, st, lo, hi,
+					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)std::min<int64_t>((hi - lo + 63) / 64, 2 * ncu)), dim3(1024), 0, st, lo, hi,
 					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
 					                   (u32)std::max<int64_t>(std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),
@@ -1465,6 +1553,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
 				act_sel ^= 1;
 			}
+			const int stop_lvl = probe_now ? stop : -1; // the expansion returns at once when the probe left <= stop pairs open
 			if (push) {
 				if (!queue_valid) {
 					KernelTimer kt(st, K_QUEUE);
@@ -1477,7 +1566,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					KernelTimer kt(st, K_PUSH);
 					hipLaunchKernelGGL(k_push<WD>, dim3(push_grid), dim3(256), 0, st, c->off, c->adj, cur->buf.as<u64>(),
 					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur,
-					                   ws->qbuf[par].as<u64>(), par, qcap, pchunk, stop, d_cnt);
+					                   ws->qbuf[par].as<u64>(), par, qcap, pchunk, stop_lvl, d_cnt);
 					kt.stop();
 				}
 				nxt->dirty = true;
@@ -1496,13 +1585,13 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				if (c->n_pull_hub_vertices > 0) {
 					KernelTimer kt(st, K_PULL_HUB);
 					hipLaunchKernelGGL(k_pull_hub_zero<WD>, dim3(blocks_for(c->n_pull_hub_vertices * WD)), dim3(256), 0,
-					                   st, c->pull_hub_vertices, c->n_pull_hub_vertices, nxt->buf.as<u64>(), stop, d_cnt);
+					                   st, c->pull_hub_vertices, c->n_pull_hub_vertices, nxt->buf.as<u64>(), stop_lvl, d_cnt);
 					hipLaunchKernelGGL(k_pull_hub<WD>, dim3(blocks_for(c->n_pull_hub_items * 64)), dim3(256), 0, st,
 					                   c->pull_hubs, c->n_pull_hub_items, c->radj, cur->buf.as<u64>(), cur->nz.as<u32>(),
-					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, stop, d_cnt);
+					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), act_cur, stop_lvl, d_cnt);
 					hipLaunchKernelGGL(k_pull_hub_fold<WD>, dim3(blocks_for(c->n_pull_hub_vertices)), dim3(256), 0, st,
 					                   c->pull_hub_vertices, c->n_pull_hub_vertices, c->off, ws->seen.as<u64>(),
-					                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), stop, d_cnt);
+					                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), stop_lvl, d_cnt);
 					kt.stop();
 				}
 				// frontier sparse in lane-words, or few lane-words still wanted -> edge-organised sparse kernel
@@ -1515,7 +1604,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				if (lanes_level) {
 					KernelTimer kt(st, K_PULL_SPARSE);
 					PGQ_TRY(pull_lanes_level(c, ws, WD, cur->buf.as<u64>(), cur->nz.as<u32>(), ws->seen.as<u64>(),
-					                         nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, stop, d_cnt));
+					                         nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, stop_lvl, d_cnt));
 					kt.stop();
 				} else if (sparse_level) {
 					const u32 cw_cap = (u32)std::min<int64_t>((int64_t)front_words + 64, 0x7FFFFFF0ll);
@@ -1532,7 +1621,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					hipLaunchKernelGGL(k_compact_frontier<WD>, dim3(std::min(blocks_for(V / 8 + 1), 2u * ncu)), dim3(256), 0, st,
 					                   cur->nz.as<u32>(), cur->buf.as<u64>(), V, ws->cmeta.as<FrontMeta>(),
 					                   ws->cwords.as<u64>(), ws->cbits.as<u32>(), ws->cbbase.as<u32>(), d_total, cw_cap,
-					                   stop, d_cnt);
+					                   stop_lvl, d_cnt);
 					// graphs whose frontier bit map + block bases fit in LDS beside the accumulators run 1024-thread
 					// workgroups that keep them there (SF100: 56 KB + 28 KB)
 					const size_t dyn_bytes = (size_t)bit_words * 4 + (size_t)bit_words * 2;
@@ -1555,12 +1644,12 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			hipLaunchKernelGGL(kfn, dim3(ncu), dim3(1024), dyn_bytes, st, c->roff, c->radj, c->rown, c->off, c->pull_parts,      \
 			                   c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(), ws->cmeta.as<FrontMeta>(),  \
 			                   ws->cwords.as<u64>(), ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(),        \
-			                   act_cur, bit_words, opt.sparse_spill, stop, d_cnt);                                     \
+			                   act_cur, bit_words, opt.sparse_spill, stop_lvl, d_cnt);                                     \
 		} else {                                                                                                       \
 			hipLaunchKernelGGL((k_pull_sparse<WD, UNR, 4, VR>), dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj,       \
 			                   c->rown, c->off, c->pull_parts, c->n_pull_parts, ws->cbits.as<u32>(), ws->cbbase.as<u32>(),      \
 			                   ws->cmeta.as<FrontMeta>(), ws->cwords.as<u64>(), ws->seen.as<u64>(),                    \
-			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, bit_words, opt.sparse_spill, stop, d_cnt); \
+			                   nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, bit_words, opt.sparse_spill, stop_lvl, d_cnt); \
 		}                                                                                                              \
 	} while (0)
 					const int pw = std::max(1, std::min(3, opt.sparse_pw));
@@ -1581,7 +1670,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					hipLaunchKernelGGL(k_pull<WD>, dim3(pull_grid), dim3(256), 0, st, c->roff, c->radj, c->off,
 					                   c->pull_parts, c->n_pull_parts, cur->buf.as<u64>(), cur->nz.as<u32>(),
 					                   ws->seen.as<u64>(), nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, (int)V, chunk,
-					                   stop, d_cnt);
+					                   stop_lvl, d_cnt);
 					kt.stop();
 				}
 				nxt->dirty = true;
@@ -1593,10 +1682,10 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				hipLaunchKernelGGL(k_lane_degree_sums<WD>, dim3(4 * ncu), dim3(256), 0, st, nxt->buf.as<u64>(), c->off, V,
 				                   ws->lane_sums.as<u64>() + (size_t)t * L);
 			}
-			if (!use_probe) {
+			if (!probe_now) {
 				// -- detect finished pairs (iterativelength.cpp:119-129), rebuild the active-lane mask
 				KernelTimer kt(st, K_DETECT);
-				hipLaunchKernelGGL(k_detect<WD>, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
+				hipLaunchKernelGGL(k_detect<WD>, dim3(std::min(blocks_for(hi - lo), 16u * ncu)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
 				                   sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane, ws->seen.as<u64>(), t,
 				                   act_nxt, d_cnt);
 				kt.stop();
@@ -1619,7 +1708,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				for (int w = 0; w < WD; w++) nzw += hc.act[act_sel][w] != 0;
 				active_frac = (double)nzw / WD;
 			}
-			if (use_probe && unresolved <= (u32)stop) { // the expansion kernels returned immediately
+			if (probe_now && unresolved <= (u32)stop) { // the expansion kernels returned immediately
 				if (push) S.push_levels--;
 				else S.pull_levels--;
 				if (unresolved > 0) {
@@ -1771,7 +1860,9 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// cost less than the MS-BFS levels they replace: bytes ~ rows x E[in-degree x out-degree] x 4 (the cheaper
 	// endpoint is expanded: ~0.6 of that) against ~16 B per edge per 2048-lane batch.
 	const Options &mopt = options();
-	const bool may_meet = mopt.meet && !outp.want_te && outp.depth == 0 && c->E > 0 && c->fdesc != nullptr;
+	// depth 1 = the stragglers a lane batch deferred (a few far pairs of a cross product): the pre-pass answers them from
+	// two-hop scans instead of another round of whole-graph levels
+	const bool may_meet = mopt.meet && !outp.want_te && outp.depth <= 1 && !outp.from_meet && c->E > 0 && c->fdesc != nullptr;
 	const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
 	const double batch_bytes = mopt.meet_bias * (double)c->E * 16.0;
 	auto meet_pays = [&](int64_t distinct_sources) {
@@ -1796,6 +1887,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			PGQ_TRY(ws->def_off.reserve((size_t)nd * 8));
 			PGQ_TRY(inner.acquire());
 			so2.depth = outp.depth + 1;
+			so2.from_meet = true;
 			S.pairs -= nd; // counted once
 			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
 			                      ws->def_len.as<int64_t>(), true, ws->def_off.as<int64_t>(), nullptr, 0, so2));
@@ -1835,6 +1927,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			PGQ_TRY(inner.acquire());
 			SearchOutput so2;
 			so2.depth = outp.depth + 1;
+			so2.from_meet = true;
 			S.pairs -= nd; // counted once
 			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
 			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
@@ -1852,6 +1945,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			PGQ_TRY(inner.acquire());
 			SearchOutput so2;
 			so2.depth = outp.depth + 1;
+			so2.from_meet = true;
 			S.pairs -= nd; // counted once
 			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
 			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));

@@ -207,7 +207,9 @@ __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__
 		{ // entries of the groups requested in this round: the round's entries pro rata of its groups
 			u32 e = d.z;
 			for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
-			const unsigned long long groups = min((unsigned long long)issued * 64ull, (unsigned long long)r.total);
+			// this wavefront's requests hold 64 groups each, except the round's last one
+			unsigned long long groups = (unsigned long long)issued * 64ull;
+			if (issued > 0 && next - nw == nchunk - 1) groups -= (unsigned long long)nchunk * 64ull - r.total;
 			entries += (unsigned long long)e * groups / r.total;
 			requested += groups * 4ull;
 		}

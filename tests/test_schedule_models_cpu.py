@@ -272,7 +272,10 @@ def seg_walk_model(desc_list, padj, w, nw, depth, stop_after=None):
             if stop_after is not None and len(seen) >= stop_after:
                 halted = True
                 break
-        groups += min(issued * 64, total)
+        g = issued * 64  # 64 groups per request, except the round's last one
+        if issued and nxt - nw == nchunk - 1:
+            g -= nchunk * 64 - total
+        groups += g
         if halted:
             break
         pb += 64

@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // strided sample of the rows goes through an LDS hash set, thread 0 inverts E[distinct] = U (1 - (1 - 1/U)^sample) and
 // compares the two cost estimates ON THE DEVICE: the pre-pass kernels are launched straight behind and return at once
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
-constexpr int kSampleRows = 4096, kSampleSlots = 16384;
+constexpr int kSampleRows = 2048, kSampleSlots = 4096;
 struct MeetDecision {
 	u32 go;           // 1: the pre-pass runs
 	u32 sample_rows;  // non-NULL rows sampled
@@ -931,13 +931,18 @@ __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *
 	if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
 	__syncthreads();
 	const int64_t sample = n < kSampleRows ? n : kSampleRows;
+	// the sample = runs of 64 consecutive rows at evenly spaced offsets.  A join emits a cross product grouped by source:
+	// single rows at a fixed stride can land on a different source every time (stride = group size) and make it look
+	// like distinct pairs; inside a run a grouped input shows its repeats, and a shuffled one is sampled as well as by
+	// single rows
+	const double stride = (double)n / (double)((sample + 63) >> 6);
 	u32 fresh = 0, rows = 0;
 	for (int64_t k = threadIdx.x; k < sample; k += 1024) {
-		const int64_t v = src[k * n / sample];
+		const int64_t v = src[min(n - 1, (int64_t)((double)(k >> 6) * stride) + (k & 63))];
 		if (v < 0) continue; // NULL row
 		rows++;
 		const u32 x = (u32)v;
-		u32 h = (x * 0x9E3779B1u) >> 18; // 14 bits
+		u32 h = (x * 0x9E3779B1u) >> 20; // 12 bits
 		for (;;) {
 			const u32 old = atomicCAS(&s_set[h], kMeetEmpty, x);
 			if (old == kMeetEmpty) fresh++;
@@ -960,7 +965,7 @@ __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *
 		// pow() per step made this one-thread tail 35 us of a 42-us kernel that sits in front of every large call)
 		float lo = (float)d, hi = (float)n;
 		const float fs = (float)sr, fd = (float)d;
-		for (int it = 0; it < 32; it++) {
+		for (int it = 0; it < 18; it++) {
 			const float mid = 0.5f * (lo + hi);
 			const float e = mid * (1.0f - __expf(fs * log1pf(-1.0f / mid)));
 			if (e < fd) lo = mid;

@@ -63,6 +63,16 @@ __global__ void k_cheapest_init(const int32_t *__restrict__ usrc, int64_t U, int
 
 // One wavefront per changed vertex v; lane l = search l.  Walks v's out-edges (wave-uniform loop, scalar
 // adjacency/weight loads), every lane relaxes its own distance: coalesced 512-byte rows of dist[n][*].
+// One round of the batched relaxation.  Two things keep it from being a plain Jacobi sweep (which re-relaxes a vertex
+// every time its label improves: ~14 sweeps of the whole graph per batch on the weighted knows graph):
+//  * ORDER: only labels below `thr` are expanded this round, the others stay dirty (re-queued) — a band-wise approach
+//    to Dijkstra's order, so that most vertices are expanded once, with their final label.  The host raises `thr` by
+//    a fraction of the mean weight per round and jumps over empty bands (min_deferred).
+//  * BOUND: a lane never expands a vertex whose label already reaches the largest tentative label among the lane's own
+//    destinations (`bound`, refreshed every round): with non-negative weights nothing beyond can improve an answer.
+// Neither changes the fixpoint at the destinations (every vertex on a cheaper path has a smaller label than the bound
+// and is expanded after its last improvement), nor the left-to-right fold of the reference (cheapest_path_length.cpp:29-36),
+// so int64 and double results stay bit-identical.  Labels are compared as their (non-negative) bit patterns.
 template <typename T>
 __global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                const T *__restrict__ w, int64_t *__restrict__ dist,
@@ -71,18 +81,34 @@ __global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, 
                                                int32_t *__restrict__ qnxt, u32 *__restrict__ nq_nxt,
                                                u32 *__restrict__ qflag, u32 epoch, u32 *__restrict__ tflag,
                                                u32 tepoch, int32_t *__restrict__ touched, u32 *__restrict__ tcount,
-                                               u64 *__restrict__ relaxed_edges) {
+                                               u64 *__restrict__ relaxed_edges, long long thr,
+                                               const long long *__restrict__ bound, long long *__restrict__ min_deferred,
+                                               u32 *__restrict__ relaxed_vertices) {
 	const int lane = threadIdx.x & 63;
 	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
 	const u32 nq = *nq_ptr;
+	const long long my_bound = bound[lane];
 	u64 edges = 0;
+	u32 expanded = 0;
+	long long min_def = 0x7FFFFFFFFFFFFFFFll;
 	for (u32 i = wave; i < nq; i += nwaves) {
 		const int v = qcur[i];
 		const u64 mask = dirty_cur[v];
 		if (lane == 0) dirty_cur[v] = 0; // consumed; nobody else touches dirty_cur this round
-		const bool mine = (mask >> lane) & 1ull;
 		const int64_t dvb = dist[(size_t)v * LC + lane];
+		const bool live = ((mask >> lane) & 1ull) && dvb < my_bound;
+		const bool mine = live && dvb < thr;
+		const u64 deferred = __ballot(live && !mine);
+		if (deferred) { // stays dirty for a later round
+			if (live && !mine) min_def = min(min_def, (long long)dvb);
+			if (lane == 0) {
+				atomicOr(&dirty_nxt[v], deferred);
+				if (qflag[v] != epoch && atomicExch(&qflag[v], epoch) != epoch) qnxt[atomicAdd(nq_nxt, 1u)] = v;
+			}
+		}
+		if (!__any(mine)) continue;
+		expanded++;
 		const int64_t b = off[v], e = off[v + 1];
 		edges += (u64)(e - b);
 		for (int64_t k = b; k < e; k++) {
@@ -110,15 +136,40 @@ __global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, 
 			}
 		}
 	}
-	if (lane == 0 && edges) atomicAdd(relaxed_edges, edges);
+	for (int o = 32; o > 0; o >>= 1) min_def = min(min_def, (long long)__shfl_xor(min_def, o));
+	if (lane == 0) {
+		if (edges) atomicAdd(relaxed_edges, edges);
+		if (expanded) atomicAdd(relaxed_vertices, expanded);
+		if (min_def != 0x7FFFFFFFFFFFFFFFll) atomicMin(min_deferred, min_def);
+	}
 }
 
+// bound[lane] = the largest tentative label among the lane's destinations (rows [lo, hi) are sorted by lane); INF while
+// one of them is unlabelled.  Workgroup-local maxima in LDS, one atomicMax per lane and workgroup.
+__global__ __launch_bounds__(256) void k_lane_bounds(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
+                                                     const int32_t *__restrict__ sdst, u32 base_lane,
+                                                     const int64_t *__restrict__ dist, long long *__restrict__ bound) {
+	__shared__ long long s_b[64];
+	if (threadIdx.x < 64) s_b[threadIdx.x] = 0;
+	__syncthreads();
+	for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+		const u32 l = skey[i] - base_lane;
+		const long long d = (long long)dist[(size_t)sdst[i] * LC + l];
+		if (d > s_b[l]) atomicMax(&s_b[l], d);
+	}
+	__syncthreads();
+	if (threadIdx.x < 64 && s_b[threadIdx.x] > 0) atomicMax(&bound[threadIdx.x], s_b[threadIdx.x]);
+}
 
 struct RelaxCounters {
 	u32 nq[2];
 	u32 tcount;
 	u32 rounds; // rounds executed by the last k_relax_small launch
 	u64 relaxed_edges;
+	long long min_deferred; // smallest label (bit pattern) a round left for later (k_relax's threshold)
+	u32 relaxed_vertices;   // vertices a round expanded
+	u32 pad;
+	long long bound[64];    // per lane: the largest tentative label among its destinations (nothing beyond it matters)
 };
 
 #define PGQ_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -665,6 +716,40 @@ static int ensure_reverse_weights(pgq_csr *c, Workspace *ws) {
 	return rc;
 }
 
+// mean edge weight (int64 or double), computed once per CSR: the band width of the ordered relaxation rounds
+static int ensure_weight_mean(pgq_csr *c, Workspace *ws) {
+	std::lock_guard<std::mutex> g(g_rw_lock);
+	if (c->w_mean > 0 || c->E == 0 || !c->w) return PGQ_OK;
+	hipStream_t st = ws->stream;
+	DevBuf tmp, sum;
+	auto body = [&]() -> int {
+		PGQ_TRY(sum.reserve(64));
+		size_t rb = 0;
+		double total = 0;
+		if (c->w_type == PGQ_W_DOUBLE) {
+			PGQ_HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, rb, (const double *)c->w, sum.as<double>(), (int)c->E, st));
+			PGQ_TRY(tmp.reserve(rb + 16));
+			PGQ_HIP_TRY(hipcub::DeviceReduce::Sum(tmp.p, rb, (const double *)c->w, sum.as<double>(), (int)c->E, st));
+			PGQ_HIP_TRY(hipMemcpyAsync(&total, sum.p, 8, hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+		} else {
+			int64_t t = 0;
+			PGQ_HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, rb, (const int64_t *)c->w, sum.as<int64_t>(), (int)c->E, st));
+			PGQ_TRY(tmp.reserve(rb + 16));
+			PGQ_HIP_TRY(hipcub::DeviceReduce::Sum(tmp.p, rb, (const int64_t *)c->w, sum.as<int64_t>(), (int)c->E, st));
+			PGQ_HIP_TRY(hipMemcpyAsync(&t, sum.p, 8, hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			total = (double)t;
+		}
+		c->w_mean = std::max(total / (double)c->E, 1e-300);
+		return PGQ_OK;
+	};
+	const int rc = body();
+	tmp.release();
+	sum.release();
+	return rc;
+}
+
 // rows [0, nd) in ws->def_src / def_dst / def_idx (the chain pre-pass's open rows): answered rows get their value and
 // flag written into d_out / d_ok, the others keep ok = 2.  *left = rows still open.
 static int weighted_pairs_prepass(pgq_csr *c, Workspace *ws, u32 nd, int64_t *d_out, uint8_t *d_ok, u32 *left) {
@@ -843,6 +928,19 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 		int par = 0;
 		u32 nq_now = (u32)std::min<int64_t>(LC, (int64_t)U - base);
 		const u32 small_limit = (u32)std::max(0, options().relax_small_limit);
+		// band width of the ordered rounds: a fraction of the mean weight (0: plain Jacobi rounds, everything at once)
+		T band = T(0);
+		if (options().relax_delta_div > 0) {
+			PGQ_TRY(ensure_weight_mean(c, ws));
+			if constexpr (std::is_same<T, double>::value) band = c->w_mean / options().relax_delta_div;
+			else band = (T)std::max<int64_t>(1, (int64_t)(c->w_mean / options().relax_delta_div));
+		}
+		auto bits_of = [](T x) -> long long {
+			long long r;
+			memcpy(&r, &x, 8);
+			return r;
+		};
+		T thr_val = band;
 		for (;;) {
 			if (nq_now <= small_limit) {
 				// few changed vertices: rounds loop on the device inside one workgroup
@@ -866,13 +964,20 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 			}
 			epoch++;
 			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par ^ 1], 0, 4, st));
+			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->relaxed_vertices, 0, 4, st));
+			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->min_deferred, 0x7F, 8, st)); // > every label
+			PGQ_HIP_TRY(hipMemsetAsync(d_rc->bound, 0, sizeof(d_rc->bound), st));
+			const long long thr_bits = band > T(0) ? bits_of(thr_val) : (long long)0x7FFFFFFFFFFFFFFFll;
 			{
 				KernelTimer kt(st, K_RELAX);
+				hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned)std::min<int64_t>(blocks_for(hi - lo), 256)), dim3(256), 0, st, lo, hi,
+				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, ws->dist.as<int64_t>(), d_rc->bound);
 				hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, c->adj, (const T *)c->w,
 				                   ws->dist.as<int64_t>(), ws->dirty[par].as<u64>(), ws->dirty[par ^ 1].as<u64>(),
 				                   ws->qbuf[par].as<int32_t>(), &d_rc->nq[par], ws->qbuf[par ^ 1].as<int32_t>(),
 				                   &d_rc->nq[par ^ 1], ws->qflag.as<u32>(), epoch, ws->tflag.as<u32>(), tepoch,
-				                   ws->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges);
+				                   ws->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
+				                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices);
 				kt.stop();
 			}
 			PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
@@ -882,6 +987,14 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 			par ^= 1;
 			nq_now = h_rc->nq[par];
 			if (nq_now == 0) break;
+			if (band > T(0)) { // next band; an empty one is skipped: straight to the smallest label left
+				thr_val = thr_val + band;
+				if (h_rc->relaxed_vertices == 0 && h_rc->min_deferred != 0x7F7F7F7F7F7F7F7Fll) {
+					T m;
+					memcpy(&m, &h_rc->min_deferred, 8);
+					if (m + band > thr_val) thr_val = m + band;
+				}
+			}
 		}
 		S.edges_scanned += (int64_t)h_rc->relaxed_edges;
 		S.algo_bytes[K_RELAX] += (double)h_rc->relaxed_edges * (4.0 + 8.0 + 2.0 * 8.0 * LC);

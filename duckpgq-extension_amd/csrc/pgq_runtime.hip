@@ -64,6 +64,7 @@ static std::vector<OptRef> option_table() {
 		{ "force_pull", &o.force_pull, nullptr },
 		{ "blocks_per_cu", &o.blocks_per_cu, nullptr },
 		{ "relax_small_limit", &o.relax_small_limit, nullptr },
+		{ "relax_delta_div", &o.relax_delta_div, nullptr },
 		{ "chain", &o.chain, nullptr },
 		{ "chain_cap", &o.chain_cap, nullptr },
 		{ "alloc_cache_mb", &o.alloc_cache_mb, nullptr },

@@ -21,7 +21,7 @@ def _defaults():
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
-                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 4)):
+                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 4), ("relax_delta_div", 0)):
         pgq.set_option(k, v)
     yield
 
@@ -393,9 +393,13 @@ def test_cheapest_path_bit_exact(kind):
     s, d, e = random_graph(rng, V, E, skew=True)
     w = rng.integers(1, 1000, E) if kind == "int64" else rng.random(E) + 0.01
     st, ora = both(V, (s, d, e), w=w)
-    for n in (1, 70, 300, 1500):
+    for n, div in ((1, 64), (70, 64), (300, 64), (300, 0), (300, 1), (300, 100000), (1500, 64), (1500, 4)):
         pgq.set_option("relax_small_limit", 0 if n == 300 else (50 if n == 70 else 2048))  # host rounds / mixed / device rounds
+        # band width of the ordered rounds = mean weight / div: 0 = plain rounds, 1 = a few wide bands, 100000 = a band per label
+        pgq.set_option("relax_delta_div", div)
         ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        if div == 4:  # many rows per lane: the per-lane bound is the largest of its destinations' labels
+            ps = ps[rng.integers(0, 40, n)]
         out, ok = st.cheapest_path_length(0, V, ps, pd)
         lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
         assert (ok == lok).all()

@@ -283,6 +283,199 @@ static int pagerank_compute(pgq_csr *c, Workspace *ws) {
 	return PGQ_OK;
 }
 
+// ---- weakly connected components ---------------------------------------------------------------------------------------
+// The reference's component id is NOT a canonical label: it is the root its sequential union-find ends in
+// (weakly_connected_component.cpp:14-34,83-90: Link(i, neighbour) hangs i's root under the neighbour's root, vertices
+// and slots in CSR order; the goldens pin e.g. id 2 for the cycle 0-1-2-3).  Two facts make that computable in parallel:
+//   * an edge changes the forest iff its endpoints are in different trees when it is processed, i.e. iff it is an edge
+//     of the MINIMUM SPANNING FOREST under the weights "CSR slot index" (the sequential pass IS Kruskal's algorithm in
+//     slot order; the weights are distinct, so the forest is unique) — all other edges are no-ops;
+//   * replaying only those <= V - 1 edges, in slot order, with the reference's Link gives the same forest roots.
+// So the O(E) part runs on the device — Boruvka rounds: every component takes the smallest slot leaving it (atomicMin
+// from both endpoints), hooks onto the other side (a mutual pair keeps the smaller root), pointer jumping — and the
+// O(V alpha(V)) replay of the chosen edges runs on the host (it is the reference's own schedule, restricted to the edges
+// that matter).  Computed once per CSR handle, like the reference's bind-data state.
+__global__ void k_wcc_slot_src(int64_t V, const int64_t *__restrict__ off, u32 *__restrict__ slot_src) {
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+	for (int64_t v = wave; v < V; v += nwaves)
+		for (int64_t k = off[v] + lane; k < off[v + 1]; k += 64) slot_src[k] = (u32)v;
+}
+__global__ void k_wcc_init(int64_t V, u32 *__restrict__ comp) {
+	const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < V) comp[v] = (u32)v;
+}
+__global__ void k_wcc_min_edge(int64_t E, const u32 *__restrict__ slot_src, const int32_t *__restrict__ adj,
+                               const u32 *__restrict__ comp, unsigned long long *__restrict__ best) {
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= E) return;
+	const u32 cu = comp[slot_src[k]], cv = comp[(u32)adj[k]];
+	if (cu == cv) return;
+	if (best[cu] > (unsigned long long)k) atomicMin(&best[cu], (unsigned long long)k);
+	if (best[cv] > (unsigned long long)k) atomicMin(&best[cv], (unsigned long long)k);
+}
+// roots hook onto the component on the other side of their smallest leaving slot; two roots that chose the same slot
+// would point at each other: the larger one hooks, the smaller one stays a root (with distinct weights no longer cycle
+// can form).  comp[] is only read here (every entry names a root of the round's start); the new parents go to hook[],
+// which every root writes (itself when it stays a root).  Chosen slots are flagged for the host replay.
+__global__ void k_wcc_hook(int64_t V, const u32 *__restrict__ slot_src, const int32_t *__restrict__ adj,
+                           const u32 *__restrict__ comp, const unsigned long long *__restrict__ best, u32 *__restrict__ hook,
+                           uint8_t *__restrict__ msf, u32 *__restrict__ hooks) {
+	const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= V || comp[c] != (u32)c) return;
+	const unsigned long long k = best[c];
+	u32 target = (u32)c;
+	if (k != ~0ull) {
+		const u32 ra = comp[slot_src[k]], rb = comp[(u32)adj[k]];
+		const u32 other = ra == (u32)c ? rb : ra;
+		msf[k] = 1;
+		if (!(best[other] == k && (u32)c < other)) { // mutual choice: the larger root hooks
+			target = other;
+			atomicAdd(hooks, 1u);
+		}
+	}
+	hook[c] = target;
+}
+// pointer jumping over the hooks of the round's roots (a chain graph hooks every vertex onto its predecessor: without
+// it the walk below would be quadratic)
+__global__ void k_wcc_jump(int64_t V, const u32 *__restrict__ comp, u32 *__restrict__ hook, u32 *__restrict__ changed) {
+	const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= V || comp[c] != (u32)c) return;
+	const u32 p = __hip_atomic_load(&hook[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const u32 g = __hip_atomic_load(&hook[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (g != p) {
+		__hip_atomic_store(&hook[c], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		*changed = 1;
+	}
+}
+// every vertex follows the hooks from the root it had at the round's start to the new root
+__global__ void k_wcc_flatten(int64_t V, const u32 *__restrict__ hook, const u32 *__restrict__ comp, u32 *__restrict__ comp_new) {
+	const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= V) return;
+	u32 x = comp[v];
+	for (;;) {
+		const u32 p = hook[x];
+		if (p == x) break;
+		x = p;
+	}
+	comp_new[v] = x;
+}
+__global__ void k_wcc_gather_edges(u32 n, const u32 *__restrict__ slots, const u32 *__restrict__ slot_src,
+                                   const int32_t *__restrict__ adj, int32_t *__restrict__ out) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	out[2 * (size_t)i] = (int32_t)slot_src[slots[i]];
+	out[2 * (size_t)i + 1] = adj[slots[i]];
+}
+
+static std::mutex g_wcc_lock;
+
+static int wcc_compute(pgq_csr *c, Workspace *ws) {
+	std::lock_guard<std::mutex> g(g_wcc_lock);
+	if (c->wcc) return PGQ_OK;
+	hipStream_t st = ws->stream;
+	const int64_t V = c->V, E = c->E, vs = V + 2;
+	DevBuf slot_src, comp, comp2, hook, best, msf, sel, tmp, edges, cnt;
+	std::vector<int64_t> forest((size_t)vs, 0);
+	auto body = [&]() -> int {
+		std::vector<int32_t> h_edges;
+		u32 n_msf = 0;
+		if (E > 0 && V > 0) {
+			PGQ_TRY(slot_src.reserve((size_t)E * 4));
+			PGQ_TRY(comp.reserve((size_t)V * 4));
+			PGQ_TRY(comp2.reserve((size_t)V * 4));
+			PGQ_TRY(hook.reserve((size_t)V * 4));
+			PGQ_TRY(best.reserve((size_t)V * 8));
+			PGQ_TRY(msf.reserve((size_t)E));
+			PGQ_TRY(cnt.reserve(64));
+			hipLaunchKernelGGL(k_wcc_slot_src, dim3(256 * 8), dim3(256), 0, st, V, c->off, slot_src.as<u32>());
+			hipLaunchKernelGGL(k_wcc_init, dim3(blocks_for(V)), dim3(256), 0, st, V, comp.as<u32>());
+			PGQ_HIP_TRY(hipMemsetAsync(msf.p, 0, (size_t)E, st));
+			u32 *cur = comp.as<u32>(), *nxt = comp2.as<u32>();
+			for (int round = 0; round < 64; round++) { // the number of components at least halves per round
+				PGQ_HIP_TRY(hipMemsetAsync(best.p, 0xFF, (size_t)V * 8, st));
+				PGQ_HIP_TRY(hipMemsetAsync(cnt.p, 0, 4, st));
+				hipLaunchKernelGGL(k_wcc_min_edge, dim3(blocks_for(E)), dim3(256), 0, st, E, slot_src.as<u32>(), c->adj, cur,
+				                   best.as<unsigned long long>());
+				hipLaunchKernelGGL(k_wcc_hook, dim3(blocks_for(V)), dim3(256), 0, st, V, slot_src.as<u32>(), c->adj, cur,
+				                   best.as<unsigned long long>(), hook.as<u32>(), msf.as<uint8_t>(), cnt.as<u32>());
+				u32 hooks = 0;
+				PGQ_HIP_TRY(hipMemcpyAsync(&hooks, cnt.p, 4, hipMemcpyDeviceToHost, st));
+				PGQ_HIP_TRY(hipStreamSynchronize(st));
+				if (hooks == 0) break;
+				for (int j = 0; j < 40; j++) { // halves the hook chains per pass
+					u32 changed = 0;
+					PGQ_HIP_TRY(hipMemsetAsync(cnt.as<u32>() + 1, 0, 4, st));
+					hipLaunchKernelGGL(k_wcc_jump, dim3(blocks_for(V)), dim3(256), 0, st, V, cur, hook.as<u32>(), cnt.as<u32>() + 1);
+					PGQ_HIP_TRY(hipMemcpyAsync(&changed, cnt.as<u32>() + 1, 4, hipMemcpyDeviceToHost, st));
+					PGQ_HIP_TRY(hipStreamSynchronize(st));
+					if (!changed) break;
+				}
+				hipLaunchKernelGGL(k_wcc_flatten, dim3(blocks_for(V)), dim3(256), 0, st, V, hook.as<u32>(), cur, nxt);
+				std::swap(cur, nxt);
+			}
+			// the chosen slots in ascending order (= the order the reference processes them in)
+			PGQ_TRY(sel.reserve((size_t)std::min<int64_t>(E, V) * 4 + 64));
+			size_t sb = 0;
+			hipcub::CountingInputIterator<u32> iota(0u);
+			PGQ_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, sb, iota, msf.as<uint8_t>(), sel.as<u32>(), cnt.as<u32>(), (int)E, st));
+			PGQ_TRY(tmp.reserve(sb + 16));
+			PGQ_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, sb, iota, msf.as<uint8_t>(), sel.as<u32>(), cnt.as<u32>(), (int)E, st));
+			PGQ_HIP_TRY(hipMemcpyAsync(&n_msf, cnt.p, 4, hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			if ((int64_t)n_msf >= V) return fail(PGQ_ERR_HIP, "internal error: spanning forest with more than V - 1 edges");
+			if (n_msf > 0) {
+				PGQ_TRY(edges.reserve((size_t)n_msf * 8));
+				hipLaunchKernelGGL(k_wcc_gather_edges, dim3(blocks_for(n_msf)), dim3(256), 0, st, n_msf, sel.as<u32>(),
+				                   slot_src.as<u32>(), c->adj, edges.as<int32_t>());
+				h_edges.resize((size_t)n_msf * 2);
+				PGQ_TRY(staged_download(h_edges.data(), edges.p, (size_t)n_msf * 8, st));
+			}
+		}
+		// the reference's schedule on the edges that matter (weakly_connected_component.cpp:14-34,77-90); entry V + 1 is
+		// left at 0 by the reference's resize and never linked
+		for (int64_t i = 0; i < vs - 1; i++) forest[(size_t)i] = i;
+		auto root = [&](int64_t x) {
+			for (;;) {
+				const int64_t p = forest[(size_t)x];
+				if (p == x) return x;
+				forest[(size_t)x] = forest[(size_t)p];
+				x = p;
+			}
+		};
+		for (u32 i = 0; i < n_msf; i++) {
+			const int64_t ra = root(h_edges[2 * (size_t)i]), rb = root(h_edges[2 * (size_t)i + 1]);
+			if (ra != rb) forest[(size_t)ra] = rb;
+		}
+		std::vector<int64_t> ids((size_t)vs);
+		for (int64_t v = 0; v < vs; v++) ids[(size_t)v] = root(v); // v = V + 1: forest entry 0 -> the root of vertex 0 (:94-96 accepts it)
+		int64_t *d_ids = nullptr;
+		PGQ_TRY(dev_alloc_as(&d_ids, (size_t)vs));
+		hipError_t e1 = hipMemcpyAsync(d_ids, ids.data(), (size_t)vs * 8, hipMemcpyHostToDevice, st);
+		hipError_t e2 = hipStreamSynchronize(st);
+		if (e1 != hipSuccess || e2 != hipSuccess) {
+			dev_free(d_ids);
+			return fail(PGQ_ERR_HIP, "copying the component ids failed");
+		}
+		c->wcc = d_ids;
+		return PGQ_OK;
+	};
+	const int rc = body();
+	(void)hipStreamSynchronize(st);
+	for (DevBuf *b : { &slot_src, &comp, &comp2, &hook, &best, &msf, &sel, &tmp, &edges, &cnt }) b->release();
+	return rc;
+}
+
+__global__ void k_wcc_gather(int64_t n, const int64_t *__restrict__ src, int64_t vs, const int64_t *__restrict__ ids,
+                             int64_t *__restrict__ out, uint8_t *__restrict__ ok) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int64_t s = src[i];
+	const bool valid = s >= 0 && s < vs; // weakly_connected_component.cpp:94-100
+	ok[i] = valid ? 1 : 0;
+	out[i] = valid ? ids[s] : 0;
+}
+
 __global__ void k_pr_gather(int64_t n, const int64_t *__restrict__ src, int64_t vs, const double *__restrict__ rank,
                             double *__restrict__ out, uint8_t *__restrict__ ok) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,6 +558,50 @@ int pgq_pagerank(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, double *ou
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, ids.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
 	hipLaunchKernelGGL(k_pr_gather, dim3(blocks_for(n)), dim3(256), 0, ws->stream, n, ws->in_src.as<int64_t>(), V + 2,
 	                   csr->pagerank, ws->out_val.as<double>(), ws->out_ok.as<uint8_t>());
+	std::vector<uint8_t> ok((size_t)n);
+	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
+	PGQ_TRY(staged_download(out, ws->out_val.p, (size_t)n * 8, ws->stream));
+	PGQ_TRY(staged_download(ok.data(), ws->out_ok.p, (size_t)n, ws->stream));
+	mask_fill_valid(out_valid, n);
+	for (int64_t i = 0; i < n; i++)
+		if (!ok[(size_t)i]) mask_set_invalid(out_valid, i);
+	return PGQ_OK;
+}
+
+int pgq_weakly_connected_component_device(pgq_csr_t *csr, int64_t *d_ids) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	PGQ_TRY(wcc_compute(csr, lease.ws));
+	if (d_ids) PGQ_HIP_TRY(hipMemcpy(d_ids, csr->wcc, (size_t)(csr->V + 2) * 8, hipMemcpyDeviceToDevice));
+	return PGQ_OK;
+}
+
+int pgq_weakly_connected_component(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, int64_t *out, uint64_t *out_valid) {
+	PGQ_TRY(ensure_init());
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
+	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");
+	if (n < 0 || (n > 0 && (!out || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	Workspace *ws = lease.ws;
+	PGQ_TRY(wcc_compute(csr, ws));
+	if (n == 0) return PGQ_OK;
+	// rows: NULL -> NULL; ids outside [0, V + 2) -> NULL (weakly_connected_component.cpp:94-100)
+	std::vector<int64_t> ids((size_t)n);
+	const int64_t *data = static_cast<const int64_t *>(src.data);
+	for (int64_t r = 0; r < n; r++) {
+		const int64_t p = src.sel ? (int64_t)src.sel[r] : r;
+		const bool valid = !src.validity || ((src.validity[p >> 6] >> (p & 63)) & 1ULL);
+		ids[(size_t)r] = valid ? data[p] : -1;
+	}
+	PGQ_TRY(ws->in_src.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_val.reserve((size_t)n * 8));
+	PGQ_TRY(ws->out_ok.reserve((size_t)n));
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, ids.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
+	hipLaunchKernelGGL(k_wcc_gather, dim3(blocks_for(n)), dim3(256), 0, ws->stream, n, ws->in_src.as<int64_t>(), V + 2,
+	                   csr->wcc, ws->out_val.as<int64_t>(), ws->out_ok.as<uint8_t>());
 	std::vector<uint8_t> ok((size_t)n);
 	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
 	PGQ_TRY(staged_download(out, ws->out_val.p, (size_t)n * 8, ws->stream));

@@ -176,6 +176,7 @@ struct pgq_csr {
 	// PageRank over this CSR (V + 2 doubles), computed once per handle like the reference's bind-data state
 	void *rw = nullptr;          // E x 8 B: in-edge weights in reverse-CSR order (built on first use by the weighted pair search)
 	double w_mean = 0;
+	int64_t *wcc = nullptr;      // weakly_connected_component ids of the V + 2 forest entries (computed once per handle)
 	double *pagerank = nullptr;
 	int pagerank_iterations = 0;
 	std::vector<pgq_csr *> replicas;

@@ -964,6 +964,7 @@ static void destroy_csr(pgq_csr *c) {
 	dev_free(c->fdesc);
 	dev_free(c->rdesc);
 	dev_free(c->pagerank);
+	dev_free(c->wcc);
 	dev_free(c->rw);
 	delete c;
 }

@@ -53,10 +53,6 @@ struct HostCSR {
 	// read outside csr_lock by the double-checked initialisation the reference uses (csr_creation.cpp:15,44,64)
 	std::atomic<bool> initialized_v { false }, initialized_e { false }, initialized_w { false };
 	std::atomic<pgq_csr_t *> device { nullptr };
-	// weakly_connected_component: union-find forest after the reference's sequential schedule (built once, under wcc_lock)
-	std::vector<int64_t> forest;
-	std::mutex wcc_lock;
-	std::atomic<bool> wcc_done { false };
 	~HostCSR() {
 		if (device.load()) pgq_csr_free(device.load());
 	}
@@ -395,46 +391,16 @@ int pgq_udf_pagerank(pgq_state_t *s, int32_t id, int64_t n, pgq_vec_t src, doubl
 	return 0;
 }
 
-// weakly_connected_component.cpp:14-104, literally: FindTreeRoot with path halving, Link(i, neighbour) hangs i's root under
-// the neighbour's root, vertices and slots in CSR order; the forest is built once per CSR (info.state_converged).
+// weakly_connected_component.cpp:36-104 on the device (pgq_weakly_connected_component: the spanning forest under the
+// reference's processing order by Boruvka rounds, then the reference's own Link over its <= V - 1 edges); the ids are
+// computed once per CSR like the reference's bind-data forest (info.state_converged).
 int pgq_udf_weakly_connected_component(pgq_state_t *s, int32_t id, int64_t n, pgq_vec_t srcv, int64_t *out, uint64_t *out_valid) {
 	CsrRef c;
 	if (analytics_prologue(s, id, "doing weakly connected components.", &c)) return -1;
-	const int64_t vs = (int64_t)c->vsize;
-	auto root = [&](int64_t x) {
-		for (;;) {
-			const int64_t p = c->forest[(size_t)x];
-			if (p == x) return x;
-			c->forest[(size_t)x] = c->forest[(size_t)p];
-			x = p;
-		}
-	};
-	std::lock_guard<std::mutex> g(c->wcc_lock); // lookups compress paths too: one caller at a time, like info.wcc_lock
-	if (!c->wcc_done) {
-		try {
-			c->forest.assign((size_t)vs, 0);
-		} catch (const std::exception &) {
-			return fail("Out of Memory Error: cannot allocate the component forest");
-		}
-		const int64_t E = (int64_t)c->e.size();
-		for (int64_t i = 0; i < vs - 1; i++) c->forest[(size_t)i] = i;
-		for (int64_t i = 0; i < vs - 1; i++)
-			for (int64_t j = c->v[(size_t)i].load(std::memory_order_relaxed); j < c->v[(size_t)i + 1].load(std::memory_order_relaxed) && j < E; j++) {
-				const int64_t nb = c->e[(size_t)j];
-				if (nb < 0 || nb >= vs - 1) return fail("Invalid Input Error: edge destination out of range [0,V]");
-				const int64_t ra = root(i), rb = root(nb);
-				if (ra != rb) c->forest[(size_t)ra] = rb;
-			}
-		c->wcc_done = true;
-	}
-	View src(srcv);
-	fill_valid(out_valid, n);
-	for (int64_t r = 0; r < n; r++) {
-		const int64_t p = src.pos(r);
-		const int64_t v = src.data[p];
-		if (src.ok(p) && v >= 0 && v < vs - 1) out[r] = root(v); // :94-100 (the trailing offset entry is never a vertex id)
-		else set_invalid(out_valid, r);
-	}
+	const int64_t V = (int64_t)c->vsize - 2;
+	pgq_csr_t *d = device_csr(s, c, V);
+	if (!d) return device_fail();
+	if (pgq_weakly_connected_component(d, V, n, srcv, out, out_valid) != PGQ_OK) return device_fail();
 	std::lock_guard<std::mutex> g2(s->csr_lock);
 	s->csr_to_delete.insert(id); // :103
 	return 0;

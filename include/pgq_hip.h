@@ -184,6 +184,16 @@ int pgq_local_clustering_coefficient_bulk_device(pgq_csr_t *csr, int64_t n, cons
 int pgq_pagerank(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, double *out, uint64_t *out_valid);
 int pgq_pagerank_device(pgq_csr_t *csr, double *d_rank, int *iterations);
 
+/* weakly_connected_component(csr_id, id) -> BIGINT   src/core/functions/scalar/weakly_connected_component.cpp:36-104: the
+ * component id is the root the reference's sequential union-find (Link(i, neighbour): i's root under the neighbour's,
+ * vertices and slots in CSR order) ends in.  The edges that change that forest are the minimum spanning forest under
+ * the weights "slot index": found on the device (Boruvka rounds), replayed in slot order by the reference's own Link
+ * (V - 1 edges at most).  Computed once per handle.  NULL id -> NULL; ids outside [0, V + 2) -> NULL; the two trailing
+ * forest entries behave like the reference's (V: its own root; V + 1: the root of vertex 0).
+ * pgq_weakly_connected_component_device copies all V + 2 ids into d_ids (may be NULL: just compute). */
+int pgq_weakly_connected_component(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, int64_t *out, uint64_t *out_valid);
+int pgq_weakly_connected_component_device(pgq_csr_t *csr, int64_t *d_ids);
+
 /* ---- tuning & measurement --------------------------------------------------------------------------------- */
 
 /* Knobs (also readable from the environment at pgq_init: PGQ_WORDS, PGQ_PUSH_DIV, PGQ_PROFILE ...).

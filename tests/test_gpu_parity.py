@@ -1020,3 +1020,39 @@ def test_replicas_follow_the_enabled_device_list():
         pgq.init_devices([0])
     c = dev.iterativelength_multi(ps, pd)
     assert (a == c).all()
+
+
+def test_weakly_connected_component_device_matches_goldens_and_oracle():
+    """weakly_connected_component on the device (spanning forest under the reference's processing order by Boruvka rounds,
+    then the reference's own Link over its edges): the component id is the root the reference's sequential union-find
+    ends in (goldens: id 2 for the cycle 0-1-2-3), not a canonical label."""
+    for case in load_golden("wcc.json")["cases"]:  # weakly_connected_component.test
+        s, d, e = undirected_rows(case["edges"])
+        st = pgq.PgqState()
+        st.build_csr(0, case["V"], s, d, e)
+        out, ok = st.weakly_connected_component(0, np.arange(case["V"]))
+        assert ok.all() and [[i, int(c)] for i, c in enumerate(out)] == case["rows"], case["source"]
+    rng = np.random.default_rng(6)
+    graphs = []
+    V, E = 3000, 2500  # sparse: many components
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    graphs.append((V,) + undirected_rows(np.stack([s, d], axis=1)))
+    V = 5000  # a directed chain and a reversed one: every vertex hooks onto its neighbour (deep hook chains)
+    graphs.append((V, np.arange(V - 1, dtype=np.int64), np.arange(1, V, dtype=np.int64), np.arange(V - 1, dtype=np.int64)))
+    graphs.append((V, np.arange(1, V, dtype=np.int64), np.arange(V - 1, dtype=np.int64), np.arange(V - 1, dtype=np.int64)))
+    graphs.append((4000,) + random_graph(rng, 4000, 30000, skew=True))  # directed, duplicates, self loops, hubs
+    graphs.append((3, np.array([1], dtype=np.int64), np.array([1], dtype=np.int64), np.zeros(1, dtype=np.int64)))  # one self loop
+    V2, s2, d2 = graphgen.reply_forest(1 << 17, seed=3)
+    graphs.append((V2, s2, d2, np.arange(len(s2), dtype=np.int64)))
+    for k, (V, us, ud, ue) in enumerate(graphs):
+        st = pgq.PgqState()
+        st.build_csr(k, V, us, ud, ue)
+        # the two trailing forest entries are accepted like the reference does (V: its own root; V + 1: the root of vertex
+        # 0, the zero a resize left there); NULL and out-of-range ids give NULL
+        ids = np.concatenate([np.arange(V + 2), [-1, V + 2, V + 50]])
+        out, ok = st.weakly_connected_component(k, ids)
+        want, wok = OracleCSR.from_edges(V, us, ud, ue).weakly_connected_component(ids)
+        assert (ok == wok).all() and ok[:V + 2].all() and not ok[V + 2:].any(), k
+        assert (out[ok] == want[wok]).all(), k
+    with pytest.raises(pgq.PgqError, match="CSR not found. Is the graph populated"):
+        st.weakly_connected_component(99, [0])

@@ -198,30 +198,6 @@ def test_udf_argument_checks_return_errors_instead_of_crashing():
         st.create_csr_edge(1, 5, len(s), len(s), s[3:], d[3:], e[3:], w=np.ones(len(s) - 3, dtype=np.float64))
 
 
-def test_weakly_connected_component_host_mirror_matches_goldens_and_oracle():
-    # the component id is the root the reference's sequential union-find ends in (goldens: id 2 for the cycle 0-1-2-3)
-    from helpers import undirected_rows
-    from oracle.pgq_oracle import OracleCSR
-    for case in load_golden("wcc.json")["cases"]:
-        s, d, e = undirected_rows(case["edges"])
-        st = pgq.PgqState()
-        st.build_csr(0, case["V"], s, d, e)
-        out, ok = st.weakly_connected_component(0, np.arange(case["V"]))
-        assert ok.all() and [[i, int(c)] for i, c in enumerate(out)] == case["rows"], case["source"]
-    rng = np.random.default_rng(6)
-    V, E = 3000, 2500  # sparse: many components
-    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
-    us, ud, ue = undirected_rows(np.stack([s, d], axis=1))
-    st = pgq.PgqState()
-    st.build_csr(1, V, us, ud, ue)
-    ids = np.concatenate([np.arange(V), [-1, V + 5]])
-    out, ok = st.weakly_connected_component(1, ids)
-    want, wok = OracleCSR.from_edges(V, us, ud, ue).weakly_connected_component(np.arange(V))
-    assert ok[:V].all() and not ok[V:].any() and (out[:V] == want).all()
-    with pytest.raises(pgq.PgqError, match="CSR not found. Is the graph populated"):
-        st.weakly_connected_component(9, [0])
-
-
 def test_duckdb_glue_type_checks_against_stub_headers():
     """glue/pgq_glue.cpp (replacement bodies of the search UDFs + ~CSR patch + whole-relation entry point) compiles
     against stubs of the DuckDB declarations it touches: DuckDB itself is not vendored here."""

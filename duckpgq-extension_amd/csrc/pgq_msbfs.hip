@@ -984,8 +984,8 @@ __global__ __launch_bounds__(256) void k_probe(int64_t lo, int64_t hi, const u32
 	const int lane = threadIdx.x & 63;
 	const int64_t n = hi - lo;
 	const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-	// few rows: G wavefronts share a chunk (each takes every G-th open row of it), so that a wavefront scans the in-lists
-	// of a handful of rows, not of 64
+	// few rows: G wavefronts share a chunk (each takes every G-th row of it), so that a wavefront scans the in-lists of a
+	// handful of rows, not of 64
 	const int64_t nchunks = (n + 63) >> 6;
 	const int G = (int)max((int64_t)1, min((int64_t)64, nwaves / max(nchunks, (int64_t)1)));
 	const int g = (int)(gw % G);
@@ -1000,11 +1000,10 @@ __global__ __launch_bounds__(256) void k_probe(int64_t lo, int64_t hi, const u32
 			my_d = sdst[i];
 		}
 		u64 todo = __ballot(mine_open);
-		int rank = 0;
 		while (todo) {
 			const int k = __ffsll((long long)todo) - 1;
 			todo &= todo - 1;
-			if (rank++ % G != g) continue;
+			if (k % G != g) continue; // by row index: the split must not depend on what the chunk's other wavefronts have answered
 			const u32 l = (u32)__builtin_amdgcn_readlane((int)my_l, k);
 			const int d = __builtin_amdgcn_readlane(my_d, k);
 			const int w = (int)(l >> 6);
@@ -1066,12 +1065,16 @@ __global__ __launch_bounds__(1024) void k_probe2(int64_t lo, int64_t hi, const u
 	const int lane = threadIdx.x & 63;
 	const int wib = threadIdx.x >> 6, nw = blockDim.x >> 6;
 	if (threadIdx.x == 0) s_answered = 0;
-	for (int64_t c0 = lo + (int64_t)blockIdx.x * 64; c0 < hi; c0 += (int64_t)gridDim.x * 64) {
+	// few rows: B workgroups share a 64-row chunk (each takes every B-th open row of it)
+	const int64_t nchunks = (hi - lo + 63) >> 6;
+	const int B = (int)max((int64_t)1, min((int64_t)64, (int64_t)gridDim.x / max(nchunks, (int64_t)1)));
+	const int bsub = (int)(blockIdx.x % B);
+	for (int64_t c0 = lo + (int64_t)(blockIdx.x / B) * 64; c0 < hi; c0 += (int64_t)(gridDim.x / B) * 64) {
 		__syncthreads();
 		if (threadIdx.x == 0) s_n = 0;
 		__syncthreads();
-		if (threadIdx.x < 64) {
-			const int64_t i = c0 + threadIdx.x;
+		if (threadIdx.x < 64 && (int)(threadIdx.x % B) == bsub) { // this workgroup's share of the chunk: by row index, so that
+			const int64_t i = c0 + threadIdx.x;                  // the split does not depend on what the others have answered
 			if (i < hi && sres[i] == -1) s_list[atomicAdd(&s_n, 1u)] = (u32)(i - c0);
 		}
 		__syncthreads();
@@ -1539,11 +1542,12 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			}
 			if (probe_now) {
 				KernelTimer kt(st, K_DETECT);
-				hipLaunchKernelGGL(k_probe<WD>, dim3(std::min(blocks_for(hi - lo), 8u * ncu)), dim3(256), 0, st, lo, hi,
+				// up to one wavefront per row (few rows: the wavefronts of a 64-row chunk share its open rows), at most 8192
+				hipLaunchKernelGGL(k_probe<WD>, dim3(std::min(blocks_for((hi - lo) * 64), 8u * ncu)), dim3(256), 0, st, lo, hi,
 				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
 				if (opt.probe2 && !with_paths)
-					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)std::min<int64_t>((hi - lo + 63) / 64, 2 * ncu)), dim3(1024), 0, st, lo, hi,
+					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)std::min<int64_t>(hi - lo, 2 * ncu)), dim3(1024), 0, st, lo, hi,
 					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
 					                   (u32)std::max<int64_t>(std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),

@@ -9,7 +9,7 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 rdir = os.path.join(root, "profiles", rnd)
 
 
@@ -29,17 +29,25 @@ def fmt(x, spec="{:,.0f}"):
 
 L = ["# profiles — round %s measurements (MI355X, one GPU per gpurun box)" % rnd.lstrip("r0"), "",
      "Produced by committed tooling only: `tools/measure_pass.sh` on the GPU box runs `bench.py` per workload (one JSON "
-     "line each), `rocprofv3 --kernel-trace --stats` of the default bench command and of the lane-batched path alone "
-     "(`PGQ_MEET=0`), separate `--pmc` passes (summarised by `tools/pmc_summary.py` into `profiles/pmc_<workload>.json`, "
+     "line each), `rocprofv3 --kernel-trace --stats` of the default bench command without its second leg (`--no-legs`: "
+     "every `k_meet3` / `k_meet4d` call is a 65,536-row one) and of the cross-product workload (`--workload snb_cross`), "
+     "separate `--pmc` passes of both (summarised by `tools/pmc_summary.py` into `profiles/pmc_<workload>.json`, "
      "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), `tools/chunk_latency.py` and `tools/membench`.  "
-     "Regenerate this file with `python tools/make_profile_readme.py %s`.  `profiles/r01/` is the previous round." % rnd,
+     "Regenerate this file with `python tools/make_profile_readme.py %s`.  `profiles/r01/`, `profiles/r02/` are the "
+     "previous rounds." % rnd,
      ""]
-names = [("snb_sf100", "C4 shard: SF100-shaped knows, iterativelength, 65,536 pairs (default bench)"),
-         ("snb_sf100_8192", "same graph, 8192 pairs (round 1's default)"),
-         ("snb_sf100_8192_msbfs_only", "same, 8192 pairs, `PGQ_MEET=0` (lane-batched MS-BFS only)"),
+names = [("snb_sf100", "C4 shard: SF100-shaped knows, iterativelength, 65,536 random pairs (default bench; every row through the pre-pass)"),
+         ("snb_sf100_8192", "same graph, 8192 random pairs"),
+         ("snb_sf100_8192_msbfs_only", "same, 8192 random pairs, `PGQ_MEET=0` (lane-batched MS-BFS only)"),
+         ("snb_cross", "same graph, cross product 2048 sources x 1024 destinations = 2.1 M rows (lane-batched MS-BFS; the `msbfs_cross` leg)"),
+         ("snb_cross_2048x32", "same graph, cross product 2048 sources x 32 destinations = 65,536 rows"),
+         ("snb_cross_allv", "same graph, 32 sources x every vertex = 14.4 M rows"),
          ("rmat22", "C2: R-MAT scale 22, iterativelength, 1024 pairs"),
          ("snb_paths", "C3: SF100-shaped knows, shortestpath + reconstruction, 4096 pairs"),
-         ("forest_cheapest", "C5: reply forest V=2^24, int64 weights, cheapest_path_length, 4096 reachable pairs")]
+         ("forest_cheapest", "C5: reply forest V=2^24, int64 weights, cheapest_path_length, 4096 reachable pairs"),
+         ("forest_cheapest_double", "C5, double weights"),
+         ("forest_cheapest_2_28", "C5 at the named scale: reply forest V=2^28 (268 M vertices, 215 M edges), int64 weights, 4096 pairs"),
+         ("snb_cheapest_512", "general graph: weighted knows graph (weights 1..999), cheapest_path_length, 512 pairs (batched relaxation)")]
 L += ["## bench.py, 1 GPU (10 steps, 2 warm-up; timed region runs unprofiled, the roofline columns come from an untimed "
       "pass with one batch in flight and HIP events around every kernel)", "",
       "| workload | ms/step | pairs/s | MTEPS | rows answered by the pre-pass | dominant kernel class | launches/step | "
@@ -69,9 +77,12 @@ L += ["", "Kernel classes of the untimed one-batch-in-flight pass (ms per step, 
 for w, _ in names:
     j = load("bench_%s.json" % w)
     if j and j.get("roofline_by_kernel"):
+        fe = (j.get("roofline") or {}).get("frontier_expansion")
         L.append("* **%s**: " % w + ", ".join(
             "%s %.3f ms%s" % (k, v["ms_per_step"], (" (%.0f GB/s)" % v["GBps"]) if v.get("GBps") else "")
-            for k, v in j["roofline_by_kernel"].items()))
+            for k, v in j["roofline_by_kernel"].items()) +
+            ("; frontier expansion (push + pull + pull_sparse) %.3f ms at %.0f GB/s = %.3f of peak" % (
+                fe["ms_per_step"], fe["GBps"], fe["frac"]) if fe else ""))
 L += ["", "## rocprofv3 --kernel-trace --stats (top kernels)", ""]
 for p in sorted(glob.glob(os.path.join(rdir, "*kernel_stats.csv"))):
     L += ["`profiles/%s/%s`" % (rnd, os.path.basename(p)), "", "| kernel | calls | avg µs | % |", "|---|---|---|---|"]

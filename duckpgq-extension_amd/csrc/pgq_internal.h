@@ -64,6 +64,7 @@ struct Options {
 	int probe2 = 1;         // two-hop destination probe when few pairs are left
 	int probe2_div = 4;     // ... when open pairs <= lanes / probe2_div
 	int probe2_abs = 4096;  // ... or when at most this many pairs are open, whatever the batch width
+	int detect_grid_mult = 8;  // k_detect grid = this many 256-thread workgroups per CU at most (rows are taken grid-stride)
 	int probe_always = 0;   // 1: probe before every level of a batch that uses the probe (round-2 behaviour; tests)
 	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)

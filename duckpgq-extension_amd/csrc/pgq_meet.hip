@@ -1188,7 +1188,9 @@ if (paths)
 	}
 	S.meet_pairs += n - (int64_t)open;
 	S.edges_scanned += (int64_t)entries;
-	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
+	// 4 B per adjacency entry / one-hop id, 16 B per slot descriptor, and per row its ids (16 B), the four offsets of its
+	// endpoints (32 B) and its result (8 B)
+	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices + 56.0 * (double)n;
 	*n_open = open;
 	return PGQ_OK;
 }

@@ -1689,7 +1689,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			if (!probe_now) {
 				// -- detect finished pairs (iterativelength.cpp:119-129), rebuild the active-lane mask
 				KernelTimer kt(st, K_DETECT);
-				hipLaunchKernelGGL(k_detect<WD>, dim3(std::min(blocks_for(hi - lo), 16u * ncu)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
+				hipLaunchKernelGGL(k_detect<WD>, dim3(std::min(blocks_for(hi - lo), (unsigned)std::max(1, opt.detect_grid_mult) * ncu)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
 				                   sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane, ws->seen.as<u64>(), t,
 				                   act_nxt, d_cnt);
 				kt.stop();

@@ -76,6 +76,7 @@ static std::vector<OptRef> option_table() {
 		{ "probe2_div", &o.probe2_div, nullptr },
 		{ "probe2_abs", &o.probe2_abs, nullptr },
 		{ "probe_always", &o.probe_always, nullptr },
+		{ "detect_grid_mult", &o.detect_grid_mult, nullptr },
 		{ "part_weight", &o.part_weight, nullptr },
 		{ "sparse_below", nullptr, &o.sparse_below },
 		{ "sparse_unroll", &o.sparse_unroll, nullptr },

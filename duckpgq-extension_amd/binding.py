@@ -93,6 +93,11 @@ def load_hip():
     L.pgq_csr_replicate.argtypes = [C.c_void_p]
     L.pgq_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.pgq_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+    L.pgq_csr_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.pgq_csr_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+    L.pgq_iterativelength_bidirectional.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, Vec, C.c_void_p, C.c_void_p]
+    L.pgq_weakly_connected_component.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, C.c_void_p, C.c_void_p]
+    L.pgq_weakly_connected_component_device.argtypes = [C.c_void_p, C.c_void_p]
     L.pgq_get_stats.argtypes = [C.POINTER(Stats)]
     L.pgq_measure_copy_bandwidth.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_double)]
     _hip = L
@@ -408,6 +413,15 @@ class DeviceCSR:
 
     def replicate(self):
         _check(self.L.pgq_csr_replicate(self.h))
+
+    def set_option(self, key, value):
+        """An option of THIS handle only (pgq_csr_set_option); the process-wide set stays as it is."""
+        _check(self.L.pgq_csr_set_option(self.h, str(key).encode(), str(value).encode()))
+
+    def get_option(self, key):
+        v = C.c_double(0.0)
+        _check(self.L.pgq_csr_get_option(self.h, str(key).encode(), C.byref(v)))
+        return v.value
 
     def traversed_edges_bulk_ptr(self, n, d_src, d_dst, d_out_len, d_out_te):
         _check(self.L.pgq_traversed_edges_bulk_device(self.h, n, C.c_void_p(d_src), C.c_void_p(d_dst),

@@ -493,6 +493,7 @@ using namespace pgq;
 extern "C" {
 
 int pgq_local_clustering_coefficient_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, float *d_out) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!d_src || !d_out))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
@@ -502,6 +503,7 @@ int pgq_local_clustering_coefficient_bulk_device(pgq_csr_t *csr, int64_t n, cons
 }
 
 int pgq_local_clustering_coefficient(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, float *out, uint64_t *out_valid) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
 	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");
@@ -524,6 +526,7 @@ int pgq_local_clustering_coefficient(pgq_csr_t *csr, int64_t V, int64_t n, pgq_v
 }
 
 int pgq_pagerank_device(pgq_csr_t *csr, double *d_rank, int *iterations) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
 	WorkspaceLease lease;
@@ -535,6 +538,7 @@ int pgq_pagerank_device(pgq_csr_t *csr, double *d_rank, int *iterations) {
 }
 
 int pgq_pagerank(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, double *out, uint64_t *out_valid) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
 	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");
@@ -569,6 +573,7 @@ int pgq_pagerank(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, double *ou
 }
 
 int pgq_weakly_connected_component_device(pgq_csr_t *csr, int64_t *d_ids) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
 	WorkspaceLease lease;
@@ -579,6 +584,7 @@ int pgq_weakly_connected_component_device(pgq_csr_t *csr, int64_t *d_ids) {
 }
 
 int pgq_weakly_connected_component(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, int64_t *out, uint64_t *out_valid) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "Constraint Error: CSR not found. Is the graph populated?");
 	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");

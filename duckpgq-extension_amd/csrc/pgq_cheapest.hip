@@ -1032,6 +1032,7 @@ extern "C" {
 
 int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                          void *d_out, uint8_t *d_out_valid) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_weighted(csr));
 	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out || !d_out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
@@ -1044,6 +1045,7 @@ int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_
 
 int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, void *out,
                              uint64_t *out_valid) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_weighted(csr));
 	if (V != csr->V) return fail(PGQ_ERR_INVALID_ARG, "V does not match the uploaded CSR");

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -106,6 +107,10 @@ struct Options {
 	int meet_align = 32;    // entries a padded list is aligned and padded to (4 = one 16-byte group; 16 / 32 = whole 64 / 128-byte lines: -4 % / -6 % on the pre-pass)
 };
 Options &options();
+// per-handle options (pgq_csr_set_option): the override a host thread works under, and a scope that installs a
+// handle's for the duration of a C-ABI call
+Options *options_override();
+void set_options_override(Options *o);
 
 // ---- kernel classes (stats) -----------------------------------------------------------------------------
 enum KClass {
@@ -166,6 +171,7 @@ struct pgq_csr {
 	uint2 *fseg = nullptr, *rseg = nullptr;    // V
 	uint4 *fdesc = nullptr, *rdesc = nullptr;  // E (+ 1): slot order of adj / radj
 	int64_t padj_groups = 0, rpadj_groups = 0;
+	std::unique_ptr<pgq::Options> opt;   // this handle's own options (pgq_csr_set_option); null: the process-wide set
 	std::atomic<int> meet_far_rows { 1 }; // the last pre-pass call left rows for k_bibfs (it is launched only then; pgq_meet.hip)
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
@@ -188,6 +194,15 @@ struct pgq_csr {
 };
 
 namespace pgq {
+
+struct OptionScope {
+	Options *saved;
+	explicit OptionScope(const pgq_csr *c) : saved(options_override()) {
+		if (c && c->opt) set_options_override(c->opt.get());
+	}
+	explicit OptionScope(Options *o) : saved(options_override()) { set_options_override(o); }
+	~OptionScope() { set_options_override(saved); }
+};
 
 // host mirror used by the chunk entry points: resolves UnifiedVectorFormat into flat arrays
 struct FlatPairs {

@@ -1998,8 +1998,10 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		std::vector<pgq_stats_t> wstats((size_t)workers);
 		std::vector<std::thread> pool;
 		const int dev = current_device();
+		Options *const parent_opt = options_override();
 		for (int t = 1; t < workers; t++)
 			pool.emplace_back([&, t]() {
+				OptionScope opt_scope(parent_opt); // the handle's own options, if the call runs under them
 				bind_thread_device(dev); // the caller's device (a multi-GPU shard may not be on the default one)
 				int r = ensure_init(); // binds the device for this host thread
 				if (r == PGQ_OK) {
@@ -2141,8 +2143,10 @@ static int run_shards(pgq_csr_t *csr, int64_t n, Body body) {
 		return body(k, lo, hi, replicas[(size_t)k], lease.ws);
 	};
 	std::vector<std::thread> pool;
+	Options *const parent_opt = options_override();
 	for (int k = 1; k < W; k++)
 		pool.emplace_back([&, k]() {
+			OptionScope opt_scope(parent_opt);
 			(void)pgq_reset_stats();
 			rcs[(size_t)k] = shard(k);
 			if (rcs[(size_t)k] != PGQ_OK) errs[(size_t)k] = pgq_last_error();
@@ -2184,6 +2188,7 @@ int pgq_release_cached_memory(void) {
 
 static int iterativelength_bulk(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out_len,
                                 bool bidir) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out_len))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
@@ -2195,14 +2200,17 @@ static int iterativelength_bulk(pgq_csr_t *csr, int64_t n, const int64_t *d_src,
 }
 int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t *d_out_len) {
+	OptionScope opt_scope(csr);
 	return iterativelength_bulk(csr, n, d_src, d_dst, d_out_len, false);
 }
 int pgq_iterativelength_bidirectional_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                                   int64_t *d_out_len) {
+	OptionScope opt_scope(csr);
 	return iterativelength_bulk(csr, n, d_src, d_dst, d_out_len, true);
 }
 int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t *d_out_len, int64_t *d_out_te) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out_len || !d_out_te))) return fail(PGQ_ERR_INVALID_ARG, "NULL device array");
@@ -2222,6 +2230,7 @@ int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_
 int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                  int64_t *d_out_len, int64_t *d_out_offset, int64_t *d_child, int64_t child_cap,
                                  int64_t *child_used) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_out_len || !d_out_offset || !d_child)))
@@ -2239,6 +2248,7 @@ int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src
 // the CSR, and the results land in the caller's host array (the gather).  No collective inside the search
 // (results are a pure function of (CSR, src, dst)).
 int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!src || !dst || !out_len))) return fail(PGQ_ERR_INVALID_ARG, "NULL array");
@@ -2262,6 +2272,7 @@ int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, con
 // the preceding shards' sizes — the gather of the ragged [v,e,v,...] lists.
 int pgq_shortestpath_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len,
                            int64_t *out_offset, int64_t *child, int64_t child_cap, int64_t *child_used) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!src || !dst || !out_len || !out_offset)) || child_cap < 0 || (child_cap > 0 && !child))
@@ -2323,6 +2334,7 @@ int pgq_shortestpath_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const 
 // bytes (1 = a path exists)
 int pgq_cheapest_path_length_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, void *out,
                                    uint8_t *out_valid) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
 	if (n < 0 || (n > 0 && (!src || !dst || !out || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL array");
@@ -2351,6 +2363,7 @@ int pgq_cheapest_path_length_multi(pgq_csr_t *csr, int64_t n, const int64_t *src
 
 static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
                                  uint64_t *out_valid, bool bidir) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_csr(csr, V));
 	if (n < 0 || (n > 0 && (!out_len || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
@@ -2377,15 +2390,18 @@ static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t
 }
 int pgq_iterativelength(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
                         uint64_t *out_valid) {
+	OptionScope opt_scope(csr);
 	return iterativelength_chunk(csr, V, n, src, dst, out_len, out_valid, false);
 }
 int pgq_iterativelength_bidirectional(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
                                       uint64_t *out_valid) {
+	OptionScope opt_scope(csr);
 	return iterativelength_chunk(csr, V, n, src, dst, out_len, out_valid, true);
 }
 
 int pgq_shortestpath(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, uint64_t *out_offset,
                      uint64_t *out_length, uint64_t *out_valid, const int64_t **out_child, uint64_t *out_child_len) {
+	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_csr(csr, V));
 	if (n < 0 || (n > 0 && (!out_offset || !out_length || !out_valid)) || !out_child || !out_child_len)

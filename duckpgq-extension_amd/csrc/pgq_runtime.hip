@@ -37,7 +37,12 @@ int current_device() { return t_device >= 0 ? t_device : g_device; }
 void bind_thread_device(int device) { t_device = device; }
 const std::vector<int> &enabled_devices() { return g_devices; }
 static Options g_opt;
-Options &options() { return g_opt; }
+// a search call on a handle that carries its own options (pgq_csr_set_option) sees those, on every host thread that
+// works for the call; everything else sees the process-wide set
+static thread_local Options *t_opt = nullptr;
+Options &options() { return t_opt ? *t_opt : g_opt; }
+Options *options_override() { return t_opt; }
+void set_options_override(Options *o) { t_opt = o; }
 
 ThreadStats::ThreadStats() { memset(&s, 0, sizeof(s)); }
 ThreadStats &tstats() {
@@ -51,8 +56,7 @@ struct OptRef {
 	int *i;
 	double *d;
 };
-static std::vector<OptRef> option_table() {
-	Options &o = options();
+static std::vector<OptRef> option_table(Options &o) {
 	return {
 		{ "words", &o.words, nullptr },
 		{ "max_words", &o.max_words, nullptr },
@@ -145,7 +149,7 @@ static int do_init(int device) {
 	g_device = device;
 	if (g_devices.empty()) g_devices.push_back(device);
 	// every option of the table can be preset from the environment: PGQ_<NAME IN CAPITALS>
-	for (const OptRef &r : option_table()) {
+	for (const OptRef &r : option_table(g_opt)) {
 		std::string name = "PGQ_";
 		for (const char *q = r.name; *q; q++) name += (char)toupper((unsigned char)*q);
 		if (r.i) env_int(name.c_str(), *r.i);
@@ -1316,9 +1320,9 @@ int64_t pgq_csr_device_bytes(const pgq_csr_t *csr) { return csr ? csr->bytes : -
 
 extern "C" {
 
-int pgq_set_option(const char *key, const char *value) {
+static int set_option_in(Options &o, const char *key, const char *value) {
 	if (!key || !value) return fail(PGQ_ERR_INVALID_ARG, "NULL option");
-	for (const OptRef &r : option_table()) {
+	for (const OptRef &r : option_table(o)) {
 		if (strcmp(r.name, key) != 0) continue;
 		if (r.i) *r.i = atoi(value);
 		else *r.d = atof(value);
@@ -1326,15 +1330,31 @@ int pgq_set_option(const char *key, const char *value) {
 	}
 	return fail(PGQ_ERR_INVALID_ARG, std::string("unknown option: ") + key);
 }
-
-int pgq_get_option(const char *key, double *value) {
+static int get_option_in(Options &o, const char *key, double *value) {
 	if (!key || !value) return fail(PGQ_ERR_INVALID_ARG, "NULL option");
-	for (const OptRef &r : option_table()) {
+	for (const OptRef &r : option_table(o)) {
 		if (strcmp(r.name, key) != 0) continue;
 		*value = r.i ? (double)*r.i : *r.d;
 		return PGQ_OK;
 	}
 	return fail(PGQ_ERR_INVALID_ARG, std::string("unknown option: ") + key);
+}
+
+int pgq_set_option(const char *key, const char *value) { return set_option_in(g_opt, key, value); }
+int pgq_get_option(const char *key, double *value) { return get_option_in(g_opt, key, value); }
+
+// Options of ONE handle: the first call copies the process-wide set, later searches on this handle use the copy (two
+// DuckDB connections, or a test, can tune their own CSR without touching each other's).  Upload-time options
+// (meet_align, hub_chunk, ...) were consumed when the handle was built and are not affected.
+int pgq_csr_set_option(pgq_csr_t *csr, const char *key, const char *value) {
+	if (!csr || csr->is_replica) return fail(PGQ_ERR_INVALID_ARG, "pgq_csr_set_option: NULL or replica handle");
+	std::lock_guard<std::mutex> g(csr->replica_lock);
+	if (!csr->opt) csr->opt.reset(new Options(g_opt));
+	return set_option_in(*csr->opt, key, value);
+}
+int pgq_csr_get_option(pgq_csr_t *csr, const char *key, double *value) {
+	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "pgq_csr_get_option: NULL handle");
+	return get_option_in(csr->opt ? *csr->opt : g_opt, key, value);
 }
 
 const char *pgq_kclass_name(int k) {

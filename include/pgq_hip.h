@@ -201,6 +201,12 @@ int pgq_weakly_connected_component_device(pgq_csr_t *csr, int64_t *d_ids);
 int pgq_set_option(const char *key, const char *value);
 /* Current value of a knob (integers are returned as doubles). */
 int pgq_get_option(const char *key, double *value);
+/* Options of ONE handle: the first pgq_csr_set_option copies the process-wide set into the handle; searches on this
+ * handle then run under the copy (on every host thread that works for the call), so that two connections, or a test,
+ * can tune their own CSR without touching each other's.  Options consumed at upload (meet_align, hub_chunk, ...) are
+ * not affected. */
+int pgq_csr_set_option(pgq_csr_t *csr, const char *key, const char *value);
+int pgq_csr_get_option(pgq_csr_t *csr, const char *key, double *value);
 
 /* Per-thread counters of the searches run since the last reset, and per-kernel-class HIP-event time
  * (only accumulated while option "profile" = "1"). */

@@ -1056,3 +1056,35 @@ def test_weakly_connected_component_device_matches_goldens_and_oracle():
         assert (out[ok] == want[wok]).all(), k
     with pytest.raises(pgq.PgqError, match="CSR not found. Is the graph populated"):
         st.weakly_connected_component(99, [0])
+
+
+def test_options_of_one_handle_do_not_leak_into_another():
+    """pgq_csr_set_option: a handle's own copy of the options (round 2's were process-wide only: two connections, or
+    a test, tuned each other's searches)."""
+    import torch
+    rng = np.random.default_rng(17)
+    V, E = 20000, 200000
+    s, d, e = random_graph(rng, V, E)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    a, b = pgq.DeviceCSR(V, off, adj, eid), pgq.DeviceCSR(V, off, adj, eid)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    pgq.set_option("meet", 1)
+    a.set_option("meet", 0)           # handle a: lane batches only, with another batch width
+    a.set_option("words", 2)
+    assert a.get_option("meet") == 0 and b.get_option("meet") == 1 and pgq.get_option("meet") == 1
+    n = 3000
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+    want = np.where(ook, oln, -1)
+    d_src, d_dst = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+    d_len = torch.empty(n, dtype=torch.int64, device="cuda")
+    for dev, expect_meet in ((a, False), (b, True), (a, False)):
+        pgq.reset_stats()
+        dev.iterativelength_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr())
+        assert (d_len.cpu().numpy() == want).all()
+        st = pgq.get_stats()
+        assert (st["meet_pairs"] > 0) == expect_meet  # handle a never sees the pre-pass, handle b does
+        if not expect_meet:
+            assert st["levels"] > 0
+    with pytest.raises(pgq.PgqError, match="unknown option"):
+        a.set_option("no_such_option", 1)

@@ -924,7 +924,7 @@ struct MeetDecision {
 	double estimate;  // distinct sources of the whole input
 };
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
-                                                     double batch_bytes, MeetDecision *__restrict__ out) {
+                                                     double edge_bytes, MeetDecision *__restrict__ out) {
 	__shared__ u32 s_set[kSampleSlots];
 	__shared__ u32 s_count[2];
 	for (int k = threadIdx.x; k < kSampleSlots; k += 1024) s_set[k] = kMeetEmpty;
@@ -974,8 +974,7 @@ __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *
 		est = fmin((double)n, ceil((double)hi));
 	}
 	const double distinct = fmin(est, (double)V);
-	const double batches = floor((distinct + 2047.0) / 2048.0);
-	out->go = meet_bytes <= batch_bytes * batches ? 1u : 0u;
+	out->go = meet_bytes <= lanes_cost_bytes(edge_bytes, distinct) ? 1u : 0u;
 	out->sample_rows = s_count[1];
 	out->sample_fresh = s_count[0];
 	out->estimate = est;
@@ -1013,10 +1012,10 @@ __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int
 // others are compacted into ws->def_src/def_dst/def_idx and counted in *n_open.  The whole chain — decision (large
 // inputs), k_meet3, the bit-map kernel, the bidirectional search for a handful of leftovers, the compactions between
 // them — is launched back to back; every kernel reads what it needs (the go flag, the number of rows still open) from
-// device memory, so the host waits ONCE per call.  decide: k_meet_decide compares `meet_bytes` with `batch_bytes` x
-// batches of distinct sources first; *ran = false when it said no (nothing was written to d_out).
+// device memory, so the host waits ONCE per call.  decide: k_meet_decide compares `meet_bytes` with the lanes' cost for
+// the sampled number of distinct sources (lanes_cost_bytes) first; *ran = false when it said no (nothing was written to d_out).
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, bool paths, bool decide, double meet_bytes, double batch_bytes, bool *ran) {
+                 u32 *n_open, bool paths, bool decide, double meet_bytes, double edge_bytes, bool *ran) {
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
 	const Options &opt = options();
@@ -1039,7 +1038,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	const u32 *d_go = decide ? &db->dec.go : nullptr;
 	PGQ_HIP_TRY(hipMemsetAsync(db, 0, sizeof(DevBlock), st));
 	if (decide)
-		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, batch_bytes, &db->dec);
+		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec);
 	{
 		const int64_t cap = std::max(1, paths ? opt.meet_cap_paths : opt.meet_cap);
 		KernelTimer kt(st, K_MEET);

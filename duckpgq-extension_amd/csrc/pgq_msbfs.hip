@@ -1867,12 +1867,15 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// depth 1 = the stragglers a lane batch deferred (a few far pairs of a cross product): the pre-pass answers them from
 	// two-hop scans instead of another round of whole-graph levels
 	const bool may_meet = mopt.meet && !outp.want_te && outp.depth <= 1 && !outp.from_meet && c->E > 0 && c->fdesc != nullptr;
+	// Cost model (bytes at streaming rate): the pre-pass walks, per row, the cheaper endpoint's two-hop neighbourhood
+	// (~0.6 of E[in-degree x out-degree] entries when it has to walk all of it; it usually stops far earlier: the estimate
+	// is on the safe side).  A lane batch of `wd` lane-words costs about one sparse and one dense bottom-up level
+	// (or the probes that replace it): E x (12 + 3 wd) bytes — calibrated on the 2048-lane batch of the SF100-shaped
+	// graph (0.94 ms ~ 4.3 GB at streaming rate; round 2 priced a batch at 16 B per edge and sent a 2048 x 32 cross product
+	// through the lanes at three times the cost of the pre-pass).  `meet_bias` scales the lanes' side.
 	const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
-	const double batch_bytes = mopt.meet_bias * (double)c->E * 16.0;
-	auto meet_pays = [&](int64_t distinct_sources) {
-		const double batches = (double)((distinct_sources + 2047) / 2048);
-		return meet_bytes <= batch_bytes * batches;
-	};
+	const double edge_bytes = mopt.meet_bias * (double)c->E; // x (12 + 3 wd) per batch
+	auto meet_pays = [&](int64_t distinct_sources) { return meet_bytes <= lanes_cost_bytes(edge_bytes, (double)distinct_sources); };
 	// few rows: every row is taken as a distinct source (the pessimistic case for the pre-pass); many rows: a sampled
 	// estimate of the distinct sources decides ON THE DEVICE, in the same launch chain (cross products share their lanes)
 	const bool decide = n > 16384;
@@ -1880,7 +1883,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// packed first, the lists of the rows left to the lane-batched search are appended behind them
 	auto run_meet_paths = [&](bool *ran) -> int {
 		u32 nd = 0;
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, true, decide, meet_bytes, batch_bytes, ran));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, true, decide, meet_bytes, edge_bytes, ran));
 		if (!*ran) return PGQ_OK;
 		int64_t total = 0;
 		PGQ_TRY(meet_path_offsets(ws, n, d_out_len, &total));
@@ -1923,7 +1926,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	auto run_meet = [&](bool *ran) -> int {
 		if (with_paths) return run_meet_paths(ran);
 		u32 nd = 0;
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, false, decide, meet_bytes, batch_bytes, ran));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, false, decide, meet_bytes, edge_bytes, ran));
 		if (!*ran) return PGQ_OK;
 		if (nd > 0) {
 			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));

@@ -1,5 +1,6 @@
 // pgq_search.h — per-call workspace and lane assignment shared by the BFS and cheapest-path drivers
 #pragma once
+#include <cmath>
 #include <memory>
 
 #include "pgq_internal.h"
@@ -57,6 +58,19 @@ struct WorkspaceLease {
 	~WorkspaceLease();
 };
 
+// bytes (at streaming rate) the lane-batched search is priced at for `distinct` sources: full 2048-lane batches of 32
+// lane-words plus one narrower batch for the rest, E x (12 + 3 wd) each; `edge_bytes` = meet_bias x E.  Shared by the
+// host-side decision (few rows) and k_meet_decide (sampled distinct sources).
+__host__ __device__ static inline double lanes_cost_bytes(double edge_bytes, double distinct) {
+	const double full = floor(distinct / 2048.0), rest = distinct - full * 2048.0;
+	double wd = 0.0;
+	if (rest > 0.0) {
+		wd = 1.0;
+		while (wd * 64.0 < rest) wd *= 2.0;
+	}
+	return edge_bytes * (full * (12.0 + 3.0 * 32.0) + (rest > 0.0 ? 12.0 + 3.0 * wd : 0.0));
+}
+
 static inline unsigned blocks_for(int64_t n, int block = 256) {
 	return (unsigned)std::max<int64_t>(1, (n + block - 1) / block);
 }
@@ -70,7 +84,7 @@ int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const 
 // compacts the others into ws->def_src/def_dst/def_idx; meet_apply scatters their lengths back.  decide: whether the
 // pre-pass pays (distinct sources, sampled) is settled on the device in the same launch chain; *ran = false: it did not run.
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, bool paths, bool decide, double meet_bytes, double batch_bytes, bool *ran);
+                 u32 *n_open, bool paths, bool decide, double meet_bytes, double edge_bytes, bool *ran);
 // iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its
 // caps are compacted like the pre-pass's open rows
 int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,

@@ -292,10 +292,10 @@ def test_meet_prepass_large_inputs_cross_product_vs_distinct_sources():
     assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
     # cross product: lane batches (only stragglers a batch defers may come back through the pre-pass)
     assert pgq.get_stats()["meet_pairs"] < len(ps) // 4 and pgq.get_stats()["levels"] > 0
-    # grouped by source with a group size that a fixed sampling stride would alias with (2048 sources x 16 rows: one
-    # sampled row per source would look like 32768 distinct pairs); the sampler takes runs of consecutive rows
-    srcs = rng.choice(V, 2048, replace=False)
-    ps = np.repeat(srcs, 16)
+    # grouped by source with a group size that a fixed sampling stride would alias with (64 sources x 512 rows: one
+    # sampled row per group at a fixed stride would look like distinct pairs); the sampler takes runs of consecutive rows
+    srcs = rng.choice(V, 64, replace=False)
+    ps = np.repeat(srcs, 512)
     pd = rng.integers(0, V, len(ps))
     oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
     pgq.reset_stats()

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "pgq_search.h"
+#include <chrono>
 
 namespace pgq {
 
@@ -61,81 +62,236 @@ __global__ void k_cheapest_init(const int32_t *__restrict__ usrc, int64_t U, int
 	touched[atomicAdd(tcount, 1u)] = v;
 }
 
-// One wavefront per changed vertex v; lane l = search l.  Walks v's out-edges (wave-uniform loop, scalar
-// adjacency/weight loads), every lane relaxes its own distance: coalesced 512-byte rows of dist[n][*].
-// One round of the batched relaxation.  Two things keep it from being a plain Jacobi sweep (which re-relaxes a vertex
-// every time its label improves: ~14 sweeps of the whole graph per batch on the weighted knows graph):
-//  * ORDER: only labels below `thr` are expanded this round, the others stay dirty (re-queued) — a band-wise approach
-//    to Dijkstra's order, so that most vertices are expanded once, with their final label.  The host raises `thr` by
-//    a fraction of the mean weight per round and jumps over empty bands (min_deferred).
+// ---------------------------------------------------------------------------------------------------------------
+// One round of the batched relaxation: one wavefront per changed vertex v, lane l = search l.  Every lane relaxes its
+// own label over v's out-edges: coalesced 512-byte rows of dist[n][*].  Two things keep it from being a plain Jacobi
+// sweep:
+//  * ORDER (optional, relax_delta_div): only labels below `thr` are expanded this round, the others stay dirty.
 //  * BOUND: a lane never expands a vertex whose label already reaches the largest tentative label among the lane's own
 //    destinations (`bound`, refreshed every round): with non-negative weights nothing beyond can improve an answer.
 // Neither changes the fixpoint at the destinations (every vertex on a cheaper path has a smaller label than the bound
 // and is expanded after its last improvement), nor the left-to-right fold of the reference (cheapest_path_length.cpp:29-36),
 // so int64 and double results stay bit-identical.  Labels are compared as their (non-negative) bit patterns.
+//
+// What a round costs is the number of DEPENDENT memory round trips a wavefront makes per vertex (the per-round trace of
+// the weighted knows graph: ~420 K changed vertices with 4-6 useful edges each, for a dozen rounds), so the kernel is
+// written to keep that chain short:
+//  * the edges are handled eight at a time: adjacency+weights, then the eight label rows, then the eight atomicMin,
+//    then — lanes 0..7, one improved neighbour each — the returning atomicOr on the neighbour's dirty word, whose old
+//    value 0 says "first to dirty it this round: append it" (no separate queue flag), and the first-touch flag;
+//  * appends to the next queue / the touched list are collected per wavefront in LDS and written 64 at a time (one
+//    atomicAdd per VERTEX on the list counters serialised at ~12 ns each: 5 ms per round);
+//  * the header of the wavefront's next vertex (dirty word, label row, list bounds) is requested before the current
+//    vertex's edges are walked, the vertex after that is read from the queue.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int kRelaxUnroll = 8;
+static constexpr int kPendCap = 64 + kRelaxUnroll;
+
+// wave-level buffered append: lanes with `fresh` add n to the wavefront's pending list (LDS), 64 entries go out at once
+__device__ __forceinline__ void relax_append(int *s_buf, int &pend, bool fresh, int n, int32_t *__restrict__ list,
+                                             u32 *__restrict__ counter, int lane) {
+	const u64 fm = __ballot(fresh);
+	if (!fm) return;
+	if (fresh) s_buf[pend + __popcll(fm & ((1ull << lane) - 1ull))] = n;
+	pend += __popcll(fm);
+	__builtin_amdgcn_wave_barrier();
+	if (pend >= 64) {
+		u32 base = 0;
+		if (lane == 0) base = atomicAdd(counter, 64u);
+		base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+		list[base + lane] = s_buf[lane];
+		const int rest = pend - 64; // < kRelaxUnroll
+		const int r = lane < rest ? s_buf[64 + lane] : 0;
+		__builtin_amdgcn_wave_barrier();
+		if (lane < rest) s_buf[lane] = r;
+		pend = rest;
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+__device__ __forceinline__ void relax_flush(int *s_buf, int &pend, int32_t *__restrict__ list, u32 *__restrict__ counter,
+                                            int lane) {
+	if (pend == 0) return;
+	u32 base = 0;
+	if (lane == 0) base = atomicAdd(counter, (u32)pend);
+	base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+	if (lane < pend) list[base + lane] = s_buf[lane];
+	pend = 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                const T *__restrict__ w, int64_t *__restrict__ dist,
                                                u64 *__restrict__ dirty_cur, u64 *__restrict__ dirty_nxt,
                                                const int32_t *__restrict__ qcur, const u32 *__restrict__ nq_ptr,
                                                int32_t *__restrict__ qnxt, u32 *__restrict__ nq_nxt,
-                                               u32 *__restrict__ qflag, u32 epoch, u32 *__restrict__ tflag,
-                                               u32 tepoch, int32_t *__restrict__ touched, u32 *__restrict__ tcount,
-                                               u64 *__restrict__ relaxed_edges, long long thr,
+                                               u32 *__restrict__ tflag, u32 tepoch, int32_t *__restrict__ touched,
+                                               u32 *__restrict__ tcount, u64 *__restrict__ relaxed_edges, long long thr,
                                                const long long *__restrict__ bound, long long *__restrict__ min_deferred,
-                                               u32 *__restrict__ relaxed_vertices) {
+                                               u32 *__restrict__ relaxed_vertices, int sorted, T wcap,
+                                               int heavy_pass, u64 *__restrict__ heavy_ctr, int32_t *__restrict__ hv,
+                                               u64 *__restrict__ hmask, u32 *__restrict__ hstart, u32 *__restrict__ hmap) {
+	// Long lists are not walked by the wavefront that finds them (a round would take as long as its longest list: one
+	// hub of 1 800 edges = 230 dependent trips).  Pass 0 (heavy_pass = 0) appends such a vertex to the heavy list — one
+	// packed 64-bit atomicAdd hands out its entry index and the first of its chunk numbers together — and writes
+	// hmap[chunk] = entry; pass 1 (a second launch, items = chunks) walks kHeavyChunk edges per wavefront.  Over
+	// weight-sorted lists only the prefix under the cap counts: a list is heavy if its 129th edge is still under it.
+	constexpr int64_t kHeavyMin = 128;
+	constexpr int64_t kHeavyChunk = 64;
+	constexpr int UNR = kRelaxUnroll;
+	__shared__ int s_pq[4][kPendCap];
+	__shared__ int s_pt[4][kPendCap];
 	const int lane = threadIdx.x & 63;
+	const int wib = threadIdx.x >> 6;
 	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
-	const u32 nq = *nq_ptr;
+	const u32 nq = heavy_pass ? (u32)(*heavy_ctr & 0xFFFFFFFFull) : *nq_ptr;
 	const long long my_bound = bound[lane];
 	u64 edges = 0;
 	u32 expanded = 0;
 	long long min_def = 0x7FFFFFFFFFFFFFFFll;
-	for (u32 i = wave; i < nq; i += nwaves) {
-		const int v = qcur[i];
-		const u64 mask = dirty_cur[v];
-		if (lane == 0) dirty_cur[v] = 0; // consumed; nobody else touches dirty_cur this round
-		const int64_t dvb = dist[(size_t)v * LC + lane];
-		const bool live = ((mask >> lane) & 1ull) && dvb < my_bound;
-		const bool mine = live && dvb < thr;
-		const u64 deferred = __ballot(live && !mine);
-		if (deferred) { // stays dirty for a later round
-			if (live && !mine) min_def = min(min_def, (long long)dvb);
-			if (lane == 0) {
-				atomicOr(&dirty_nxt[v], deferred);
-				if (qflag[v] != epoch && atomicExch(&qflag[v], epoch) != epoch) qnxt[atomicAdd(nq_nxt, 1u)] = v;
+	int pend_q = 0, pend_t = 0; // wave-uniform
+	int *const pq = s_pq[wib];
+	int *const pt = s_pt[wib];
+
+	// relax the edges [b, e) of v (label row dvb, lanes `mine`)
+	auto walk = [&](int v, int64_t dvb, bool mine, int64_t b, int64_t e) {
+		if (!sorted) edges += (u64)(e - b);
+		bool stop = false;
+		for (int64_t k0 = b; k0 < e && !stop; k0 += UNR) {
+			int nn[UNR];
+			T ww[UNR];
+			int64_t cand[UNR], curv[UNR];
+#pragma unroll
+			for (int u = 0; u < UNR; u++) {
+				const bool in = k0 + u < e;
+				nn[u] = in ? adj[k0 + u] : v;
+				ww[u] = in ? w[k0 + u] : T(0);
 			}
+#pragma unroll
+			for (int u = 0; u < UNR; u++) {
+				if constexpr (std::is_same<T, double>::value) cand[u] = __double_as_longlong(__longlong_as_double(dvb) + ww[u]);
+				else cand[u] = dvb + (int64_t)ww[u];
+				curv[u] = dist[(size_t)nn[u] * LC + lane]; // unconditional: all eight rows are in flight together
+			}
+			// how many of the eight count: up to the end of the list, the cap of the phase, or the first edge no lane's
+			// candidate gets under its bound with (the list ascends by weight: no later one can either)
+			int nv = 0;
+#pragma unroll
+			for (int u = 0; u < UNR; u++) {
+				if (stop || k0 + u >= e) break;
+				if (sorted && (ww[u] > wcap || !__any(mine && cand[u] < my_bound))) {
+					stop = true;
+					break;
+				}
+				nv++;
+			}
+			if (sorted) edges += (u64)nv;
+#pragma unroll
+			for (int u = 0; u < UNR; u++) {
+				const bool go = u < nv && mine && (!sorted || cand[u] < my_bound) && cand[u] < curv[u];
+				curv[u] = cand[u]; // "not improved" unless the atomic says otherwise
+				if (go) curv[u] = atomicMin((long long *)&dist[(size_t)nn[u] * LC + lane], (long long)cand[u]);
+			}
+			u64 my_im = 0;
+			int my_n = 0;
+#pragma unroll
+			for (int u = 0; u < UNR; u++) {
+				const u64 im = __ballot(cand[u] < curv[u]);
+				if (lane == u) {
+					my_im = im;
+					my_n = nn[u];
+				}
+			}
+			if (!__any(my_im != 0)) continue;
+			bool fresh_q = false, fresh_t = false;
+			if (my_im) { // lanes 0..7, one improved neighbour each
+				fresh_q = atomicOr(&dirty_nxt[my_n], my_im) == 0ull;
+				fresh_t = tflag[my_n] != tepoch && atomicExch(&tflag[my_n], tepoch) != tepoch;
+			}
+			relax_append(pq, pend_q, fresh_q, my_n, qnxt, nq_nxt, lane);
+			relax_append(pt, pend_t, fresh_t, my_n, touched, tcount, lane);
 		}
-		if (!__any(mine)) continue;
-		expanded++;
-		const int64_t b = off[v], e = off[v + 1];
-		edges += (u64)(e - b);
-		for (int64_t k = b; k < e; k++) {
-			const int n = adj[k];
-			const T wt = w[k];
-			bool improved = false;
-			if (mine) {
-				int64_t cand;
-				if constexpr (sizeof(T) == 8 && std::is_same<T, double>::value) {
-					cand = __double_as_longlong(__longlong_as_double(dvb) + wt);
+	};
+
+	if (heavy_pass) {
+		for (u32 i = wave; i < nq; i += nwaves) {
+			const u32 ent = hmap[i];
+			const int v = hv[ent];
+			const int64_t b = off[v] + (int64_t)(i - hstart[ent]) * kHeavyChunk;
+			const int64_t e = min(b + kHeavyChunk, off[v + 1]);
+			if (sorted && w[b] > wcap) continue; // the whole chunk lies above this phase's cap
+			// the label may have improved since pass 0 queued v: any label is the length of a real path, the smaller the better
+			const int64_t dvb = dist[(size_t)v * LC + lane];
+			walk(v, dvb, (hmask[ent] >> lane) & 1ull, b, e);
+		}
+	} else {
+		// software pipeline over the wavefront's vertices: queue entry two ahead, header one ahead
+		u32 i = wave, i1 = wave + nwaves, i2 = wave + 2 * nwaves;
+		int v = i < nq ? qcur[i] : 0;
+		int v1 = i1 < nq ? qcur[i1] : 0;
+		u64 mask = 0;
+		int64_t dvb = 0, b = 0, e = 0;
+		if (i < nq) {
+			mask = dirty_cur[v];
+			dvb = dist[(size_t)v * LC + lane];
+			b = off[v];
+			e = off[v + 1];
+		}
+		while (i < nq) {
+			u64 mask1 = 0;
+			int64_t dvb1 = 0, b1 = 0, e1 = 0;
+			if (i1 < nq) {
+				mask1 = dirty_cur[v1];
+				dvb1 = dist[(size_t)v1 * LC + lane];
+				b1 = off[v1];
+				e1 = off[v1 + 1];
+			}
+			const int v2 = i2 < nq ? qcur[i2] : 0;
+			if (lane == 0) dirty_cur[v] = 0; // consumed; nobody else touches dirty_cur this round
+			const bool live = ((mask >> lane) & 1ull) && dvb < my_bound;
+			const bool mine = live && dvb < thr;
+			const u64 deferred = __ballot(live && !mine);
+			if (deferred) { // stays dirty for a later round
+				if (live && !mine) min_def = min(min_def, (long long)dvb);
+				bool fresh = false;
+				if (lane == 0) fresh = atomicOr(&dirty_nxt[v], deferred) == 0ull;
+				relax_append(pq, pend_q, fresh, v, qnxt, nq_nxt, lane);
+			}
+			const u64 mine_mask = __ballot(mine);
+			if (mine_mask) {
+				expanded++;
+				bool is_heavy = false;
+				if (heavy_ctr && e - b > kHeavyMin) is_heavy = !sorted || !(w[b + kHeavyMin] > wcap);
+				if (is_heavy) {
+					const u32 nch = (u32)((e - b + kHeavyChunk - 1) / kHeavyChunk);
+					u64 t = 0;
+					if (lane == 0) t = atomicAdd(heavy_ctr, (1ull << 32) | (u64)nch);
+					const u32 cs = (u32)__builtin_amdgcn_readfirstlane((int)(u32)t);
+					const u32 ent = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(t >> 32));
+					if (lane == 0) {
+						hv[ent] = v;
+						hmask[ent] = mine_mask;
+						hstart[ent] = cs;
+					}
+					for (u32 c = lane; c < nch; c += 64) hmap[cs + c] = ent;
 				} else {
-					cand = dvb + (int64_t)wt;
-				}
-				int64_t *dp = &dist[(size_t)n * LC + lane];
-				if (cand < *dp) {
-					const int64_t old = atomicMin((long long *)dp, (long long)cand);
-					improved = cand < old;
+					walk(v, dvb, mine, b, e);
 				}
 			}
-			const u64 imask = __ballot(improved);
-			if (imask && lane == 0) {
-				atomicOr(&dirty_nxt[n], imask);
-				if (qflag[n] != epoch && atomicExch(&qflag[n], epoch) != epoch) qnxt[atomicAdd(nq_nxt, 1u)] = n;
-				if (tflag[n] != tepoch && atomicExch(&tflag[n], tepoch) != tepoch) touched[atomicAdd(tcount, 1u)] = n;
-			}
+			i = i1;
+			i1 = i2;
+			i2 += nwaves;
+			v = v1;
+			v1 = v2;
+			mask = mask1;
+			dvb = dvb1;
+			b = b1;
+			e = e1;
 		}
 	}
+	relax_flush(pq, pend_q, qnxt, nq_nxt, lane);
+	relax_flush(pt, pend_t, touched, tcount, lane);
 	for (int o = 32; o > 0; o >>= 1) min_def = min(min_def, (long long)__shfl_xor(min_def, o));
 	if (lane == 0) {
 		if (edges) atomicAdd(relaxed_edges, edges);
@@ -169,6 +325,7 @@ struct RelaxCounters {
 	long long min_deferred; // smallest label (bit pattern) a round left for later (k_relax's threshold)
 	u32 relaxed_vertices;   // vertices a round expanded
 	u32 pad;
+	u64 heavy;              // (entries << 32) | chunks of the round's heavy list (k_relax)
 	long long bound[64];    // per lane: the largest tentative label among its destinations (nothing beyond it matters)
 };
 
@@ -716,6 +873,63 @@ static int ensure_reverse_weights(pgq_csr *c, Workspace *ws) {
 	return rc;
 }
 
+// a new phase (higher cap on the edge weight): every labelled vertex is expanded again over the longer prefix of its list
+__global__ void k_redirty(const int32_t *__restrict__ touched, const u32 *__restrict__ tcount, u64 *__restrict__ dirty,
+                          int32_t *__restrict__ q, u32 *__restrict__ nq) {
+	const u32 n = *tcount;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int v = touched[i];
+		dirty[v] = ~0ull; // lanes without a label are skipped by their bound test
+		q[i] = v;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) *nq = n;
+}
+
+// the forward adjacency with every vertex's list sorted by weight (non-negative weights: their bit patterns sort like the
+// values, int64 and double alike) — segmented radix sort, once per CSR — and the largest weight
+static int ensure_weight_sorted(pgq_csr *c, Workspace *ws) {
+	std::lock_guard<std::mutex> g(g_rw_lock);
+	if (c->wadj || c->E == 0 || !c->w) return PGQ_OK;
+	hipStream_t st = ws->stream;
+	const int64_t E = c->E;
+	DevBuf tmp, mx;
+	int32_t *wadj = nullptr;
+	void *wsorted = nullptr;
+	auto body = [&]() -> int {
+		PGQ_TRY(dev_alloc_as(&wadj, (size_t)E + 4));
+		PGQ_TRY(dev_alloc(&wsorted, (size_t)E * 8));
+		PGQ_TRY(mx.reserve(64));
+		size_t sb = 0, rb = 0;
+		const unsigned long long *keys = (const unsigned long long *)c->w;
+		unsigned long long *keys_out = (unsigned long long *)wsorted;
+		PGQ_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, sb, keys, keys_out, c->adj, wadj, (int)E, (int)c->V, c->off,
+		                                                        c->off + 1, 0, 64, st));
+		PGQ_HIP_TRY(hipcub::DeviceReduce::Max(nullptr, rb, keys, mx.as<unsigned long long>(), (int)E, st));
+		PGQ_TRY(tmp.reserve(std::max(sb, rb) + 16));
+		PGQ_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp.p, sb, keys, keys_out, c->adj, wadj, (int)E, (int)c->V, c->off,
+		                                                        c->off + 1, 0, 64, st));
+		PGQ_HIP_TRY(hipcub::DeviceReduce::Max(tmp.p, rb, keys, mx.as<unsigned long long>(), (int)E, st));
+		unsigned long long m = 0;
+		PGQ_HIP_TRY(hipMemcpyAsync(&m, mx.p, 8, hipMemcpyDeviceToHost, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		if (c->w_type == PGQ_W_DOUBLE) memcpy(&c->w_max, &m, 8);
+		else c->w_max = (double)(long long)m;
+		return PGQ_OK;
+	};
+	const int rc = body();
+	(void)hipStreamSynchronize(st);
+	tmp.release();
+	mx.release();
+	if (rc != PGQ_OK) {
+		dev_free(wadj);
+		dev_free(wsorted);
+		return rc;
+	}
+	c->wsorted = wsorted;
+	c->wadj = wadj;
+	return PGQ_OK;
+}
+
 // mean edge weight (int64 or double), computed once per CSR: the band width of the ordered relaxation rounds
 static int ensure_weight_mean(pgq_csr *c, Workspace *ws) {
 	std::lock_guard<std::mutex> g(g_rw_lock);
@@ -898,6 +1112,11 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 	PGQ_TRY(ws->touched.reserve((size_t)std::max<int64_t>(V, 1) * 4));
 	PGQ_TRY(ws->qflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
 	PGQ_TRY(ws->tflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	// heavy list of a round: entries (vertex, lanes, first chunk) and the chunk -> entry map (<= E/64 + V chunks)
+	PGQ_TRY(ws->hv.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->hmask.reserve((size_t)std::max<int64_t>(V, 1) * 8));
+	PGQ_TRY(ws->hstart.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(ws->hmap.reserve((size_t)(c->E / 64 + std::max<int64_t>(V, 1)) * 4));
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
 	static_assert(sizeof(RelaxCounters) <= sizeof(Counters), "counter block too small");
 	RelaxCounters *d_rc = reinterpret_cast<RelaxCounters *>(ws->counters.p);
@@ -910,7 +1129,23 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 	PGQ_HIP_TRY(hipMemsetAsync(ws->qflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
 	PGQ_HIP_TRY(hipMemsetAsync(ws->tflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
 	u32 epoch = 0, tepoch = 0;
-	const unsigned grid = 256 * 8;
+	// the persistent grid of a round: exactly what is resident at once (each wavefront takes every nwaves-th vertex; a
+	// grid larger than the chip makes the last workgroups start when the first finish: 8192 waves on 7168 slots was 2x)
+	static std::mutex grid_lock;
+	static unsigned grid_cached[2] = { 0, 0 };
+	unsigned grid;
+	{
+		std::lock_guard<std::mutex> g(grid_lock);
+		unsigned &gc = grid_cached[type_tag - 1];
+		if (!gc) {
+			int per_cu = 0, dev = 0, cus = 0;
+			PGQ_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_relax<T>, 256, 0));
+			PGQ_HIP_TRY(hipGetDevice(&dev));
+			PGQ_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+			gc = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
+		}
+		grid = gc;
+	}
 	for (int b = 0; b < nb; b++) {
 		const int64_t lo = bs[b], hi = bs[b + 1];
 		if (lo == hi) continue;
@@ -941,8 +1176,25 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 			return r;
 		};
 		T thr_val = band;
+		// "light edges first" (relax_light): the rounds run over weight-sorted lists under a cap on the edge weight that
+		// doubles phase by phase — early phases touch a few per cent of the edges and give every lane a tight bound on
+		// its destinations, later phases hardly relax anything (a vertex stops at the first edge whose weight cannot beat
+		// its lanes' bounds) — until the cap reaches the largest bound (heavier edges cannot be on a cheaper path)
+		const bool light = options().relax_light != 0 && c->E > 0;
+		const bool heavy = options().relax_split != 0;
+		static const bool trace = getenv("PGQ_RELAX_TRACE") != nullptr; // per-round line on stderr (measurement only)
+		auto t_round = std::chrono::steady_clock::now();
+		T wcap = T(0);
+		if (light) {
+			PGQ_TRY(ensure_weight_sorted(c, ws));
+			PGQ_TRY(ensure_weight_mean(c, ws));
+			if constexpr (std::is_same<T, double>::value) wcap = c->w_mean / std::max(1, options().relax_light_div);
+			else wcap = (T)std::max<int64_t>(1, (int64_t)(c->w_mean / std::max(1, options().relax_light_div)));
+		}
+		const int32_t *r_adj = light ? c->wadj : c->adj;
+		const T *r_w = light ? (const T *)c->wsorted : (const T *)c->w;
 		for (;;) {
-			if (nq_now <= small_limit) {
+			if (!light && nq_now <= small_limit) {
 				// few changed vertices: rounds loop on the device inside one workgroup
 				const int max_rounds = 4096;
 				KernelTimer kt(st, K_RELAX);
@@ -967,26 +1219,69 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->relaxed_vertices, 0, 4, st));
 			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->min_deferred, 0x7F, 8, st)); // > every label
 			PGQ_HIP_TRY(hipMemsetAsync(d_rc->bound, 0, sizeof(d_rc->bound), st));
+			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->heavy, 0, 8, st));
 			const long long thr_bits = band > T(0) ? bits_of(thr_val) : (long long)0x7FFFFFFFFFFFFFFFll;
 			{
 				KernelTimer kt(st, K_RELAX);
 				hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned)std::min<int64_t>(blocks_for(hi - lo), 256)), dim3(256), 0, st, lo, hi,
 				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, ws->dist.as<int64_t>(), d_rc->bound);
-				hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, c->adj, (const T *)c->w,
+				hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, r_adj, r_w,
 				                   ws->dist.as<int64_t>(), ws->dirty[par].as<u64>(), ws->dirty[par ^ 1].as<u64>(),
 				                   ws->qbuf[par].as<int32_t>(), &d_rc->nq[par], ws->qbuf[par ^ 1].as<int32_t>(),
-				                   &d_rc->nq[par ^ 1], ws->qflag.as<u32>(), epoch, ws->tflag.as<u32>(), tepoch,
+				                   &d_rc->nq[par ^ 1], ws->tflag.as<u32>(), tepoch,
 				                   ws->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
-				                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices);
+				                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices, light ? 1 : 0, wcap,
+				                   0, heavy ? &d_rc->heavy : (u64 *)nullptr, ws->hv.as<int32_t>(), ws->hmask.as<u64>(),
+				                   ws->hstart.as<u32>(), ws->hmap.as<u32>());
+				if (heavy) // the long lists of the round, a chunk per wavefront
+					hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, r_adj, r_w,
+					                   ws->dist.as<int64_t>(), ws->dirty[par].as<u64>(), ws->dirty[par ^ 1].as<u64>(),
+					                   ws->qbuf[par].as<int32_t>(), &d_rc->nq[par], ws->qbuf[par ^ 1].as<int32_t>(),
+					                   &d_rc->nq[par ^ 1], ws->tflag.as<u32>(), tepoch,
+					                   ws->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
+					                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices, light ? 1 : 0, wcap,
+					                   1, &d_rc->heavy, ws->hv.as<int32_t>(), ws->hmask.as<u64>(), ws->hstart.as<u32>(),
+					                   ws->hmap.as<u32>());
 				kt.stop();
 			}
 			PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
 			PGQ_HIP_TRY(hipStreamSynchronize(st));
 			KernelTimer::flush();
+			if (trace) {
+				const auto t1 = std::chrono::steady_clock::now();
+				fprintf(stderr, "relax b=%d round=%lld cap=%g nq=%u expanded=%u heavy=%u/%u edges=%llu next=%u us=%.1f\n", b,
+				        (long long)S.levels, (double)wcap, nq_now, h_rc->relaxed_vertices, (u32)(h_rc->heavy >> 32),
+				        (u32)h_rc->heavy, (unsigned long long)h_rc->relaxed_edges, h_rc->nq[par ^ 1],
+				        std::chrono::duration<double, std::micro>(t1 - t_round).count());
+				t_round = t1;
+			}
 			S.levels++;
 			par ^= 1;
 			nq_now = h_rc->nq[par];
-			if (nq_now == 0) break;
+			if (nq_now == 0) {
+				if (!light) break;
+				// the phase has reached its fixpoint.  Done when no heavier edge can matter: the cap has reached the largest
+				// bound of a lane (the bounds of the last round: labels only got smaller since) or the largest weight
+				T max_bound = T(0);
+				bool unbounded = false;
+				for (int l = 0; l < LC; l++) {
+					if (h_rc->bound[l] >= (long long)inf_bits) unbounded = true;
+					T bv;
+					memcpy(&bv, &h_rc->bound[l], 8);
+					if (bv > max_bound) max_bound = bv;
+				}
+				if ((double)wcap >= c->w_max || (!unbounded && wcap >= max_bound)) break;
+				wcap = wcap + wcap;
+				// every labelled vertex again, over the longer prefix of its list
+				PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par], 0, 4, st));
+				hipLaunchKernelGGL(k_redirty, dim3(256 * 4), dim3(256), 0, st, ws->touched.as<int32_t>(), &d_rc->tcount,
+				                   ws->dirty[par].as<u64>(), ws->qbuf[par].as<int32_t>(), &d_rc->nq[par]);
+				PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
+				PGQ_HIP_TRY(hipStreamSynchronize(st));
+				nq_now = h_rc->nq[par];
+				if (nq_now == 0) break;
+				continue;
+			}
 			if (band > T(0)) { // next band; an empty one is skipped: straight to the smallest label left
 				thr_val = thr_val + band;
 				if (h_rc->relaxed_vertices == 0 && h_rc->min_deferred != 0x7F7F7F7F7F7F7F7Fll) {

@@ -57,6 +57,10 @@ struct Options {
 	int chain_cap = 4096;   // steps after which a chain is taken for a cycle and left to the batched relaxation
 	int alloc_cache_mb = 8192; // freed CSR / upload blocks kept for the next upload, per process (0: straight hipFree)
 	int relax_small_limit = 2048; // changed vertices at or below which relaxation rounds loop on the device
+	int relax_light = 1;      // batched relaxation over weight-sorted lists: edges above a cap that doubles phase by phase are not
+	                          // scanned, and a vertex stops at the first edge that cannot beat its lanes' bounds (0: plain rounds)
+	int relax_light_div = 4;  // first cap = mean weight / this
+	int relax_split = 1;      // lists longer than 128 edges are relaxed 64 edges per wavefront by a second launch of the round
 	int relax_delta_div = 0;  // batched relaxation: > 0 = a round only expands labels below a threshold that grows by mean weight / this
 	                          // per round.  Off: measured on the weighted knows graph it does not pay (lanes reach a vertex in different
 	                          // bands, so its adjacency is re-read per lane: 1.9 s per 512 pairs at 64, 1.24 s at 16, 1.16 s plain)
@@ -183,6 +187,11 @@ struct pgq_csr {
 	// PageRank over this CSR (V + 2 doubles), computed once per handle like the reference's bind-data state
 	void *rw = nullptr;          // E x 8 B: in-edge weights in reverse-CSR order (built on first use by the weighted pair search)
 	double w_mean = 0;
+	// cheapest_path_length on general graphs: the forward adjacency with every vertex's list sorted by weight, and the
+	// weights in that order (built on first use); w_max = the largest weight
+	int32_t *wadj = nullptr;
+	void *wsorted = nullptr;
+	double w_max = 0;
 	int64_t *wcc = nullptr;      // weakly_connected_component ids of the V + 2 forest entries (computed once per handle)
 	double *pagerank = nullptr;
 	int pagerank_iterations = 0;

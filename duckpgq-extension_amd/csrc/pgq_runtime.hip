@@ -69,6 +69,9 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "blocks_per_cu", &o.blocks_per_cu, nullptr },
 		{ "relax_small_limit", &o.relax_small_limit, nullptr },
 		{ "relax_delta_div", &o.relax_delta_div, nullptr },
+		{ "relax_light", &o.relax_light, nullptr },
+		{ "relax_light_div", &o.relax_light_div, nullptr },
+		{ "relax_split", &o.relax_split, nullptr },
 		{ "chain", &o.chain, nullptr },
 		{ "chain_cap", &o.chain_cap, nullptr },
 		{ "alloc_cache_mb", &o.alloc_cache_mb, nullptr },
@@ -971,6 +974,8 @@ static void destroy_csr(pgq_csr *c) {
 	dev_free(c->pagerank);
 	dev_free(c->wcc);
 	dev_free(c->rw);
+	dev_free(c->wadj);
+	dev_free(c->wsorted);
 	delete c;
 }
 

@@ -26,6 +26,9 @@
 
 #include "pgq_search.h"
 #include <chrono>
+#include <thread>
+#include <vector>
+#include <string>
 
 namespace pgq {
 
@@ -109,18 +112,8 @@ __device__ __forceinline__ void relax_append(int *s_buf, int &pend, bool fresh, 
 	}
 }
 
-__device__ __forceinline__ void relax_flush(int *s_buf, int &pend, int32_t *__restrict__ list, u32 *__restrict__ counter,
-                                            int lane) {
-	if (pend == 0) return;
-	u32 base = 0;
-	if (lane == 0) base = atomicAdd(counter, (u32)pend);
-	base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-	if (lane < pend) list[base + lane] = s_buf[lane];
-	pend = 0;
-}
-
 template <typename T>
-__global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+__global__ __launch_bounds__(256, 6) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                const T *__restrict__ w, int64_t *__restrict__ dist,
                                                u64 *__restrict__ dirty_cur, u64 *__restrict__ dirty_nxt,
                                                const int32_t *__restrict__ qcur, const u32 *__restrict__ nq_ptr,
@@ -141,6 +134,20 @@ __global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, 
 	constexpr int UNR = kRelaxUnroll;
 	__shared__ int s_pq[4][kPendCap];
 	__shared__ int s_pt[4][kPendCap];
+	// what the workgroup hands to the round's counters goes through LDS first: ~5 atomics per WAVEFRONT on one cache
+	// line (two list tails, three statistics) were 25 K serialised L2 operations per launch — ~150 us, the whole
+	// time of a round with few changed vertices
+	__shared__ u64 s_edges;
+	__shared__ u32 s_expanded;
+	__shared__ long long s_min_def;
+	__shared__ int s_pend[2][4];
+	__shared__ u32 s_base[2];
+	if (threadIdx.x == 0) {
+		s_edges = 0;
+		s_expanded = 0;
+		s_min_def = 0x7FFFFFFFFFFFFFFFll;
+	}
+	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int wib = threadIdx.x >> 6;
 	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -290,14 +297,32 @@ __global__ __launch_bounds__(256) void k_relax(const int64_t *__restrict__ off, 
 			e = e1;
 		}
 	}
-	relax_flush(pq, pend_q, qnxt, nq_nxt, lane);
-	relax_flush(pt, pend_t, touched, tcount, lane);
 	for (int o = 32; o > 0; o >>= 1) min_def = min(min_def, (long long)__shfl_xor(min_def, o));
 	if (lane == 0) {
-		if (edges) atomicAdd(relaxed_edges, edges);
-		if (expanded) atomicAdd(relaxed_vertices, expanded);
-		if (min_def != 0x7FFFFFFFFFFFFFFFll) atomicMin(min_deferred, min_def);
+		if (edges) atomicAdd(&s_edges, edges);
+		if (expanded) atomicAdd(&s_expanded, expanded);
+		if (min_def != 0x7FFFFFFFFFFFFFFFll) atomicMin(&s_min_def, min_def);
+		s_pend[0][wib] = pend_q;
+		s_pend[1][wib] = pend_t;
 	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const u32 tq = (u32)(s_pend[0][0] + s_pend[0][1] + s_pend[0][2] + s_pend[0][3]);
+		const u32 tt = (u32)(s_pend[1][0] + s_pend[1][1] + s_pend[1][2] + s_pend[1][3]);
+		s_base[0] = tq ? atomicAdd(nq_nxt, tq) : 0u;
+		s_base[1] = tt ? atomicAdd(tcount, tt) : 0u;
+		if (s_edges) atomicAdd(relaxed_edges, s_edges);
+		if (s_expanded) atomicAdd(relaxed_vertices, s_expanded);
+		if (s_min_def != 0x7FFFFFFFFFFFFFFFll) atomicMin(min_deferred, s_min_def);
+	}
+	__syncthreads();
+	u32 oq = s_base[0], ot = s_base[1];
+	for (int k = 0; k < wib; k++) {
+		oq += (u32)s_pend[0][k];
+		ot += (u32)s_pend[1][k];
+	}
+	if (lane < pend_q) qnxt[oq + lane] = pq[lane];
+	if (lane < pend_t) touched[ot + lane] = pt[lane];
 }
 
 // bound[lane] = the largest tentative label among the lane's destinations (rows [lo, hi) are sorted by lane); INF while
@@ -1083,51 +1108,45 @@ static int cheapest_with_chains(pgq_csr *c, Workspace *ws, int64_t n, const int6
 	return PGQ_OK;
 }
 
+// The batches b0, b0 + bstride, ... of a call: `ws` holds the sorted rows and the distinct sources (read-only here),
+// `priv` everything a batch writes (labels, dirty words, queues) and the stream.  Batches are independent, so several
+// host threads run this side by side on their own workspaces (cheapest_device).
 template <typename T>
-static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
-                           int64_t *d_out, uint8_t *d_ok, bool chain) {
-	if (chain && options().chain && n > 0 && n < (1LL << 31)) return cheapest_with_chains<T>(c, ws, n, d_src, d_dst, d_out, d_ok);
-	hipStream_t st = ws->stream;
+static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int bstride, int nb, u32 U, int64_t *d_out,
+                         uint8_t *d_ok) {
+	hipStream_t st = priv->stream;
 	const int64_t V = c->V;
 	const int64_t inf_bits = Inf<T>::bits;
 	pgq_stats_t &S = tstats().s;
-	S.pairs += n;
-	if (n == 0) return PGQ_OK;
-	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
-	u32 U = 0;
-	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U));
-	S.unique_sources += U;
-	const int nb = (int)(((int64_t)U + LC - 1) / LC);
-	PGQ_TRY(batch_bounds(ws, n, LC, nb));
 	const int64_t *bs = ws->h_bstart;
 	const size_t cells = (size_t)std::max<int64_t>(V, 1) * LC;
 	// distances start at INF; a full fill only when the array is new, afterwards only touched rows are reset
 	const int type_tag = std::is_same<T, double>::value ? 2 : 1; // the INF pattern differs between int64 and double
-	const bool fresh = ws->dist.cap < cells * 8 || ws->dist_V != V || ws->dist_lanes != type_tag;
-	ws->dist_V = -1; // stays invalid if we bail out half-way; restored at the end
-	PGQ_TRY(ws->dist.reserve(cells * 8));
-	for (int k = 0; k < 2; k++) PGQ_TRY(ws->dirty[k].reserve((size_t)std::max<int64_t>(V, 1) * 8));
-	PGQ_TRY(ws->qbuf[0].reserve((size_t)std::max<int64_t>(V, 1) * 4));
-	PGQ_TRY(ws->qbuf[1].reserve((size_t)std::max<int64_t>(V, 1) * 4));
-	PGQ_TRY(ws->touched.reserve((size_t)std::max<int64_t>(V, 1) * 4));
-	PGQ_TRY(ws->qflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
-	PGQ_TRY(ws->tflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	const bool fresh = priv->dist.cap < cells * 8 || priv->dist_V != V || priv->dist_lanes != type_tag;
+	priv->dist_V = -1; // stays invalid if we bail out half-way; restored at the end
+	PGQ_TRY(priv->dist.reserve(cells * 8));
+	for (int k = 0; k < 2; k++) PGQ_TRY(priv->dirty[k].reserve((size_t)std::max<int64_t>(V, 1) * 8));
+	PGQ_TRY(priv->qbuf[0].reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(priv->qbuf[1].reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(priv->touched.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(priv->qflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(priv->tflag.reserve((size_t)std::max<int64_t>(V, 1) * 4));
 	// heavy list of a round: entries (vertex, lanes, first chunk) and the chunk -> entry map (<= E/64 + V chunks)
-	PGQ_TRY(ws->hv.reserve((size_t)std::max<int64_t>(V, 1) * 4));
-	PGQ_TRY(ws->hmask.reserve((size_t)std::max<int64_t>(V, 1) * 8));
-	PGQ_TRY(ws->hstart.reserve((size_t)std::max<int64_t>(V, 1) * 4));
-	PGQ_TRY(ws->hmap.reserve((size_t)(c->E / 64 + std::max<int64_t>(V, 1)) * 4));
-	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	PGQ_TRY(priv->hv.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(priv->hmask.reserve((size_t)std::max<int64_t>(V, 1) * 8));
+	PGQ_TRY(priv->hstart.reserve((size_t)std::max<int64_t>(V, 1) * 4));
+	PGQ_TRY(priv->hmap.reserve((size_t)(c->E / 64 + std::max<int64_t>(V, 1)) * 4));
+	PGQ_TRY(priv->counters.reserve(sizeof(Counters)));
 	static_assert(sizeof(RelaxCounters) <= sizeof(Counters), "counter block too small");
-	RelaxCounters *d_rc = reinterpret_cast<RelaxCounters *>(ws->counters.p);
-	RelaxCounters *h_rc = reinterpret_cast<RelaxCounters *>(ws->h_cnt);
+	RelaxCounters *d_rc = reinterpret_cast<RelaxCounters *>(priv->counters.p);
+	RelaxCounters *h_rc = reinterpret_cast<RelaxCounters *>(priv->h_cnt);
 	if (fresh) {
-		hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, ws->dist.as<int64_t>(), (int64_t)cells, inf_bits);
+		hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, priv->dist.as<int64_t>(), (int64_t)cells, inf_bits);
 	}
-	PGQ_HIP_TRY(hipMemsetAsync(ws->dirty[0].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
-	PGQ_HIP_TRY(hipMemsetAsync(ws->dirty[1].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
-	PGQ_HIP_TRY(hipMemsetAsync(ws->qflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
-	PGQ_HIP_TRY(hipMemsetAsync(ws->tflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
+	PGQ_HIP_TRY(hipMemsetAsync(priv->dirty[0].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
+	PGQ_HIP_TRY(hipMemsetAsync(priv->dirty[1].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
+	PGQ_HIP_TRY(hipMemsetAsync(priv->qflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
+	PGQ_HIP_TRY(hipMemsetAsync(priv->tflag.p, 0, (size_t)std::max<int64_t>(V, 1) * 4, st));
 	u32 epoch = 0, tepoch = 0;
 	// the persistent grid of a round: exactly what is resident at once (each wavefront takes every nwaves-th vertex; a
 	// grid larger than the chip makes the last workgroups start when the first finish: 8192 waves on 7168 slots was 2x)
@@ -1146,7 +1165,7 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 		}
 		grid = gc;
 	}
-	for (int b = 0; b < nb; b++) {
+	for (int b = b0; b < nb; b += bstride) {
 		const int64_t lo = bs[b], hi = bs[b + 1];
 		if (lo == hi) continue;
 		S.batches++;
@@ -1156,8 +1175,8 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 		{
 			KernelTimer kt(st, K_PREP);
 			hipLaunchKernelGGL(k_cheapest_init, dim3(1), dim3(64), 0, st, ws->usrc.as<int32_t>(), (int64_t)U, base,
-			                   ws->dist.as<int64_t>(), ws->dirty[0].as<u64>(), ws->tflag.as<u32>(), tepoch,
-			                   ws->touched.as<int32_t>(), &d_rc->nq[0], &d_rc->tcount, ws->qbuf[0].as<int32_t>());
+			                   priv->dist.as<int64_t>(), priv->dirty[0].as<u64>(), priv->tflag.as<u32>(), tepoch,
+			                   priv->touched.as<int32_t>(), &d_rc->nq[0], &d_rc->tcount, priv->qbuf[0].as<int32_t>());
 			kt.stop();
 		}
 		int par = 0;
@@ -1199,10 +1218,10 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 				const int max_rounds = 4096;
 				KernelTimer kt(st, K_RELAX);
 				hipLaunchKernelGGL(k_relax_small<T>, dim3(1), dim3(1024), 0, st, c->off, c->adj, (const T *)c->w,
-				                   ws->dist.as<int64_t>(), ws->dirty[0].as<u64>(), ws->dirty[1].as<u64>(),
-				                   ws->qbuf[0].as<int32_t>(), ws->qbuf[1].as<int32_t>(), d_rc, par, small_limit,
-				                   ws->qflag.as<u32>(), epoch + 1, ws->tflag.as<u32>(), tepoch,
-				                   ws->touched.as<int32_t>(), max_rounds);
+				                   priv->dist.as<int64_t>(), priv->dirty[0].as<u64>(), priv->dirty[1].as<u64>(),
+				                   priv->qbuf[0].as<int32_t>(), priv->qbuf[1].as<int32_t>(), d_rc, par, small_limit,
+				                   priv->qflag.as<u32>(), epoch + 1, priv->tflag.as<u32>(), tepoch,
+				                   priv->touched.as<int32_t>(), max_rounds);
 				kt.stop();
 				PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
 				PGQ_HIP_TRY(hipStreamSynchronize(st));
@@ -1224,24 +1243,24 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 			{
 				KernelTimer kt(st, K_RELAX);
 				hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned)std::min<int64_t>(blocks_for(hi - lo), 256)), dim3(256), 0, st, lo, hi,
-				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, ws->dist.as<int64_t>(), d_rc->bound);
-				hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, r_adj, r_w,
-				                   ws->dist.as<int64_t>(), ws->dirty[par].as<u64>(), ws->dirty[par ^ 1].as<u64>(),
-				                   ws->qbuf[par].as<int32_t>(), &d_rc->nq[par], ws->qbuf[par ^ 1].as<int32_t>(),
-				                   &d_rc->nq[par ^ 1], ws->tflag.as<u32>(), tepoch,
-				                   ws->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
+				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, priv->dist.as<int64_t>(), d_rc->bound);
+				hipLaunchKernelGGL(k_relax<T>, dim3(std::min(grid, std::max(1u, (nq_now + 3) / 4))), dim3(256), 0, st, c->off, r_adj, r_w,
+				                   priv->dist.as<int64_t>(), priv->dirty[par].as<u64>(), priv->dirty[par ^ 1].as<u64>(),
+				                   priv->qbuf[par].as<int32_t>(), &d_rc->nq[par], priv->qbuf[par ^ 1].as<int32_t>(),
+				                   &d_rc->nq[par ^ 1], priv->tflag.as<u32>(), tepoch,
+				                   priv->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
 				                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices, light ? 1 : 0, wcap,
-				                   0, heavy ? &d_rc->heavy : (u64 *)nullptr, ws->hv.as<int32_t>(), ws->hmask.as<u64>(),
-				                   ws->hstart.as<u32>(), ws->hmap.as<u32>());
+				                   0, heavy ? &d_rc->heavy : (u64 *)nullptr, priv->hv.as<int32_t>(), priv->hmask.as<u64>(),
+				                   priv->hstart.as<u32>(), priv->hmap.as<u32>());
 				if (heavy) // the long lists of the round, a chunk per wavefront
 					hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, r_adj, r_w,
-					                   ws->dist.as<int64_t>(), ws->dirty[par].as<u64>(), ws->dirty[par ^ 1].as<u64>(),
-					                   ws->qbuf[par].as<int32_t>(), &d_rc->nq[par], ws->qbuf[par ^ 1].as<int32_t>(),
-					                   &d_rc->nq[par ^ 1], ws->tflag.as<u32>(), tepoch,
-					                   ws->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
+					                   priv->dist.as<int64_t>(), priv->dirty[par].as<u64>(), priv->dirty[par ^ 1].as<u64>(),
+					                   priv->qbuf[par].as<int32_t>(), &d_rc->nq[par], priv->qbuf[par ^ 1].as<int32_t>(),
+					                   &d_rc->nq[par ^ 1], priv->tflag.as<u32>(), tepoch,
+					                   priv->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
 					                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices, light ? 1 : 0, wcap,
-					                   1, &d_rc->heavy, ws->hv.as<int32_t>(), ws->hmask.as<u64>(), ws->hstart.as<u32>(),
-					                   ws->hmap.as<u32>());
+					                   1, &d_rc->heavy, priv->hv.as<int32_t>(), priv->hmask.as<u64>(), priv->hstart.as<u32>(),
+					                   priv->hmap.as<u32>());
 				kt.stop();
 			}
 			PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
@@ -1274,8 +1293,8 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 				wcap = wcap + wcap;
 				// every labelled vertex again, over the longer prefix of its list
 				PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par], 0, 4, st));
-				hipLaunchKernelGGL(k_redirty, dim3(256 * 4), dim3(256), 0, st, ws->touched.as<int32_t>(), &d_rc->tcount,
-				                   ws->dirty[par].as<u64>(), ws->qbuf[par].as<int32_t>(), &d_rc->nq[par]);
+				hipLaunchKernelGGL(k_redirty, dim3(256 * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
+				                   priv->dirty[par].as<u64>(), priv->qbuf[par].as<int32_t>(), &d_rc->nq[par]);
 				PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
 				PGQ_HIP_TRY(hipStreamSynchronize(st));
 				nq_now = h_rc->nq[par];
@@ -1294,19 +1313,84 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 		S.edges_scanned += (int64_t)h_rc->relaxed_edges;
 		S.algo_bytes[K_RELAX] += (double)h_rc->relaxed_edges * (4.0 + 8.0 + 2.0 * 8.0 * LC);
 		hipLaunchKernelGGL(k_cheapest_results, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
-		                   ws->sidx.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, ws->dist.as<int64_t>(), inf_bits,
+		                   ws->sidx.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, priv->dist.as<int64_t>(), inf_bits,
 		                   d_out, d_ok);
-		hipLaunchKernelGGL(k_reset_touched, dim3(256 * 4), dim3(256), 0, st, ws->touched.as<int32_t>(), &d_rc->tcount,
-		                   ws->dist.as<int64_t>(), inf_bits);
+		hipLaunchKernelGGL(k_reset_touched, dim3(256 * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
+		                   priv->dist.as<int64_t>(), inf_bits);
 	}
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	priv->dist_V = V; // every touched row is back at INF
+	priv->dist_lanes = type_tag;
+	return PGQ_OK;
+}
+
+template <typename T>
+static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                           int64_t *d_out, uint8_t *d_ok, bool chain) {
+	if (chain && options().chain && n > 0 && n < (1LL << 31)) return cheapest_with_chains<T>(c, ws, n, d_src, d_dst, d_out, d_ok);
+	hipStream_t st = ws->stream;
+	pgq_stats_t &S = tstats().s;
+	S.pairs += n;
+	if (n == 0) return PGQ_OK;
+	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
+	u32 U = 0;
+	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U));
+	S.unique_sources += U;
+	const int nb = (int)(((int64_t)U + LC - 1) / LC);
+	PGQ_TRY(batch_bounds(ws, n, LC, nb));
+	const int64_t *bs = ws->h_bstart;
+	if (options().relax_light != 0 && c->E > 0) { // once per CSR, before the workers need them
+		PGQ_TRY(ensure_weight_sorted(c, ws));
+		PGQ_TRY(ensure_weight_mean(c, ws));
+	} else if (options().relax_delta_div > 0) {
+		PGQ_TRY(ensure_weight_mean(c, ws));
+	}
+	// Independent batches overlap on several streams (one host thread each, like the lane batches of the unweighted
+	// search): the rounds with few changed vertices — a third of a batch's rounds — leave most of the chip idle.
+	const int workers = std::max(1, std::min(options().streams, nb));
+	int rc = PGQ_OK;
+	if (workers == 1) {
+		rc = relax_batches<T>(c, ws, ws, 0, 1, nb, U, d_out, d_ok);
+	} else {
+		std::vector<WorkspaceLease> leases((size_t)workers - 1);
+		for (auto &l : leases) PGQ_TRY(l.acquire());
+		std::vector<int> rcs((size_t)workers, PGQ_OK);
+		std::vector<std::string> errs((size_t)workers);
+		std::vector<pgq_stats_t> wstats((size_t)workers);
+		std::vector<std::thread> pool;
+		const int dev = current_device();
+		Options *const parent_opt = options_override();
+		for (int t = 1; t < workers; t++)
+			pool.emplace_back([&, t]() {
+				OptionScope opt_scope(parent_opt);
+				bind_thread_device(dev);
+				int r = ensure_init();
+				if (r == PGQ_OK) {
+					(void)pgq_reset_stats();
+					r = relax_batches<T>(c, ws, leases[(size_t)t - 1].ws, t, workers, nb, U, d_out, d_ok);
+				}
+				rcs[(size_t)t] = r;
+				if (r != PGQ_OK) errs[(size_t)t] = pgq_last_error();
+				wstats[(size_t)t] = tstats().s;
+			});
+		rcs[0] = relax_batches<T>(c, ws, ws, 0, workers, nb, U, d_out, d_ok);
+		for (auto &th : pool) th.join();
+		for (int t = 0; t < workers; t++) {
+			if (rcs[(size_t)t] != PGQ_OK && rc == PGQ_OK) {
+				rc = rcs[(size_t)t];
+				if (t > 0) set_error(errs[(size_t)t]);
+			}
+			if (t > 0) merge_stats(S, wstats[(size_t)t]);
+		}
+	}
+	if (rc != PGQ_OK) return rc;
 	const int64_t lo_t = bs[nb + 1], lo_n = bs[nb + 2];
 	if (n > lo_t)
 		hipLaunchKernelGGL(k_cheapest_tails, dim3(blocks_for(n - lo_t)), dim3(256), 0, st, lo_t, lo_n, n,
 		                   ws->sidx.as<u32>(), d_out, d_ok);
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	KernelTimer::flush();
-	ws->dist_V = V; // every touched row is back at INF
-	ws->dist_lanes = type_tag;
 	return PGQ_OK;
 }
 

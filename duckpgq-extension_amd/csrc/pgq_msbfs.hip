@@ -1834,7 +1834,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 	return PGQ_OK;
 }
 
-static void merge_stats(pgq_stats_t &into, const pgq_stats_t &from) {
+void merge_stats(pgq_stats_t &into, const pgq_stats_t &from) {
 	into.batches += from.batches;
 	into.levels += from.levels;
 	into.push_levels += from.push_levels;

@@ -103,5 +103,6 @@ int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, co
                   bool dst_rule = true);
 // bstart (pinned host) <- sorted-row boundaries of nb batches of L lanes (+ trivial / NULL tails)
 int batch_bounds(Workspace *ws, int64_t n, int64_t L, int nb);
+void merge_stats(pgq_stats_t &into, const pgq_stats_t &from); // a worker thread's counters into the caller's
 
 } // namespace pgq

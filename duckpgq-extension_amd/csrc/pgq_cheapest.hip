@@ -1348,7 +1348,13 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 	}
 	// Independent batches overlap on several streams (one host thread each, like the lane batches of the unweighted
 	// search): the rounds with few changed vertices — a third of a batch's rounds — leave most of the chip idle.
-	const int workers = std::max(1, std::min(options().streams, nb));
+	int workers = std::max(1, std::min(options().relax_streams > 0 ? options().relax_streams : options().streams, nb));
+	if (workers > 1) { // every extra worker holds its own label array (V x 64 x 8 bytes): only while half the free memory covers them
+		size_t free_b = 0, total_b = 0;
+		PGQ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		const size_t per_worker = (size_t)std::max<int64_t>(c->V, 1) * (LC * 8 + 64) + (size_t)(c->E / 64) * 4;
+		workers = (int)std::min<size_t>((size_t)workers, 1 + free_b / 2 / per_worker);
+	}
 	int rc = PGQ_OK;
 	if (workers == 1) {
 		rc = relax_batches<T>(c, ws, ws, 0, 1, nb, U, d_out, d_ok);

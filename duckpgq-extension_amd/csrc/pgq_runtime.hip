@@ -72,6 +72,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "relax_light", &o.relax_light, nullptr },
 		{ "relax_light_div", &o.relax_light_div, nullptr },
 		{ "relax_split", &o.relax_split, nullptr },
+		{ "relax_streams", &o.relax_streams, nullptr },
 		{ "chain", &o.chain, nullptr },
 		{ "chain_cap", &o.chain_cap, nullptr },
 		{ "alloc_cache_mb", &o.alloc_cache_mb, nullptr },

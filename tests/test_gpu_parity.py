@@ -21,7 +21,7 @@ def _defaults():
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
-                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 4), ("relax_delta_div", 0), ("relax_light", 1), ("relax_light_div", 32)):
+                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 4), ("relax_delta_div", 0), ("relax_light", 1), ("relax_light_div", 4), ("relax_split", 1)):
         pgq.set_option(k, v)
     yield
 
@@ -393,8 +393,13 @@ def test_cheapest_path_bit_exact(kind):
     s, d, e = random_graph(rng, V, E, skew=True)
     w = rng.integers(1, 1000, E) if kind == "int64" else rng.random(E) + 0.01
     st, ora = both(V, (s, d, e), w=w)
-    for n, div, light in ((1, 64, 0), (70, 64, 0), (300, 64, 0), (300, 0, 0), (300, 1, 0), (300, 100000, 0), (1500, 64, 0), (1500, 4, 0),
-                          (1, 0, 1), (300, 0, 1), (300, 0, 4), (1500, 0, 1), (1500, 4, 1000)):
+    for n, div, light, split, streams in (
+            (1, 64, 0, 1, 2), (70, 64, 0, 1, 2), (300, 64, 0, 1, 2), (300, 0, 0, 1, 2), (300, 1, 0, 0, 2), (300, 100000, 0, 1, 2),
+            (1500, 64, 0, 1, 2), (1500, 4, 0, 0, 1), (1500, 0, 0, 1, 4),
+            (1, 0, 1, 1, 2), (300, 0, 1, 1, 2), (300, 0, 4, 0, 2), (1500, 0, 1, 1, 4), (1500, 0, 4, 1, 1), (1500, 4, 1000, 1, 3)):
+        # lists longer than 128 edges (the hubs of the skewed graph) relaxed 64 edges per wavefront by a second launch, or not
+        pgq.set_option("relax_split", split)
+        pgq.set_option("streams", streams)  # batches of 64 sources side by side on their own label arrays
         pgq.set_option("relax_small_limit", 0 if n == 300 else (50 if n == 70 else 2048))  # host rounds / mixed / device rounds
         # light edges first: weight-sorted lists under a cap that doubles per phase, first cap = mean weight / light (0: off)
         pgq.set_option("relax_light", 1 if light else 0)

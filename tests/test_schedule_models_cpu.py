@@ -317,3 +317,93 @@ def test_padded_layout_and_packed_walk_visit_exactly_the_lists():
                 assert all(cg[k] >= cw[k] for k in cw)
             seen, g = seg_walk_model(lst, padj, 0, 1, depth=2, stop_after=1)  # early exit after the first pass
             assert (0 < g <= 128) if want else g == 0
+
+
+def light_first_model(V, off, adj, w, lanes, dests, cap0, rng, dtype):
+    """k_relax under relax_light (pgq_cheapest.hip): lists sorted by weight, Jacobi rounds over the prefix under a cap
+    that doubles per phase; a lane expands a vertex only while its label is under the lane's bound (largest tentative
+    label among its destinations, refreshed per round); a vertex's walk stops at the first edge above the cap or whose
+    candidate gets no dirty lane under its bound; a phase ends at its fixpoint, the search when the cap has reached the
+    largest weight or every lane's bound.  Vertices of a round are taken in random order and read the labels as they are
+    (the kernel's wavefronts run concurrently over one label array)."""
+    inf = np.iinfo(np.int64).max if dtype == np.int64 else np.inf
+    L = len(lanes)
+    wsorted, wadj = w.copy(), adj.copy()
+    for v in range(V):
+        o = np.argsort(w[off[v]:off[v + 1]], kind="stable")
+        wsorted[off[v]:off[v + 1]] = w[off[v]:off[v + 1]][o]
+        wadj[off[v]:off[v + 1]] = adj[off[v]:off[v + 1]][o]
+    dist = np.full((V, L), inf, dtype=dtype)
+    dirty = np.zeros((V, L), dtype=bool)
+    for l, s in enumerate(lanes):
+        dist[s, l] = 0
+        dirty[s, l] = True
+    touched = set(int(s) for s in lanes)
+    w_max = wsorted.max() if len(wsorted) else 0
+    cap = dtype(cap0)
+    while True:
+        while dirty.any():  # rounds of a phase
+            bound = np.array([max((dist[d, l] for d in dests[l]), default=dtype(0)) for l in range(L)], dtype=dtype)
+            queue = np.flatnonzero(dirty.any(axis=1))
+            rng.shuffle(queue)
+            nxt = np.zeros_like(dirty)
+            for v in queue.tolist():
+                mine = dirty[v] & (dist[v] < bound)
+                dv = dist[v].copy()
+                if not mine.any():
+                    continue
+                for k in range(off[v], off[v + 1]):
+                    wt = wsorted[k]
+                    cand = dv + wt if dtype != np.int64 else np.where(dv == inf, inf, dv + np.where(dv == inf, 0, wt))
+                    if wt > cap or not (mine & (cand < bound)).any():
+                        break
+                    n = wadj[k]
+                    imp = mine & (cand < bound) & (cand < dist[n])
+                    dist[n, imp] = cand[imp]
+                    nxt[n] |= imp
+                    if imp.any():
+                        touched.add(int(n))
+            dirty = nxt
+        bound = np.array([max((dist[d, l] for d in dests[l]), default=dtype(0)) for l in range(L)], dtype=dtype)
+        if cap >= w_max or ((bound < inf).all() and cap >= bound.max()):
+            break
+        cap = cap + cap
+        for v in touched:  # k_redirty: every labelled vertex again, over the longer prefix
+            dirty[v] = dist[v] < inf
+    return dist
+
+
+def test_light_edges_first_schedule_matches_dijkstra():
+    rng = np.random.default_rng(23)
+    checked = 0
+    for trial in range(50):
+        V = int(rng.integers(5, 50))
+        E = int(rng.integers(V, V * 7))
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        dtype = np.int64 if trial % 2 == 0 else np.float64
+        if dtype == np.int64:
+            w = rng.integers(0 if trial % 4 == 0 else 1, 60, E).astype(np.int64)  # zero weights every other int graph
+        else:
+            w = rng.random(E) * (10.0 ** rng.integers(-3, 4, E))  # sums that round: the fold order matters
+        off, adj, _, _, ww, _, order = _csr(V, s, d, w)
+        ora = OracleCSR.adopt(V, off, adj, np.arange(E, dtype=np.int64), ww)
+        L = int(rng.integers(1, 7))
+        lanes = rng.choice(V, size=min(L, V), replace=False)
+        dests = [rng.integers(0, V, int(rng.integers(0, 4))).tolist() for _ in lanes]  # a lane may have no destination left
+        cap0 = max(1, int(w.mean() / 4)) if dtype == np.int64 else max(float(w.mean()) / 4, 1e-300)
+        dist = light_first_model(V, off, adj, ww, lanes, dests, cap0, rng, dtype)
+        for l, src in enumerate(lanes.tolist()):
+            if not dests[l]:
+                continue
+            ps = np.full(len(dests[l]), src, dtype=np.int64)
+            out, ok = ora.lean_cheapest_path_length(V, ps, np.asarray(dests[l], dtype=np.int64))
+            for dd, want, k in zip(dests[l], out.tolist(), ok.tolist()):
+                got = dist[dd, l]
+                if not k:
+                    assert got == (np.iinfo(np.int64).max if dtype == np.int64 else np.inf)
+                elif dtype == np.int64:
+                    assert int(got) == want
+                else:
+                    assert np.float64(got).tobytes() == np.float64(want).tobytes()  # bit for bit
+                checked += 1
+    assert checked > 150

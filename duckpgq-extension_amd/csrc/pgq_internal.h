@@ -60,7 +60,7 @@ struct Options {
 	int relax_light = 1;      // batched relaxation over weight-sorted lists: edges above a cap that doubles phase by phase are not
 	                          // scanned, and a vertex stops at the first edge that cannot beat its lanes' bounds (0: plain rounds)
 	int relax_light_div = 4;  // first cap = mean weight / this
-	int relax_streams = 0;    // batches of the relaxation side by side (0: `streams`)
+	int relax_streams = 6;    // batches of the relaxation side by side on their own label arrays (0: `streams`)
 	int relax_split = 1;      // lists longer than 128 edges are relaxed 64 edges per wavefront by a second launch of the round
 	int relax_delta_div = 0;  // batched relaxation: > 0 = a round only expands labels below a threshold that grows by mean weight / this
 	                          // per round.  Off: measured on the weighted knows graph it does not pay (lanes reach a vertex in different

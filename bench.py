@@ -18,7 +18,8 @@ Default workload = BASELINE.json configs[3] (the config the metric "MS-BFS MTEPS
           (match.cpp:467-495: a cross product of endpoints — 2048 distinct sources x 1024 destinations each = 2.1 M
           rows), which the library routes to the lane-batched MS-BFS frontier expansion (one lane per distinct source);
           each leg has its own ms/step, pairs/s, logical and physical MTEPS, roofline of its dominant kernel class and a
-          CPU-port comparison.
+          CPU-port comparison.  A third leg, `cheapest_general`, times cheapest_path_length of 4096 pairs on the same
+          graph with int64 weights (one step; the general-graph case of the batched relaxation).
   N > 1:  --scaling strong by default (configs[3] is 65,536 pairs in total, cut across the GPUs); the weak figure
           (65,536 pairs on every GPU) is measured in the same run and reported under "weak".
 Other BASELINE configs: --workload rmat22 (configs[1]), snb_paths (configs[2]), forest_cheapest (configs[4]);
@@ -80,7 +81,8 @@ def parse():
     ap.add_argument("--cross-sources", type=int, default=2048, help="snb_cross / msbfs_cross leg: distinct sources")
     ap.add_argument("--cross-dests", type=int, default=1024, help="snb_cross / msbfs_cross leg: destinations per source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="N = 1 default workload: skip the msbfs_cross leg")
+    ap.add_argument("--no-legs", action="store_true", help="N = 1 default workload: skip the msbfs_cross and cheapest_general legs")
+    ap.add_argument("--cheapest-pairs", type=int, default=4096, help="cheapest_general leg: pairs (0: skip the leg)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs timed on one CPU thread (0 = 8192 snb / 1024 rmat)")
     ap.add_argument("--weights", default="int64", choices=["int64", "double"], help="forest_cheapest / snb_cheapest: weight type")
     ap.add_argument("--backend", default="nccl")
@@ -262,8 +264,9 @@ class Bench:
             out_val = None
         # Untimed pass with one batch in flight and HIP events around every launch (recorded on the library's own stream):
         # nothing overlaps, so a launch's event duration is that kernel's duration.
-        n_streams = int(pgq.get_option("streams"))
+        n_streams, n_relax_streams = int(pgq.get_option("streams")), int(pgq.get_option("relax_streams"))
         pgq.set_option("streams", 1)
+        pgq.set_option("relax_streams", 1)
         pgq.set_option("profile", 1)
         iso_steps = max(1, min(steps, 3))
         step(0)
@@ -279,6 +282,7 @@ class Bench:
         iso = pgq.get_stats()
         pgq.set_option("profile", 0)
         pgq.set_option("streams", n_streams)
+        pgq.set_option("relax_streams", n_relax_streams)
         return {"n": n, "elapsed": elapsed, "stats": stats, "iso": iso, "iso_steps": iso_steps, "iso_elapsed": iso_elapsed,
                 "te_local": te_local, "reach": reach, "out_len": out_len, "out_val": out_val, "d_ok": d_ok, "d_te": d_te,
                 "steps": steps}
@@ -414,6 +418,22 @@ def main():
         cross["workload"] = "%d distinct sources x %d destinations each = %d rows (match.cpp:467-495 shape)" % (
             a.cross_sources, len(cp) // a.cross_sources, len(cp))
 
+    wleg = None
+    if world == 1 and a.workload == "snb_sf100" and not a.no_legs and a.cheapest_pairs > 0:
+        # cheapest_path_length on the same graph with int64 weights 1..999 per CSR slot: the general-graph case (batched
+        # relaxation); one timed step, results compared with the oracle's Dijkstra on a bounded sample
+        w_np = np.random.default_rng(PAIR_SEED["snb_cheapest"]).integers(1, 1000, E)
+        t_w2 = torch.from_numpy(w_np).to(dev)
+        csr_w = pgq.DeviceCSR.from_device_ptrs(V, t_off.data_ptr(), t_adj.data_ptr(), t_eid.data_ptr(), t_w2.data_ptr(), 1)
+        wp = np.random.default_rng(PAIR_SEED["snb_cheapest"] + 100).integers(0, V, size=(a.cheapest_pairs, 2))
+        mw = bench.run("snb_cheapest", csr_w, torch.from_numpy(wp).to(dev), len(wp), 1, 1, cheapest=True)
+        wleg, _ = leg_summary(bench, mw, "snb_cheapest", len(wp), copy_gbps)
+        wleg["workload"] = "%d random pairs, int64 weights 1..999 on the knows graph (cheapest_path_length.cpp:52-136)" % len(wp)
+        if not a.no_cpu_baseline and rank == 0:
+            ns = min(len(wp), 32)  # a Dijkstra on this graph is ~0.5 s
+            wleg["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w_np, wp[:ns], mw["out_val"][:ns], mw["d_ok"][:ns])
+        del csr_w, t_w2
+
     if rank == 0:
         if cheapest:
             metric, unit, value = "cheapest_path_pairs_per_s", "pairs/s", main_leg["pairs_per_s"]
@@ -465,6 +485,8 @@ def main():
             legs["prepass"]["workload"] = "%d random pairs (default_rng(4)): every row answered by the pair-centric kernels" % total_pairs
             if "cpu_baseline" in out:
                 legs["prepass"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "pairs_per_s")}
+            if wleg is not None:
+                legs["cheapest_general"] = {k: wleg[k] for k in wleg if k != "roofline_by_kernel"}
             out["legs"] = legs
         print(json.dumps(out), flush=True)
     if world > 1:

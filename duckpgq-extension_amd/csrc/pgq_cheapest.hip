@@ -1364,11 +1364,11 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 		std::vector<int> rcs((size_t)workers, PGQ_OK);
 		std::vector<std::string> errs((size_t)workers);
 		std::vector<pgq_stats_t> wstats((size_t)workers);
-		std::vector<std::thread> pool;
+		std::vector<std::shared_ptr<WorkerTask>> pool;
 		const int dev = current_device();
 		Options *const parent_opt = options_override();
 		for (int t = 1; t < workers; t++)
-			pool.emplace_back([&, t]() {
+			pool.push_back(worker_submit(dev, [&, t]() {
 				OptionScope opt_scope(parent_opt);
 				bind_thread_device(dev);
 				int r = ensure_init();
@@ -1379,9 +1379,9 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 				rcs[(size_t)t] = r;
 				if (r != PGQ_OK) errs[(size_t)t] = pgq_last_error();
 				wstats[(size_t)t] = tstats().s;
-			});
+			}));
 		rcs[0] = relax_batches<T>(c, ws, ws, 0, workers, nb, U, d_out, d_ok);
-		for (auto &th : pool) th.join();
+		for (auto &th : pool) worker_wait(th);
 		for (int t = 0; t < workers; t++) {
 			if (rcs[(size_t)t] != PGQ_OK && rc == PGQ_OK) {
 				rc = rcs[(size_t)t];

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -114,6 +115,12 @@ struct Options {
 Options &options();
 // per-handle options (pgq_csr_set_option): the override a host thread works under, and a scope that installs a
 // handle's for the duration of a C-ABI call
+// Host worker threads that outlive a call (one idle list per device: a worker keeps its HIP events and its device
+// binding): `worker_submit` hands `fn` to an idle worker of `device` or starts a new one, `worker_wait` blocks until it
+// has run.  A call used to start a std::thread per extra batch stream; nested use cannot deadlock (the pool grows).
+struct WorkerTask;
+std::shared_ptr<WorkerTask> worker_submit(int device, std::function<void()> fn);
+void worker_wait(const std::shared_ptr<WorkerTask> &t);
 Options *options_override();
 void set_options_override(Options *o);
 

@@ -1999,11 +1999,11 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		std::vector<std::string> errs((size_t)workers);
 		std::vector<SearchOutput> outs((size_t)workers, outp);
 		std::vector<pgq_stats_t> wstats((size_t)workers);
-		std::vector<std::thread> pool;
+		std::vector<std::shared_ptr<WorkerTask>> pool;
 		const int dev = current_device();
 		Options *const parent_opt = options_override();
 		for (int t = 1; t < workers; t++)
-			pool.emplace_back([&, t]() {
+			pool.push_back(worker_submit(dev, [&, t]() {
 				OptionScope opt_scope(parent_opt); // the handle's own options, if the call runs under them
 				bind_thread_device(dev); // the caller's device (a multi-GPU shard may not be on the default one)
 				int r = ensure_init(); // binds the device for this host thread
@@ -2014,9 +2014,9 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 				rcs[(size_t)t] = r;
 				if (r != PGQ_OK) errs[(size_t)t] = pgq_last_error();
 				wstats[(size_t)t] = tstats().s;
-			});
+			}));
 		rcs[0] = run(ws, 0, workers, outs[0]);
-		for (auto &th : pool) th.join();
+		for (auto &th : pool) worker_wait(th);
 		for (int t = 0; t < workers; t++) {
 			if (rcs[(size_t)t] != PGQ_OK && rc == PGQ_OK) {
 				rc = rcs[(size_t)t];
@@ -2145,20 +2145,20 @@ static int run_shards(pgq_csr_t *csr, int64_t n, Body body) {
 		PGQ_TRY(lease.acquire());
 		return body(k, lo, hi, replicas[(size_t)k], lease.ws);
 	};
-	std::vector<std::thread> pool;
+	std::vector<std::shared_ptr<WorkerTask>> pool;
 	Options *const parent_opt = options_override();
 	for (int k = 1; k < W; k++)
-		pool.emplace_back([&, k]() {
+		pool.push_back(worker_submit(devs[(size_t)k], [&, k]() {
 			OptionScope opt_scope(parent_opt);
 			(void)pgq_reset_stats();
 			rcs[(size_t)k] = shard(k);
 			if (rcs[(size_t)k] != PGQ_OK) errs[(size_t)k] = pgq_last_error();
 			wstats[(size_t)k] = tstats().s;
-		});
+		}));
 	rcs[0] = shard(0);
 	bind_thread_device(-1);
 	(void)ensure_init();
-	for (auto &th : pool) th.join();
+	for (auto &th : pool) worker_wait(th);
 	int rc = PGQ_OK;
 	for (int k = 0; k < W; k++) {
 		if (rcs[(size_t)k] != PGQ_OK && rc == PGQ_OK) {

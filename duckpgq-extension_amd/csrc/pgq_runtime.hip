@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -43,6 +45,82 @@ static thread_local Options *t_opt = nullptr;
 Options &options() { return t_opt ? *t_opt : g_opt; }
 Options *options_override() { return t_opt; }
 void set_options_override(Options *o) { t_opt = o; }
+
+// ---- persistent host workers -------------------------------------------------------------------------------
+struct WorkerTask {
+	std::function<void()> fn;
+	std::mutex m;
+	std::condition_variable cv;
+	bool done = false;
+};
+namespace {
+struct Worker {
+	std::mutex m;
+	std::condition_variable cv;
+	std::shared_ptr<WorkerTask> job;
+	int device = 0;
+};
+std::mutex g_worker_lock;
+// leaked on purpose: detached workers may still be parked on their condition variables while statics are destroyed
+std::map<int, std::vector<Worker *>> &idle_workers() {
+	static auto *m = new std::map<int, std::vector<Worker *>>();
+	return *m;
+}
+void worker_loop(Worker *w) {
+	for (;;) {
+		std::shared_ptr<WorkerTask> t;
+		{
+			std::unique_lock<std::mutex> lk(w->m);
+			w->cv.wait(lk, [&] { return w->job != nullptr; });
+			t.swap(w->job);
+		}
+		try {
+			t->fn();
+		} catch (...) { // the jobs report through return codes; nothing may unwind into the pool
+		}
+		t->fn = nullptr; // drop the captures before the submitter is released
+		{
+			std::lock_guard<std::mutex> g(g_worker_lock);
+			idle_workers()[w->device].push_back(w);
+		}
+		{
+			std::lock_guard<std::mutex> g(t->m);
+			t->done = true;
+		}
+		t->cv.notify_all();
+	}
+}
+} // namespace
+
+std::shared_ptr<WorkerTask> worker_submit(int device, std::function<void()> fn) {
+	auto t = std::make_shared<WorkerTask>();
+	t->fn = std::move(fn);
+	Worker *w = nullptr;
+	{
+		std::lock_guard<std::mutex> g(g_worker_lock);
+		auto &idle = idle_workers()[device];
+		if (!idle.empty()) {
+			w = idle.back();
+			idle.pop_back();
+		}
+	}
+	if (!w) {
+		w = new Worker();
+		w->device = device;
+		std::thread(worker_loop, w).detach();
+	}
+	{
+		std::lock_guard<std::mutex> g(w->m);
+		w->job = t;
+	}
+	w->cv.notify_one();
+	return t;
+}
+
+void worker_wait(const std::shared_ptr<WorkerTask> &t) {
+	std::unique_lock<std::mutex> lk(t->m);
+	t->cv.wait(lk, [&] { return t->done; });
+}
 
 ThreadStats::ThreadStats() { memset(&s, 0, sizeof(s)); }
 ThreadStats &tstats() {

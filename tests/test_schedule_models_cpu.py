@@ -1,6 +1,7 @@
-"""CPU models of two device schedules whose exactness rests on an argument rather than on the reference's loop order:
-k_bibfs (pgq_meet.hip: level-synchronous bidirectional BFS per row) and k_wbibfs (pgq_cheapest.hip: bidirectional
-band-wise label correcting per row).  The models follow the kernels' control flow (side selection, termination tests,
+"""CPU models of device schedules whose exactness rests on an argument rather than on the reference's loop order:
+k_bibfs (pgq_meet.hip: level-synchronous bidirectional BFS per row), k_wbibfs (pgq_cheapest.hip: bidirectional
+band-wise label correcting per row), the packed list walk of the pre-pass (pgq_walk.h) and k_relax under relax_light
+(pgq_cheapest.hip: rounds over weight-sorted lists under a doubling cap with per-lane bounds).  The models follow the kernels' control flow (side selection, termination tests,
 far-queue refill with band skipping, duplicates in the near queue, arbitrary relaxation order) and are compared with the
 oracle's per-pair BFS / Dijkstra.  They exist to pin the *schedule*; the kernels themselves are checked on the GPU
 (tests/test_gpu_parity.py: test_bibfs_few_open_rows_any_distance, test_weighted_pair_search_bit_exact)."""

@@ -912,12 +912,21 @@ __global__ void k_redirty(const int32_t *__restrict__ touched, const u32 *__rest
 
 // the forward adjacency with every vertex's list sorted by weight (non-negative weights: their bit patterns sort like the
 // values, int64 and double alike) — segmented radix sort, once per CSR — and the largest weight
+// sort keys of double weights: the bit pattern orders non-negative doubles like their values, once -0.0 (accepted: it
+// is not < 0, and adds like +0.0) has lost its sign and a NaN (never relaxes an edge: `dist + w < dist[n]` is false,
+// here as in the reference) counts as +inf
+__global__ void k_weight_keys(const unsigned long long *__restrict__ w, int64_t E, unsigned long long *__restrict__ key) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= E) return;
+	key[i] = min(w[i] & 0x7FFFFFFFFFFFFFFFull, 0x7FF0000000000000ull);
+}
+
 static int ensure_weight_sorted(pgq_csr *c, Workspace *ws) {
 	std::lock_guard<std::mutex> g(g_rw_lock);
 	if (c->wadj || c->E == 0 || !c->w) return PGQ_OK;
 	hipStream_t st = ws->stream;
 	const int64_t E = c->E;
-	DevBuf tmp, mx;
+	DevBuf tmp, mx, canon;
 	int32_t *wadj = nullptr;
 	void *wsorted = nullptr;
 	auto body = [&]() -> int {
@@ -926,6 +935,11 @@ static int ensure_weight_sorted(pgq_csr *c, Workspace *ws) {
 		PGQ_TRY(mx.reserve(64));
 		size_t sb = 0, rb = 0;
 		const unsigned long long *keys = (const unsigned long long *)c->w;
+		if (c->w_type == PGQ_W_DOUBLE) {
+			PGQ_TRY(canon.reserve((size_t)E * 8));
+			hipLaunchKernelGGL(k_weight_keys, dim3(blocks_for(E)), dim3(256), 0, st, keys, E, canon.as<unsigned long long>());
+			keys = canon.as<unsigned long long>();
+		}
 		unsigned long long *keys_out = (unsigned long long *)wsorted;
 		PGQ_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, sb, keys, keys_out, c->adj, wadj, (int)E, (int)c->V, c->off,
 		                                                        c->off + 1, 0, 64, st));
@@ -937,14 +951,14 @@ static int ensure_weight_sorted(pgq_csr *c, Workspace *ws) {
 		unsigned long long m = 0;
 		PGQ_HIP_TRY(hipMemcpyAsync(&m, mx.p, 8, hipMemcpyDeviceToHost, st));
 		PGQ_HIP_TRY(hipStreamSynchronize(st));
-		if (c->w_type == PGQ_W_DOUBLE) memcpy(&c->w_max, &m, 8);
-		else c->w_max = (double)(long long)m;
+		c->w_max_bits = m; // the largest weight, as its bit pattern (int64: the value)
 		return PGQ_OK;
 	};
 	const int rc = body();
 	(void)hipStreamSynchronize(st);
 	tmp.release();
 	mx.release();
+	canon.release();
 	if (rc != PGQ_OK) {
 		dev_free(wadj);
 		dev_free(wsorted);
@@ -1199,7 +1213,9 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 		// doubles phase by phase — early phases touch a few per cent of the edges and give every lane a tight bound on
 		// its destinations, later phases hardly relax anything (a vertex stops at the first edge whose weight cannot beat
 		// its lanes' bounds) — until the cap reaches the largest bound (heavier edges cannot be on a cheaper path)
-		const bool light = options().relax_light != 0 && c->E > 0;
+		// (a mean that is not a positive finite number — NaN / inf weights, an int64 sum that wrapped — gives no first cap:
+		// plain rounds then)
+		const bool light = options().relax_light != 0 && c->E > 0 && c->wadj && c->w_mean > 0 && c->w_mean < 1e300;
 		const bool heavy = options().relax_split != 0;
 		static const bool trace = getenv("PGQ_RELAX_TRACE") != nullptr; // per-round line on stderr (measurement only)
 		auto t_round = std::chrono::steady_clock::now();
@@ -1289,8 +1305,12 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 					memcpy(&bv, &h_rc->bound[l], 8);
 					if (bv > max_bound) max_bound = bv;
 				}
-				if ((double)wcap >= c->w_max || (!unbounded && wcap >= max_bound)) break;
-				wcap = wcap + wcap;
+				// (negated comparisons: a cap that is NaN or inf ends the search like one that has reached the largest weight)
+				T w_max;
+				memcpy(&w_max, &c->w_max_bits, 8);
+				if (!(wcap < w_max) || (!unbounded && !(wcap < max_bound))) break;
+				if constexpr (std::is_same<T, double>::value) wcap = wcap + wcap;
+				else wcap = wcap > std::numeric_limits<int64_t>::max() / 2 ? std::numeric_limits<int64_t>::max() : wcap + wcap;
 				// every labelled vertex again, over the longer prefix of its list
 				PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par], 0, 4, st));
 				hipLaunchKernelGGL(k_redirty, dim3(256 * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,

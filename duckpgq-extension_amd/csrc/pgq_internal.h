@@ -196,10 +196,10 @@ struct pgq_csr {
 	void *rw = nullptr;          // E x 8 B: in-edge weights in reverse-CSR order (built on first use by the weighted pair search)
 	double w_mean = 0;
 	// cheapest_path_length on general graphs: the forward adjacency with every vertex's list sorted by weight, and the
-	// weights in that order (built on first use); w_max = the largest weight
+	// weights in that order (built on first use); w_max_bits = the largest weight as its bit pattern
 	int32_t *wadj = nullptr;
 	void *wsorted = nullptr;
-	double w_max = 0;
+	unsigned long long w_max_bits = 0;
 	int64_t *wcc = nullptr;      // weakly_connected_component ids of the V + 2 forest entries (computed once per handle)
 	double *pagerank = nullptr;
 	int pagerank_iterations = 0;

@@ -426,6 +426,35 @@ def test_cheapest_path_bit_exact(kind):
     assert (ok == (rok & dv)).all()
 
 
+@pytest.mark.parametrize("case", ["signed_zero", "inf_nan", "wide_int64"])
+def test_cheapest_path_special_weights(case):
+    """Weights the weight-sorted relaxation must not trip over: -0.0 (accepted — it is not < 0 — and its bit pattern would
+    sort last), +inf / NaN (never relax an edge; no usable mean, so plain rounds), int64 weights over 40 binary orders
+    (many cap doublings).  Against the literal Bellman-Ford restatement (cheapest_path_length.cpp:52-136)."""
+    rng = np.random.default_rng(77)
+    V, E = 2000, 14000
+    s, d, e = random_graph(rng, V, E, skew=True)
+    if case == "wide_int64":
+        w = (2.0 ** (rng.random(E) * 40)).astype(np.int64)
+    else:
+        w = rng.random(E) + 0.01
+        w[rng.random(E) < 0.06] = -0.0
+        w[rng.random(E) < 0.06] = 0.0
+        if case == "inf_nan":
+            w[rng.random(E) < 0.02] = np.inf
+            w[rng.random(E) < 0.02] = np.nan
+    st, ora = both(V, (s, d, e), w=w)
+    for light, streams in ((1, 1), (1, 3), (0, 2)):
+        pgq.set_option("relax_light", light)
+        pgq.set_option("streams", streams)
+        pgq.set_option("relax_small_limit", 0 if light else 2048)
+        ps, pd = rng.integers(0, V, 300), rng.integers(0, V, 300)
+        out, ok = st.cheapest_path_length(0, V, ps, pd)
+        rout, rok = ora.cheapest_path_length(V, ps, pd)
+        assert (ok == rok).all()
+        assert out[ok].tobytes() == rout[ok].tobytes()  # bit for bit (a -0.0 label would differ from +0.0 here)
+
+
 @pytest.mark.parametrize("delta_div", [8, 1, 100000])
 def test_weighted_pair_search_bit_exact(delta_div):
     # k_wbibfs (pgq_cheapest.hip): bidirectional band-wise label correcting per row, int64 weights; delta_div sets the

@@ -209,6 +209,8 @@ PathFindingResult PathFindingRelation(DuckPGQState &state, int32_t csr_id, const
 		// replica of the CSR per device, the ragged lists gathered behind each other
 		vector<int64_t> len(n), off(n);
 		int64_t used = 0;
+		// first guess: a list of h hops holds 2h + 1 elements, 16 per row covers paths of up to 7 hops on average (social
+		// graphs: 3-4); a call that needs more says how much in `used` and is repeated once
 		r.child.resize(16 * n);
 		int rc = pgq_shortestpath_multi(device, (int64_t)n, src.data(), dst.data(), len.data(), off.data(), r.child.data(),
 		                                (int64_t)r.child.size(), &used);

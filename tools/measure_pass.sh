@@ -42,8 +42,12 @@ if [ "${1:-}" != "quick" ]; then
 	timeout 120 tools/membench copy > $O/membench_copy.jsonl 2>&1
 	timeout 120 tools/membench segments > $O/membench_segments.jsonl 2>&1
 	(cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/membench_gather -o p -- $R/tools/membench gather > $O/membench_gather.jsonl 2>&1; rm -f $O/membench_gather/*kernel_trace.csv)
-	# the general-graph case of cheapest_path_length (batched relaxation; 512 of the 4096 pairs: a step is ~1.2 s)
-	timeout 200 python bench.py --workload snb_cheapest --steps 1 --warmup 0 --pairs-per-gpu 512 > $O/bench_snb_cheapest_512.json 2>/dev/null; cut -c1-160 $O/bench_snb_cheapest_512.json
+	# the general-graph case of cheapest_path_length (batched relaxation, light edges first): 4096 pairs int64 / double, the
+	# per-round trace of one 64-source batch, rocprofv3 kernel stats of 512 pairs with one batch in flight
+	timeout 300 python bench.py --workload snb_cheapest --steps 1 --warmup 1 > $O/bench_snb_cheapest_4096.json 2>/dev/null; cut -c1-160 $O/bench_snb_cheapest_4096.json
+	timeout 300 python bench.py --workload snb_cheapest --weights double --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_snb_cheapest_4096_double.json 2>/dev/null; cut -c1-160 $O/bench_snb_cheapest_4096_double.json
+	PGQ_RELAX_STREAMS=1 PGQ_RELAX_TRACE=1 timeout 300 python bench.py --workload snb_cheapest --steps 1 --warmup 1 --no-cpu-baseline --pairs-per-gpu 64 > /dev/null 2> $O/relax_trace_64.txt
+	(cd /tmp && export TMPDIR=/tmp && PGQ_RELAX_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb_cheapest -o s -- python $R/bench.py --workload snb_cheapest --no-cpu-baseline --steps 1 --warmup 0 --pairs-per-gpu 512 > $O/stats_snb_cheapest.log 2>&1; rm -f $O/stats_snb_cheapest/*kernel_trace.csv)
 	timeout 200 python tools/chunk_latency.py > $O/chunk_latency.json 2> $O/chunk_latency.err
 fi
 ls $O

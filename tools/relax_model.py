@@ -4,7 +4,7 @@ knows graph: how many vertex expansions, edge visits and label-row segments one 
 schedule.  Counts only — no GPU, nothing the product uses; it exists to choose between schedules before GPU minutes are
 spent on them.  The destination labels of every run are checked against scipy's Dijkstra.
 
-usage: python tools/relax_model.py [--lanes 64] [--div 4] [--growth 2] [--restrict-phase-start] [--lazy M] [--band B] [--seed 6]
+usage: python tools/relax_model.py [--lanes 64] [--div 4] [--growth 2] [--restrict-phase-start] [--lazy M] [--band B] [--landmarks K [--prune-targets]] [--seed 6]
 """
 import argparse
 import os
@@ -31,7 +31,7 @@ def load(a):
     return V, off, adj[order].astype(np.int64), w[order].astype(np.int64)
 
 
-def run(V, off, wadj, ws, src, dst_of, a):
+def run(V, off, wadj, ws, src, dst_of, a, lb=None):
     L = len(src)
     dist = np.full((V, L), INF, dtype=np.int64)
     dirty = np.zeros((V, L), dtype=bool)
@@ -54,7 +54,7 @@ def run(V, off, wadj, ws, src, dst_of, a):
             q = np.flatnonzero(dirty.any(axis=1))
             if len(q) == 0:
                 break
-            live = dirty[q] & (dist[q] < bound[None, :])
+            live = dirty[q] & ((dist[q] if lb is None else dist[q] + lb[q]) < bound[None, :])
             if a.lazy > 0 and not phase_first:  # expand only with >= lazy dirty lanes, or after waiting 2 rounds
                 few = (live.sum(axis=1) < a.lazy) & (waited[q] < 2)
                 waited[q[few]] += 1
@@ -107,6 +107,8 @@ def run(V, off, wadj, ws, src, dst_of, a):
                 st["seg_reads"] += int(can.reshape(len(act), L // 8 if L >= 8 else 1, -1).any(axis=2).sum())
                 n = wadj[k]
                 imp = can & (cand < dist[n])
+                if lb is not None and a.prune_targets:  # a label that cannot lead under the bound is not written
+                    imp &= (cand + lb[n]) < bound[None, :]
                 r, c = np.nonzero(imp)
                 if len(r):
                     np.minimum.at(dist, (n[r], c), cand[r, c])
@@ -140,6 +142,8 @@ def main():
     ap.add_argument("--restrict-phase-start", action="store_true")
     ap.add_argument("--lazy", type=int, default=0)
     ap.add_argument("--band", type=int, default=0, help="ordered rounds: width of the label band a round expands (0: off)")
+    ap.add_argument("--landmarks", type=int, default=0, help="goal direction: ALT lower bounds from this many landmarks")
+    ap.add_argument("--prune-targets", action="store_true", help="with --landmarks: also skip relaxations whose target cannot lead under the bound")
     ap.add_argument("--seed", type=int, default=6)
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
@@ -147,7 +151,24 @@ def main():
     pairs = np.random.default_rng(a.seed).integers(0, V, size=(a.lanes, 2))  # distinct sources: one destination per lane
     src = pairs[:, 0]
     dst_of = [np.array([pairs[l, 1]]) for l in range(a.lanes)]
-    dist, st = run(V, off, wadj, ws, src, dst_of, a)
+    lb = None
+    if a.landmarks > 0:  # ALT lower bounds, two distance arrays per landmark: lb[v, l] <= d(v, t_l)
+        from scipy.sparse import csr_matrix
+        from scipy.sparse.csgraph import dijkstra
+        m = csr_matrix((ws.astype(np.float64), wadj, off), shape=(V, V))
+        deg = np.diff(off)
+        marks = np.random.default_rng(1).choice(V, size=a.landmarks, replace=False, p=deg / deg.sum())
+        # the weights are per directed slot: d(v, t) >= d(v, L) - d(t, L) and >= d(L, t) - d(L, v)
+        d_from = dijkstra(m, directed=True, indices=marks)                 # d(L, x)
+        d_to = dijkstra(m.T.tocsr(), directed=True, indices=marks)         # d(x, L)
+        lb = np.zeros((V, a.lanes), dtype=np.int64)
+        t = pairs[:, 1]
+        for k in range(a.landmarks):
+            for x, y in ((d_to[k][:, None], d_to[k][t][None, :]), (d_from[k][t][None, :], d_from[k][:, None])):
+                diff = x - y
+                diff[~np.isfinite(diff)] = 0
+                lb = np.maximum(lb, np.floor(diff).astype(np.int64))
+    dist, st = run(V, off, wadj, ws, src, dst_of, a, lb)
     answers = [int(dist[pairs[l, 1], l]) for l in range(a.lanes)]
     print({"V": V, "E": len(wadj), **{k: v for k, v in vars(a).items() if k not in ("vertices", "friendships", "verbose")}})
     print(st)

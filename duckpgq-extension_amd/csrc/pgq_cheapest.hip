@@ -174,6 +174,9 @@ __global__ __launch_bounds__(256, 6) void k_relax(const int64_t *__restrict__ of
 				const bool in = k0 + u < e;
 				nn[u] = in ? adj[k0 + u] : v;
 				ww[u] = in ? w[k0 + u] : T(0);
+				// labels are compared as bit patterns: a NaN sum with the sign bit set would look like an improvement.  A NaN
+				// weight never relaxes an edge in the reference (`dist + w < dist[n]` is false): +inf behaves the same here
+				if constexpr (std::is_same<T, double>::value) ww[u] = ww[u] == ww[u] ? ww[u] : __longlong_as_double(0x7FF0000000000000ll);
 			}
 #pragma unroll
 			for (int u = 0; u < UNR; u++) {
@@ -398,7 +401,8 @@ __global__ __launch_bounds__(1024) void k_relax_small(const int64_t *__restrict_
 			edges += (u64)(e - b);
 			for (int64_t k = b; k < e; k++) {
 				const int n = adj[k];
-				const T wt = w[k];
+				T wt = w[k];
+				if constexpr (std::is_same<T, double>::value) wt = wt == wt ? wt : __longlong_as_double(0x7FF0000000000000ll); // NaN: like k_relax
 				bool improved = false;
 				if (mine) {
 					int64_t cand;
@@ -473,6 +477,7 @@ __global__ void k_chain_walk(int64_t n, const int64_t *__restrict__ src, const i
                              const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const T *__restrict__ w,
                              T *__restrict__ out, uint8_t *__restrict__ ok, int cap, u32 *__restrict__ counters) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const T sentinel = std::numeric_limits<T>::max() / 2;
 	int step = 0;
 	if (i < n) {
 		const int64_t s = src[i], d = dst[i];
@@ -493,7 +498,12 @@ __global__ void k_chain_walk(int64_t n, const int64_t *__restrict__ src, const i
 					state = 2;
 					break;
 				}
-				acc = acc + w[b];
+				// the reference relaxes `dist[v] + w < dist[n]` against the max/2 sentinel (cheapest_path_length.cpp:15,29-36):
+				// a sum that does not get under it (inf or NaN weights, sums past max/2) never labels the next vertex, and
+				// nothing else leads on from a vertex with one out-edge
+				const T nacc = acc + w[b];
+				if (!(nacc < sentinel)) break; // state stays 0: NULL
+				acc = nacc;
 				x = adj[b];
 			}
 		}

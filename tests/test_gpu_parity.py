@@ -426,7 +426,7 @@ def test_cheapest_path_bit_exact(kind):
     assert (ok == (rok & dv)).all()
 
 
-@pytest.mark.parametrize("case", ["signed_zero", "inf_nan", "wide_int64"])
+@pytest.mark.parametrize("case", ["signed_zero", "inf_nan", "wide_int64", "chain_inf_nan"])
 def test_cheapest_path_special_weights(case):
     """Weights the weight-sorted relaxation must not trip over: -0.0 (accepted — it is not < 0 — and its bit pattern would
     sort last), +inf / NaN (never relax an edge; no usable mean, so plain rounds), int64 weights over 40 binary orders
@@ -434,21 +434,34 @@ def test_cheapest_path_special_weights(case):
     rng = np.random.default_rng(77)
     V, E = 2000, 14000
     s, d, e = random_graph(rng, V, E, skew=True)
+    if case == "chain_inf_nan":  # a forest (one out-edge per vertex): rows answered by the chain walk, which must apply
+        # the reference's test against the max/2 sentinel — an inf / NaN / 1e308 weight on the way means NULL, not a sum
+        E = V - 1
+        s = np.arange(1, V, dtype=np.int64)
+        d = (rng.random(E) * s).astype(np.int64)
+        e = np.arange(E, dtype=np.int64)
     if case == "wide_int64":
         w = (2.0 ** (rng.random(E) * 40)).astype(np.int64)
     else:
         w = rng.random(E) + 0.01
         w[rng.random(E) < 0.06] = -0.0
         w[rng.random(E) < 0.06] = 0.0
-        if case == "inf_nan":
+        if case in ("inf_nan", "chain_inf_nan"):
             w[rng.random(E) < 0.02] = np.inf
             w[rng.random(E) < 0.02] = np.nan
+            w[rng.random(E) < 0.02] = np.copysign(np.nan, -1.0)  # sign bit set: the bit pattern is "smaller" than any label
+            w[rng.random(E) < 0.01] = 1e308                        # a finite sum that does not get under max/2
     st, ora = both(V, (s, d, e), w=w)
     for light, streams in ((1, 1), (1, 3), (0, 2)):
         pgq.set_option("relax_light", light)
         pgq.set_option("streams", streams)
         pgq.set_option("relax_small_limit", 0 if light else 2048)
         ps, pd = rng.integers(0, V, 300), rng.integers(0, V, 300)
+        if case == "chain_inf_nan":  # destinations a few hops up the chain
+            pd = ps.copy()
+            for _ in range(int(rng.integers(1, 6))):
+                up = pd > 0
+                pd[up] = d[pd[up] - 1]
         out, ok = st.cheapest_path_length(0, V, ps, pd)
         rout, rok = ora.cheapest_path_length(V, ps, pd)
         assert (ok == rok).all()

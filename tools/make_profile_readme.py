@@ -49,7 +49,7 @@ names = [("snb_sf100", "C4 shard: SF100-shaped knows, iterativelength, 65,536 ra
          ("forest_cheapest_2_28", "C5 at the named scale: reply forest V=2^28 (268 M vertices, 215 M edges), int64 weights, 4096 pairs"),
          ("snb_cheapest_4096", "general graph: weighted knows graph (int64 weights 1..999), cheapest_path_length, 4096 pairs (batched relaxation, light edges first; 3 batches side by side)"),
          ("snb_cheapest_4096_double", "same, double weights"),
-         ("snb_cheapest_4096_streams6", "same, int64, 6 batches side by side (`relax_streams=6`, the default since)")]
+         ("snb_cheapest_4096_streams6", "same, int64, 6 batches side by side (`relax_streams=6`, the default since; the kernel columns of this line come from a pass in which the 6 batches overlapped — only ms/step and pairs/s count)")]
 L += ["## bench.py, 1 GPU (10 steps, 2 warm-up; timed region runs unprofiled, the roofline columns come from an untimed "
       "pass with one batch in flight and HIP events around every kernel)", "",
       "| workload | ms/step | pairs/s | MTEPS | rows answered by the pre-pass | dominant kernel class | launches/step | "

@@ -408,3 +408,17 @@ def test_light_edges_first_schedule_matches_dijkstra():
                     assert np.float64(got).tobytes() == np.float64(want).tobytes()  # bit for bit
                 checked += 1
     assert checked > 150
+
+
+def test_relax_count_model_tool_runs_and_agrees_with_dijkstra():
+    """tools/relax_model.py (the count model DESIGN 7 quotes) on a small graph: every variant ends with the answers of
+    scipy's Dijkstra (the tool asserts it) — restricted phase start, ordered bands, landmark bounds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--restrict-phase-start"], ["--band", "8"], ["--landmarks", "4", "--prune-targets"], ["--lazy", "4"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "relax_model.py"), "--vertices", "3000",
+                              "--friendships", "40000", "--lanes", "16"] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "equal to scipy's Dijkstra: True" in out.stdout

@@ -87,7 +87,27 @@ __global__ void k_cheapest_init(const int32_t *__restrict__ usrc, int64_t U, int
 //  * the header of the wavefront's next vertex (dirty word, label row, list bounds) is requested before the current
 //    vertex's edges are walked, the vertex after that is read from the queue.
 // ---------------------------------------------------------------------------------------------------------------
-static constexpr int kRelaxUnroll = 8;
+// Compile-time variants of k_relax for tuning sweeps (tools/build_variants.sh, selected with PGQ_HIP_LIB); the defaults
+// are what ships.
+//   PGQ_RELAX_UNROLL   edges per dependent trip
+//   PGQ_RELAX_WAVES    wavefronts per SIMD asked of the register allocator
+//   PGQ_RELAX_NVFIRST  1: decide which of the trip's edges count before their label rows are requested (fewer rows, one
+//                      more dependent step) — measured together with SEGCOND once: 117 -> 130 ms per 512 pairs
+//   PGQ_RELAX_SEGCOND  1: a lane that cannot improve an edge's label reads v's first word instead of its own word of the
+//                      row (tools/relax_model.py: 4.3 of a row's 8 segments hold a lane that still can)
+#ifndef PGQ_RELAX_UNROLL
+#define PGQ_RELAX_UNROLL 8
+#endif
+#ifndef PGQ_RELAX_WAVES
+#define PGQ_RELAX_WAVES 6
+#endif
+#ifndef PGQ_RELAX_NVFIRST
+#define PGQ_RELAX_NVFIRST 0
+#endif
+#ifndef PGQ_RELAX_SEGCOND
+#define PGQ_RELAX_SEGCOND 0
+#endif
+static constexpr int kRelaxUnroll = PGQ_RELAX_UNROLL;
 static constexpr int kPendCap = 64 + kRelaxUnroll;
 
 // wave-level buffered append: lanes with `fresh` add n to the wavefront's pending list (LDS), 64 entries go out at once
@@ -113,7 +133,7 @@ __device__ __forceinline__ void relax_append(int *s_buf, int &pend, bool fresh, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 6) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+__global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                const T *__restrict__ w, int64_t *__restrict__ dist,
                                                u64 *__restrict__ dirty_cur, u64 *__restrict__ dirty_nxt,
                                                const int32_t *__restrict__ qcur, const u32 *__restrict__ nq_ptr,
@@ -182,7 +202,13 @@ __global__ __launch_bounds__(256, 6) void k_relax(const int64_t *__restrict__ of
 			for (int u = 0; u < UNR; u++) {
 				if constexpr (std::is_same<T, double>::value) cand[u] = __double_as_longlong(__longlong_as_double(dvb) + ww[u]);
 				else cand[u] = dvb + (int64_t)ww[u];
+#if !PGQ_RELAX_NVFIRST
+#if PGQ_RELAX_SEGCOND
+				curv[u] = dist[mine && (!sorted || cand[u] < my_bound) ? (size_t)nn[u] * LC + lane : (size_t)v * LC];
+#else
 				curv[u] = dist[(size_t)nn[u] * LC + lane]; // unconditional: all eight rows are in flight together
+#endif
+#endif
 			}
 			// how many of the eight count: up to the end of the list, the cap of the phase, or the first edge no lane's
 			// candidate gets under its bound with (the list ascends by weight: no later one can either)
@@ -196,6 +222,18 @@ __global__ __launch_bounds__(256, 6) void k_relax(const int64_t *__restrict__ of
 				}
 				nv++;
 			}
+#if PGQ_RELAX_NVFIRST
+			if (nv == 0) break;
+#pragma unroll
+			for (int u = 0; u < UNR; u++) { // past nv (and, with SEGCOND, in lanes that cannot improve): v's first word, a cached segment
+#if PGQ_RELAX_SEGCOND
+				const bool need = u < nv && mine && (!sorted || cand[u] < my_bound);
+#else
+				const bool need = u < nv;
+#endif
+				curv[u] = dist[need ? (size_t)nn[u] * LC + lane : (size_t)v * LC];
+			}
+#endif
 			if (sorted) edges += (u64)nv;
 #pragma unroll
 			for (int u = 0; u < UNR; u++) {

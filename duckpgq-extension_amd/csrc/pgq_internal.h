@@ -86,6 +86,9 @@ struct Options {
 	double sparse_below = 1.5; // expected wanted non-empty words per in-neighbour below which k_pull_sparse runs
 	int meet = 1;           // iterativelength: answer pairs at distance <= 3 by the pair-centric pre-pass (k_meet3) when cheaper
 	int meet_cap = 1 << 14; // adjacency entries a pair's two-hop walk may scan in k_meet3 (one wavefront); beyond: k_meet4d (16 wavefronts)
+	int chunk_zero_copy = 1;     // chunk entry points: the pre-pass kernels read / write the pinned staging block directly
+	int meet_small_rows = 16384; // calls of at most this many rows are latency-bound: k_meet3 with more requests in flight and meet_cap_small
+	int meet_cap_small = 1 << 14; // ... a lower walk cap (longer walks go to the 16-wavefront kernel sooner)
 	int meet_cap_paths = 1 << 16; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
@@ -107,7 +110,7 @@ struct Options {
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
 	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
 	int meet_trace = 0;      // debugging: per-workgroup timestamps of k_meet4d, summarised on stderr
-	int meet4_grid_mult = 4; // k_meet4 / k_meet4d grid = this many 1024-thread workgroups per CU (2 fit beside their LDS bit maps)
+	int meet4_grid_mult = 2; // k_meet4d grid = this many 1024-thread workgroups per CU (2 fit beside their LDS bit maps; rows are handed out dynamically)
 	int meet_grid_mult = 8; // k_meet3 grid = this many times the 8192 one-wavefront workgroups the chip holds (rows per workgroup = n / grid)
 	int meet_layout = 1;    // build the padded adjacency + slot descriptors at upload (the pre-pass needs them)
 	int meet_align = 32;    // entries a padded list is aligned and padded to (4 = one 16-byte group; 16 / 32 = whole 64 / 128-byte lines: -4 % / -6 % on the pre-pass)
@@ -182,6 +185,9 @@ struct pgq_csr {
 	int32_t *padj = nullptr, *rpadj = nullptr; // 4 x padj_groups / rpadj_groups entries
 	uint2 *fseg = nullptr, *rseg = nullptr;    // V
 	uint4 *fdesc = nullptr, *rdesc = nullptr;  // E (+ 1): slot order of adj / radj
+	// entries of a vertex's two-hop walk in either direction (sum of its neighbours' list lengths, saturating): the
+	// pair-centric kernels expand the endpoint whose walk is the shorter one (round 4; it was the shorter one-hop list)
+	uint32_t *fwork = nullptr, *rwork = nullptr; // V
 	int64_t padj_groups = 0, rpadj_groups = 0;
 	std::unique_ptr<pgq::Options> opt;   // this handle's own options (pgq_csr_set_option); null: the process-wide set
 	std::atomic<int> meet_far_rows { 1 }; // the last pre-pass call left rows for k_bibfs (it is launched only then; pgq_meet.hip)
@@ -228,6 +234,8 @@ struct FlatPairs {
 };
 int flatten_pairs(int64_t V, int64_t n, const pgq_vec_t &src, const pgq_vec_t &dst, FlatPairs &out,
                   bool check_dst_validity);
+
+int flatten_pairs_into(int64_t V, int64_t n, const pgq_vec_t &src, const pgq_vec_t &dst, int64_t *out_src, int64_t *out_dst);
 
 inline void mask_fill_valid(uint64_t *mask, int64_t n) {
 	for (int64_t i = 0; i < (n + 63) / 64; i++) mask[i] = ~0ULL;

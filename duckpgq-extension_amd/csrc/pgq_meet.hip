@@ -38,13 +38,13 @@ struct MeetPath {
 
 constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so that a finished row frees its slot at once
 #ifndef PGQ_MEET3_WAVES
-#define PGQ_MEET3_WAVES 7 // wavefronts per SIMD k_meet3<false> is compiled for (72 VGPRs, no spills; 6..8 measure the same)
-#endif
-#ifndef PGQ_MEET3_NT
-#define PGQ_MEET3_NT 1 // non-temporal list loads: the lists are streamed once, the offset look-ups stay in L2 (-3 %)
+#define PGQ_MEET3_WAVES 8 // wavefronts per SIMD k_meet3<false> is compiled for (64 VGPRs; 4.2 KB of LDS per wavefront: 8 fit)
 #endif
 #ifndef PGQ_MEET3_DEPTH
 #define PGQ_MEET3_DEPTH 2 // list requests in flight per wavefront
+#endif
+#ifndef PGQ_MEET3_DEPTH_SMALL
+#define PGQ_MEET3_DEPTH_SMALL 4 // ... in the variant for calls too small to fill the chip (latency, not bandwidth, is what counts)
 #endif
 #ifndef PGQ_MEET4_BLOCKS
 #define PGQ_MEET4_BLOCKS 8 // wavefronts per SIMD k_meet4d is compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs); at 84 VGPRs only one fits
@@ -55,7 +55,7 @@ constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so
 #ifndef PGQ_MEET4_DEPTH
 #define PGQ_MEET4_DEPTH 2 // the same for each of the 16 wavefronts of a k_meet4d row (more only adds overshoot past the first hit)
 #endif
-constexpr u32 kMeetKnown4Bit = 0x80000000u; // in the compacted row indices (k_collect_open): the row is known to be at distance >= 4
+constexpr u32 kMeetKnown4Bit = 0x80000000u; // in the queued row indices: the row is known to be at distance >= 4
 constexpr int kMeetStatSlots = 256; // statistics are spread over slots: 10^4 atomics on one address take longer than the walks
 struct MeetCounters {
 	unsigned long long entries[kMeetStatSlots];  // adjacency entries scanned (both kinds of list)
@@ -64,29 +64,157 @@ struct MeetCounters {
 	u32 pad[3];
 };
 
+// ---- round 4: the launch chain without compaction kernels ---------------------------------------------------------------
+// Round 3's chain was memset, k_meet3, k_collect_open, k_meet4d, k_collect_open, (k_bibfs, k_collect_open,) copy, wait:
+// ~0.05 ms of fixed cost per call, most of an 8192-row call and of a DuckDB chunk.  Now every stage kernel APPENDS the
+// rows it cannot answer to the next stage's queue itself (one atomic per open row, ~2 % of the rows) together with what
+// it already knows about them (MeetEntry: the endpoints, their list positions and lengths — the next stage needs no
+// offset look-up — and which distances are excluded), and the last workgroup of the last kernel of the chain sums the
+// statistics, writes them straight into the pinned host block and zeroes the device block for the next call: no memset,
+// no compaction launch, no copy command.  The queues ping-pong between two regions (stage 1 -> A, stage 2 -> B, ...).
+struct MeetEntry { // 48 bytes: three 16-byte loads per row for the kernel that takes it up
+	u32 row, flags, s, d;
+	u32 so, degS, di, degD; // forward list of s: adj[so .. so + degS); in-list of d: radj[di .. di + degD)
+	u32 workS, workD, pad0, pad1; // entries of the forward two-hop walk of s / the backward one of d (pgq_csr::fwork, rwork)
+};
+constexpr u32 kEntKnown4 = 1u; // distances 1..3 are excluded (k_meet3 walked to the end)
+constexpr u32 kEntKnown3 = 2u; // distances 1..2 are excluded and the two-hop walk below was cut at k_meet3's cap
+constexpr u32 kEntFwd = 4u;    // ... it walked forward from s (set = in-list of d); else backward from d (set = out-list of s)
+constexpr int kEntResumeShift = 8; // ... and was in the round of descriptors starting at flags >> 8 when it was cut
+struct MeetQueue {
+	int64_t *src, *dst; // the open rows' endpoints (what the lane-batched search and the older kernels read)
+	u32 *idx;           // row index | kMeetKnown4Bit
+	MeetEntry *ent;
+	u32 *count;
+	// Two-ended (k_meet3 -> k_meet4d only): rows with a long way to go (cut walks, lists over the register set) are
+	// appended from the front, rows proven to be at distance >= 4 from the back (position cap - 1 - k, counted in
+	// *count_back), so that the consumer — which hands out positions in ascending order — starts the long rows first:
+	// a 40-us row that starts last is 40 us of tail.  count_back == nullptr: one end.
+	u32 *count_back;
+	u32 cap;
+};
+struct MeetDecision {
+	u32 go;           // 1: the pre-pass runs
+	u32 sample_rows;  // non-NULL rows sampled
+	u32 sample_fresh; // distinct sources among them
+	u32 pad;
+	double estimate;  // distinct sources of the whole input
+};
+struct MeetDevBlock { // device side; all zero between calls
+	MeetCounters m;
+	u32 count[4]; // rows open after stage 1, 2, 3; [3]: stage 1's rows appended from the back of its queue
+	u32 ticket;   // workgroups of the chain's last kernel that are done
+	u32 next_job; // k_meet4d: the next queue position to hand out
+	u32 pad[2];
+	MeetDecision dec;
+};
+struct MeetHostBlock { // pinned host memory, written by the last workgroup of the chain
+	unsigned long long entries, vertices;
+	u32 bad, count[3];
+	MeetDecision dec;
+	u32 done, count_back;
+};
+static_assert(sizeof(MeetHostBlock) <= 8192, "pinned statistics block too small");
+__device__ __forceinline__ void queue_push(const MeetQueue &q, u32 row, const MeetEntry &e) { // one lane
+	u32 p;
+	if (q.count_back && (e.flags & kEntKnown4)) p = q.cap - 1u - atomicAdd(q.count_back, 1u);
+	else p = atomicAdd(q.count, 1u);
+	q.src[p] = (int64_t)e.s;
+	q.dst[p] = (int64_t)e.d;
+	q.idx[p] = row | ((e.flags & kEntKnown4) ? kMeetKnown4Bit : 0u);
+	uint4 *t = reinterpret_cast<uint4 *>(q.ent + p);
+	t[0] = make_uint4(e.row, e.flags, e.s, e.d);
+	t[1] = make_uint4(e.so, e.degS, e.di, e.degD);
+	t[2] = make_uint4(e.workS, e.workD, 0u, 0u);
+}
+// position of job j of a (possibly two-ended) queue with nf rows at the front
+__device__ __forceinline__ u32 queue_pos(const MeetQueue &q, u32 j, u32 nf) { return j < nf ? j : q.cap - 1u - (j - nf); }
+// Every workgroup of a stage kernel ends here (all its threads).  fin == nullptr: not the chain's last kernel.  The last
+// workgroup to arrive sums the statistic slots, writes the host block (coherent pinned memory: visible to the host once
+// the stream has drained) and leaves the device block zeroed.
+__device__ __forceinline__ void meet_finalize(MeetDevBlock *db, MeetHostBlock *fin) {
+	if (!fin) return;
+	__shared__ u32 s_last;
+	__shared__ unsigned long long s_sum[2];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__threadfence_system(); // this workgroup's results (possibly in pinned host memory) before its ticket
+		s_last = atomicAdd(&db->ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+		s_sum[0] = s_sum[1] = 0;
+	}
+	__syncthreads();
+	if (!s_last) return;
+	__threadfence();
+	unsigned long long e = 0, v = 0;
+	for (int k = threadIdx.x; k < kMeetStatSlots; k += blockDim.x) {
+		e += __hip_atomic_load(&db->m.entries[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		v += __hip_atomic_load(&db->m.vertices[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		db->m.entries[k] = 0;
+		db->m.vertices[k] = 0;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		e += __shfl_xor(e, o);
+		v += __shfl_xor(v, o);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (e) atomicAdd(&s_sum[0], e);
+		if (v) atomicAdd(&s_sum[1], v);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		fin->entries = s_sum[0];
+		fin->vertices = s_sum[1];
+		fin->bad = __hip_atomic_load(&db->m.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (int k = 0; k < 3; k++) {
+			fin->count[k] = __hip_atomic_load(&db->count[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			db->count[k] = 0;
+		}
+		fin->dec = db->dec;
+		fin->count_back = __hip_atomic_load(&db->count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		db->m.bad = 0;
+		db->count[3] = 0;
+		db->ticket = 0;
+		db->next_job = 0;
+		db->dec.go = 0;
+		__threadfence_system();
+		fin->done = 1;
+	}
+}
+// per-workgroup statistics: one pair of atomics, spread over the slots
+__device__ __forceinline__ void meet_add_stats(MeetCounters *mc, unsigned long long entries, unsigned long long vertices) {
+	if (entries) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], entries);
+	if (vertices) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], vertices);
+}
+
 // One wavefront per row.  A row costs ~4 dependent memory round trips before its walk starts (row, offsets, the two
 // one-hop lists — the expanded side's arrives as slot descriptors, so the ranges of its vertices need no look-up) and a
-// single wavefront streams only a few KB per round trip, so what counts is how many rows a CU has in flight (registers
-// permitting: 5 KB of LDS each) — the workgroup is a single wavefront so that a finished row frees its slot at once.
-// Rows are dealt round-robin (one shared counter would serialise ~10^4 claims at 12-20 ns each: more than the walks
-// take).  The walk itself is seg_walk (pgq_walk.h): the padded lists of a round of 64 expanded vertices as one virtual
-// sequence of 16-byte groups, every lane of a request useful.  `cap` bounds the entries a row may WALK (nearly every
-// walk ends at its first hit long before): a row over it stays open for k_meet4d (16 wavefronts per row).
+// single wavefront streams only a few KB per round trip, so what counts is how many rows a CU has in flight — the
+// workgroup is a single wavefront so that a finished row frees its slot at once, and since round 4 it needs 4.2 KB of
+// LDS (the filter; the set's ids sit in registers, pgq_walk.h) so that 8 wavefronts fit a SIMD.  The walk itself is
+// seg_walk (pgq_walk.h): the padded lists of a round of 64 expanded vertices as one virtual sequence of 16-byte groups,
+// every lane of a request useful.  `cap` bounds the entries a row may WALK (nearly every walk ends at its first hit long
+// before): a row over it goes to k_meet4d (16 wavefronts), which takes the walk up in the round it was cut in.
 // `go` (nullable): device flag written by k_meet_decide; 0 = the host will take the lane-batched path, do nothing.
 // PATHS: also record the path's inner vertices (MeetPath); the walk then runs from dst over the source-ordered in-lists.
-template <bool PATHS>
-__global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+// BIGV: V > 2^20, the filter folds the higher id bits in.  DEPTH: list requests in flight.
+template <bool PATHS, bool BIGV, int DEPTH>
+__global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH > 2 ? 5 : PGQ_MEET3_WAVES))) void k_meet3(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                   int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                   const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
                                                   const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
                                                   const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
+                                                  const u32 *__restrict__ fwork, const u32 *__restrict__ rwork,
                                                   int64_t *__restrict__ out, MeetPath *__restrict__ rec, int64_t cap,
-                                                  const u32 *__restrict__ go, MeetCounters *__restrict__ mc) {
+                                                  const u32 *__restrict__ go, MeetDevBlock *__restrict__ db, MeetQueue q,
+                                                  MeetHostBlock *__restrict__ fin) {
 	static_assert(kMeetWPB == 1, "one wavefront per workgroup: the LDS arrays are addressed statically");
-	__shared__ __attribute__((aligned(16))) u32 tab[kMeetSlots];
-	__shared__ __attribute__((aligned(16))) u32 bm[kMeetFilter2Words];
+	__shared__ __attribute__((aligned(16))) u32 bm[kFltWords];
 	__shared__ __attribute__((aligned(16))) unsigned char win[64];
-	if (go && *go == 0) return;
+	MeetCounters *const mc = &db->m;
+	if (go && *go == 0) {
+		meet_finalize(db, fin);
+		return;
+	}
 	const int lane = threadIdx.x & 63;
 	win[lane] = 0;
 	unsigned long long entries = 0; // wave-uniform
@@ -113,6 +241,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 			}
 		}
 		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
+		const u32 workS = fwork[s], workD = rwork[d];
 		const int degS = se - so, degD = de - di;
 		{
 			if (degS == 0 || degD == 0) { // no path can exist: NULL like an exhausted search (iterativelength.cpp:133-139)
@@ -120,18 +249,23 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 				continue;
 			}
 		}
-		// expand from the endpoint with the shorter list (its two-hop walk is the cheaper one, nearly always); the
-		// other endpoint's list is the set.  fwd: walk N_out(N_out(s)) against the set N_in(d).
-		// PATHS always expands from dst against the set N_out(src): the in-lists are ordered by source (built so at
-		// upload), so the walk meets the witnesses in the order of the reference's tie-break (smallest second-to-last
+		MeetEntry ent = { (u32)i, 0u, (u32)s, (u32)d, (u32)so, (u32)degS, (u32)di, (u32)degD, workS, workD, 0u, 0u };
+		// expand from the endpoint whose two-hop walk is the shorter one (round 4: the sums of the neighbours' list lengths
+		// are kept per vertex; the shorter one-hop LIST picked the longer walk for every row that ran into the cap, and the
+		// walks are 4 % shorter on average); the other endpoint's list is the set.  fwd: walk N_out(N_out(s)) against the
+		// set N_in(d).  PATHS always expands from dst against the set N_out(src): the in-lists are ordered by source (built
+		// so at upload), so the walk meets the witnesses in the order of the reference's tie-break (smallest second-to-last
 		// vertex first, then the smallest vertex before it) and may stop at the first one
-		bool fwd = PATHS ? false : degS <= degD;
-		if (!PATHS && (fwd ? degD : degS) > kMeetSetMax) fwd = !fwd;
+		bool fwd = PATHS ? false : workS <= workD;
+		if (!PATHS && (fwd ? degD : degS) > kSetRegMax) fwd = !fwd;
 		const int set_n = fwd ? degD : degS;
 		const int exp_n = fwd ? degS : degD;
 		{
-			if (set_n > kMeetSetMax) { // both lists too long for the table
-				if (lane == 0) out[i] = kMeetOpen;
+			if (set_n > kSetRegMax) { // both lists too long for the registers
+				if (lane == 0) {
+					out[i] = kMeetOpen;
+					queue_push(q, (u32)i, ent);
+				}
 				continue;
 			}
 		}
@@ -139,31 +273,31 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 		const uint4 *exp_desc = fwd ? fdesc + so : rdesc + di;    // the expanded side's one-hop list (slot descriptors)
 		const int32_t *xp = fwd ? padj : rpadj;                   // padded adjacency of the expanded side's direction
 		const u32 other = (u32)(fwd ? s : d);                     // distance 1: the set list contains the other endpoint
-		// both one-hop lists are requested together
+		// both one-hop lists are requested together: the set's ids into registers, the expanded side's first descriptors
+		RegSet R;
+		R.rounds = (set_n + 63) >> 6;
+#pragma unroll
+		for (int k = 0; k < kSetRegs; k++) {
+			R.r[k] = kMeetEmpty;
+			if (k < R.rounds) { // wave-uniform
+				const int p = k * 64 + lane;
+				const u32 x = (u32)set_adj[min(p, set_n - 1)];
+				R.r[k] = p < set_n ? x : kMeetEmpty;
+			}
+		}
 		uint4 d0 = make_uint4(0, 0, 0, 0);
 		if (lane < exp_n) d0 = exp_desc[lane];
 #pragma unroll
-		for (int k = 0; k < kMeetSlots / 256; k++)
-			reinterpret_cast<uint4_alias *>(tab)[k * 64 + lane] = make_uint4(kMeetEmpty, kMeetEmpty, kMeetEmpty, kMeetEmpty);
-#pragma unroll
-		for (int k = 0; k < kMeetFilter2Words / 256; k++) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+		for (int k = 0; k < kFltWords / 256; k++) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
 		__builtin_amdgcn_wave_barrier();
 		bool hit = false;
-		for (int pb = 0; pb < set_n; pb += 128) { // two rounds of 64 requested together
-			const u32 x0 = pb + lane < set_n ? (u32)set_adj[pb + lane] : kMeetEmpty;
-			const u32 x1 = pb + 64 + lane < set_n ? (u32)set_adj[pb + 64 + lane] : kMeetEmpty;
 #pragma unroll
-			for (int r = 0; r < 2; r++) {
-				const u32 x = r ? x1 : x0;
+		for (int k = 0; k < kSetRegs; k++) {
+			if (k < R.rounds) {
+				const u32 x = R.r[k];
 				if (x != kMeetEmpty) {
 					hit |= x == other;
-					atomicOr(&bm[meet_f2_word(x)], meet_f2_mask(x));
-					u32 h = meet_hash(x);
-					for (;;) {
-						const u32 old = atomicCAS(&tab[h], kMeetEmpty, x);
-						if (old == kMeetEmpty || old == x) break;
-						h = (h + 1) & (kMeetSlots - 1);
-					}
+					atomicOr(&bm[flt_word(x)], flt_mask<BIGV>(x));
 				}
 			}
 		}
@@ -176,68 +310,65 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 				continue;
 			}
 			// distance 2: the middle vertex is the smallest common one
-			u32 mid = kMeetEmpty;
-			if (lane < exp_n && meet_lookup(tab, d0.x)) mid = d0.x;
-			for (int p = 64 + lane; p < exp_n; p += 64) {
-				const u32 v = exp_desc[p].x;
-				if (meet_lookup(tab, v)) mid = min(mid, v);
+			u32 mid = kMeetEmpty; // wave-uniform
+			for (int pb = 0; pb < exp_n; pb += 64) {
+				const int p = pb + lane;
+				u32 v = kMeetEmpty;
+				if (pb == 0) v = lane < exp_n ? d0.x : kMeetEmpty;
+				else if (p < exp_n) v = exp_desc[p].x;
+				const u32 pass = v != kMeetEmpty ? (flt_test<BIGV>(bm[flt_word(v)], v) & 1u) : 0u;
+				verify_candidates(R, pass, make_int4((int)v, 0, 0, 0), [&](u32 x, int) { mid = min(mid, x); });
 			}
-			if (__any(mid != kMeetEmpty)) {
-				if constexpr (PATHS) {
-					const u32 m = (u32)wave_min_u64((u64)mid);
-					if (lane == 0) rec[i].v1 = (int32_t)m;
+			if (mid != kMeetEmpty) {
+				if (lane == 0) {
+					if constexpr (PATHS) rec[i].v1 = (int32_t)mid;
+					out[i] = 2;
 				}
-				if (lane == 0) out[i] = 2;
 				continue;
 			}
 		}
-		// distance 3: the padded lists of the expanded side's vertices, one hash probe per entry, ended by the first pass
-		// with a hit.  PATHS: requests are processed in walk order and the lists ascend, so every later witness has a
-		// larger (second vertex, first vertex) key than the smallest one of the pass that found the first
-		bool f = false;
-		u64 best = ~0ull; // PATHS: smallest (outer vertex << 32 | inner vertex) over the witnesses
+		// distance 3: the padded lists of the expanded side's vertices, one filter probe per entry (the exact test only for
+		// what the filter lets through), ended by the first pass with a hit.  PATHS: requests are processed in walk order
+		// and the lists ascend, so every later witness has a larger (second vertex, first vertex) key than the smallest one
+		// of the pass that found the first
+		u64 best = ~0ull; // wave-uniform: smallest (outer vertex << 32 | inner vertex) over the witnesses (PATHS), or 0 = found
 		bool capped = false;
-		entries += seg_walk<PGQ_MEET3_DEPTH, PATHS>(
-		    exp_desc, exp_n, 0, 1, xp, win, true, d0, (unsigned long long)cap, capped,
+		int resume = 0;
+		entries += seg_walk<DEPTH, PATHS>(
+		    exp_desc, exp_n, 0, 1, xp, win, true, d0, (unsigned long long)cap, capped, resume,
 		    [&](const int4 &v, bool ok, u32 ev) {
-			    if constexpr (PATHS) { // backward walk: expanded vertex = second-to-last, entry = the one before it
-				    const u32 m = ok ? meet_which4(tab, bm, v) : 0u;
-				    if (m & 1u) best = min(best, (u64)ev << 32 | (u32)v.x);
-				    if (m & 2u) best = min(best, (u64)ev << 32 | (u32)v.y);
-				    if (m & 4u) best = min(best, (u64)ev << 32 | (u32)v.z);
-				    if (m & 8u) best = min(best, (u64)ev << 32 | (u32)v.w);
-			    } else { // a lane past the round's end re-reads real entries of the last list: no mask needed
-				    f |= meet_any4(tab, bm, v);
-			    }
+			    // a lane past the round's end re-reads real entries of the last list: no mask needed for membership;
+			    // PATHS masks them (their ev is the last list's, so they would even be right, but cost a verification)
+			    const u32 pass = (PATHS && !ok) ? 0u : flt_pass4<BIGV>(bm, v);
+			    verify_candidates(R, pass, v, [&](u32 x, int L) {
+				    if constexpr (PATHS) { // backward walk: expanded vertex = second-to-last, entry = the one before it
+					    const u32 y = (u32)__builtin_amdgcn_readlane((int)ev, L);
+					    best = min(best, (u64)y << 32 | x);
+				    } else {
+					    best = 0;
+				    }
+			    });
 		    },
-		    [&]() { return PATHS ? (__any(best != ~0ull) != 0) : (__any(f) != 0); });
-		bool found;
-		if constexpr (PATHS) {
-			best = wave_min_u64(best);
-			found = best != ~0ull;
-			if (found && lane == 0) {
-				rec[i].v2 = (int32_t)(best >> 32);
-				rec[i].v1 = (int32_t)(u32)best;
+		    [&]() { return best != ~0ull; });
+		const bool found = best != ~0ull;
+		if (lane == 0) {
+			if constexpr (PATHS) {
+				if (found) {
+					rec[i].v2 = (int32_t)(best >> 32);
+					rec[i].v1 = (int32_t)(u32)best;
+				}
 			}
-		} else {
-			found = __any(f) != 0;
+			// the walk ran to its end without a witness: the distance is at least 4; it was cut short: distances 1 and 2
+			// are excluded and the next stage takes the walk up where it stopped
+			out[i] = found ? 3 : (capped ? kMeetOpen : kMeetOpen4);
+			if (!found) {
+				ent.flags = capped ? (kEntKnown3 | (fwd ? kEntFwd : 0u) | ((u32)resume << kEntResumeShift)) : kEntKnown4;
+				queue_push(q, (u32)i, ent);
+			}
 		}
-		// the walk ran to its end without a witness: the distance is at least 4; it was cut short: nothing is known
-		if (lane == 0) out[i] = found ? 3 : (capped ? kMeetOpen : kMeetOpen4);
 	}
-	// one pair of atomics per workgroup, spread over the statistic slots
-	__shared__ unsigned long long s_stat[2];
-	if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
-	__syncthreads();
-	if (lane == 0) {
-		if (entries) atomicAdd(&s_stat[0], entries);
-		if (vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
-		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
-	}
+	if (lane == 0) meet_add_stats(mc, entries, (unsigned long long)vertices);
+	meet_finalize(db, fin);
 }
 
 // ---- distance <= 4 with an exact vertex bit map, path variant (k_meet4) ---------------------------------------------
@@ -255,14 +386,17 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : PGQ_MEET3_WAVES) void k_
 // entries stay open.  Distance-only rows take k_meet4d below.
 
 template <bool PATHS, bool GM>
-__global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+__global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
-                                                const u32 *__restrict__ didx, int64_t *__restrict__ out_rows,
+                                                int64_t *__restrict__ out_rows,
                                                 MeetPath *__restrict__ rec_rows, int64_t cap, int bm_words,
-                                                MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps) {
+                                                MeetDevBlock *__restrict__ db, u32 *__restrict__ gmaps, MeetQueue qout,
+                                                MeetHostBlock *__restrict__ fin) {
 	extern __shared__ u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
-	const int64_t n = (int64_t)*n_rows; // rows left open by the kernel before (counted on the device: no host round trip)
+	const int64_t n = (int64_t)*qin.count; // rows left open by the kernel before (counted on the device: no host round trip)
+	const int64_t *const src = qin.src, *const dst = qin.dst;
+	const u32 *const didx = qin.idx;
+	MeetCounters *const mc = &db->m;
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
 	__shared__ unsigned long long s_work[2];
 	__shared__ unsigned long long s_best;
@@ -295,6 +429,11 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 		// rows k_meet3 walked to the end are known to be at distance >= 4: only the two two-hop walks remain (two
 		// dependent phases instead of six; their sizes passed k_meet3's cap, which is below this kernel's)
 		const bool known4 = (didx[i] & kMeetKnown4Bit) != 0;
+		auto leave_open = [&]() { // one thread: the row goes on to the next stage
+			out_rows[row] = kMeetOpen;
+			const MeetEntry e = { row, 0u, (u32)s, (u32)d, (u32)so, (u32)degS, (u32)di, (u32)degD };
+			queue_push(qout, row, e);
+		};
 		clear_map();
 		if (tid == 0) {
 			s_work[0] = s_work[1] = 0;
@@ -374,7 +513,7 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 				continue;
 			}
 			if ((int64_t)s_work[1] > cap) {
-				if (tid == 0) out_rows[row] = kMeetOpen;
+				if (tid == 0) leave_open();
 				continue;
 			}
 		}
@@ -418,7 +557,7 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 				continue;
 			}
 			if ((int64_t)s_work[0] > cap) {
-				if (tid == 0) out_rows[row] = kMeetOpen;
+				if (tid == 0) leave_open();
 				continue;
 			}
 		}
@@ -446,7 +585,10 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 				}
 			}
 		}
-		if (tid == 0) out_rows[row] = found4 ? 4 : kMeetOpen;
+		if (tid == 0) {
+			if (found4) out_rows[row] = 4;
+			else leave_open();
+		}
 	}
 	__shared__ unsigned long long s_stat[2];
 	__syncthreads();
@@ -456,10 +598,8 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
 	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
 	__syncthreads();
-	if (tid == 0) {
-		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
-		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
-	}
+	if (tid == 0) meet_add_stats(mc, s_stat[0], s_stat[1]);
+	meet_finalize(db, fin);
 }
 
 // ---- distance only: k_meet4d -------------------------------------------------------------------------------------------
@@ -473,26 +613,27 @@ __global__ __launch_bounds__(1024) void k_meet4(const u32 *__restrict__ n_rows, 
 //     distance 3: two-hop walk of the cheaper endpoint against the map, ended by the first hit
 //     distance 4: map = two-hop set of the cheaper endpoint, two-hop walk of the other one, ended by the first hit
 // Rows with distance >= 4 proven start at the last step (cheaper endpoint: the shorter one-hop list).
-template <bool GM>
-__global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(const u32 *__restrict__ n_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                 const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
-                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+template <bool GM, bool TRACE>
+__global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin, const int32_t *__restrict__ adj, const int32_t *__restrict__ radj,
                                                  const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
                                                  const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
-                                                 const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
-                                                 int bm_words, MeetCounters *__restrict__ mc, u32 *__restrict__ gmaps,
-                                                 unsigned long long *__restrict__ trace) {
+                                                 int64_t *__restrict__ out_rows, int64_t cap, int bm_words,
+                                                 MeetDevBlock *__restrict__ db, u32 *__restrict__ gmaps, MeetQueue qout,
+                                                 MeetHostBlock *__restrict__ fin, unsigned long long *__restrict__ trace) {
 	extern __shared__ __attribute__((aligned(16))) u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
-	const int64_t n = (int64_t)*n_rows; // rows left open by the kernel before (counted on the device: no host round trip)
+	// rows the stage before left open (counted on the device: no host round trip): nf from the front of its queue (the
+	// long ones), the rest from the back
+	const u32 nf = *qin.count, n = nf + (qin.count_back ? *qin.count_back : 0u);
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
 	__shared__ int s_flag;
-	__shared__ unsigned long long s_work[2];
+	__shared__ int s_capped;
+	__shared__ u32 s_job;
 	__shared__ __attribute__((aligned(16))) unsigned char s_win[16][64];
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 	unsigned char *win = s_win[wib]; // seg_owner's window of this wavefront
 	win[lane] = 0;
-	unsigned long long entries = 0;
-	u32 vertices = 0;
+	unsigned long long entries = 0; // wave-uniform: this wavefront's share
+	u32 vertices = 0;               // wave-uniform (wavefront 0 counts)
 	auto bit = [&](u32 x) {
 		const u32 w = GM ? __hip_atomic_load(&gmap[x >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_map[x >> 5];
 		return (w >> (x & 31)) & 1u;
@@ -520,96 +661,91 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(const u32 *__
 		return v;
 	};
 	// the padded lists hold copies of a list's last entry and the lanes past a round's end re-read its last group:
-	// both repeat real entries, which neither a bit test nor a mark minds
+	// both repeat real entries, which neither a bit test nor a mark minds.  Every wavefront may request cap / 16 entries.
 	auto walk_test = [&](const uint4 *list, int list_n, const int32_t *xp, bool have_first, uint4 first) {
 		bool f = false, capped = false;
+		int resume = 0;
 		const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
-		    list, list_n, wib, 16, xp, win, have_first, first, ~0ull, capped,
+		    list, list_n, wib, 16, xp, win, have_first, first, (unsigned long long)cap >> 4, capped, resume,
 		    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
 		    [&]() {
 			    if (__any(f)) s_flag = 1;
 			    return flag_set();
 		    });
-		if (lane == 0) entries += e2;
+		entries += e2;
 		if (__any(f)) s_flag = 1;
+		if (capped) s_capped = 1;
 	};
-	// A row is ~8 dependent memory round trips (row -> offsets -> descriptors -> lists, twice) and only two rows fit a CU
-	// (the bit map), so the kernel is bound by that chain: the NEXT row's header is requested while the current row
-	// walks (volatile loads: the compiler must not sink them to their first use), and both walks' first descriptors are
-	// requested together.
-	struct Hdr {
-		int64_t s, d;
-		u32 code;
-		int so, se, di, de;
-	};
-	auto load_ids = [&](int64_t i, Hdr &h) {
-		h.s = *(const volatile int64_t *)&src[i];
-		h.d = *(const volatile int64_t *)&dst[i];
-		h.code = *(const volatile u32 *)&didx[i];
-	};
-	auto load_offsets = [&](Hdr &h) {
-		h.so = (int)*(const volatile int64_t *)&off[h.s];
-		h.se = (int)*(const volatile int64_t *)&off[h.s + 1];
-		h.di = (int)*(const volatile int64_t *)&roff[h.d];
-		h.de = (int)*(const volatile int64_t *)&roff[h.d + 1];
+	auto walk_mark = [&](const uint4 *list, int list_n, const int32_t *xp, uint4 first) {
+		bool capped = false;
+		int resume = 0;
+		const unsigned long long e2 = seg_walk<PGQ_MEET4_MARK_DEPTH, false>(
+		    list, list_n, wib, 16, xp, win, true, first, (unsigned long long)cap >> 4, capped, resume,
+		    [&](const int4 &v, bool, u32) {
+			    mark((u32)v.x);
+			    mark((u32)v.y);
+			    mark((u32)v.z);
+			    mark((u32)v.w);
+		    },
+		    []() { return false; });
+		entries += e2;
+		if (capped) s_capped = 1;
 	};
 	// option meet_trace: per-workgroup {start, end, rows, longest row} in 10-ns ticks of the constant clock
-	const unsigned long long t_begin = trace ? wall_clock64() : 0ull;
-	unsigned long long t_row_max = 0, n_rows_done = 0, t_ph[3] = { 0, 0, 0 }; // phases: header + clear, marking walk, testing walk
-	Hdr cur = { 0, 0, 0, 0, 0, 0, 0 }, nxt = { 0, 0, 0, 0, 0, 0, 0 };
-	if ((int64_t)blockIdx.x < n) {
-		load_ids(blockIdx.x, cur);
-		load_offsets(cur);
-	}
-	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-		__syncthreads(); // the previous row's flag and map are no longer read
-		const bool have_next = i + gridDim.x < n;
-		bool next_offsets = false;
-		if (have_next) load_ids(i + gridDim.x, nxt);
-		auto prefetch_next_offsets = [&]() { // second level of the next row's header: its ids have arrived by now
-			if (have_next && !next_offsets) {
-				load_offsets(nxt);
-				next_offsets = true;
-			}
-		};
-		const int64_t d = cur.d; // rows left open by k_meet3: ids in range, src != dst, both have edges
-		const u32 row = cur.code & ~kMeetKnown4Bit;
-		const int so = cur.so, se = cur.se, di = cur.di, de = cur.de;
-		const int degS = se - so, degD = de - di;
-		const bool known4 = (cur.code & kMeetKnown4Bit) != 0;
-		const unsigned long long t_row0 = trace ? wall_clock64() : 0ull;
-		auto process_row = [&]() {
-			clear_map();
-			if (tid == 0) {
-				s_flag = 0;
-				s_work[0] = s_work[1] = 0;
-			}
+	const unsigned long long t_begin = TRACE ? wall_clock64() : 0ull;
+	unsigned long long t_row_max = 0, n_rows_done = 0;
+	// Rows are handed out in queue order by an atomic counter (the first gridDim.x positions are the workgroups' own): the
+	// long rows sit at the front, so they start first and a workgroup stuck in one simply takes fewer of the short ones —
+	// with the static stride of round 3 a slot could draw two long rows, or a long one last.  Thread 0 draws the NEXT
+	// position while the current row is processed (the atomic's round trip is off the critical path).
+	u32 job = blockIdx.x;
+	for (;;) {
+		__syncthreads(); // the previous row's flags, map and s_job are no longer read
+		if (job >= n) break;
+		u32 next_job = 0;
+		if (tid == 0) next_job = gridDim.x + atomicAdd(&db->next_job, 1u);
+		const unsigned long long t_row = TRACE ? wall_clock64() : 0ull;
+		// the row's queue entry: everything the stage before knew about it, in three 16-byte loads (the queue is a few
+		// tens of KB written moments ago), wave-uniform -> scalar registers
+		const uint4 *ep = reinterpret_cast<const uint4 *>(qin.ent + queue_pos(qin, job, nf));
+		const uint4 e0 = ep[0], e1 = ep[1], e2w = ep[2];
+		const u32 workS = (u32)__builtin_amdgcn_readfirstlane((int)e2w.x), workD = (u32)__builtin_amdgcn_readfirstlane((int)e2w.y);
+		const u32 row = (u32)__builtin_amdgcn_readfirstlane((int)e0.x), flags = (u32)__builtin_amdgcn_readfirstlane((int)e0.y);
+		const u32 es = (u32)__builtin_amdgcn_readfirstlane((int)e0.z), ed = (u32)__builtin_amdgcn_readfirstlane((int)e0.w);
+		const int so = __builtin_amdgcn_readfirstlane((int)e1.x), degS = __builtin_amdgcn_readfirstlane((int)e1.y);
+		const int di = __builtin_amdgcn_readfirstlane((int)e1.z), degD = __builtin_amdgcn_readfirstlane((int)e1.w);
+		const bool known4 = (flags & kEntKnown4) != 0, known3 = (flags & kEntKnown3) != 0;
+		clear_map();
+		if (tid == 0) {
+			s_flag = 0;
+			s_capped = 0;
+		}
+		__syncthreads();
+		if (wib == 0) vertices += (u32)(degS + degD); // both one-hop lists as descriptors
+		bool walk_fwd = workS <= workD; // which endpoint's two-hop neighbourhood is walked / marked: the smaller one
+		int64_t result = kMeetOpen;   // wave-uniform
+		int resume3 = 0;
+		bool do3 = false, do4 = true;
+		if (known3) {
+			// k_meet3 excluded distances 1 and 2 and walked part of one endpoint's two-hop neighbourhood against the
+			// other endpoint's one-hop list: the same test with 16 wavefronts, from the round it stopped in
+			walk_fwd = (flags & kEntFwd) != 0;
+			resume3 = (int)(flags >> kEntResumeShift);
+			const int32_t *set_list = walk_fwd ? radj + di : adj + so;
+			const int set_n = walk_fwd ? degD : degS;
+			for (int p = tid; p < set_n; p += 1024) mark((u32)set_list[p]);
+			if (wib == 0) entries += (unsigned long long)set_n;
 			__syncthreads();
-			if (tid == 0) vertices += (u32)(degS + degD); // both one-hop lists as descriptors
-			bool walk_fwd = degS <= degD; // which endpoint's two-hop neighbourhood is walked / marked
-			if (!known4) {
-				unsigned long long wf = 0, wb = 0;
-				bool hit = false;
-				for (int p = tid; p < degS; p += 1024) {
-					const uint4 dd = fdesc[so + p];
-					hit |= dd.x == (u32)d;
-					wf += (unsigned long long)dd.z;
-				}
-				for (int p = tid; p < degD; p += 1024) wb += (unsigned long long)rdesc[di + p].z;
-				for (int o = 32; o > 0; o >>= 1) {
-					wf += __shfl_xor(wf, o);
-					wb += __shfl_xor(wb, o);
-				}
-				if (lane == 0) {
-					if (wf) atomicAdd(&s_work[0], wf);
-					if (wb) atomicAdd(&s_work[1], wb);
-				}
-				if (__any(hit) && lane == 0) s_flag = 1;
-				if (flag_snapshot()) { // dst in N_out(src)
-					if (tid == 0) out_rows[row] = 1;
-					return;
-				}
-				const int64_t work_f = (int64_t)s_work[0], work_b = (int64_t)s_work[1];
+			do3 = true;
+		} else if (!known4) {
+			bool hit = false;
+			for (int p = tid; p < degS; p += 1024) hit |= (u32)adj[so + p] == ed;
+			if (__any(hit) && lane == 0) s_flag = 1;
+			if (flag_snapshot()) { // dst in N_out(src)
+				result = 1;
+				do4 = false;
+			} else {
+				const int64_t work_f = (int64_t)workS, work_b = (int64_t)workD; // the two-hop walks' sizes came with the row
 				walk_fwd = work_f <= work_b;
 				{ // the set: one-hop list of the endpoint that is not walked
 					const int32_t *set_list = walk_fwd ? radj + di : adj + so;
@@ -619,34 +755,38 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(const u32 *__
 				__syncthreads();
 				const int32_t *wl = walk_fwd ? adj + so : radj + di;
 				const int wn = walk_fwd ? degS : degD;
-				if (tid == 0) entries += (unsigned long long)(degS + degD);
+				if (wib == 0) entries += (unsigned long long)(degS + degD);
 				{ // distance 2: a common neighbour
 					bool f = false;
 					for (int p = tid; p < wn; p += 1024) f |= bit((u32)wl[p]) != 0;
 					if (__any(f) && lane == 0) s_flag = 1;
 				}
 				if (flag_snapshot()) {
-					if (tid == 0) out_rows[row] = 2;
-					return;
+					result = 2;
+					do4 = false;
+				} else if (min(work_f, work_b) > cap) {
+					do4 = false; // stays open
+				} else {
+					do3 = true;
+					if (max(work_f, work_b) > cap) do4 = false; // if the distance-3 walk finds nothing the row stays open
 				}
-				if (min(work_f, work_b) > cap) {
-					if (tid == 0) out_rows[row] = kMeetOpen;
-					return;
-				}
-				prefetch_next_offsets();
-				// distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
-				walk_test(walk_fwd ? fdesc + so : rdesc + di, wn, walk_fwd ? padj : rpadj, false, make_uint4(0, 0, 0, 0));
-				if (flag_snapshot()) {
-					if (tid == 0) out_rows[row] = 3;
-					return;
-				}
-				if (max(work_f, work_b) > cap) {
-					if (tid == 0) out_rows[row] = kMeetOpen;
-					return;
-				}
-				clear_map(); // every wavefront is past its reads of the map (barriers above)
+			}
+		}
+		if (do3) {
+			// distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
+			const uint4 *wl = (walk_fwd ? fdesc + so : rdesc + di) + resume3;
+			const int wn = (walk_fwd ? degS : degD) - resume3;
+			walk_test(wl, wn, walk_fwd ? padj : rpadj, false, make_uint4(0, 0, 0, 0));
+			if (flag_snapshot()) {
+				result = 3;
+				do4 = false;
+			} else {
+				if (s_capped) do4 = false;
+				if (do4) clear_map(); // every wavefront is past its reads of the map (barriers above)
 				__syncthreads();
 			}
+		}
+		if (do4) {
 			// distance 4: two-hop set of the walked endpoint, two-hop walk of the other one.  Both walks' first
 			// descriptors are requested together (one round trip instead of two)
 			const uint4 *mark_list = walk_fwd ? fdesc + so : rdesc + di, *test_list = walk_fwd ? rdesc + di : fdesc + so;
@@ -654,62 +794,62 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(const u32 *__
 			uint4 d_mark = make_uint4(0, 0, 0, 0), d_test = make_uint4(0, 0, 0, 0);
 			if (lane < mark_n) d_mark = mark_list[lane]; // every wavefront holds the round's 64 descriptors (it takes every 16th request)
 			if (lane < test_n) d_test = test_list[lane];
-			prefetch_next_offsets();
-			const unsigned long long t_p1 = trace ? wall_clock64() : 0ull;
-			{
-				bool capped = false;
-				const unsigned long long e2 = seg_walk<PGQ_MEET4_MARK_DEPTH, false>(
-				    mark_list, mark_n, wib, 16, walk_fwd ? padj : rpadj, win, true, d_mark, ~0ull, capped,
-				    [&](const int4 &v, bool, u32) {
-					    mark((u32)v.x);
-					    mark((u32)v.y);
-					    mark((u32)v.z);
-					    mark((u32)v.w);
-				    },
-				    []() { return false; });
-				if (lane == 0) entries += e2;
-			}
+			walk_mark(mark_list, mark_n, walk_fwd ? padj : rpadj, d_mark);
 			__syncthreads();
-			const unsigned long long t_p2 = trace ? wall_clock64() : 0ull;
-			walk_test(test_list, test_n, walk_fwd ? rpadj : padj, true, d_test);
-			const int f4 = flag_snapshot();
-			if (trace) {
-				t_ph[0] += t_p1 - t_row0;
-				t_ph[1] += t_p2 - t_p1;
-				t_ph[2] += wall_clock64() - t_p2;
+			int f4 = 0;
+			if (!s_capped) {
+				// Probe first: nearly every row that gets here IS at distance 4, and then about one entry in thirty of the other
+				// endpoint's two-hop neighbourhood is marked — the first request (256 entries) holds a witness.  The cooperative
+				// walk below opens with 32 requests (16 wavefronts x 2 in flight) before anyone looks at the flag: ~45 KB and
+				// their bit tests per row, for an answer the first KB gives.  Two wavefronts take one request each.
+				if (wib < 2) {
+					bool f = false, capped = false;
+					int resume = 0;
+					const unsigned long long e2 = seg_walk<1, false>(
+					    test_list, min(test_n, 64), wib, 16, walk_fwd ? rpadj : padj, win, true, d_test, 0ull, capped, resume,
+					    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
+					    []() { return true; });
+					entries += e2;
+					if (__any(f)) s_flag = 1;
+				}
+				f4 = flag_snapshot();
+				if (!f4) {
+					walk_test(test_list, test_n, walk_fwd ? rpadj : padj, true, d_test);
+					f4 = flag_snapshot();
+				}
 			}
-			if (tid == 0) out_rows[row] = f4 ? 4 : kMeetOpen;
-		};
-		const unsigned long long t_row = trace ? wall_clock64() : 0ull;
-		process_row();
-		if (trace) {
+			if (f4) result = 4;
+		}
+		if (tid == 0) {
+			out_rows[row] = result;
+			if (result == kMeetOpen) {
+				const MeetEntry e = { row, 0u, es, ed, (u32)so, (u32)degS, (u32)di, (u32)degD, workS, workD, 0u, 0u };
+				queue_push(qout, row, e);
+			}
+			s_job = next_job;
+		}
+		if constexpr (TRACE) {
 			t_row_max = max(t_row_max, wall_clock64() - t_row);
 			n_rows_done++;
 		}
-		prefetch_next_offsets();
-		cur = nxt;
+		__syncthreads();
+		job = s_job;
 	}
-	if (trace && tid == 0) {
-		trace[8 * blockIdx.x] = t_begin;
-		trace[8 * blockIdx.x + 1] = wall_clock64();
-		trace[8 * blockIdx.x + 2] = n_rows_done;
-		trace[8 * blockIdx.x + 3] = t_row_max;
-		trace[8 * blockIdx.x + 4] = t_ph[0];
-		trace[8 * blockIdx.x + 5] = t_ph[1];
-		trace[8 * blockIdx.x + 6] = t_ph[2];
+	if (TRACE && tid == 0) {
+		trace[4 * blockIdx.x] = t_begin;
+		trace[4 * blockIdx.x + 1] = wall_clock64();
+		trace[4 * blockIdx.x + 2] = n_rows_done;
+		trace[4 * blockIdx.x + 3] = t_row_max;
 	}
 	__shared__ unsigned long long s_stat[2];
 	__syncthreads();
 	if (tid < 2) s_stat[tid] = 0;
 	__syncthreads();
-	for (int o = 32; o > 0; o >>= 1) entries += __shfl_xor(entries, o);
 	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
 	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
 	__syncthreads();
-	if (tid == 0) {
-		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
-		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
-	}
+	if (tid == 0) meet_add_stats(&db->m, s_stat[0], s_stat[1]);
+	meet_finalize(db, fin);
 }
 
 // ---- any distance, few rows: bidirectional BFS per row (k_bibfs) ---------------------------------------------------
@@ -727,17 +867,33 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(const u32 *__
 // means that side's closure is complete: NULL, like the exhausted search of iterativelength.cpp:133-139.  A frontier over
 // `cap` entries or `qcap` vertices leaves the row open.
 template <bool GM>
-__global__ __launch_bounds__(1024) void k_bibfs(const u32 *__restrict__ n_rows, u32 max_rows, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+__global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
                                                 const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
-                                                const u32 *__restrict__ didx, int64_t *__restrict__ out_rows, int64_t cap,
-                                                int bm_words, int qcap, MeetCounters *__restrict__ mc,
-                                                u32 *__restrict__ gmaps, u32 *__restrict__ queues) {
+                                                int64_t *__restrict__ out_rows, int64_t cap,
+                                                int bm_words, int qcap, MeetDevBlock *__restrict__ db,
+                                                u32 *__restrict__ gmaps, u32 *__restrict__ queues, MeetQueue qout,
+                                                MeetHostBlock *__restrict__ fin) {
+	const int64_t *const src = qin.src, *const dst = qin.dst;
+	const u32 *const didx = qin.idx;
+	MeetCounters *const mc = &db->m;
 	extern __shared__ u32 s_map[]; // !GM: both maps, (bm_words + 4) words each; the spare words take the masked lanes' bits
 	// rows still open, counted on the device (no host round trip before this launch); more than a handful: not this
 	// kernel's job, the lane-batched search takes them
-	const int64_t n = (int64_t)*n_rows;
-	if (n > (int64_t)max_rows) return;
+	const int64_t n = (int64_t)*qin.count;
+	if (n > (int64_t)max_rows) {
+		// not this kernel's job: the rows pass through to the next queue unchanged (the host reads one region whatever ran)
+		for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+			qout.src[i] = src[i];
+			qout.dst[i] = dst[i];
+			qout.idx[i] = didx[i];
+			reinterpret_cast<uint4 *>(qout.ent + i)[0] = reinterpret_cast<const uint4 *>(qin.ent + i)[0];
+			reinterpret_cast<uint4 *>(qout.ent + i)[1] = reinterpret_cast<const uint4 *>(qin.ent + i)[1];
+		}
+		if (blockIdx.x == 0 && threadIdx.x == 0) *qout.count = (u32)n;
+		meet_finalize(db, fin);
+		return;
+	}
 	const int mw = bm_words + 4;
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * 2 * mw : nullptr;
 	u32 *const qbase = queues + (size_t)blockIdx.x * 4 * qcap; // [side][parity][qcap]
@@ -849,7 +1005,13 @@ __global__ __launch_bounds__(1024) void k_bibfs(const u32 *__restrict__ n_rows, 
 			par[side] ^= 1;
 			__syncthreads(); // s_cnt / s_work are reset by the next round
 		}
-		if (tid == 0) out_rows[row] = result;
+		if (tid == 0) {
+			out_rows[row] = result;
+			if (result == kMeetOpen) {
+				const MeetEntry e = { row, (didx[i] & kMeetKnown4Bit) ? kEntKnown4 : 0u, (u32)s, (u32)d, 0u, 0u, 0u, 0u };
+				queue_push(qout, row, e);
+			}
+		}
 	}
 	__shared__ unsigned long long s_stat[2];
 	__syncthreads();
@@ -859,10 +1021,8 @@ __global__ __launch_bounds__(1024) void k_bibfs(const u32 *__restrict__ n_rows, 
 	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
 	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
 	__syncthreads();
-	if (tid == 0) {
-		if (s_stat[0]) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], s_stat[0]);
-		if (s_stat[1]) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], s_stat[1]);
-	}
+	if (tid == 0) meet_add_stats(mc, s_stat[0], s_stat[1]);
+	meet_finalize(db, fin);
 }
 
 // ---- path emission -------------------------------------------------------------------------------------------------
@@ -916,13 +1076,6 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // compares the two cost estimates ON THE DEVICE: the pre-pass kernels are launched straight behind and return at once
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
 constexpr int kSampleRows = 2048, kSampleSlots = 4096;
-struct MeetDecision {
-	u32 go;           // 1: the pre-pass runs
-	u32 sample_rows;  // non-NULL rows sampled
-	u32 sample_fresh; // distinct sources among them
-	u32 pad;
-	double estimate;  // distinct sources of the whole input
-};
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
                                                      double edge_bytes, MeetDecision *__restrict__ out) {
 	__shared__ u32 s_set[kSampleSlots];
@@ -953,53 +1106,34 @@ __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *
 	if (fresh) atomicAdd(&s_count[0], fresh);
 	if (rows) atomicAdd(&s_count[1], rows);
 	__syncthreads();
-	if (threadIdx.x != 0) return;
+	// E[distinct](U) = U (1 - (1 - 1/U)^s) is increasing in U: every thread evaluates one point of a geometric grid between
+	// the distinct sources seen and n ((1 - 1/U)^s as exp(s log1p(-1/U)), single precision) and the first point that
+	// reaches the sampled count is the estimate — round 3 bisected on one thread (18 dependent steps: 4 of the 16 us this
+	// kernel sits in front of every large call with)
+	__shared__ u32 s_first;
+	if (threadIdx.x == 0) s_first = 1023u;
+	__syncthreads();
 	const double d = s_count[0], sr = s_count[1];
 	double est;
 	if (sr < 1 || d < 1) {
 		est = 1;
 	} else if (d >= sr - 0.5) { // every sampled row had its own source
 		est = (double)n;
-	} else {
-		// E[distinct](U) is increasing in U: bisection in single precision ((1 - 1/U)^s as exp(s log1p(-1/U)); a double
-		// pow() per step made this one-thread tail 35 us of a 42-us kernel that sits in front of every large call)
-		float lo = (float)d, hi = (float)n;
-		const float fs = (float)sr, fd = (float)d;
-		for (int it = 0; it < 18; it++) {
-			const float mid = 0.5f * (lo + hi);
-			const float e = mid * (1.0f - __expf(fs * log1pf(-1.0f / mid)));
-			if (e < fd) lo = mid;
-			else hi = mid;
-		}
-		est = fmin((double)n, ceil((double)hi));
+	} else { // block-uniform branch
+		const float fd = (float)d, fs = (float)sr, fn = (float)n;
+		const float u = fd * __expf(__logf(fn / fd) * ((float)threadIdx.x * (1.0f / 1023.0f)));
+		const float e = u * (1.0f - __expf(fs * log1pf(-1.0f / u)));
+		if (e >= fd) atomicMin(&s_first, threadIdx.x);
+		__syncthreads();
+		const float uf = fd * __expf(__logf(fn / fd) * ((float)s_first * (1.0f / 1023.0f)));
+		est = fmin((double)n, ceil((double)uf));
 	}
+	if (threadIdx.x != 0) return;
 	const double distinct = fmin(est, (double)V);
 	out->go = meet_bytes <= lanes_cost_bytes(edge_bytes, distinct) ? 1u : 0u;
 	out->sample_rows = s_count[1];
 	out->sample_fresh = s_count[0];
 	out->estimate = est;
-}
-
-// rows the pre-pass left open, compacted for the lane-batched search (order does not matter: results are scattered
-// back through didx)
-__global__ void k_collect_open(int64_t n, const int64_t *__restrict__ out, const int64_t *__restrict__ src,
-                               const int64_t *__restrict__ dst, int64_t *__restrict__ dsrc, int64_t *__restrict__ ddst,
-                               u32 *__restrict__ didx, u32 *__restrict__ count, const u32 *__restrict__ go) {
-	if (go && *go == 0) return; // the pre-pass was called off: d_out holds nothing
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const bool open = i < n && (out[i] == kMeetOpen || out[i] == kMeetOpen4);
-	const u64 m = __ballot(open);
-	if (!m) return;
-	const int lane = threadIdx.x & 63;
-	u32 base = 0;
-	if (lane == 0) base = atomicAdd(count, (u32)__popcll(m));
-	base = __shfl(base, 0);
-	if (open) {
-		const u32 p = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
-		dsrc[p] = src[i];
-		ddst[p] = dst[i];
-		didx[p] = (u32)i | (out[i] == kMeetOpen4 ? kMeetKnown4Bit : 0u); // bit 31: distances 1..3 are excluded (k_meet4d needs no look-up)
-	}
 }
 
 __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
@@ -1008,73 +1142,96 @@ __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int
 	if (j < nd) out[didx[j] & ~kMeetKnown4Bit] = dlen[j];
 }
 
-// Runs the pre-pass over n rows resident in HBM; rows it answers get their hop count (or -1 for NULL) in d_out, the
-// others are compacted into ws->def_src/def_dst/def_idx and counted in *n_open.  The whole chain — decision (large
-// inputs), k_meet3, the bit-map kernel, the bidirectional search for a handful of leftovers, the compactions between
-// them — is launched back to back; every kernel reads what it needs (the go flag, the number of rows still open) from
-// device memory, so the host waits ONCE per call.  decide: k_meet_decide compares `meet_bytes` with the lanes' cost for
-// the sampled number of distinct sources (lanes_cost_bytes) first; *ran = false when it said no (nothing was written to d_out).
+// The two queue regions of a workspace (A: offset 0, B: offset n) and the device / host statistic blocks.
+static int meet_buffers(Workspace *ws, int64_t n, MeetQueue q[2], MeetDevBlock **db, MeetHostBlock **hb) {
+	hipStream_t st = ws->stream;
+	const bool fresh = ws->meet_cnt.cap < sizeof(MeetDevBlock);
+	PGQ_TRY(ws->meet_cnt.reserve(sizeof(MeetDevBlock)));
+	*db = ws->meet_cnt.as<MeetDevBlock>();
+	// the chain's last kernel leaves the block zeroed; a fresh block, or one a failed call left behind, is cleared here
+	if (fresh || !ws->meet_cnt_clean) PGQ_HIP_TRY(hipMemsetAsync(*db, 0, sizeof(MeetDevBlock), st));
+	ws->meet_cnt_clean = false;
+	const size_t rows = (size_t)std::max<int64_t>(n, 1) * 2;
+	PGQ_TRY(ws->def_src.reserve(rows * 8));
+	PGQ_TRY(ws->def_dst.reserve(rows * 8));
+	PGQ_TRY(ws->def_idx.reserve(rows * 4));
+	PGQ_TRY(ws->def_ent.reserve(rows * sizeof(MeetEntry)));
+	for (int k = 0; k < 2; k++) {
+		q[k].src = ws->def_src.as<int64_t>() + (size_t)k * n;
+		q[k].dst = ws->def_dst.as<int64_t>() + (size_t)k * n;
+		q[k].idx = ws->def_idx.as<u32>() + (size_t)k * n;
+		q[k].ent = ws->def_ent.as<MeetEntry>() + (size_t)k * n;
+		q[k].count = nullptr;
+		q[k].count_back = nullptr;
+		q[k].cap = (u32)n;
+	}
+	*hb = static_cast<MeetHostBlock *>(ws->h_meet);
+	(*hb)->done = 0;
+	return PGQ_OK;
+}
+// waits for the chain and takes over what its last workgroup wrote into the pinned block
+static int meet_wait(Workspace *ws, MeetHostBlock *hb) {
+	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
+	KernelTimer::flush();
+	if (hb->done != 1) return fail(PGQ_ERR_HIP, "the pre-pass chain did not report back (statistics block not written)");
+	ws->meet_cnt_clean = true;
+	return PGQ_OK;
+}
+static void meet_attributes() {
+	static std::atomic<int> attr_set { 0 };
+	if (attr_set.load()) return;
+	(void)hipFuncSetAttribute((const void *)k_meet4d<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void)hipFuncSetAttribute((const void *)k_meet4d<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void)hipFuncSetAttribute((const void *)k_meet4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	attr_set.store(1);
+}
+
+// Runs the pre-pass over n rows (device memory, or pinned host memory the device can address: the chunk entry points
+// hand their staging block over as it is); rows it answers get their hop count (or -1 for NULL) in d_out, the others end
+// up in ws->open_src / open_dst / open_idx and are counted in *n_open.  The whole chain — decision (large inputs),
+// k_meet3, the bit-map kernel, the bidirectional search for a handful of leftovers — is launched back to back; every
+// kernel reads what it needs (the go flag, the number of rows still open) from device memory and appends what it leaves
+// open to the next one's queue, the last one reports into the pinned block: the host launches 2-4 kernels and waits ONCE.
+// decide: k_meet_decide compares `meet_bytes` with the lanes' cost for the sampled number of distinct sources
+// (lanes_cost_bytes) first; *ran = false when it said no (nothing was written to d_out).
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, bool paths, bool decide, double meet_bytes, double edge_bytes, bool *ran) {
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
 	const Options &opt = options();
 	if (ran) *ran = true;
-	struct DevBlock { // what comes back in one copy
-		MeetCounters m;
-		u32 count[4]; // rows open after k_meet3, after k_meet4 / k_meet4d, after k_bibfs
-		MeetDecision dec;
-	};
-	static_assert(sizeof(DevBlock) <= 8192, "pinned statistics block too small");
-	PGQ_TRY(ws->meet_cnt.reserve(sizeof(DevBlock)));
+	MeetQueue q[2];
+	MeetDevBlock *db = nullptr;
+	MeetHostBlock *hb = nullptr;
+	PGQ_TRY(meet_buffers(ws, n, q, &db, &hb));
 	if (paths) PGQ_TRY(ws->meet_rec.reserve((size_t)n * sizeof(MeetPath)));
 	MeetPath *rec = paths ? ws->meet_rec.as<MeetPath>() : nullptr;
-	PGQ_TRY(ws->def_src.reserve((size_t)n * 8));
-	PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
-	PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
-	DevBlock *db = ws->meet_cnt.as<DevBlock>();
-	MeetCounters *mc = &db->m;
-	u32 *d_count = db->count;
 	const u32 *d_go = decide ? &db->dec.go : nullptr;
-	PGQ_HIP_TRY(hipMemsetAsync(db, 0, sizeof(DevBlock), st));
-	if (decide)
-		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec);
-	{
-		const int64_t cap = std::max(1, paths ? opt.meet_cap_paths : opt.meet_cap);
-		KernelTimer kt(st, K_MEET);
-		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 4 rounds
-		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, (int64_t)std::max(1, opt.meet_grid_mult) * resident));
-if (paths)
-			hipLaunchKernelGGL(k_meet3<true>, grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,
-			                   c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap, d_go, mc);
-		else
-			hipLaunchKernelGGL(k_meet3<false>, grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,
-			                   c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap, d_go, mc);
-		kt.stop();
-	}
-	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count, d_go);
-	// what is left (distance >= 4, or over k_meet3's caps): the bit-map kernels, launched straight behind on a fixed grid —
-	// they read the row count from the device.  The vertex bit map sits in LDS when it fits (V <= ~1.2 M); above that
-	// every workgroup gets a slice of a global buffer (L2-resident: 0.5 MB at V = 4 M).
+	// what is left after k_meet3 (distance >= 4, or over its caps): the bit-map kernels, launched straight behind on a
+	// fixed grid — they read the row count from the device.  The vertex bit map sits in LDS when it fits (V <= ~1.2 M);
+	// above that every workgroup gets a slice of a global buffer (L2-resident: 0.5 MB at V = 4 M).
 	const int bm_words = (int)((c->V + 127) / 128) * 4;
 	const size_t lds_budget = (size_t)std::min(150, std::max(0, opt.meet4_lds_kb)) * 1024;
-	const bool lds_map = (size_t)bm_words * 4 + 512 <= lds_budget;
+	const bool lds_map = (size_t)bm_words * 4 + 2048 <= lds_budget;
 	const size_t gm_budget = (size_t)std::max(0, opt.meet4_global_mb) << 20;
 	const bool run4 = opt.meet4 && (lds_map || (size_t)bm_words * 4 <= gm_budget);
-	// k_bibfs: both sides' maps in LDS when they fit, else in the global buffer behind the queues
 	// k_bibfs serves the few rows the two-hop kernels leave open (far apart, unreachable, over the caps).  Launching it
 	// costs ~12 us of stream time even when no row is open, so it stays in the chain only while this CSR has shown such
 	// rows: the first call runs it; a call that ends with every row answered before it switches it off, and any later
 	// call that leaves rows open (they go to the lane-batched search, same answers) switches it on again.
 	const bool run_bi = !paths && opt.bibfs_rows > 0 && c->meet_far_rows.load(std::memory_order_relaxed) != 0;
 	const int mwb = bm_words + 4;
-	const bool bi_lds = (size_t)2 * mwb * 4 + 512 <= lds_budget;
+	const bool bi_lds = (size_t)2 * mwb * 4 + 2048 <= lds_budget; // k_bibfs: both sides' maps in LDS when they fit
 	const int qcap = std::max(1024, opt.bibfs_queue);
 	const u32 bi_grid = (u32)std::min(64, std::max(1, opt.bibfs_rows));
-	// two 1024-thread workgroups fit a CU beside their bit maps: a grid of exactly the resident count, so that every
-	// workgroup streams through its rows (next row's header prefetched) instead of a second generation starting cold
-	u32 grid4 = (u32)std::min<int64_t>(n, 256 * std::max(1, opt.meet4_grid_mult));
+	// two 1024-thread workgroups fit a CU beside their bit maps
+	// k_meet4d hands rows out dynamically: a grid of exactly the workgroups the chip holds (meet4_grid_mult = 2 per CU).
+	// A row alone on its CU is through in ~15 us, beside a second one in ~20 (the phases of a row are short bursts of
+	// instructions from 16 wavefronts, and two workgroups share the CU's issue slots): small calls, whose ~2 % of open rows
+	// do not fill 256 CUs anyway, get one workgroup per CU (8192 rows: 0.086 -> 0.076 ms, 2048 rows: 0.062 -> 0.053 ms)
+	const bool small_call = !paths && n <= (int64_t)opt.meet_small_rows;
+	u32 grid4 = (u32)std::min<int64_t>(n, 256 * std::max(1, paths ? 4 : (small_call ? 1 : opt.meet4_grid_mult)));
 	size_t maps_bytes = 0;
 	if (run4 && !lds_map) {
 		grid4 = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, 256), gm_budget / ((size_t)bm_words * 4)));
@@ -1085,111 +1242,133 @@ if (paths)
 	if (maps_bytes + bi_bytes > 0) PGQ_TRY(ws->meet_maps.reserve(maps_bytes + bi_bytes + 64));
 	u32 *gmaps = ws->meet_maps.as<u32>();
 	u32 *bi_maps = gmaps ? gmaps + (maps_bytes + 15) / 16 * 4 : nullptr;
-	static std::atomic<int> attr_set { 0 };
-	if (!attr_set.load()) {
-		(void)hipFuncSetAttribute((const void *)k_meet4d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_meet4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-		attr_set.store(1);
-	}
+	meet_attributes();
+	// stage k appends to region k & 1 and counts in db->count[k]
+	for (int k = 0; k < 2; k++) q[k].count = &db->count[k];
+	if (run4 && !paths) q[0].count_back = &db->count[3]; // k_meet3 -> k_meet4d: long rows from the front, the others from the back
 	unsigned long long *d_trace = nullptr;
 	if (opt.meet_trace && run4 && !paths) {
-		PGQ_TRY(ws->meet_trace.reserve((size_t)grid4 * 64));
+		PGQ_TRY(ws->meet_trace.reserve((size_t)grid4 * 32));
 		d_trace = ws->meet_trace.as<unsigned long long>();
-		PGQ_HIP_TRY(hipMemsetAsync(d_trace, 0, (size_t)grid4 * 64, st));
+		PGQ_HIP_TRY(hipMemsetAsync(d_trace, 0, (size_t)grid4 * 32, st));
 	}
-	const u32 *d_open = d_count; // the counter the next stage reads its row count from
+	const int last_stage = run_bi ? 2 : (run4 ? 1 : 0);
+	if (decide)
+		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec);
+	{
+		// calls too small to fill the chip are bound by the longest row, not by bandwidth: a lower cap hands long walks to
+		// the 16-wavefront kernel sooner, and more requests in flight shorten every row
+		const bool small = small_call;
+		const int64_t cap = std::max(1, paths ? opt.meet_cap_paths : (small ? opt.meet_cap_small : opt.meet_cap));
+		const bool bigv = c->V > (1 << 20);
+		KernelTimer kt(st, K_MEET);
+		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 8 rounds
+		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, (int64_t)std::max(1, opt.meet_grid_mult) * resident));
+		MeetHostBlock *fin = last_stage == 0 ? hb : nullptr;
+#define PGQ_MEET3(P, B, D)                                                                                               \
+	hipLaunchKernelGGL((k_meet3<P, B, D>), grid, dim3(64 * kMeetWPB), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff,  \
+	                   c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj, c->fwork, c->rwork, d_out, rec, cap, d_go, db, q[0], fin)
+		if (paths) {
+			if (bigv) PGQ_MEET3(true, true, PGQ_MEET3_DEPTH);
+			else PGQ_MEET3(true, false, PGQ_MEET3_DEPTH);
+		} else if (small) {
+			if (bigv) PGQ_MEET3(false, true, PGQ_MEET3_DEPTH_SMALL);
+			else PGQ_MEET3(false, false, PGQ_MEET3_DEPTH_SMALL);
+		} else {
+			if (bigv) PGQ_MEET3(false, true, PGQ_MEET3_DEPTH);
+			else PGQ_MEET3(false, false, PGQ_MEET3_DEPTH);
+		}
+#undef PGQ_MEET3
+		kt.stop();
+	}
+	int open_stage = 0; // the stage whose queue holds what is open at the end
 	if (run4) {
 		const size_t lds = lds_map ? (size_t)bm_words * 4 : 0;
 		const int64_t cap4 = (int64_t)std::max(1, opt.meet4_cap);
+		MeetHostBlock *fin = last_stage == 1 ? hb : nullptr;
 		{
 			KernelTimer kt(st, K_MEET);
 #define PGQ_MEET4(G)                                                                                                     \
-	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid4), dim3(1024), lds, st, d_open, ws->def_src.as<int64_t>(),          \
-	                   ws->def_dst.as<int64_t>(), c->V, c->off, c->adj, c->roff, c->radj, ws->def_idx.as<u32>(), d_out, rec, \
-	                   cap4, bm_words, mc, gmaps)
-#define PGQ_MEET4D(G)                                                                                                    \
-	hipLaunchKernelGGL((k_meet4d<G>), dim3(grid4), dim3(1024), lds, st, d_open, ws->def_src.as<int64_t>(),               \
-	                   ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj, c->fdesc, c->rdesc, c->padj, c->rpadj,   \
-	                   ws->def_idx.as<u32>(), d_out, cap4, bm_words, mc, gmaps, d_trace)
+	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid4), dim3(1024), lds, st, q[0], c->V, c->off, c->adj, c->roff, c->radj,     \
+	                   d_out, rec, cap4, bm_words, db, gmaps, q[1], fin)
+#define PGQ_MEET4D(G, T)                                                                                                    \
+	hipLaunchKernelGGL((k_meet4d<G, T>), dim3(grid4), dim3(1024), lds, st, q[0], c->adj, c->radj, c->fdesc, c->rdesc, c->padj, \
+	                   c->rpadj, d_out, cap4, bm_words, db, gmaps, q[1], fin, d_trace)
 			if (paths && lds_map) PGQ_MEET4(false);
 			else if (paths) PGQ_MEET4(true);
-			else if (lds_map) PGQ_MEET4D(false);
-			else PGQ_MEET4D(true);
+			else if (lds_map && d_trace) PGQ_MEET4D(false, true);
+			else if (lds_map) PGQ_MEET4D(false, false);
+			else PGQ_MEET4D(true, false);
 #undef PGQ_MEET4D
 #undef PGQ_MEET4
 			kt.stop();
 		}
-		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count + 1, d_go);
-		d_open = d_count + 1;
+		open_stage = 1;
 	}
 	// a handful of rows still open (far apart, unreachable, over the caps): one bidirectional search each, so that the
 	// lane-batched search — whole-graph levels — only starts for what really needs it.  The kernel checks the count itself.
 	if (run_bi) {
 		u32 *queues = bi_maps + bi_map_words;
 		const int64_t capb = (int64_t)std::max(1, opt.bibfs_cap);
+		const MeetQueue &qi = q[open_stage];
+		MeetQueue qo2 = q[open_stage ^ 1]; // the other region: the stage that filled it has been read by now
+		qo2.count = &db->count[2];
 		{
 			KernelTimer kt(st, K_MEET);
 			if (bi_lds)
-				hipLaunchKernelGGL(k_bibfs<false>, dim3(bi_grid), dim3(1024), (size_t)2 * mwb * 4, st, d_open, (u32)opt.bibfs_rows,
-				                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
-				                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, mc, bi_maps, queues);
+				hipLaunchKernelGGL(k_bibfs<false>, dim3(bi_grid), dim3(1024), (size_t)2 * mwb * 4, st, qi, (u32)opt.bibfs_rows,
+				                   c->off, c->adj, c->roff, c->radj, d_out, capb, bm_words, qcap, db, bi_maps, queues, qo2, hb);
 			else
-				hipLaunchKernelGGL(k_bibfs<true>, dim3(bi_grid), dim3(1024), 0, st, d_open, (u32)opt.bibfs_rows,
-				                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
-				                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, mc, bi_maps, queues);
+				hipLaunchKernelGGL(k_bibfs<true>, dim3(bi_grid), dim3(1024), 0, st, qi, (u32)opt.bibfs_rows, c->off, c->adj,
+				                   c->roff, c->radj, d_out, capb, bm_words, qcap, db, bi_maps, queues, qo2, hb);
 			kt.stop();
 		}
-		hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-		                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count + 2, d_go);
-		d_open = d_count + 2;
+		ws->open_src = qo2.src;
+		ws->open_dst = qo2.dst;
+		ws->open_idx = qo2.idx;
+		open_stage = 2;
+	} else {
+		ws->open_src = q[open_stage].src;
+		ws->open_dst = q[open_stage].dst;
+		ws->open_idx = q[open_stage].idx;
 	}
-	DevBlock &h = *static_cast<DevBlock *>(ws->h_meet);
-	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, db, sizeof(DevBlock), hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
-	KernelTimer::flush();
+	PGQ_TRY(meet_wait(ws, hb));
+	const MeetHostBlock &h = *hb;
 	if (d_trace) { // debugging aid: where k_meet4d's time goes
-		std::vector<unsigned long long> t((size_t)grid4 * 8);
+		std::vector<unsigned long long> t((size_t)grid4 * 4);
 		PGQ_HIP_TRY(hipMemcpy(t.data(), d_trace, t.size() * 8, hipMemcpyDeviceToHost));
-		unsigned long long t0 = ~0ull, t1 = 0, rows = 0, longest = 0, first_end = ~0ull, last_start = 0, ph[3] = { 0, 0, 0 };
+		unsigned long long t0 = ~0ull, t1 = 0, rows = 0, longest = 0, first_end = ~0ull, last_start = 0, most = 0;
 		for (u32 b = 0; b < grid4; b++) {
-			if (!t[8 * b + 1]) continue;
-			t0 = std::min(t0, t[8 * b]);
-			t1 = std::max(t1, t[8 * b + 1]);
-			first_end = std::min(first_end, t[8 * b + 1]);
-			last_start = std::max(last_start, t[8 * b]);
-			rows += t[8 * b + 2];
-			longest = std::max(longest, t[8 * b + 3]);
-			for (int k = 0; k < 3; k++) ph[k] += t[8 * b + 4 + k];
+			if (!t[4 * b + 1]) continue;
+			t0 = std::min(t0, t[4 * b]);
+			t1 = std::max(t1, t[4 * b + 1]);
+			first_end = std::min(first_end, t[4 * b + 1]);
+			last_start = std::max(last_start, t[4 * b]);
+			rows += t[4 * b + 2];
+			most = std::max(most, t[4 * b + 2]);
+			longest = std::max(longest, t[4 * b + 3]);
 		}
-		const double nr = (double)std::max<unsigned long long>(rows, 1);
-		fprintf(stderr, "[pgq] k_meet4d trace: %u workgroups, %llu rows, span %.1f us, last start +%.1f us, first end +%.1f us, longest row %.1f us; "
-		        "mean per row: header+clear %.2f us, marking walk %.2f us, testing walk %.2f us\n",
-		        grid4, rows, (double)(t1 - t0) * 0.01, (double)(last_start - t0) * 0.01, (double)(first_end - t0) * 0.01,
-		        (double)longest * 0.01, (double)ph[0] * 0.01 / nr, (double)ph[1] * 0.01 / nr, (double)ph[2] * 0.01 / nr);
+		fprintf(stderr, "[pgq] k_meet4d trace: %u workgroups, %llu rows (%u long first), at most %llu per workgroup, span %.1f us, last start +%.1f us, "
+		        "first end +%.1f us, longest row %.1f us\n",
+		        grid4, rows, h.count[0], most, (double)(t1 - t0) * 0.01, (double)(last_start - t0) * 0.01,
+		        (double)(first_end - t0) * 0.01, (double)longest * 0.01);
 	}
 	if (decide && !h.dec.go) {
 		if (ran) *ran = false;
 		*n_open = (u32)n;
 		return PGQ_OK;
 	}
-	if (h.m.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
-	unsigned long long entries = 0, vertices = 0;
-	for (int k = 0; k < kMeetStatSlots; k++) {
-		entries += h.m.entries[k];
-		vertices += h.m.vertices[k];
-	}
-	const u32 open = h.count[d_open - d_count];
+	if (h.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+	const u32 open = h.count[open_stage];
 	if (!paths && opt.bibfs_rows > 0) {
 		const u32 before_bi = h.count[run4 ? 1 : 0]; // rows open when k_bibfs was (or would have been) launched
 		c->meet_far_rows.store(before_bi > 0 ? 1 : 0, std::memory_order_relaxed);
 	}
 	S.meet_pairs += n - (int64_t)open;
-	S.edges_scanned += (int64_t)entries;
+	S.edges_scanned += (int64_t)h.entries;
 	// 4 B per adjacency entry / one-hop id, 16 B per slot descriptor, and per row its ids (16 B), the four offsets of its
 	// endpoints (32 B) and its result (8 B)
-	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices + 56.0 * (double)n;
+	S.algo_bytes[K_MEET] += 4.0 * (double)h.entries + 16.0 * (double)h.vertices + 56.0 * (double)n;
 	*n_open = open;
 	return PGQ_OK;
 }
@@ -1198,23 +1377,40 @@ if (paths)
 // The reference's IterativeLengthBidirectionalFunction (iterativelength_bidirectional.cpp:43-153) is meant to search
 // forward from src and backward from dst over the transposed CSR until the two meet (it is unreachable from the binder
 // and indexes its backward CSR wrongly).  Here that is k_bibfs for EVERY row: k_bidir_classify answers
-// what needs no search (NULL -> NULL, src == dst -> 0, an endpoint without edges in its direction -> NULL) and marks
-// the rest open; k_bibfs takes them one 1024-thread workgroup per row; rows over its caps stay open for the caller
+// what needs no search (NULL -> NULL, src == dst -> 0, an endpoint without edges in its direction -> NULL) and queues
+// the rest; k_bibfs takes them one 1024-thread workgroup per row; rows over its caps stay open for the caller
 // (the lane-batched search).  Same answers as iterativelength (the BFS distance), different schedule.
 __global__ void k_bidir_classify(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t V,
                                  const int64_t *__restrict__ off, const int64_t *__restrict__ roff, int64_t *__restrict__ out,
-                                 MeetCounters *__restrict__ mc) {
+                                 MeetDevBlock *__restrict__ db, MeetQueue q) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const int64_t s = src[i], d = dst[i];
-	int64_t r = kMeetOpen;
-	if (s < 0) r = -1; // NULL row
-	else if (s >= V || d < 0 || d >= V) {
-		mc->bad = 1;
-		r = -1;
-	} else if (s == d) r = 0;
-	else if (off[s + 1] == off[s] || roff[d + 1] == roff[d]) r = -1; // no path can exist
-	out[i] = r;
+	int64_t r = 0;
+	bool open = false;
+	int64_t s = 0, d = 0;
+	if (i < n) {
+		s = src[i], d = dst[i];
+		r = kMeetOpen;
+		if (s < 0) r = -1; // NULL row
+		else if (s >= V || d < 0 || d >= V) {
+			db->m.bad = 1;
+			r = -1;
+		} else if (s == d) r = 0;
+		else if (off[s + 1] == off[s] || roff[d + 1] == roff[d]) r = -1; // no path can exist
+		out[i] = r;
+		open = r == kMeetOpen;
+	}
+	const u64 m = __ballot(open);
+	if (!m) return;
+	const int lane = threadIdx.x & 63;
+	u32 base = 0;
+	if (lane == 0) base = atomicAdd(q.count, (u32)__popcll(m));
+	base = __shfl(base, 0);
+	if (open) {
+		const u32 p = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+		q.src[p] = s;
+		q.dst[p] = d;
+		q.idx[p] = (u32)i;
+	}
 }
 
 int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
@@ -1222,62 +1418,42 @@ int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_sr
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
 	const Options &opt = options();
-	struct DevBlock {
-		MeetCounters m;
-		u32 count[4];
-	};
-	PGQ_TRY(ws->meet_cnt.reserve(sizeof(DevBlock) + 64));
-	PGQ_TRY(ws->def_src.reserve((size_t)n * 8));
-	PGQ_TRY(ws->def_dst.reserve((size_t)n * 8));
-	PGQ_TRY(ws->def_idx.reserve((size_t)n * 4));
-	DevBlock *db = ws->meet_cnt.as<DevBlock>();
-	PGQ_HIP_TRY(hipMemsetAsync(db, 0, sizeof(DevBlock), st));
-	hipLaunchKernelGGL(k_bidir_classify, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, c->V, c->off, c->roff, d_out, &db->m);
-	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), db->count, (const u32 *)nullptr);
+	MeetQueue q[2];
+	MeetDevBlock *db = nullptr;
+	MeetHostBlock *hb = nullptr;
+	PGQ_TRY(meet_buffers(ws, n, q, &db, &hb));
+	for (int k = 0; k < 2; k++) q[k].count = &db->count[k];
+	hipLaunchKernelGGL(k_bidir_classify, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, c->V, c->off, c->roff, d_out, db, q[0]);
 	const int bm_words = (int)((c->V + 127) / 128) * 4, mwb = bm_words + 4;
 	const size_t lds_budget = (size_t)std::min(150, std::max(0, opt.meet4_lds_kb)) * 1024;
-	const bool bi_lds = (size_t)2 * mwb * 4 + 512 <= lds_budget;
+	const bool bi_lds = (size_t)2 * mwb * 4 + 2048 <= lds_budget;
 	const int qcap = std::max(1024, opt.bibfs_queue);
 	const u32 grid = (u32)std::min<int64_t>(n, 256);
 	const size_t map_words = bi_lds ? 0 : (size_t)grid * 2 * mwb;
 	PGQ_TRY(ws->meet_maps.reserve((map_words + (size_t)grid * 4 * qcap) * 4 + 64));
 	u32 *maps = ws->meet_maps.as<u32>();
 	u32 *queues = maps + map_words;
-	static std::atomic<int> attr_set { 0 };
-	if (!attr_set.load()) {
-		(void)hipFuncSetAttribute((const void *)k_bibfs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-		attr_set.store(1);
-	}
+	meet_attributes();
 	const int64_t capb = (int64_t)std::max(1, opt.bibfs_cap);
 	{
 		KernelTimer kt(st, K_MEET);
 		if (bi_lds)
-			hipLaunchKernelGGL(k_bibfs<false>, dim3(grid), dim3(1024), (size_t)2 * mwb * 4, st, (const u32 *)db->count, 0xFFFFFFFFu,
-			                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
-			                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, &db->m, maps, queues);
+			hipLaunchKernelGGL(k_bibfs<false>, dim3(grid), dim3(1024), (size_t)2 * mwb * 4, st, q[0], 0xFFFFFFFFu, c->off, c->adj,
+			                   c->roff, c->radj, d_out, capb, bm_words, qcap, db, maps, queues, q[1], hb);
 		else
-			hipLaunchKernelGGL(k_bibfs<true>, dim3(grid), dim3(1024), 0, st, (const u32 *)db->count, 0xFFFFFFFFu,
-			                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), c->off, c->adj, c->roff, c->radj,
-			                   ws->def_idx.as<u32>(), d_out, capb, bm_words, qcap, &db->m, maps, queues);
+			hipLaunchKernelGGL(k_bibfs<true>, dim3(grid), dim3(1024), 0, st, q[0], 0xFFFFFFFFu, c->off, c->adj, c->roff, c->radj,
+			                   d_out, capb, bm_words, qcap, db, maps, queues, q[1], hb);
 		kt.stop();
 	}
-	hipLaunchKernelGGL(k_collect_open, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, d_src, d_dst,
-	                   ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), db->count + 1, (const u32 *)nullptr);
-	DevBlock &h = *static_cast<DevBlock *>(ws->h_meet);
-	static_assert(sizeof(DevBlock) <= 8192, "pinned statistics block too small");
-	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_meet, db, sizeof(DevBlock), hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
-	KernelTimer::flush();
-	if (h.m.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
-	unsigned long long entries = 0, vertices = 0;
-	for (int k = 0; k < kMeetStatSlots; k++) {
-		entries += h.m.entries[k];
-		vertices += h.m.vertices[k];
-	}
+	ws->open_src = q[1].src;
+	ws->open_dst = q[1].dst;
+	ws->open_idx = q[1].idx;
+	PGQ_TRY(meet_wait(ws, hb));
+	const MeetHostBlock &h = *hb;
+	if (h.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
 	S.meet_pairs += n - (int64_t)h.count[1];
-	S.edges_scanned += (int64_t)entries;
-	S.algo_bytes[K_MEET] += 4.0 * (double)entries + 16.0 * (double)vertices;
+	S.edges_scanned += (int64_t)h.entries;
+	S.algo_bytes[K_MEET] += 4.0 * (double)h.entries + 16.0 * (double)h.vertices;
 	*n_open = h.count[1];
 	return PGQ_OK;
 }
@@ -1319,13 +1495,13 @@ __global__ void k_apply_open_paths(int64_t nd, const u32 *__restrict__ didx, con
 }
 int meet_apply_paths(Workspace *ws, int64_t nd, const int64_t *d_len, const int64_t *d_off, int64_t base,
                      int64_t *d_out_len, int64_t *d_out_off) {
-	hipLaunchKernelGGL(k_apply_open_paths, dim3(blocks_for(nd)), dim3(256), 0, ws->stream, nd, ws->def_idx.as<u32>(), d_len,
+	hipLaunchKernelGGL(k_apply_open_paths, dim3(blocks_for(nd)), dim3(256), 0, ws->stream, nd, ws->open_idx, d_len,
 	                   d_off, base, d_out_len, d_out_off);
 	return PGQ_OK;
 }
 
 int meet_apply(Workspace *ws, int64_t nd, const int64_t *d_len, int64_t *d_out) {
-	hipLaunchKernelGGL(k_apply_open, dim3(blocks_for(nd)), dim3(256), 0, ws->stream, nd, ws->def_idx.as<u32>(), d_len, d_out);
+	hipLaunchKernelGGL(k_apply_open, dim3(blocks_for(nd)), dim3(256), 0, ws->stream, nd, ws->open_idx, d_len, d_out);
 	return PGQ_OK;
 }
 

@@ -1270,11 +1270,12 @@ Workspace::~Workspace() {
 	if (stream) (void)hipStreamDestroy(stream);
 	if (h_cnt) (void)hipHostFree(h_cnt);
 	if (h_meet) (void)hipHostFree(h_meet);
+	if (h_io) (void)hipHostFree(h_io);
 	if (h_bstart) (void)hipHostFree(h_bstart);
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &def_off, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &wb_scratch })
+	                   &def_idx, &def_off, &def_ent, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &wb_scratch })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -1850,6 +1851,21 @@ void merge_stats(pgq_stats_t &into, const pgq_stats_t &from) {
 	}
 }
 
+// Whether the pair-centric pre-pass may run for this call at all, and whether the host-side cost model sends n rows
+// (each taken as a distinct source) to it.  Shared by search_device and the chunk entry point (zero-copy staging).
+constexpr int64_t kMeetDecideRows = 16384; // above: the distinct sources are sampled and the decision is taken on the device
+static bool prepass_may(const pgq_csr *c, const SearchOutput &outp) {
+	// depth 1 = the stragglers a lane batch deferred (a few far pairs of a cross product): the pre-pass answers them from
+	// two-hop scans instead of another round of whole-graph levels
+	return options().meet && !outp.want_te && outp.depth <= 1 && !outp.from_meet && c->E > 0 && c->fdesc != nullptr;
+}
+static bool prepass_takes(const pgq_csr *c, int64_t n, const SearchOutput &outp) {
+	if (!prepass_may(c, outp)) return false;
+	const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
+	const double edge_bytes = options().meet_bias * (double)c->E;
+	return meet_bytes <= lanes_cost_bytes(edge_bytes, (double)std::min<int64_t>(n, c->V));
+}
+
 // Lane assignment + sorting of the rows, then the templated batch loop; results scattered back to row order.
 static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                          int64_t *d_out_len, bool with_paths, int64_t *d_out_off, int64_t *d_child_ext,
@@ -1864,9 +1880,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// cost less than the MS-BFS levels they replace: bytes ~ rows x E[in-degree x out-degree] x 4 (the cheaper
 	// endpoint is expanded: ~0.6 of that) against ~16 B per edge per 2048-lane batch.
 	const Options &mopt = options();
-	// depth 1 = the stragglers a lane batch deferred (a few far pairs of a cross product): the pre-pass answers them from
-	// two-hop scans instead of another round of whole-graph levels
-	const bool may_meet = mopt.meet && !outp.want_te && outp.depth <= 1 && !outp.from_meet && c->E > 0 && c->fdesc != nullptr;
+	const bool may_meet = prepass_may(c, outp);
 	// Cost model (bytes at streaming rate): the pre-pass walks, per row, the cheaper endpoint's two-hop neighbourhood
 	// (~0.6 of E[in-degree x out-degree] entries when it has to walk all of it; it usually stops far earlier: the estimate
 	// is on the safe side).  A lane batch of `wd` lane-words costs about one sparse and one dense bottom-up level
@@ -1878,7 +1892,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	auto meet_pays = [&](int64_t distinct_sources) { return meet_bytes <= lanes_cost_bytes(edge_bytes, (double)distinct_sources); };
 	// few rows: every row is taken as a distinct source (the pessimistic case for the pre-pass); many rows: a sampled
 	// estimate of the distinct sources decides ON THE DEVICE, in the same launch chain (cross products share their lanes)
-	const bool decide = n > 16384;
+	const bool decide = n > kMeetDecideRows;
 	// shortestpath: the pre-pass also records each answered row's inner vertices (reference tie-break); their lists are
 	// packed first, the lists of the rows left to the lane-batched search are appended behind them
 	auto run_meet_paths = [&](bool *ran) -> int {
@@ -1896,7 +1910,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			so2.depth = outp.depth + 1;
 			so2.from_meet = true;
 			S.pairs -= nd; // counted once
-			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+			PGQ_TRY(search_device(c, inner.ws, nd, ws->open_src, ws->open_dst,
 			                      ws->def_len.as<int64_t>(), true, ws->def_off.as<int64_t>(), nullptr, 0, so2));
 		}
 		const int64_t need = total + so2.child_used;
@@ -1936,7 +1950,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			so2.depth = outp.depth + 1;
 			so2.from_meet = true;
 			S.pairs -= nd; // counted once
-			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+			PGQ_TRY(search_device(c, inner.ws, nd, ws->open_src, ws->open_dst,
 			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
 			PGQ_TRY(meet_apply(ws, nd, ws->def_len.as<int64_t>(), d_out_len));
 			PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
@@ -1954,7 +1968,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			so2.depth = outp.depth + 1;
 			so2.from_meet = true;
 			S.pairs -= nd; // counted once
-			PGQ_TRY(search_device(c, inner.ws, nd, ws->def_src.as<int64_t>(), ws->def_dst.as<int64_t>(),
+			PGQ_TRY(search_device(c, inner.ws, nd, ws->open_src, ws->open_dst,
 			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
 			PGQ_TRY(meet_apply(ws, nd, ws->def_len.as<int64_t>(), d_out_len));
 			PGQ_HIP_TRY(hipStreamSynchronize(st));
@@ -2364,6 +2378,21 @@ int pgq_cheapest_path_length_multi(pgq_csr_t *csr, int64_t n, const int64_t *src
 	});
 }
 
+// pinned, device-addressable staging block of a workspace (grown on demand)
+static int io_block(Workspace *ws, size_t bytes, void **host, void **dev) {
+	if (ws->h_io_cap < bytes) {
+		if (ws->h_io) (void)hipHostFree(ws->h_io);
+		ws->h_io = nullptr;
+		ws->h_io_cap = 0;
+		const size_t want = std::max<size_t>(bytes * 2, 64 << 10);
+		PGQ_HIP_TRY(hipHostMalloc(&ws->h_io, want));
+		ws->h_io_cap = want;
+	}
+	*host = ws->h_io;
+	PGQ_HIP_TRY(hipHostGetDevicePointer(dev, ws->h_io, 0));
+	return PGQ_OK;
+}
+
 static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
                                  uint64_t *out_valid, bool bidir) {
 	OptionScope opt_scope(csr);
@@ -2371,11 +2400,35 @@ static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t
 	PGQ_TRY(check_csr(csr, V));
 	if (n < 0 || (n > 0 && (!out_len || !out_valid))) return fail(PGQ_ERR_INVALID_ARG, "NULL output");
 	if (n == 0) return PGQ_OK;
-	FlatPairs fp;
-	PGQ_TRY(flatten_pairs(V, n, src, dst, fp, false));
 	WorkspaceLease lease;
 	PGQ_TRY(lease.acquire());
 	Workspace *ws = lease.ws;
+	if (!bidir && options().chunk_zero_copy && prepass_takes(csr, n, SearchOutput()) && n <= kMeetDecideRows) {
+		// One DuckDB chunk through the pair-centric kernels: they read the rows straight out of a pinned staging block and
+		// write the hop counts straight back into it (2048 rows = 32 KB in, 16 KB out over PCIe, one access per row), so the
+		// call is two or three kernel launches and ONE wait — no copy commands (each is a stream operation of its own:
+		// two in, two out cost more than the search of a chunk).
+		void *hp = nullptr, *dp = nullptr;
+		PGQ_TRY(io_block(ws, (size_t)n * 24, &hp, &dp));
+		int64_t *h = static_cast<int64_t *>(hp), *d = static_cast<int64_t *>(dp);
+		PGQ_TRY(flatten_pairs_into(V, n, src, dst, h, h + n));
+		SearchOutput so;
+		PGQ_TRY(search_device(csr, ws, n, d, d + n, d + 2 * n, false, nullptr, nullptr, 0, so));
+		const int64_t *res = h + 2 * n;
+		for (int64_t w = 0; w < (n + 63) / 64; w++) { // payload of a NULL row stays -1 like iterativelength.cpp:100,137
+			uint64_t m = 0;
+			const int64_t lo = w * 64, cnt = std::min<int64_t>(64, n - lo);
+			for (int64_t k = 0; k < cnt; k++) {
+				const int64_t v = res[lo + k];
+				out_len[lo + k] = v;
+				m |= (uint64_t)(v >= 0) << k;
+			}
+			out_valid[w] = cnt == 64 ? m : (m | (~0ULL << cnt)); // bits past n stay set, as mask_fill_valid leaves them
+		}
+		return PGQ_OK;
+	}
+	FlatPairs fp;
+	PGQ_TRY(flatten_pairs(V, n, src, dst, fp, false));
 	PGQ_TRY(ws->in_src.reserve((size_t)n * 8));
 	PGQ_TRY(ws->in_dst.reserve((size_t)n * 8));
 	PGQ_TRY(ws->out_len.reserve((size_t)n * 8));

@@ -173,6 +173,9 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "lanes", &o.lanes, nullptr },
 		{ "meet", &o.meet, nullptr },
 		{ "meet_cap", &o.meet_cap, nullptr },
+		{ "meet_cap_small", &o.meet_cap_small, nullptr },
+		{ "chunk_zero_copy", &o.chunk_zero_copy, nullptr },
+		{ "meet_small_rows", &o.meet_small_rows, nullptr },
 		{ "meet_cap_paths", &o.meet_cap_paths, nullptr },
 		{ "meet4", &o.meet4, nullptr },
 		{ "meet4_cap", &o.meet4_cap, nullptr },
@@ -408,6 +411,40 @@ void DevBuf::release() {
 }
 
 // ---- UnifiedVectorFormat -> flat arrays --------------------------------------------------------------------
+// The same resolution straight into caller-provided arrays (the pinned staging block of the chunk entry points), dst
+// validity not consulted (iterativelength.cpp:98,122); flat vectors without selection or validity take a branch-free loop.
+int flatten_pairs_into(int64_t V, int64_t n, const pgq_vec_t &src, const pgq_vec_t &dst, int64_t *out_src, int64_t *out_dst) {
+	const int64_t *sd = static_cast<const int64_t *>(src.data);
+	const int64_t *dd = static_cast<const int64_t *>(dst.data);
+	if (n > 0 && (!sd || !dd)) return fail(PGQ_ERR_INVALID_ARG, "src/dst data pointer is NULL");
+	if (!src.sel && !dst.sel && !src.validity && !dst.validity) {
+		uint64_t bad = 0;
+		for (int64_t r = 0; r < n; r++) {
+			const int64_t s = sd[r], d = dd[r];
+			bad |= (uint64_t)(s < 0) | (uint64_t)(s >= V) | (uint64_t)(d < 0) | (uint64_t)(d >= V);
+			out_src[r] = s;
+			out_dst[r] = d;
+		}
+		if (!bad) return PGQ_OK; // else: the general loop below names the offender
+	}
+	for (int64_t r = 0; r < n; r++) {
+		const int64_t sp = src.sel ? (int64_t)src.sel[r] : r;
+		const int64_t dp = dst.sel ? (int64_t)dst.sel[r] : r;
+		const bool s_ok = !src.validity || ((src.validity[sp >> 6] >> (sp & 63)) & 1ULL);
+		const bool d_ok = !dst.validity || ((dst.validity[dp >> 6] >> (dp & 63)) & 1ULL);
+		int64_t s = s_ok ? sd[sp] : -1;
+		const int64_t d = dd[dp];
+		if (s_ok && (s < 0 || s >= V)) return fail(PGQ_ERR_INVALID_ARG, "source rowid out of range [0,V)");
+		if (s_ok && (d < 0 || d >= V)) {
+			if (d_ok) return fail(PGQ_ERR_INVALID_ARG, "destination rowid out of range [0,V)");
+			s = -1; // NULL dst with garbage payload: report NULL instead of reading out of bounds
+		}
+		out_src[r] = s;
+		out_dst[r] = d;
+	}
+	return PGQ_OK;
+}
+
 int flatten_pairs(int64_t V, int64_t n, const pgq_vec_t &src, const pgq_vec_t &dst, FlatPairs &out,
                   bool check_dst_validity) {
 	out.src.resize(n);
@@ -819,8 +856,33 @@ __global__ void k_fill_desc(int64_t E, const int32_t *__restrict__ adj, const ui
 	desc[e] = make_uint4(u, s.x, s.y, 0u);
 }
 
+// entries of every vertex's two-hop walk in one direction = sum of its neighbours' list lengths (saturating u32).  One
+// workgroup per 256 consecutive vertices: their slots are one contiguous range, read coalesced; a slot's vertex by
+// binary search over the 257 offsets in LDS.
+__global__ __launch_bounds__(256) void k_two_hop_work(int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                      const uint2 *__restrict__ seg, u32 *__restrict__ work) {
+	__shared__ int64_t s_off[257];
+	__shared__ unsigned long long s_w[256];
+	const int64_t v0 = (int64_t)blockIdx.x * 256;
+	const int nv = (int)min((int64_t)256, V - v0);
+	for (int t = threadIdx.x; t <= nv; t += 256) s_off[t] = off[v0 + t];
+	s_w[threadIdx.x] = 0;
+	__syncthreads();
+	for (int64_t e = s_off[0] + threadIdx.x; e < s_off[nv]; e += 256) {
+		int lo = 0, hi = nv; // largest t with s_off[t] <= e
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (s_off[mid] <= e) lo = mid;
+			else hi = mid;
+		}
+		atomicAdd(&s_w[lo], (unsigned long long)seg[(u32)adj[e]].y);
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < nv) work[v0 + threadIdx.x] = (u32)min(s_w[threadIdx.x], 0xFFFFFFFFull);
+}
+
 static int build_meet_layout_dir(pgq_csr *c, const int64_t *off, const int32_t *adj, int32_t **padj, uint2 **seg,
-                                 uint4 **desc, int64_t *groups_out, hipStream_t st) {
+                                 uint4 **desc, u32 **work, int64_t *groups_out, hipStream_t st) {
 	const int64_t V = c->V, E = c->E;
 	u32 align = (u32)std::max(4, options().meet_align) & ~3u;
 	// group indices are 32-bit: E / 4 + V x align / 4 bounds the padded size; one group per list start always fits
@@ -855,13 +917,15 @@ static int build_meet_layout_dir(pgq_csr *c, const int64_t *off, const int32_t *
 	hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, off, d_gb, *seg);
 	hipLaunchKernelGGL(k_fill_padded, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, off, adj, *seg, total, *padj);
 	hipLaunchKernelGGL(k_fill_desc, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, E, adj, *seg, *desc);
+	PGQ_TRY(dev_alloc_as(work, (size_t)V));
+	hipLaunchKernelGGL(k_two_hop_work, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, off, adj, *seg, *work);
 	*groups_out = (int64_t)total;
 	return PGQ_OK;
 }
 static int build_meet_layout(pgq_csr *c, hipStream_t st) {
 	if (!options().meet_layout || c->V <= 0 || c->E <= 0) return PGQ_OK;
-	PGQ_TRY(build_meet_layout_dir(c, c->off, c->adj, &c->padj, &c->fseg, &c->fdesc, &c->padj_groups, st));
-	PGQ_TRY(build_meet_layout_dir(c, c->roff, c->radj, &c->rpadj, &c->rseg, &c->rdesc, &c->rpadj_groups, st));
+	PGQ_TRY(build_meet_layout_dir(c, c->off, c->adj, &c->padj, &c->fseg, &c->fdesc, &c->fwork, &c->padj_groups, st));
+	PGQ_TRY(build_meet_layout_dir(c, c->roff, c->radj, &c->rpadj, &c->rseg, &c->rdesc, &c->rwork, &c->rpadj_groups, st));
 	return PGQ_OK;
 }
 
@@ -1021,7 +1085,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	tr.mark("padded adjacency + slot descriptors");
 	c->bytes = (V + 1) * 16 + 8 * V + E * (4 + 4 + 1 + (c->rpk ? 4 : 0)) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
 	           n_items * (int64_t)sizeof(HubItem) +
-	           (c->fdesc ? 2 * E * 16 + 2 * V * 8 + (c->padj_groups + c->rpadj_groups) * 16 : 0);
+	           (c->fdesc ? 2 * E * 16 + 2 * V * 12 + (c->padj_groups + c->rpadj_groups) * 16 : 0);
 	return PGQ_OK;
 }
 
@@ -1048,6 +1112,8 @@ static void destroy_csr(pgq_csr *c) {
 	dev_free(c->rpadj);
 	dev_free(c->fseg);
 	dev_free(c->rseg);
+	dev_free(c->fwork);
+	dev_free(c->rwork);
 	dev_free(c->fdesc);
 	dev_free(c->rdesc);
 	dev_free(c->pagerank);
@@ -1345,6 +1411,8 @@ static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
 	PGQ_TRY(copy((void **)&r->rpadj, c->rpadj, (size_t)c->rpadj_groups * 16 + 16));
 	PGQ_TRY(copy((void **)&r->fseg, c->fseg, (size_t)c->V * 8));
 	PGQ_TRY(copy((void **)&r->rseg, c->rseg, (size_t)c->V * 8));
+	PGQ_TRY(copy((void **)&r->fwork, c->fwork, (size_t)c->V * 4));
+	PGQ_TRY(copy((void **)&r->rwork, c->rwork, (size_t)c->V * 4));
 	PGQ_TRY(copy((void **)&r->fdesc, c->fdesc, (En + 1) * 16));
 	PGQ_TRY(copy((void **)&r->rdesc, c->rdesc, (En + 1) * 16));
 	PGQ_HIP_TRY(hipDeviceSynchronize());

@@ -36,12 +36,19 @@ struct Workspace {
 	int device = 0; // where its buffers live (workspaces are pooled per device)
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
-	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps, meet_trace, wb_scratch, hv, hmask, hstart, hmap;
+	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, def_ent, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps, meet_trace, wb_scratch, hv, hmask, hstart, hmap;
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
 	int64_t wb_V = -1;  // what wb_scratch's label arrays are initialised for
 	int wb_grid = 0;
-	void *h_meet = nullptr;    // pinned, 8 KB: the pre-pass statistics come back here (a pageable target is staged by the runtime)
+	void *h_meet = nullptr;    // pinned, 8 KB: the last workgroup of the pre-pass chain writes its statistics here
+	bool meet_cnt_clean = false; // the device statistics block is all zero (the chain's last kernel leaves it so)
+	// where the pre-pass left the rows it could not answer (one of the two queue regions inside def_src / def_dst / def_idx)
+	int64_t *open_src = nullptr, *open_dst = nullptr;
+	u32 *open_idx = nullptr;
+	// chunk entry points: pinned staging block the kernels read the rows from / write the results to (device-addressable)
+	void *h_io = nullptr;
+	size_t h_io_cap = 0;
 	int64_t *h_bstart = nullptr;
 	size_t h_bstart_cap = 0;
 	u32 epoch = 0;

@@ -143,79 +143,156 @@ __device__ __forceinline__ int4 load_group_nt(const int32_t *__restrict__ xp, u3
 template <int DEPTH, bool WANT_EV, typename F, typename Stop>
 __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__ list, int list_n, int w, int nw,
                                                        const int32_t *__restrict__ xp, unsigned char *win, bool have_first,
-                                                       uint4 first, unsigned long long max_entries, bool &capped, F f, Stop stop) {
+                                                       uint4 first, unsigned long long max_entries, bool &capped, int &resume,
+                                                       F f, Stop stop) {
 	const int lane = threadIdx.x & 63;
 	unsigned long long entries = 0, requested = 0; // requested: groups x 4, against max_entries
 	capped = false;
+	resume = 0; // first descriptor of the round the walk was in when it ended (a capped walk can be taken up there)
+	const uint4 zero4 = make_uint4(0, 0, 0, 0);
+	uint4 d = zero4;
+	if (have_first) d = first;
+	else if (lane < list_n) d = list[lane];
 	for (int pb = 0; pb < list_n; pb += 64) {
-		const int p = pb + lane;
-		uint4 d = make_uint4(0, 0, 0, 0);
-		if (pb == 0 && have_first) d = first;
-		else if (p < list_n) d = list[p];
-		if (p >= list_n) d = make_uint4(0, 0, 0, 0);
+		if (pb + lane >= list_n) d = zero4;
+		// round 4: the NEXT round's descriptors are requested before this round is walked (a one-hop list of mean length 89
+		// has two rounds: their descriptors used to cost a dependent round trip between the rounds).  Unconditional, the
+		// index clamped: a load under a per-lane condition is waited for at the end of the branch
+		uint4 dn = zero4;
+		if (pb + 64 < list_n) dn = list[min(pb + 64 + lane, list_n - 1)];
 		const SegRound r = seg_round(d.y, d.z);
-		if (r.total == 0) continue;
-		const int nchunk = (int)((r.total + 63u) >> 6);
-		int next = w; // this wavefront's next request of the round
-		int issued = 0;
-		int4 x[DEPTH];
-		int xc[DEPTH];
-		bool xok[DEPTH];
-		u32 xv[DEPTH];
-		auto fetch = [&](int u) {
-			xc[u] = -1;
-			if (next < nchunk) { // wave-uniform
-				const u32 xx = (u32)next * 64u + (u32)lane;
-				const bool ok = xx < r.total;
-				const u32 xs = ok ? xx : r.total - 1u; // lanes past the end re-read the last group (same line, masked by ok)
-				const int j = seg_owner(r, (u32)next * 64u, win); // lanes past the end: the last list, like xs
-				x[u] = load_group_nt(xp, (u32)__shfl((int)r.D, j) + xs);
-				xok[u] = ok;
-				if constexpr (WANT_EV) xv[u] = (u32)__shfl((int)d.x, j);
-				else xv[u] = 0;
-				xc[u] = next;
-				next += nw;
-				issued++;
-			}
-		};
+		if (r.total != 0) {
+			const int nchunk = (int)((r.total + 63u) >> 6);
+			int next = w; // this wavefront's next request of the round
+			int issued = 0;
+			int4 x[DEPTH];
+			int xc[DEPTH];
+			bool xok[DEPTH];
+			u32 xv[DEPTH];
+			auto fetch = [&](int u) {
+				xc[u] = -1;
+				if (next < nchunk) { // wave-uniform
+					const u32 xx = (u32)next * 64u + (u32)lane;
+					const bool ok = xx < r.total;
+					const u32 xs = ok ? xx : r.total - 1u; // lanes past the end re-read the last group (same line, masked by ok)
+					const int j = seg_owner(r, (u32)next * 64u, win); // lanes past the end: the last list, like xs
+					x[u] = load_group_nt(xp, (u32)__shfl((int)r.D, j) + xs);
+					xok[u] = ok;
+					if constexpr (WANT_EV) xv[u] = (u32)__shfl((int)d.x, j);
+					else xv[u] = 0;
+					xc[u] = next;
+					next += nw;
+					issued++;
+				}
+			};
 #pragma unroll
-		for (int u = 0; u < DEPTH; u++) fetch(u);
-		bool halt = false;
-		for (;;) {
-			bool any_chunk = false;
+			for (int u = 0; u < DEPTH; u++) fetch(u);
+			bool halt = false;
+			for (;;) {
+				bool any_chunk = false;
 #pragma unroll
-			for (int u = 0; u < DEPTH; u++) {
-				if (xc[u] < 0) continue; // wave-uniform
-				any_chunk = true;
-				const int4 v = x[u];
-				const bool ok = xok[u];
-				const u32 ev = xv[u];
-				fetch(u); // refills slot u: everything about the current request was copied above
-				f(v, ok, ev);
+				for (int u = 0; u < DEPTH; u++) {
+					if (xc[u] < 0) continue; // wave-uniform
+					any_chunk = true;
+					const int4 v = x[u];
+					const bool ok = xok[u];
+					const u32 ev = xv[u];
+					fetch(u); // refills slot u: everything about the current request was copied above
+					f(v, ok, ev);
+				}
+				if (!any_chunk) break;
+				if (stop()) {
+					halt = true;
+					break;
+				}
+				if (requested + (unsigned long long)issued * 256ull > max_entries) {
+					capped = true;
+					halt = true;
+					break;
+				}
 			}
-			if (!any_chunk) break;
-			if (stop()) {
-				halt = true;
-				break;
+			{ // entries of the groups requested in this round: the round's entries pro rata of its groups
+				u32 e = d.z;
+				for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
+				// this wavefront's requests hold 64 groups each, except the round's last one
+				unsigned long long groups = (unsigned long long)issued * 64ull;
+				if (issued > 0 && next - nw == nchunk - 1) groups -= (unsigned long long)nchunk * 64ull - r.total;
+				entries += (unsigned long long)e * groups / r.total;
+				requested += groups * 4ull;
 			}
-			if (requested + (unsigned long long)issued * 256ull > max_entries) {
-				capped = true;
-				halt = true;
+			if (halt) {
+				resume = pb;
 				break;
 			}
 		}
-		{ // entries of the groups requested in this round: the round's entries pro rata of its groups
-			u32 e = d.z;
-			for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
-			// this wavefront's requests hold 64 groups each, except the round's last one
-			unsigned long long groups = (unsigned long long)issued * 64ull;
-			if (issued > 0 && next - nw == nchunk - 1) groups -= (unsigned long long)nchunk * 64ull - r.total;
-			entries += (unsigned long long)e * groups / r.total;
-			requested += groups * 4ull;
-		}
-		if (halt) break;
+		d = dn;
 	}
 	return entries;
+}
+
+// ---- round 4: the set side as a two-bit filter in LDS + the ids themselves in registers ---------------------------------
+// Round 3 kept the set (the non-expanded endpoint's one-hop list, <= 512 ids) in an open-addressing table of 4 KB next to
+// a 2-KB filter: 6.2 KB of LDS per wavefront = 6.25 wavefronts per SIMD, and tools/membench's segment gather (1-KB
+// segments out of a table far larger than the Infinity Cache) moves 3.7 TB/s at 4 wavefronts per SIMD and 5.9 TB/s at 8.
+// The exact test does not need LDS: the ids sit in 8 registers per lane (lane l holds ids l, l + 64, ...), and a
+// candidate the filter lets through — wave-uniform after a readlane — is compared with all 512 of them in 8 v_cmp.  The
+// filter takes the whole 4 KB (32768 bits, both bits of an id in ONE word: word = id bits 5..14, bits = id bits 0..4 and
+// 15..19, higher id bits folded in when V needs them), so a wavefront needs 4.2 KB and 8 fit a SIMD.  For V < 2^20 the
+// filter is exact up to cross-combinations of two set members that share a word (~0.002 % of the probes for a 100-id set).
+constexpr int kSetRegs = 8;                  // 64 x 8 = 512 ids in registers
+constexpr int kSetRegMax = 64 * kSetRegs;
+constexpr int kFltWords = 1024;              // 4 KB per wavefront
+template <bool BIGV> __device__ __forceinline__ u32 flt_b(u32 x) { // only the low 5 bits are used (as a shift amount)
+	return BIGV ? ((x >> 15) ^ (x >> 20) ^ (x >> 25)) : (x >> 15);
+}
+__device__ __forceinline__ u32 flt_word(u32 x) { return (x >> 5) & (kFltWords - 1); }
+template <bool BIGV> __device__ __forceinline__ u32 flt_mask(u32 x) { return (1u << (x & 31)) | (1u << (flt_b<BIGV>(x) & 31)); }
+// bit 0 of the result: both bits of x are set in its word w
+template <bool BIGV> __device__ __forceinline__ u32 flt_test(u32 w, u32 x) { return (w >> (x & 31)) & (w >> (flt_b<BIGV>(x) & 31)); }
+struct RegSet {
+	u32 r[kSetRegs]; // lane l: ids l, l + 64, ... of the set list; kMeetEmpty past its end
+	int rounds;      // registers in use (wave-uniform)
+};
+// exact membership of a wave-uniform id
+__device__ __forceinline__ bool regset_has(const RegSet &s, u32 x) {
+	bool in = false;
+#pragma unroll
+	for (int k = 0; k < kSetRegs; k++)
+		if (k < s.rounds) in |= s.r[k] == x;
+	return __any(in) != 0;
+}
+// the four filter words of a lane's group: independent LDS reads, no branches.  Bit k of the result: entry k passed.
+template <bool BIGV> __device__ __forceinline__ u32 flt_pass4(const u32 *bm, const int4 v) {
+	const u32 w0 = bm[flt_word((u32)v.x)], w1 = bm[flt_word((u32)v.y)], w2 = bm[flt_word((u32)v.z)], w3 = bm[flt_word((u32)v.w)];
+	const u32 t0 = flt_test<BIGV>(w0, (u32)v.x), t1 = flt_test<BIGV>(w1, (u32)v.y);
+	const u32 t2 = flt_test<BIGV>(w2, (u32)v.z), t3 = flt_test<BIGV>(w3, (u32)v.w);
+	return (t0 & 1u) | ((t1 & 1u) << 1) | ((t2 & 1u) << 2) | ((t3 & 1u) << 3);
+}
+// Calls hit(x, L) for every entry the filter let through (p: bit k = entry k of this lane's group v) that IS in the set;
+// x and the lane L holding it are wave-uniform.  The loop runs over the lanes with candidates only (none, nearly always).
+template <typename H> __device__ __forceinline__ void verify_candidates(const RegSet &s, u32 p, const int4 &v, H hit) {
+	u64 m = __ballot(p != 0);
+	while (m) {
+		const int L = __ffsll((long long)m) - 1;
+		m &= m - 1;
+		const u32 pl = (u32)__builtin_amdgcn_readlane((int)p, L);
+		if (pl & 1u) {
+			const u32 x = (u32)__builtin_amdgcn_readlane(v.x, L);
+			if (regset_has(s, x)) hit(x, L);
+		}
+		if (pl & 2u) {
+			const u32 x = (u32)__builtin_amdgcn_readlane(v.y, L);
+			if (regset_has(s, x)) hit(x, L);
+		}
+		if (pl & 4u) {
+			const u32 x = (u32)__builtin_amdgcn_readlane(v.z, L);
+			if (regset_has(s, x)) hit(x, L);
+		}
+		if (pl & 8u) {
+			const u32 x = (u32)__builtin_amdgcn_readlane(v.w, L);
+			if (regset_has(s, x)) hit(x, L);
+		}
+	}
 }
 
 // ---- the set side of a pair-centric walk: blocked two-bit filter + exact table ---------------------------------------------

@@ -25,12 +25,14 @@ Default workload = BASELINE.json configs[3] (the config the metric "MS-BFS MTEPS
 Other BASELINE configs: --workload rmat22 (configs[1]), snb_paths (configs[2]), forest_cheapest (configs[4]);
 snb_cross / snb_cross_allv run the cross-product shapes as the main workload; snb_cheapest = weighted knows graph.
 
-value    = MTEPS, LOGICAL ("value_kind"): traversed edges / second / 1e6, summed over ranks.  Traversed edges of a
-           pair = out-degrees of all vertices its own level-synchronous BFS expands up to the level that reaches dst
-           (all levels if unreachable) — what the reference's per-pair lane traverses; a pure function of (graph, src,
-           dst), counted once on the GPU outside the timed region (pgq_traversed_edges_bulk_device) and pinned against
-           the CPU oracle in tests/.  It is NOT a hardware throughput: `mteps_physical` (adjacency entries the kernels
-           really scanned) and `pairs_per_s` are.
+value    = (src, dst) pairs answered per second, whole job (metric "src_dst_pairs_per_s"; BASELINE's metric is "MS-BFS
+           MTEPS + src-dst pairs/sec").  Beside it: `mteps_physical` = adjacency entries the kernels really scanned per
+           second / 1e6 (a hardware rate), and `mteps_logical` = traversed edges / second / 1e6 where the traversed edges
+           of a pair = out-degrees of all vertices its own level-synchronous BFS expands up to the level that reaches
+           dst (all levels if unreachable) — what the reference's per-pair lane traverses; a pure function of (graph,
+           src, dst), counted once on the GPU outside the timed region (pgq_traversed_edges_bulk_device) and pinned
+           against the CPU oracle in tests/.  The logical figure counts work the pair-centric kernels AVOID: it is not
+           a hardware throughput and is no longer the headline (round 3's `value`).
 roofline = the dominant kernel class of an untimed pass with one batch in flight and per-launch HIP events on the
            library's own stream (no overlap: a launch's event duration is its own duration); achieved = algorithmic
            bytes / that time (DESIGN.md has the formulas).  `step` = all kernel classes' algorithmic bytes over the
@@ -63,6 +65,8 @@ PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5, 
 CHEAPEST = ("forest_cheapest", "snb_cheapest")  # weighted workloads: value = pairs/s
 SNB = ("snb_sf100", "snb_paths", "snb_cheapest", "snb_cross", "snb_cross_allv")
 EXPANSION = ("push", "pull", "pull_hub", "pull_sparse")  # the MS-BFS frontier-expansion kernel classes
+KERNEL_OF = {"meet": "k_meet3", "meet4": "k_meet4d", "bibfs": "k_bibfs", "pull_sparse": "k_pull_lanes"}
+PREPASS = ("meet", "meet4", "bibfs")  # the pair-centric kernels: k_meet3, k_meet4d / k_meet4, k_bibfs
 
 
 def parse():
@@ -283,9 +287,13 @@ class Bench:
         pgq.set_option("profile", 0)
         pgq.set_option("streams", n_streams)
         pgq.set_option("relax_streams", n_relax_streams)
-        return {"n": n, "elapsed": elapsed, "stats": stats, "iso": iso, "iso_steps": iso_steps, "iso_elapsed": iso_elapsed,
-                "te_local": te_local, "reach": reach, "out_len": out_len, "out_val": out_val, "d_ok": d_ok, "d_te": d_te,
-                "steps": steps}
+        res = {"n": n, "elapsed": elapsed, "stats": stats, "iso": iso, "iso_steps": iso_steps, "iso_elapsed": iso_elapsed,
+               "te_local": te_local, "reach": reach, "out_len": out_len, "out_val": out_val, "d_ok": d_ok, "d_te": d_te,
+               "steps": steps}
+        if paths:  # what the isolated pass (same rows, same answers) left in buffer 0: offsets + payload of every list
+            res["out_off"], res["out_child"] = d_off[(iso_steps - 1) & 1].clone(), d_child[(iso_steps - 1) & 1].clone()
+            assert bool((d_len[(iso_steps - 1) & 1] == out_len).all())
+        return res
 
     def reduce(self, m):
         """max over ranks of the timed region, sums of the work units."""
@@ -316,7 +324,7 @@ def roofline_of(m, workload, copy_gbps, elapsed):
         except Exception:
             traffic = None
     step_bytes = sum(m["stats"]["algo_bytes"].values())
-    roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": KERNEL_OF.get(dom, "k_" + dom), "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "traffic_GBps": traffic_gbps, "traffic_frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else None,
             "launches": int(kl[dom]), "avg_launch_ms": kms[dom] / max(kl[dom], 1),
@@ -326,6 +334,15 @@ def roofline_of(m, workload, copy_gbps, elapsed):
             # all kernel classes' algorithmic bytes over the wall time of the timed region
             "step": {"algorithmic_bytes": step_bytes / steps, "GBps": step_bytes / 1e9 / elapsed,
                      "frac": step_bytes / 1e9 / elapsed / HBM_PEAK_GBPS}}
+    chain = [k for k in PREPASS if kms.get(k, 0.0) > 0]
+    if chain:  # the pair-centric kernels together: k_meet3 + the bit-map kernel (+ k_bibfs), bytes and launch time summed
+        c_ms, c_b = sum(kms[k] for k in chain), sum(kb[k] for k in chain)
+        roof["prepass_chain"] = {"classes": chain, "ms_per_step": c_ms / iso_steps, "algorithmic_bytes_per_step": c_b / iso_steps,
+                                 "GBps": c_b / 1e9 / (c_ms / 1e3), "frac": c_b / 1e9 / (c_ms / 1e3) / HBM_PEAK_GBPS}
+        try:  # PMC traffic of the whole chain per step (tools/pmc_summary.py)
+            roof["prepass_chain"]["traffic_per_step"] = json.load(open(pmc))["prepass_chain"]["hbm_bytes_per_step"]
+        except Exception:
+            roof["prepass_chain"]["traffic_per_step"] = None
     exp_ms = sum(kms.get(k, 0.0) for k in EXPANSION)
     exp_b = sum(kb.get(k, 0.0) for k in EXPANSION)
     if exp_ms > 0:  # the MS-BFS frontier-expansion kernels (top-down + bottom-up) together
@@ -430,22 +447,28 @@ def main():
         wleg, _ = leg_summary(bench, mw, "snb_cheapest", len(wp), copy_gbps)
         wleg["workload"] = "%d random pairs, int64 weights 1..999 on the knows graph (cheapest_path_length.cpp:52-136)" % len(wp)
         if not a.no_cpu_baseline and rank == 0:
-            ns = min(len(wp), 32)  # a Dijkstra on this graph is ~0.5 s
-            wleg["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w_np, wp[:ns], mw["out_val"][:ns], mw["d_ok"][:ns])
+            sel = np.arange(min(len(wp), 256), dtype=np.int64) * max(1, len(wp) // 256)  # strided; a Dijkstra here is ~0.5 s
+            tsel = torch.from_numpy(sel).to(dev)
+            wleg["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w_np, wp[sel], mw["out_val"][tsel], mw["d_ok"][tsel],
+                                                         how="%d rows at stride %d" % (len(sel), max(1, len(wp) // 256)))
         del csr_w, t_w2
 
     if rank == 0:
-        if cheapest:
-            metric, unit, value = "cheapest_path_pairs_per_s", "pairs/s", main_leg["pairs_per_s"]
-        else:
-            metric, unit, value = "msbfs_mteps", "MTEPS", main_leg["mteps_logical"]
+        # value = what the hardware did: (src, dst) pairs answered per second (BASELINE metric "MS-BFS MTEPS + src-dst
+        # pairs/sec"; the default workload's rows are answered by the pair-centric kernels, no BFS level runs, so pairs/s
+        # is its throughput).  mteps_physical (adjacency entries the kernels scanned) and mteps_logical (edges the
+        # reference's per-pair lanes would traverse: a count of avoided work, not a hardware rate) ride along.
+        metric = "cheapest_path_pairs_per_s" if cheapest else "src_dst_pairs_per_s"
+        unit, value = "pairs/s", main_leg["pairs_per_s"]
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u64" if not cheapest else ("f64" if a.weights == "double" else "int64"),
             "data": "synthetic",
             # value counts the edges the reference's per-pair BFS lanes would traverse, not adjacency entries read
-            "value_kind": "pairs/s" if cheapest else "logical (reference-lane traversed edges; see mteps_physical, pairs_per_s)",
+            "value_kind": "pairs answered per second, whole job; mteps_physical = adjacency entries scanned per second / 1e6; "
+                          "mteps_logical = reference-lane traversed edges per second / 1e6 (work avoided, not a hardware rate)",
+            "mteps_logical": main_leg["mteps_logical"],
             "config": {"workload": "%s %s, %d pairs %s, CSR replicated" % (
                 name, OPS[a.workload], pairs_cfg, "per GPU" if scaling == "weak" else "in total"),
                 "V": V, "E": E, "pairs_total": total_pairs,
@@ -476,11 +499,16 @@ def main():
         if not a.no_cpu_baseline and world == 1 and a.workload in ("snb_sf100", "rmat22", "snb_cross"):  # rank 0, N=1 only
             out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, m["d_te"], m["out_len"])
         if not a.no_cpu_baseline and world == 1 and cheapest:
-            ns = len(mine) if a.workload == "forest_cheapest" else min(len(mine), 128)  # a Dijkstra on the knows graph is ~0.1 s
-            out["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w, mine[:ns], m["out_val"][:ns], m["d_ok"][:ns])
+            ns = len(mine) if a.workload == "forest_cheapest" else min(len(mine), 512)  # a Dijkstra on the knows graph is ~0.5 s
+            sel = np.arange(ns, dtype=np.int64) * max(1, len(mine) // ns)
+            tsel = torch.from_numpy(sel).to(dev)
+            out["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w, mine[sel], m["out_val"][tsel], m["d_ok"][tsel],
+                                                        how="%d rows at stride %d" % (ns, max(1, len(mine) // ns)))
+        if not a.no_cpu_baseline and world == 1 and paths:
+            out["cpu_baseline"] = cpu_baseline_paths(a, V, off, adj, eid, mine, m)
         if cross is not None:
             if not a.no_cpu_baseline:
-                cross["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, cp, mc["d_te"], mc["out_len"], sample=8192)
+                cross["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, cp, mc["d_te"], mc["out_len"], sample=8192)  # strided: every source
             legs = {"prepass": {k: main_leg[k] for k in main_leg if k != "roofline_by_kernel"}, "msbfs_cross": cross}
             legs["prepass"]["workload"] = "%d random pairs (default_rng(4)): every row answered by the pair-centric kernels" % total_pairs
             if "cpu_baseline" in out:
@@ -503,8 +531,16 @@ def cpu_baseline(a, V, off, adj, eid, mine, d_te, out_len, sample=0):
     from oracle.pgq_oracle import OracleCSR
     cores = os.cpu_count() or 1
     ora = OracleCSR.adopt(V, off, adj, eid)
-    if sample:
-        mine = mine[:sample]
+    how = "first"
+    if sample and sample < len(mine):
+        # a STRIDED sample: the rows of a cross product are grouped by source, so the first rows would cover a handful of
+        # sources (= lanes of one batch); every (len / sample)-th row touches every source of the product
+        sel = np.arange(sample, dtype=np.int64) * (len(mine) // sample)
+        mine = mine[sel]
+        import torch
+        tsel = torch.from_numpy(sel).to(out_len.device)
+        d_te, out_len = d_te[tsel], out_len[tsel]
+        how = "strided (every %d-th row: all sources of the product)" % (len(mine) and int(sel[1] - sel[0]) if len(sel) > 1 else 1)
     ns1 = min(a.cpu_sample or (8192 if a.workload in SNB else 1024), len(mine))
     res = {}
     if not sample:
@@ -527,30 +563,67 @@ def cpu_baseline(a, V, off, adj, eid, mine, d_te, out_len, sample=0):
     agree_m = bool(((gpu_m >= 0) == okm).all() and (gpu_m[okm] == lnm[okm]).all())
     tem = float(d_te[:nsm].sum().item())
     res.update({"value": tem / dtm / 1e6, "unit": "MTEPS", "cores": threads, "kind": "port",
-                "sample": "first %d pairs of rank 0's shard in 2048-row chunks, one thread per chunk (%d threads), literal "
+                "sample": how + " %d pairs of rank 0's shard in 2048-row chunks, one thread per chunk (%d threads), literal "
                           "512-lane restatement (oracle/pgq_oracle.cpp), %.1f s; results equal the GPU's timed output: %s" % (
                               nsm, threads, dtm, agree_m),
                 "pairs_per_s": nsm / dtm, "host_cores_available": cores})
     return res
 
 
-def cpu_baseline_cheapest(V, off, adj, eid, w, mine, d_val, d_ok):
+def cpu_baseline_cheapest(V, off, adj, eid, w, mine, d_val, d_ok, how="all"):
     """Per-pair Dijkstra of the oracle (lean restatement: same distances as the reference's batched Bellman-Ford, which
-    needs 8 KiB per vertex per call and does not fit a 2^24-vertex graph) on this rank's pairs, one thread; every value
-    of the timed output compared bit for bit."""
+    needs 8 KiB per vertex per call and does not fit a 2^24-vertex graph) on a sample of this rank's pairs, the rows dealt
+    to one thread per host core (the searches are independent; the oracle call releases the GIL); every value of the
+    timed output compared bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle.pgq_oracle import OracleCSR
     ora = OracleCSR.adopt(V, off, adj, eid, w)
+    threads = max(1, min(os.cpu_count() or 1, len(mine) // 4 or 1))
+    parts = np.array_split(np.arange(len(mine)), threads)
     t0 = time.perf_counter()
-    want, wok = ora.lean_cheapest_path_length(V, mine[:, 0], mine[:, 1])
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda ix: ora.lean_cheapest_path_length(V, mine[ix, 0], mine[ix, 1]), parts))
     dt = time.perf_counter() - t0
+    want = np.concatenate([r[0] for r in res])
+    wok = np.concatenate([r[1] for r in res])
     ok = d_ok.cpu().numpy().astype(bool)
     got = d_val.cpu().numpy()
     if want.dtype.kind == "f":
         got = got.view(np.float64)
     agree = bool((ok == wok).all() and (got[ok] == want[wok]).all())
-    return {"value": len(mine) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": "all %d pairs, per-pair Dijkstra (oracle/pgq_oracle.cpp lean restatement), %.1f s; results equal the "
-                      "GPU's timed output: %s" % (len(mine), dt, agree)}
+    return {"value": len(mine) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "%s (%d pairs), per-pair Dijkstra (oracle/pgq_oracle.cpp lean restatement) on %d threads, %.1f s; "
+                      "results equal the GPU's timed output: %s" % (how, len(mine), threads, dt, agree)}
+
+
+def cpu_baseline_paths(a, V, off, adj, eid, mine, m):
+    """shortestpath (configs[2]): (1) the literal restatement of ShortestPathFunction (512 lanes, two parent arrays of
+    V x 512 int64 = 3.7 GB per chunk in flight on the SF100-shaped graph: ONE thread, one 512-lane batch) timed on the
+    first 512 pairs — its cost does not depend on how many of the 512 lanes are used; (2) every list of the TIMED output
+    compared with the oracle's lean restatement (per-pair BFS + the reference's parent rule) on a strided sample."""
+    from oracle.pgq_oracle import OracleCSR
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    nb = min(512, len(mine))
+    t0 = time.perf_counter()
+    ln, ok = ora.baseline_run("shortestpath", V, mine[:nb, 0], mine[:nb, 1], nthreads=1)
+    dt = time.perf_counter() - t0
+    got_len = m["out_len"][:nb].cpu().numpy()
+    agree_len = bool(((got_len >= 0) == ok).all() and (got_len[ok] == ln[ok]).all())
+    ns = min(len(mine), 1024)
+    sel = np.arange(ns, dtype=np.int64) * max(1, len(mine) // ns)
+    t0 = time.perf_counter()
+    want = ora.lean_shortestpath(V, mine[sel, 0], mine[sel, 1])
+    dt2 = time.perf_counter() - t0
+    lens, offs, child = m["out_len"].cpu().numpy(), m["out_off"].cpu().numpy(), m["out_child"].cpu().numpy()
+    same = 0
+    for k, i in enumerate(sel):
+        got = None if lens[i] < 0 else child[offs[i]:offs[i] + 2 * lens[i] + 1].tolist()
+        same += int(got == want[k])
+    return {"value": nb / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "first %d pairs = one 512-lane batch of the literal restatement (oracle/pgq_oracle.cpp, 3.7 GB of parent "
+                      "arrays: thread count capped at 1), %.1f s, hop counts equal the GPU's timed output: %s; full lists "
+                      "of %d strided rows against the lean restatement (%.1f s): %d equal" % (nb, dt, agree_len, ns, dt2, same),
+            "paths_compared": ns, "paths_equal": same}
 
 
 if __name__ == "__main__":

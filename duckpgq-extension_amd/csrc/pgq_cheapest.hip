@@ -1449,7 +1449,13 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 				wstats[(size_t)t] = tstats().s;
 			}));
 		rcs[0] = relax_batches<T>(c, ws, ws, 0, workers, nb, U, d_out, d_ok);
-		for (auto &th : pool) worker_wait(th);
+		for (size_t k = 0; k < pool.size(); k++) { // a job that threw never wrote its return code: take the pool's word for it
+			const int wr = worker_wait(pool[k]);
+			if (wr != PGQ_OK) {
+				rcs[k + 1] = wr;
+				errs[k + 1] = pgq_last_error();
+			}
+		}
 		for (int t = 0; t < workers; t++) {
 			if (rcs[(size_t)t] != PGQ_OK && rc == PGQ_OK) {
 				rc = rcs[(size_t)t];

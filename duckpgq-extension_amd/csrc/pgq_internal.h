@@ -123,7 +123,7 @@ Options &options();
 // has run.  A call used to start a std::thread per extra batch stream; nested use cannot deadlock (the pool grows).
 struct WorkerTask;
 std::shared_ptr<WorkerTask> worker_submit(int device, std::function<void()> fn);
-void worker_wait(const std::shared_ptr<WorkerTask> &t);
+int worker_wait(const std::shared_ptr<WorkerTask> &t); // PGQ_OK, or the error of a job that threw (its results are missing)
 Options *options_override();
 void set_options_override(Options *o);
 
@@ -138,8 +138,10 @@ enum KClass {
 	K_RECON = 6,     // path reconstruction
 	K_RELAX = 7,     // cheapest path relaxation
 	K_PULL_SPARSE = 8, // bottom-up expansion, edge-organised sparse variant
-	K_MEET = 9,      // pair-centric two-hop pre-pass (pgq_meet.hip)
-	K_COUNT = 10
+	K_MEET = 9,      // pair-centric two-hop pre-pass: k_meet3, one wavefront per row (pgq_meet.hip)
+	K_MEET4 = 10,    // ... its bit-map kernels for the rows k_meet3 leaves open (k_meet4d / k_meet4)
+	K_BIBFS = 11,    // ... one bidirectional search per row (k_bibfs)
+	K_COUNT = 12
 };
 
 struct ThreadStats {

@@ -109,7 +109,7 @@ struct MeetDevBlock { // device side; all zero between calls
 	MeetDecision dec;
 };
 struct MeetHostBlock { // pinned host memory, written by the last workgroup of the chain
-	unsigned long long entries, vertices;
+	unsigned long long entries[3], vertices[3]; // per stage: k_meet3, the bit-map kernel, k_bibfs
 	u32 bad, count[3];
 	MeetDecision dec;
 	u32 done, count_back;
@@ -135,35 +135,33 @@ __device__ __forceinline__ u32 queue_pos(const MeetQueue &q, u32 j, u32 nf) { re
 __device__ __forceinline__ void meet_finalize(MeetDevBlock *db, MeetHostBlock *fin) {
 	if (!fin) return;
 	__shared__ u32 s_last;
-	__shared__ unsigned long long s_sum[2];
+	__shared__ unsigned long long s_sum[6];
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		__threadfence_system(); // this workgroup's results (possibly in pinned host memory) before its ticket
 		s_last = atomicAdd(&db->ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-		s_sum[0] = s_sum[1] = 0;
+		for (int k = 0; k < 6; k++) s_sum[k] = 0;
 	}
 	__syncthreads();
 	if (!s_last) return;
 	__threadfence();
-	unsigned long long e = 0, v = 0;
+	// one thread per slot (the first 256 threads of the workgroup; a one-wavefront workgroup loops): the slot's stage is
+	// fixed by its index, so the per-stage sums are three LDS accumulators
 	for (int k = threadIdx.x; k < kMeetStatSlots; k += blockDim.x) {
-		e += __hip_atomic_load(&db->m.entries[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		v += __hip_atomic_load(&db->m.vertices[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned long long e = __hip_atomic_load(&db->m.entries[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned long long v = __hip_atomic_load(&db->m.vertices[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		db->m.entries[k] = 0;
 		db->m.vertices[k] = 0;
-	}
-	for (int o = 32; o > 0; o >>= 1) {
-		e += __shfl_xor(e, o);
-		v += __shfl_xor(v, o);
-	}
-	if ((threadIdx.x & 63) == 0) {
-		if (e) atomicAdd(&s_sum[0], e);
-		if (v) atomicAdd(&s_sum[1], v);
+		const int st = k < 192 ? 0 : (k < 224 ? 1 : 2);
+		if (e) atomicAdd(&s_sum[2 * st], e);
+		if (v) atomicAdd(&s_sum[2 * st + 1], v);
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		fin->entries = s_sum[0];
-		fin->vertices = s_sum[1];
+		for (int k = 0; k < 3; k++) {
+			fin->entries[k] = s_sum[2 * k];
+			fin->vertices[k] = s_sum[2 * k + 1];
+		}
 		fin->bad = __hip_atomic_load(&db->m.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		for (int k = 0; k < 3; k++) {
 			fin->count[k] = __hip_atomic_load(&db->count[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -180,10 +178,12 @@ __device__ __forceinline__ void meet_finalize(MeetDevBlock *db, MeetHostBlock *f
 		fin->done = 1;
 	}
 }
-// per-workgroup statistics: one pair of atomics, spread over the slots
-__device__ __forceinline__ void meet_add_stats(MeetCounters *mc, unsigned long long entries, unsigned long long vertices) {
-	if (entries) atomicAdd(&mc->entries[blockIdx.x % kMeetStatSlots], entries);
-	if (vertices) atomicAdd(&mc->vertices[blockIdx.x % kMeetStatSlots], vertices);
+// per-workgroup statistics: one pair of atomics, spread over the slots of the kernel's stage (k_meet3: 192 slots for up to
+// 65,536 workgroups; the bit-map kernels and k_bibfs: 32 each), so that every kernel's algorithmic bytes can be stated
+__device__ __forceinline__ void meet_add_stats(MeetCounters *mc, int stage, unsigned long long entries, unsigned long long vertices) {
+	const int base = stage == 0 ? 0 : (stage == 1 ? 192 : 224), cnt = stage == 0 ? 192 : 32;
+	if (entries) atomicAdd(&mc->entries[base + blockIdx.x % cnt], entries);
+	if (vertices) atomicAdd(&mc->vertices[base + blockIdx.x % cnt], vertices);
 }
 
 // One wavefront per row.  A row costs ~4 dependent memory round trips before its walk starts (row, offsets, the two
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 			}
 		}
 	}
-	if (lane == 0) meet_add_stats(mc, entries, (unsigned long long)vertices);
+	if (lane == 0) meet_add_stats(mc, 0, entries, (unsigned long long)vertices);
 	meet_finalize(db, fin);
 }
 
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
 	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
 	__syncthreads();
-	if (tid == 0) meet_add_stats(mc, s_stat[0], s_stat[1]);
+	if (tid == 0) meet_add_stats(mc, 1, s_stat[0], s_stat[1]);
 	meet_finalize(db, fin);
 }
 
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
 	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
 	__syncthreads();
-	if (tid == 0) meet_add_stats(&db->m, s_stat[0], s_stat[1]);
+	if (tid == 0) meet_add_stats(&db->m, 1, s_stat[0], s_stat[1]);
 	meet_finalize(db, fin);
 }
 
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 	if (lane == 0 && entries) atomicAdd(&s_stat[0], entries);
 	if (tid == 0 && vertices) atomicAdd(&s_stat[1], (unsigned long long)vertices);
 	__syncthreads();
-	if (tid == 0) meet_add_stats(mc, s_stat[0], s_stat[1]);
+	if (tid == 0) meet_add_stats(mc, 2, s_stat[0], s_stat[1]);
 	meet_finalize(db, fin);
 }
 
@@ -1287,7 +1287,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		const int64_t cap4 = (int64_t)std::max(1, opt.meet4_cap);
 		MeetHostBlock *fin = last_stage == 1 ? hb : nullptr;
 		{
-			KernelTimer kt(st, K_MEET);
+			KernelTimer kt(st, K_MEET4);
 #define PGQ_MEET4(G)                                                                                                     \
 	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid4), dim3(1024), lds, st, q[0], c->V, c->off, c->adj, c->roff, c->radj,     \
 	                   d_out, rec, cap4, bm_words, db, gmaps, q[1], fin)
@@ -1314,7 +1314,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		MeetQueue qo2 = q[open_stage ^ 1]; // the other region: the stage that filled it has been read by now
 		qo2.count = &db->count[2];
 		{
-			KernelTimer kt(st, K_MEET);
+			KernelTimer kt(st, K_BIBFS);
 			if (bi_lds)
 				hipLaunchKernelGGL(k_bibfs<false>, dim3(bi_grid), dim3(1024), (size_t)2 * mwb * 4, st, qi, (u32)opt.bibfs_rows,
 				                   c->off, c->adj, c->roff, c->radj, d_out, capb, bm_words, qcap, db, bi_maps, queues, qo2, hb);
@@ -1365,10 +1365,13 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		c->meet_far_rows.store(before_bi > 0 ? 1 : 0, std::memory_order_relaxed);
 	}
 	S.meet_pairs += n - (int64_t)open;
-	S.edges_scanned += (int64_t)h.entries;
-	// 4 B per adjacency entry / one-hop id, 16 B per slot descriptor, and per row its ids (16 B), the four offsets of its
-	// endpoints (32 B) and its result (8 B)
-	S.algo_bytes[K_MEET] += 4.0 * (double)h.entries + 16.0 * (double)h.vertices + 56.0 * (double)n;
+	S.edges_scanned += (int64_t)(h.entries[0] + h.entries[1] + h.entries[2]);
+	// 4 B per adjacency entry / one-hop id, 16 B per slot descriptor; k_meet3: per row its ids (16 B), the four offsets and
+	// two walk sizes of its endpoints (40 B) and its result (8 B); the bit-map kernel: per queued row its entry (48 B)
+	// and its result (8 B)
+	S.algo_bytes[K_MEET] += 4.0 * (double)h.entries[0] + 16.0 * (double)h.vertices[0] + 64.0 * (double)n;
+	S.algo_bytes[K_MEET4] += 4.0 * (double)h.entries[1] + 16.0 * (double)h.vertices[1] + 56.0 * (double)(h.count[0] + h.count_back);
+	S.algo_bytes[K_BIBFS] += 4.0 * (double)h.entries[2] + 16.0 * (double)h.vertices[2];
 	*n_open = open;
 	return PGQ_OK;
 }
@@ -1436,7 +1439,7 @@ int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_sr
 	meet_attributes();
 	const int64_t capb = (int64_t)std::max(1, opt.bibfs_cap);
 	{
-		KernelTimer kt(st, K_MEET);
+		KernelTimer kt(st, K_BIBFS);
 		if (bi_lds)
 			hipLaunchKernelGGL(k_bibfs<false>, dim3(grid), dim3(1024), (size_t)2 * mwb * 4, st, q[0], 0xFFFFFFFFu, c->off, c->adj,
 			                   c->roff, c->radj, d_out, capb, bm_words, qcap, db, maps, queues, q[1], hb);
@@ -1452,8 +1455,8 @@ int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_sr
 	const MeetHostBlock &h = *hb;
 	if (h.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
 	S.meet_pairs += n - (int64_t)h.count[1];
-	S.edges_scanned += (int64_t)h.entries;
-	S.algo_bytes[K_MEET] += 4.0 * (double)h.entries + 16.0 * (double)h.vertices;
+	S.edges_scanned += (int64_t)h.entries[2];
+	S.algo_bytes[K_BIBFS] += 4.0 * (double)h.entries[2] + 16.0 * (double)h.vertices[2];
 	*n_open = h.count[1];
 	return PGQ_OK;
 }

@@ -2030,7 +2030,13 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 				wstats[(size_t)t] = tstats().s;
 			}));
 		rcs[0] = run(ws, 0, workers, outs[0]);
-		for (auto &th : pool) worker_wait(th);
+		for (size_t k = 0; k < pool.size(); k++) { // a job that threw never wrote its return code: take the pool's word for it
+			const int wr = worker_wait(pool[k]);
+			if (wr != PGQ_OK) {
+				rcs[k + 1] = wr;
+				errs[k + 1] = pgq_last_error();
+			}
+		}
 		for (int t = 0; t < workers; t++) {
 			if (rcs[(size_t)t] != PGQ_OK && rc == PGQ_OK) {
 				rc = rcs[(size_t)t];
@@ -2172,7 +2178,13 @@ static int run_shards(pgq_csr_t *csr, int64_t n, Body body) {
 	rcs[0] = shard(0);
 	bind_thread_device(-1);
 	(void)ensure_init();
-	for (auto &th : pool) worker_wait(th);
+	for (size_t k = 0; k < pool.size(); k++) { // a job that threw never wrote its return code: take the pool's word for it
+		const int wr = worker_wait(pool[k]);
+		if (wr != PGQ_OK) {
+			rcs[k + 1] = wr;
+			errs[k + 1] = pgq_last_error();
+		}
+	}
 	int rc = PGQ_OK;
 	for (int k = 0; k < W; k++) {
 		if (rcs[(size_t)k] != PGQ_OK && rc == PGQ_OK) {

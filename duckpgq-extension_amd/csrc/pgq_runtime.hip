@@ -52,6 +52,8 @@ struct WorkerTask {
 	std::mutex m;
 	std::condition_variable cv;
 	bool done = false;
+	int failed = PGQ_OK; // the job threw (std::bad_alloc in a worker's vectors, ...): its rows were never written
+	std::string what;
 };
 namespace {
 struct Worker {
@@ -76,7 +78,15 @@ void worker_loop(Worker *w) {
 		}
 		try {
 			t->fn();
-		} catch (...) { // the jobs report through return codes; nothing may unwind into the pool
+		} catch (const std::bad_alloc &) { // the jobs report through return codes; nothing may unwind into the pool, and a
+			t->failed = PGQ_ERR_OOM;       // job that threw must not look like one that ran: worker_wait hands the failure on
+			t->what = "a worker thread ran out of host memory";
+		} catch (const std::exception &e) {
+			t->failed = PGQ_ERR_HIP;
+			t->what = std::string("a worker thread failed: ") + e.what();
+		} catch (...) {
+			t->failed = PGQ_ERR_HIP;
+			t->what = "a worker thread failed with an unknown exception";
 		}
 		t->fn = nullptr; // drop the captures before the submitter is released
 		{
@@ -117,9 +127,10 @@ std::shared_ptr<WorkerTask> worker_submit(int device, std::function<void()> fn) 
 	return t;
 }
 
-void worker_wait(const std::shared_ptr<WorkerTask> &t) {
+int worker_wait(const std::shared_ptr<WorkerTask> &t) {
 	std::unique_lock<std::mutex> lk(t->m);
 	t->cv.wait(lk, [&] { return t->done; });
+	return t->failed == PGQ_OK ? PGQ_OK : fail(t->failed, t->what);
 }
 
 ThreadStats::ThreadStats() { memset(&s, 0, sizeof(s)); }
@@ -1511,7 +1522,7 @@ int pgq_csr_get_option(pgq_csr_t *csr, const char *key, double *value) {
 
 const char *pgq_kclass_name(int k) {
 	static const char *names[K_COUNT] = { "prep",   "push",   "pull",  "pull_hub",
-		                                  "queue",  "detect", "recon", "relax", "pull_sparse", "meet" };
+		                                  "queue",  "detect", "recon", "relax", "pull_sparse", "meet", "meet4", "bibfs" };
 	return (k >= 0 && k < K_COUNT) ? names[k] : nullptr;
 }
 int pgq_get_stats(pgq_stats_t *out) {

@@ -141,6 +141,9 @@ int pgq_release_cached_memory(void);
 /* d_src/d_dst/d_out_len: n int64 each in HBM.  d_out_len[i] = hop count, 0 for src==dst, -1 for NULL. */
 int pgq_iterativelength_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t *d_out_len);
+/* the same rows through one bidirectional search each (pgq_iterativelength_bidirectional without the chunk ceiling) */
+int pgq_iterativelength_bidirectional_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                                                  int64_t *d_out_len);
 /* Rows in host memory, answered by all enabled devices: contiguous shards, one host thread and one CSR replica per
  * device, results gathered into out_len (same values as pgq_iterativelength_bulk_device: hop count, 0, or -1). */
 int pgq_iterativelength_multi(pgq_csr_t *csr, int64_t n, const int64_t *src, const int64_t *dst, int64_t *out_len);

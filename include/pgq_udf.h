@@ -79,6 +79,7 @@ int pgq_udf_reachability(pgq_state_t *, int32_t id, int64_t V, int64_t n, pgq_ve
  * pgq_weakly_connected_component).  The component id of weakly_connected_component is the root the reference's
  * sequential union-find schedule ends in (weakly_connected_component.cpp:14-34,83-90 — the goldens pin it): the device
  * finds the spanning forest under that schedule's edge order, the reference's Link replays its edges. */
+int pgq_udf_local_clustering_coefficient(pgq_state_t *, int32_t id, int64_t n, pgq_vec_t src, float *out, uint64_t *out_valid);
 int pgq_udf_pagerank(pgq_state_t *, int32_t id, int64_t n, pgq_vec_t src, double *out, uint64_t *out_valid);
 int pgq_udf_weakly_connected_component(pgq_state_t *, int32_t id, int64_t n, pgq_vec_t src, int64_t *out, uint64_t *out_valid);
 

@@ -663,6 +663,87 @@ def test_c5_weighted_cheapest_path_at_scale_int64_and_double():
         assert (ok == wok).all() and (out[ok] == want[wok]).all()
 
 
+def _dijkstra_threads(ora, V, ps, pd, threads=16):
+    """the oracle's per-pair Dijkstra on slices of the rows, one slice per host thread (the call releases the GIL and
+    the oracle CSR is read-only)"""
+    from concurrent.futures import ThreadPoolExecutor
+    parts = np.array_split(np.arange(len(ps)), threads)
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda ix: ora.lean_cheapest_path_length(V, ps[ix], pd[ix]), parts))
+    return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+
+@pytest.mark.slow
+def test_sf100_cross_product_2048x1024_and_weighted_pairs_against_the_oracle():
+    """The bench's other two legs at their full size, against the oracle (round-3 review: the bench compared the first
+    8192 rows of the cross product = 8 of its 2048 sources, and 32 weighted rows; no test ran either shape at SF100 scale).
+    (1) 2048 distinct sources x 1024 destinations = 2.1 M rows through the product's own routing (lane-batched MS-BFS,
+    k_pull<32> at 32 lane-words on the real graph): a strided sample of 8192 rows that touches every source, against the
+    oracle's per-pair BFS.  (2) 512 random pairs on the same graph with int64 weights 1..999 and with double weights,
+    cheapest_path_length against the oracle's Dijkstra, bit for bit."""
+    import torch
+    for k, v in (("meet", 1), ("meet_bias", 1.0), ("streams", 3), ("probe2_abs", 4096), ("push_div", 24)):
+        pgq.set_option(k, v)  # the shipped values
+    V, s, d = graphgen.snb_knows_like()
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    rng = np.random.default_rng(7)
+    src = rng.choice(V, size=2048, replace=False)
+    ps = np.repeat(src, 1024)
+    pd = rng.integers(0, V, len(ps))
+    d_src, d_dst = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+    d_out = torch.full((len(ps),), -7, dtype=torch.int64, device="cuda")
+    pgq.reset_stats()
+    dev.iterativelength_bulk_ptr(len(ps), d_src.data_ptr(), d_dst.data_ptr(), d_out.data_ptr())
+    st = pgq.get_stats()
+    assert st["levels"] > 0 and st["unique_sources"] == 2048  # the lane-batched search ran, one lane per source
+    sel = np.arange(8192) * (len(ps) // 8192)
+    assert len(np.unique(ps[sel])) == 2048
+    got = d_out.cpu().numpy()
+    assert (got != -7).all()
+    oln, ook = ora.lean_iterativelength(V, ps[sel], pd[sel], nthreads=16)
+    assert ((got[sel] >= 0) == ook).all() and (got[sel][ook] == oln[ook]).all()
+    dev.close()
+    wp = np.random.default_rng(106).integers(0, V, size=(512, 2))
+    wrng = np.random.default_rng(6)
+    for w in (wrng.integers(1, 1000, len(adj)), wrng.integers(1, 1000, len(adj)).astype(np.float64) / 7.0):
+        devw = pgq.DeviceCSR(V, off, adj, eid, w)
+        out, ok = devw.cheapest_path_length(wp[:, 0], wp[:, 1])
+        want, wok = _dijkstra_threads(OracleCSR.adopt(V, off, adj, eid, w), V, wp[:, 0], wp[:, 1])
+        assert (ok == wok).all() and (out[ok] == want[wok]).all() and ok.sum() > 500
+        devw.close()
+
+
+def test_upload_reads_only_the_first_v_V_entries():
+    """The undirected CTE allocates e / edge_ids / w at twice the size the CSR uses (compressed_sparse_row.cpp:127,166: both
+    size arguments are the doubled count; only e[0 .. v[V]) is meaningful, the tail is whatever the allocation held).
+    Host arrays with a junk tail past v[V] — ids outside [0, V), huge weights — must give the same device CSR."""
+    V, s, d = graphgen.rmat(10, seed=3)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    E = int(off[V])
+    rng = np.random.default_rng(1)
+    w = rng.integers(1, 50, E)
+    junk = np.full(E + 17, 1 << 40, dtype=np.int64)
+    adj_j, eid_j, w_j = (np.concatenate([x, junk]) for x in (adj, eid, w))
+    adj_j[E:] = -5  # not a vertex
+    off_j = np.concatenate([off, [E]])  # the reference allocates V + 2 offsets
+    ps, pd = rng.integers(0, V, 600), rng.integers(0, V, 600)
+    ora = OracleCSR.adopt(V, off, adj, eid, w)
+    for meet in (0, 1):
+        pgq.set_option("meet", meet)
+        pgq.set_option("meet_bias", 1e9)
+        dev = pgq.DeviceCSR(V, off_j, adj_j, eid_j, w_j)
+        ln, ok = dev.iterativelength(ps, pd)
+        oln, ook = ora.lean_iterativelength(V, ps, pd)
+        assert (ok == ook).all() and (ln[ok] == oln[ook]).all()
+        assert dev.shortestpath(ps[:200], pd[:200]) == ora.lean_shortestpath(V, ps[:200], pd[:200])
+        out, cok = dev.cheapest_path_length(ps[:200], pd[:200])
+        want, wok = ora.lean_cheapest_path_length(V, ps[:200], pd[:200])
+        assert (cok == wok).all() and (out[cok] == want[wok]).all()
+        dev.close()
+
+
 def test_bulk_device_entry_points_match_chunk_api():
     """pgq_shortestpath_bulk_device / pgq_cheapest_path_length_bulk_device (external child buffer, overflow return,
     straggler append) against the chunk API and the oracle."""

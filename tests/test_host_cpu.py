@@ -28,6 +28,21 @@ def test_abi_exports_every_declared_symbol(header, loader):
     assert missing == []
 
 
+@pytest.mark.parametrize("header,libname", [("pgq_hip.h", "libpgq_hip.so"), ("pgq_udf.h", "libpgq_udf.so")])
+def test_abi_declares_every_exported_symbol(header, libname):
+    """The other direction: every pgq_* function a library exports is declared in its public header (a definition whose
+    prototype was lost in a header edit still links, loads and passes the test above)."""
+    import subprocess
+    so = os.path.join(ROOT, "duckpgq-extension_amd", "csrc", libname)
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("pgq_")})
+    assert len(exported) >= 10
+    declared = set(declared_symbols(header))
+    if header == "pgq_udf.h":  # the host mirror re-exports nothing of the device library
+        exported = [s for s in exported if s.startswith("pgq_udf_") or s.startswith("pgq_state_")]
+    assert [s for s in exported if s not in declared] == []
+
+
 def test_host_csr_build_matches_getpgschema_golden():
     g = load_golden("student_csr_layout.json")  # getpgschema.test:85-107
     st = pgq.PgqState()

@@ -89,7 +89,7 @@ struct Options {
 	int chunk_zero_copy = 1;     // chunk entry points: the pre-pass kernels read / write the pinned staging block directly
 	int meet_small_rows = 16384; // calls of at most this many rows are latency-bound: k_meet3 with more requests in flight and meet_cap_small
 	int meet_cap_small = 1 << 14; // ... a lower walk cap (longer walks go to the 16-wavefront kernel sooner)
-	int meet_cap_paths = 1 << 16; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
+	int meet_cap_paths = 1 << 14; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
 	int wbibfs = 0;            // cheapest_path_length, int64 weights: a bidirectional delta-stepping search per row before the batched

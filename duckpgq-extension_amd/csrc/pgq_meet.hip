@@ -388,6 +388,8 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 template <bool PATHS, bool GM>
 __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
+                                                const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
                                                 int64_t *__restrict__ out_rows,
                                                 MeetPath *__restrict__ rec_rows, int64_t cap, int bm_words,
                                                 MeetDevBlock *__restrict__ db, u32 *__restrict__ gmaps, MeetQueue qout,
@@ -398,9 +400,11 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 	const u32 *const didx = qin.idx;
 	MeetCounters *const mc = &db->m;
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * bm_words : nullptr;
-	__shared__ unsigned long long s_work[2];
 	__shared__ unsigned long long s_best;
+	__shared__ __attribute__((aligned(16))) unsigned char s_win[16][64];
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	unsigned char *win = s_win[wib]; // seg_owner's window of this wavefront
+	win[lane] = 0;
 	unsigned long long entries = 0;
 	u32 vertices = 0;
 	// GM: bits are set by L2 atomics, so they are read with device-scope atomic loads (a plain load may hit a stale L1 line)
@@ -429,16 +433,18 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 		// rows k_meet3 walked to the end are known to be at distance >= 4: only the two two-hop walks remain (two
 		// dependent phases instead of six; their sizes passed k_meet3's cap, which is below this kernel's)
 		const bool known4 = (didx[i] & kMeetKnown4Bit) != 0;
+		// the sizes of the two two-hop walks came with the row (k_meet3's queue entry; round 3 summed 2 x degree offset
+		// pairs per row here)
+		const uint4 ew = reinterpret_cast<const uint4 *>(qin.ent + i)[2];
+		const int64_t work_f = (int64_t)(u32)__builtin_amdgcn_readfirstlane((int)ew.x);
+		const int64_t work_b = (int64_t)(u32)__builtin_amdgcn_readfirstlane((int)ew.y);
 		auto leave_open = [&]() { // one thread: the row goes on to the next stage
 			out_rows[row] = kMeetOpen;
-			const MeetEntry e = { row, 0u, (u32)s, (u32)d, (u32)so, (u32)degS, (u32)di, (u32)degD };
+			const MeetEntry e = { row, 0u, (u32)s, (u32)d, (u32)so, (u32)degS, (u32)di, (u32)degD, (u32)work_f, (u32)work_b, 0u, 0u };
 			queue_push(qout, row, e);
 		};
 		clear_map();
-		if (tid == 0) {
-			s_work[0] = s_work[1] = 0;
-			s_best = ~0ull;
-		}
+		if (tid == 0) s_best = ~0ull;
 		__syncthreads();
 		// the smallest vertex of N_in(dst) whose bit is set (distance 2: the middle vertex; distance 3: the second one)
 		auto min_in_neighbour_of_dst = [&]() {
@@ -475,25 +481,8 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 			vertices += (u32)(degS + degD);
 		}
 		if (!known4) {
-			// B = N_out(src); sizes of both two-hop walks
-			unsigned long long wf = 0, wb = 0;
-			for (int p = tid; p < degS; p += 1024) {
-				const u32 v = (u32)adj[so + p];
-				mark(v);
-				wf += (unsigned long long)(off[v + 1] - off[v]);
-			}
-			for (int p = tid; p < degD; p += 1024) {
-				const u32 u = (u32)radj[di + p];
-				wb += (unsigned long long)(roff[u + 1] - roff[u]);
-			}
-			for (int o = 32; o > 0; o >>= 1) {
-				wf += __shfl_xor(wf, o);
-				wb += __shfl_xor(wb, o);
-			}
-			if (lane == 0) {
-				if (wf) atomicAdd(&s_work[0], wf);
-				if (wb) atomicAdd(&s_work[1], wb);
-			}
+			// B = N_out(src)
+			for (int p = tid; p < degS; p += 1024) mark((u32)adj[so + p]);
 			__syncthreads();
 			if (bit((u32)d)) { // dst in N_out(src)
 				if (tid == 0) out_rows[row] = 1;
@@ -512,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 				}
 				continue;
 			}
-			if ((int64_t)s_work[1] > cap) {
+			if (work_b > cap) {
 				if (tid == 0) leave_open();
 				continue;
 			}
@@ -520,14 +509,25 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 		// The backward walk: in-lists of N_in(dst) in list order = ascending second-to-last vertex y, entries ascending, so
 		// the smallest key (y << 32 | x) over the entries x whose bit is set is the reference's choice (smallest parent at
 		// every step back from dst).  A wavefront stops once its lists are past the best y any wavefront has published.
+		// Round 4: the walk is seg_walk in cooperative form (every wavefront takes every 16th request of a round of 64 in-lists,
+		// pgq_walk.h) over the slot descriptors — no offset look-up per expanded vertex, every lane of a request useful; round
+		// 3 dealt whole lists to the wavefronts (meet_walk).  Requests are taken in walk order, so the stop rule holds as
+		// before: what a wavefront has not requested yet lies behind the lists it has seen.
 		auto backward_walk = [&]() {
 			unsigned long long best = ~0ull;
 			u32 last = 0;
-			const unsigned long long e2 = meet_walk(
-			    radj + di, degD, wib, 16, roff, radj,
-			    [&](u32 x, u32 ev) {
-				    last = ev;
-				    if (bit(x)) best = min(best, (unsigned long long)ev << 32 | x);
+			bool capped = false;
+			int resume = 0;
+			const unsigned long long e2 = seg_walk<2, true>(
+			    rdesc + di, degD, wib, 16, rpadj, win, false, make_uint4(0, 0, 0, 0), ~0ull, capped, resume,
+			    [&](const int4 &v, bool ok, u32 ev) {
+				    last = ev; // lanes past the round's end carry the last list's vertex: not smaller than any real one
+				    if (ok) {
+					    if (bit((u32)v.x)) best = min(best, (unsigned long long)ev << 32 | (u32)v.x);
+					    if (bit((u32)v.y)) best = min(best, (unsigned long long)ev << 32 | (u32)v.y);
+					    if (bit((u32)v.z)) best = min(best, (unsigned long long)ev << 32 | (u32)v.z);
+					    if (bit((u32)v.w)) best = min(best, (unsigned long long)ev << 32 | (u32)v.w);
+				    }
 			    },
 			    [&]() {
 				    if (__any(best != ~0ull)) {
@@ -556,16 +556,24 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 				}
 				continue;
 			}
-			if ((int64_t)s_work[0] > cap) {
+			if (work_f > cap) {
 				if (tid == 0) leave_open();
 				continue;
 			}
 		}
 		// B += N_out(N_out(src))
 		{
-			const unsigned long long e2 = meet_walk(adj + so, degS, wib, 16, off, adj,
-			                                        [&](u32 x, u32) { mark(x); },
-			                                        []() { return false; });
+			bool capped = false;
+			int resume = 0;
+			const unsigned long long e2 = seg_walk<2, false>(
+			    fdesc + so, degS, wib, 16, padj, win, false, make_uint4(0, 0, 0, 0), ~0ull, capped, resume,
+			    [&](const int4 &v, bool, u32) { // padding and re-read groups repeat real entries: a mark does not mind
+				    mark((u32)v.x);
+				    mark((u32)v.y);
+				    mark((u32)v.z);
+				    mark((u32)v.w);
+			    },
+			    []() { return false; });
 			if (lane == 0) entries += e2;
 		}
 		__syncthreads();
@@ -1036,36 +1044,45 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
                                                     const int64_t *__restrict__ len, const MeetPath *__restrict__ rec,
                                                     const int64_t *__restrict__ poff, const int64_t *__restrict__ off,
                                                     const int32_t *__restrict__ adj, const int64_t *__restrict__ edge_ids,
-                                                    int64_t *__restrict__ child, int64_t *__restrict__ out_off) {
-	const int lane = threadIdx.x & 63;
-	// 64-bit row index: one wavefront per row, n may exceed 2^26 rows (the thread index would wrap in 32 bits)
-	const int64_t i = (int64_t)blockIdx.x * (int64_t)(blockDim.x >> 6) + (int64_t)(threadIdx.x >> 6);
+                                                    int64_t *__restrict__ child, int64_t child_cap, int64_t *__restrict__ out_off) {
+	// One 256-thread workgroup per row, wavefront h = hop h of the path (at most four hops here): the four first-slot
+	// searches are independent once the inner vertices are known, so they run side by side, each 256 entries per round
+	// trip (round 3: one wavefront per row, the hops one after the other, 64 entries per trip — 28 us for 4096 rows).
+	const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+	const int64_t i = (int64_t)blockIdx.x; // 64-bit row index
 	if (i >= n) return;
 	const int64_t k = len[i];
-	if (k < 0) return;
-	int64_t *out = child + poff[i];
-	if (lane == 0) out_off[i] = poff[i];
+	if (k < 0 || h >= (k == 0 ? 1 : k)) return; // open / NULL rows: nothing here; wavefronts past the last hop
+	const int64_t base_out = poff[i];
+	if (base_out + 2 * k + 1 > child_cap) return; // the caller's buffer is too small: it is told so (lengths stay valid)
+	int64_t *out = child + base_out;
+	if (h == 0 && lane == 0) {
+		out_off[i] = base_out;
+		out[0] = src[i];
+	}
+	if (k == 0) return;
 	const MeetPath r = rec[i];
-	int64_t vs[5];
-	vs[0] = src[i];
-	vs[1] = k >= 2 ? r.v1 : dst[i];
-	vs[2] = k >= 3 ? r.v2 : dst[i];
-	vs[3] = k >= 4 ? r.v3 : dst[i];
-	vs[4] = dst[i];
-	if (lane == 0) out[0] = vs[0];
-	for (int h = 0; h < (int)k; h++) {
-		const int64_t p = vs[h], c = h + 1 == (int)k ? dst[i] : vs[h + 1];
-		int64_t slot = -1;
-		for (int64_t base = off[p]; base < off[p + 1] && slot < 0; base += 64) {
-			const int64_t t = base + lane;
-			const bool eq = t < off[p + 1] && (int64_t)adj[t] == c;
-			const u64 m = __ballot(eq);
-			if (m) slot = base + (__ffsll((long long)m) - 1);
+	// vertices of the path: src, v1 .. v(k-1), dst
+	auto vertex = [&](int j) -> int64_t { return j == 0 ? src[i] : (j == (int)k ? dst[i] : (j == 1 ? r.v1 : (j == 2 ? r.v2 : r.v3))); };
+	const int64_t p = vertex(h), c = vertex(h + 1);
+	const int64_t b = off[p], e = off[p + 1];
+	int64_t slot = -1;
+	for (int64_t base = b; base < e && slot < 0; base += 256) {
+		int32_t x[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int64_t t = base + 64 * u + lane;
+			x[u] = t < e ? adj[t] : -1;
 		}
-		if (lane == 0) {
-			out[2 * h + 1] = slot < 0 ? -1 : (edge_ids ? edge_ids[slot] : slot);
-			out[2 * h + 2] = c;
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const u64 m = __ballot((int64_t)x[u] == c);
+			if (m && slot < 0) slot = base + 64 * u + (__ffsll((long long)m) - 1);
 		}
+	}
+	if (lane == 0) {
+		out[2 * h + 1] = slot < 0 ? -1 : (edge_ids ? edge_ids[slot] : slot);
+		out[2 * h + 2] = c;
 	}
 }
 
@@ -1196,7 +1213,8 @@ static void meet_attributes() {
 // decide: k_meet_decide compares `meet_bytes` with the lanes' cost for the sampled number of distinct sources
 // (lanes_cost_bytes) first; *ran = false when it said no (nothing was written to d_out).
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, bool paths, bool decide, double meet_bytes, double edge_bytes, bool *ran) {
+                 u32 *n_open, MeetPathsOut *po, bool decide, double meet_bytes, double edge_bytes, bool *ran) {
+	const bool paths = po != nullptr;
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
 	const Options &opt = options();
@@ -1253,6 +1271,9 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		PGQ_HIP_TRY(hipMemsetAsync(d_trace, 0, (size_t)grid4 * 32, st));
 	}
 	const int last_stage = run_bi ? 2 : (run4 ? 1 : 0);
+	// shortestpath on a large input: if the decision kernel calls the pre-pass off, nothing writes d_out — the list layout
+	// below must then see "no list" everywhere (-1 in every row), not what the buffer happened to hold
+	if (decide && paths) PGQ_HIP_TRY(hipMemsetAsync(d_out, 0xFF, (size_t)n * 8, st));
 	if (decide)
 		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec);
 	{
@@ -1290,7 +1311,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			KernelTimer kt(st, K_MEET4);
 #define PGQ_MEET4(G)                                                                                                     \
 	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid4), dim3(1024), lds, st, q[0], c->V, c->off, c->adj, c->roff, c->radj,     \
-	                   d_out, rec, cap4, bm_words, db, gmaps, q[1], fin)
+	                   c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap4, bm_words, db, gmaps, q[1], fin)
 #define PGQ_MEET4D(G, T)                                                                                                    \
 	hipLaunchKernelGGL((k_meet4d<G, T>), dim3(grid4), dim3(1024), lds, st, q[0], c->adj, c->radj, c->fdesc, c->rdesc, c->padj, \
 	                   c->rpadj, d_out, cap4, bm_words, db, gmaps, q[1], fin, d_trace)
@@ -1298,6 +1319,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			else if (paths) PGQ_MEET4(true);
 			else if (lds_map && d_trace) PGQ_MEET4D(false, true);
 			else if (lds_map) PGQ_MEET4D(false, false);
+			else if (d_trace) PGQ_MEET4D(true, true);
 			else PGQ_MEET4D(true, false);
 #undef PGQ_MEET4D
 #undef PGQ_MEET4
@@ -1332,7 +1354,27 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		ws->open_dst = q[open_stage].dst;
 		ws->open_idx = q[open_stage].idx;
 	}
+	// shortestpath: the lists of the rows answered so far are laid out (element counts -> exclusive scan) and written in the
+	// same chain — the total comes back in the pinned block beside the statistics, so the call still waits once (round 3:
+	// three waits — chain, scan total, emission)
+	int64_t *h_total = reinterpret_cast<int64_t *>(static_cast<char *>(ws->h_meet) + 4096);
+	if (paths) {
+		PGQ_TRY(ws->meet_poff.reserve((size_t)(n + 1) * 8 * 2));
+		int64_t *cnt = ws->meet_poff.as<int64_t>() + (n + 1), *poff = ws->meet_poff.as<int64_t>();
+		hipLaunchKernelGGL(k_path_counts, dim3(blocks_for(n)), dim3(256), 0, st, n, d_out, cnt);
+		PGQ_HIP_TRY(hipMemsetAsync(cnt + n, 0, 8, st));
+		size_t tmp = 0;
+		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt, poff, (int)(n + 1), st));
+		PGQ_TRY(ws->scan_tmp.reserve(tmp + 16));
+		PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp, cnt, poff, (int)(n + 1), st));
+		PGQ_HIP_TRY(hipMemcpyAsync(h_total, poff + n, 8, hipMemcpyDeviceToHost, st));
+		KernelTimer kt(st, K_RECON);
+		hipLaunchKernelGGL(k_emit_paths, dim3((unsigned)n), dim3(256), 0, st, n, d_src, d_dst, d_out, rec, poff, c->off, c->adj,
+		                   c->edge_ids, po->d_child, po->child_cap, po->d_out_off);
+		kt.stop();
+	}
 	PGQ_TRY(meet_wait(ws, hb));
+	if (paths) po->total = *h_total;
 	const MeetHostBlock &h = *hb;
 	if (d_trace) { // debugging aid: where k_meet4d's time goes
 		std::vector<unsigned long long> t((size_t)grid4 * 4);
@@ -1461,30 +1503,6 @@ int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_sr
 	return PGQ_OK;
 }
 
-// Path lists of the rows the pre-pass answered: element counts -> exclusive scan -> *total; when d_child is given the
-// lists are written there (entry i at the scanned offset, also stored in d_out_off[i]).
-int meet_path_offsets(Workspace *ws, int64_t n, const int64_t *d_len, int64_t *total) {
-	hipStream_t st = ws->stream;
-	PGQ_TRY(ws->meet_poff.reserve((size_t)(n + 1) * 8 * 2));
-	int64_t *cnt = ws->meet_poff.as<int64_t>() + (n + 1), *poff = ws->meet_poff.as<int64_t>();
-	hipLaunchKernelGGL(k_path_counts, dim3(blocks_for(n)), dim3(256), 0, st, n, d_len, cnt);
-	PGQ_HIP_TRY(hipMemsetAsync(cnt + n, 0, 8, st));
-	size_t tmp = 0;
-	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt, poff, (int)(n + 1), st));
-	PGQ_TRY(ws->scan_tmp.reserve(tmp + 16));
-	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp, cnt, poff, (int)(n + 1), st));
-	PGQ_HIP_TRY(hipMemcpyAsync(total, poff + n, 8, hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
-	return PGQ_OK;
-}
-int meet_emit_paths(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, const int64_t *d_len,
-                    int64_t *d_child, int64_t *d_out_off) {
-	KernelTimer kt(ws->stream, K_RECON);
-	hipLaunchKernelGGL(k_emit_paths, dim3(blocks_for(n * 64)), dim3(256), 0, ws->stream, n, d_src, d_dst, d_len,
-	                   ws->meet_rec.as<MeetPath>(), ws->meet_poff.as<int64_t>(), c->off, c->adj, c->edge_ids, d_child, d_out_off);
-	kt.stop();
-	return PGQ_OK;
-}
 // lengths and list offsets (shifted by `base`: their payload was appended there) of the rows the lane-batched search
 // answered, scattered back to row order
 __global__ void k_apply_open_paths(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,

@@ -1897,10 +1897,22 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// packed first, the lists of the rows left to the lane-batched search are appended behind them
 	auto run_meet_paths = [&](bool *ran) -> int {
 		u32 nd = 0;
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, true, decide, meet_bytes, edge_bytes, ran));
+		// the lists of the rows the pre-pass answers have at most 9 elements (distance <= 4): the buffer for them is sized
+		// up front, so that they are written in the same launch chain as the search
+		MeetPathsOut po;
+		po.d_out_off = d_out_off;
+		if (d_child_ext) {
+			po.d_child = d_child_ext;
+			po.child_cap = child_cap_ext;
+		} else {
+			PGQ_TRY(ws->child.reserve((size_t)std::max<int64_t>(n * 9, 1) * 8));
+			po.d_child = ws->child.as<int64_t>();
+			po.child_cap = (int64_t)(ws->child.cap / 8);
+		}
+		PGQ_HIP_TRY(hipMemsetAsync(d_out_off, 0, (size_t)n * 8, st));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, &po, decide, meet_bytes, edge_bytes, ran));
 		if (!*ran) return PGQ_OK;
-		int64_t total = 0;
-		PGQ_TRY(meet_path_offsets(ws, n, d_out_len, &total));
+		const int64_t total = po.total;
 		WorkspaceLease inner;
 		SearchOutput so2;
 		if (nd > 0) {
@@ -1914,24 +1926,26 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			                      ws->def_len.as<int64_t>(), true, ws->def_off.as<int64_t>(), nullptr, 0, so2));
 		}
 		const int64_t need = total + so2.child_used;
-		int64_t *d_child = d_child_ext;
+		int64_t *d_child = po.d_child;
 		if (d_child_ext) {
 			if (need > child_cap_ext) outp.overflow = true;
-		} else {
-			PGQ_TRY(ws->child.reserve((size_t)std::max<int64_t>(need, 1) * 8));
+		} else if ((size_t)need * 8 > ws->child.cap) { // the open rows' lists do not fit behind the others: a bigger buffer
+			DevBuf bigger;
+			PGQ_TRY(bigger.reserve((size_t)need * 8));
+			if (total > 0) PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			ws->child.release();
+			ws->child = bigger;
 			d_child = ws->child.as<int64_t>();
 		}
-		PGQ_HIP_TRY(hipMemsetAsync(d_out_off, 0, (size_t)n * 8, st));
-		if (!outp.overflow) {
-			PGQ_TRY(meet_emit_paths(c, ws, n, d_src, d_dst, d_out_len, d_child, d_out_off));
-			if (so2.child_used > 0)
+		if (nd > 0) {
+			if (!outp.overflow && so2.child_used > 0)
 				PGQ_HIP_TRY(hipMemcpyAsync(d_child + total, inner.ws->child.p, (size_t)so2.child_used * 8,
 				                           hipMemcpyDeviceToDevice, st));
-		}
-		if (nd > 0)
 			PGQ_TRY(meet_apply_paths(ws, nd, ws->def_len.as<int64_t>(), ws->def_off.as<int64_t>(), total, d_out_len, d_out_off));
-		PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
-		KernelTimer::flush();
+			PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+			KernelTimer::flush();
+		}
 		outp.child_used = need;
 		if (outp.overflow)
 			return fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(need) + " elements");
@@ -1940,7 +1954,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	auto run_meet = [&](bool *ran) -> int {
 		if (with_paths) return run_meet_paths(ran);
 		u32 nd = 0;
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, false, decide, meet_bytes, edge_bytes, ran));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide, meet_bytes, edge_bytes, ran));
 		if (!*ran) return PGQ_OK;
 		if (nd > 0) {
 			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));

@@ -869,7 +869,9 @@ __global__ void k_fill_desc(int64_t E, const int32_t *__restrict__ adj, const ui
 
 // entries of every vertex's two-hop walk in one direction = sum of its neighbours' list lengths (saturating u32).  One
 // workgroup per 256 consecutive vertices: their slots are one contiguous range, read coalesced; a slot's vertex by
-// binary search over the 257 offsets in LDS.
+// binary search over the 257 offsets in LDS.  The 64 consecutive slots a wavefront holds belong to a few vertices (to ONE
+// inside a hub's list): a segmented scan over the lanes adds them up first and only the last lane of a run touches the
+// LDS accumulator — one atomic per slot serialised on a hub's single address (R-MAT-22: 9 ms per direction).
 __global__ __launch_bounds__(256) void k_two_hop_work(int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                       const uint2 *__restrict__ seg, u32 *__restrict__ work) {
 	__shared__ int64_t s_off[257];
@@ -879,14 +881,30 @@ __global__ __launch_bounds__(256) void k_two_hop_work(int64_t V, const int64_t *
 	for (int t = threadIdx.x; t <= nv; t += 256) s_off[t] = off[v0 + t];
 	s_w[threadIdx.x] = 0;
 	__syncthreads();
-	for (int64_t e = s_off[0] + threadIdx.x; e < s_off[nv]; e += 256) {
-		int lo = 0, hi = nv; // largest t with s_off[t] <= e
-		while (hi - lo > 1) {
-			const int mid = (lo + hi) >> 1;
-			if (s_off[mid] <= e) lo = mid;
-			else hi = mid;
+	const int lane = threadIdx.x & 63;
+	const int64_t e_end = s_off[nv];
+	for (int64_t base = s_off[0] + (threadIdx.x & ~63); base < e_end; base += 256) { // wave-uniform bound: shuffles stay converged
+		const int64_t e = base + lane;
+		int lo = -1;
+		unsigned long long val = 0;
+		if (e < e_end) {
+			lo = 0;
+			int hi = nv; // largest t with s_off[t] <= e
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (s_off[mid] <= e) lo = mid;
+				else hi = mid;
+			}
+			val = (unsigned long long)seg[(u32)adj[e]].y;
 		}
-		atomicAdd(&s_w[lo], (unsigned long long)seg[(u32)adj[e]].y);
+		// inclusive segmented scan keyed by the vertex (runs are contiguous: slots ascend with the vertex)
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned long long up = __shfl_up(val, o);
+			const int klo = __shfl_up(lo, o);
+			if (lane >= o && klo == lo) val += up;
+		}
+		const int next = __shfl_down(lo, 1);
+		if (lo >= 0 && (lane == 63 || next != lo)) atomicAdd(&s_w[lo], val);
 	}
 	__syncthreads();
 	if ((int)threadIdx.x < nv) work[v0 + threadIdx.x] = (u32)min(s_w[threadIdx.x], 0xFFFFFFFFull);

@@ -90,17 +90,22 @@ int pull_lanes_level(pgq_csr *c, Workspace *ws, int wd, const u64 *front, const 
 // Pair-centric pre-pass (pgq_meet.hip): answers rows at distance <= 3 (and NULL / trivial / dead-end rows) into d_out,
 // compacts the others into ws->def_src/def_dst/def_idx; meet_apply scatters their lengths back.  decide: whether the
 // pre-pass pays (distinct sources, sampled) is settled on the device in the same launch chain; *ran = false: it did not run.
+// shortestpath through the pre-pass: where the lists of the rows it answers go ([src, e, v, ..., dst], first-slot edges;
+// entry i at the scanned offset, also stored in d_out_off[i]; a list that does not fit child_cap is not written) and how
+// many elements they take
+struct MeetPathsOut {
+	int64_t *d_child = nullptr;
+	int64_t child_cap = 0;
+	int64_t *d_out_off = nullptr;
+	int64_t total = 0;
+};
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, bool paths, bool decide, double meet_bytes, double edge_bytes, bool *ran);
+                 u32 *n_open, MeetPathsOut *po, bool decide, double meet_bytes, double edge_bytes, bool *ran);
 // iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its
 // caps are compacted like the pre-pass's open rows
 int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                        u32 *n_open);
-// shortestpath through the pre-pass: element counts of the answered rows' lists -> offsets (ws->meet_poff) and *total;
-// the lists themselves ([src, e, v, ..., dst], first-slot edges); lengths + shifted offsets of the rows answered elsewhere
-int meet_path_offsets(Workspace *ws, int64_t n, const int64_t *d_len, int64_t *total);
-int meet_emit_paths(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, const int64_t *d_len,
-                    int64_t *d_child, int64_t *d_out_off);
+// lengths + shifted offsets of the rows answered elsewhere, scattered back to row order
 int meet_apply_paths(Workspace *ws, int64_t nd, const int64_t *d_len, const int64_t *d_off, int64_t base,
                      int64_t *d_out_len, int64_t *d_out_off);
 int meet_apply(Workspace *ws, int64_t nd, const int64_t *d_len, int64_t *d_out);

@@ -52,6 +52,11 @@ constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so
 #ifndef PGQ_MEET4_MARK_DEPTH
 #define PGQ_MEET4_MARK_DEPTH 2 // the marking walk of k_meet4d never stops early: deeper costs nothing but registers
 #endif
+#ifndef PGQ_BIBFS_DEPTH
+#define PGQ_BIBFS_DEPTH 2 // list requests in flight per wavefront of k_bibfs (4: R-MAT-22's far rows 0.12 -> 0.15 ms, more read past the meeting point)
+#endif
+// (a k_meet4d variant with 8 requests in flight per wavefront for small calls — one workgroup per CU has the registers —
+// measured no better on R-MAT-22's long rows, which wait for L2 atomics, not for loads, and worse on the SF100 graph)
 #ifndef PGQ_MEET4_DEPTH
 #define PGQ_MEET4_DEPTH 2 // the same for each of the 16 wavefronts of a k_meet4d row (more only adds overshoot past the first hit)
 #endif
@@ -211,9 +216,9 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 	__shared__ __attribute__((aligned(16))) u32 bm[kFltWords];
 	__shared__ __attribute__((aligned(16))) unsigned char win[64];
 	MeetCounters *const mc = &db->m;
-	if (go && *go == 0) {
-		meet_finalize(db, fin);
-		return;
+	if (go && *go == 0) { // (a scalar load: one word read by every wavefront through the vector path is a hot spot on one L2
+		meet_finalize(db, fin); // channel — polling it per row while the decision kernel ran beside this one made k_meet3
+		return;                 // 0.28 ms instead of 0.16, and with 256 spread copies the two extra stream operations ate the 12 us)
 	}
 	const int lane = threadIdx.x & 63;
 	win[lane] = 0;
@@ -311,13 +316,25 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 			}
 			// distance 2: the middle vertex is the smallest common one
 			u32 mid = kMeetEmpty; // wave-uniform
-			for (int pb = 0; pb < exp_n; pb += 64) {
-				const int p = pb + lane;
-				u32 v = kMeetEmpty;
-				if (pb == 0) v = lane < exp_n ? d0.x : kMeetEmpty;
-				else if (p < exp_n) v = exp_desc[p].x;
+			{
+				const u32 v = lane < exp_n ? d0.x : kMeetEmpty;
 				const u32 pass = v != kMeetEmpty ? (flt_test<BIGV>(bm[flt_word(v)], v) & 1u) : 0u;
 				verify_candidates(R, pass, make_int4((int)v, 0, 0, 0), [&](u32 x, int) { mid = min(mid, x); });
+			}
+			// the rest of a long one-hop list, 256 ids per round trip (a hub's 5000 neighbours were 78 dependent trips of 64)
+			for (int pb = 64; pb < exp_n; pb += 256) {
+				u32 v[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int p = pb + 64 * u + lane;
+					v[u] = exp_desc[min(p, exp_n - 1)].x;
+					if (p >= exp_n) v[u] = kMeetEmpty;
+				}
+				u32 pass = 0;
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					if (v[u] != kMeetEmpty) pass |= (flt_test<BIGV>(bm[flt_word(v[u])], v[u]) & 1u) << u;
+				verify_candidates(R, pass, make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]), [&](u32 x, int) { mid = min(mid, x); });
 			}
 			if (mid != kMeetEmpty) {
 				if (lane == 0) {
@@ -956,7 +973,7 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 			}
 			__syncthreads();
 			bool hit = false;
-			const unsigned long long e2 = meet_walk_chunks(
+			const unsigned long long e2 = meet_walk_chunks<PGQ_BIBFS_DEPTH>(
 			    reinterpret_cast<const int32_t *>(cur), nf[side], wib, 16, xoff, xadj,
 			    [&](const int4 &v, u32 valid, u32) {
 				    u32 xs[4] = { (u32)v.x, (u32)v.y, (u32)v.z, (u32)v.w };
@@ -1094,7 +1111,8 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
 constexpr int kSampleRows = 2048, kSampleSlots = 4096;
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
-                                                     double edge_bytes, MeetDecision *__restrict__ out) {
+                                                     double edge_bytes, MeetDevBlock *__restrict__ db) {
+	MeetDecision *const out = &db->dec;
 	__shared__ u32 s_set[kSampleSlots];
 	__shared__ u32 s_count[2];
 	for (int k = threadIdx.x; k < kSampleSlots; k += 1024) s_set[k] = kMeetEmpty;
@@ -1274,8 +1292,10 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	// shortestpath on a large input: if the decision kernel calls the pre-pass off, nothing writes d_out — the list layout
 	// below must then see "no list" everywhere (-1 in every row), not what the buffer happened to hold
 	if (decide && paths) PGQ_HIP_TRY(hipMemsetAsync(d_out, 0xFF, (size_t)n * 8, st));
+	// (tried in round 4: the decision kernel on a stream of its own beside k_meet3, which polls a stop flag — the event
+	// record / wait pair costs what the 12 us kernel does, and the polled word must be spread over many lines)
 	if (decide)
-		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec);
+		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, db);
 	{
 		// calls too small to fill the chip are bound by the longest row, not by bandwidth: a lower cap hands long walks to
 		// the 16-wavefront kernel sooner, and more requests in flight shorten every row

@@ -145,87 +145,125 @@ __device__ __forceinline__ unsigned long long seg_walk(const uint4 *__restrict__
                                                        const int32_t *__restrict__ xp, unsigned char *win, bool have_first,
                                                        uint4 first, unsigned long long max_entries, bool &capped, int &resume,
                                                        F f, Stop stop) {
+	// Round 4: the DEPTH requests in flight are no longer tied to one round of 64 descriptors.  A request's slot keeps
+	// everything needed to process it (its group, whether the lane holds one, the expanded vertex), so the slot freed by a
+	// processed request is refilled from the NEXT round when the current one has nothing left for this wavefront: the
+	// rounds overlap.  Before, every round ended with a drain — a dependent round trip per round, which is all a round
+	// costs when its lists are short (R-MAT: a hub's 5000 neighbours are 78 rounds of mostly one request each = 78 round
+	// trips; a mean-degree-89 list is two rounds).  The next round's descriptors are requested one round ahead as before.
 	const int lane = threadIdx.x & 63;
-	unsigned long long entries = 0, requested = 0; // requested: groups x 4, against max_entries
+	unsigned long long entries = 0, requested = 0; // requested: entries of the groups requested, against max_entries
 	capped = false;
-	resume = 0; // first descriptor of the round the walk was in when it ended (a capped walk can be taken up there)
+	resume = 0; // first descriptor of the earliest round with an unprocessed request when the walk ended
 	const uint4 zero4 = make_uint4(0, 0, 0, 0);
+	if (list_n <= 0) return 0;
+	// ---- round state ----
+	int pb = 0;
 	uint4 d = zero4;
 	if (have_first) d = first;
 	else if (lane < list_n) d = list[lane];
-	for (int pb = 0; pb < list_n; pb += 64) {
-		if (pb + lane >= list_n) d = zero4;
-		// round 4: the NEXT round's descriptors are requested before this round is walked (a one-hop list of mean length 89
-		// has two rounds: their descriptors used to cost a dependent round trip between the rounds).  Unconditional, the
-		// index clamped: a load under a per-lane condition is waited for at the end of the branch
-		uint4 dn = zero4;
-		if (pb + 64 < list_n) dn = list[min(pb + 64 + lane, list_n - 1)];
-		const SegRound r = seg_round(d.y, d.z);
-		if (r.total != 0) {
-			const int nchunk = (int)((r.total + 63u) >> 6);
-			int next = w; // this wavefront's next request of the round
-			int issued = 0;
-			int4 x[DEPTH];
-			int xc[DEPTH];
-			bool xok[DEPTH];
-			u32 xv[DEPTH];
-			auto fetch = [&](int u) {
-				xc[u] = -1;
-				if (next < nchunk) { // wave-uniform
-					const u32 xx = (u32)next * 64u + (u32)lane;
-					const bool ok = xx < r.total;
-					const u32 xs = ok ? xx : r.total - 1u; // lanes past the end re-read the last group (same line, masked by ok)
-					const int j = seg_owner(r, (u32)next * 64u, win); // lanes past the end: the last list, like xs
-					x[u] = load_group_nt(xp, (u32)__shfl((int)r.D, j) + xs);
-					xok[u] = ok;
-					if constexpr (WANT_EV) xv[u] = (u32)__shfl((int)d.x, j);
-					else xv[u] = 0;
-					xc[u] = next;
-					next += nw;
-					issued++;
-				}
-			};
+	if (lane >= list_n) d = zero4;
+	// the next round's descriptors: unconditional, the index clamped (a load under a per-lane condition is waited for at
+	// the end of the branch)
+	uint4 dn = zero4;
+	if (64 < list_n) dn = list[min(64 + lane, list_n - 1)];
+	SegRound r = seg_round(d.y, d.z);
+	int nchunk = (int)((r.total + 63u) >> 6);
+	int next = w;   // this wavefront's next request of the round
+	int issued = 0; // ... and how many of the round's it has made
+	bool open = true; // rounds are left
+	// ---- requests in flight ----
+	int4 x[DEPTH];
+	int xc[DEPTH]; // < 0: empty; else the first descriptor of the request's round
+	bool xok[DEPTH];
+	u32 xv[DEPTH];
 #pragma unroll
-			for (int u = 0; u < DEPTH; u++) fetch(u);
-			bool halt = false;
-			for (;;) {
-				bool any_chunk = false;
+	for (int u = 0; u < DEPTH; u++) xc[u] = -1;
+	auto issue = [&](int u) { // the current round's next request into slot u (caller: next < nchunk)
+		const u32 xx = (u32)next * 64u + (u32)lane;
+		const bool ok = xx < r.total;
+		const u32 xs = ok ? xx : r.total - 1u; // lanes past the end re-read the last group (same line, masked by ok)
+		const int j = seg_owner(r, (u32)next * 64u, win); // lanes past the end: the last list, like xs
+		x[u] = load_group_nt(xp, (u32)__shfl((int)r.D, j) + xs);
+		xok[u] = ok;
+		if constexpr (WANT_EV) xv[u] = (u32)__shfl((int)d.x, j);
+		else xv[u] = 0;
+		xc[u] = pb;
+		requested += 4ull * (unsigned long long)min(64u, r.total - (u32)next * 64u);
+		next += nw;
+		issued++;
+	};
+	bool halt = false;
+	for (;;) {
+		// top-up (and the first fill): slots left empty because the round had nothing more for this wavefront take
+		// requests of the following rounds — the ONE place a round ends and the next begins
+		while (open) {
+			bool have_empty = false;
 #pragma unroll
-				for (int u = 0; u < DEPTH; u++) {
-					if (xc[u] < 0) continue; // wave-uniform
-					any_chunk = true;
-					const int4 v = x[u];
-					const bool ok = xok[u];
-					const u32 ev = xv[u];
-					fetch(u); // refills slot u: everything about the current request was copied above
-					f(v, ok, ev);
+			for (int u = 0; u < DEPTH; u++) have_empty |= xc[u] < 0;
+			if (!have_empty) break;
+			if (next >= nchunk) {
+				if (issued > 0) { // entries of the groups this wavefront requested in the round: pro rata of the round's groups
+					u32 e = d.z;
+					for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
+					unsigned long long groups = (unsigned long long)issued * 64ull; // 64 per request, except the round's last one
+					if (next - nw == nchunk - 1) groups -= (unsigned long long)nchunk * 64ull - r.total;
+					entries += (unsigned long long)e * groups / r.total;
 				}
-				if (!any_chunk) break;
-				if (stop()) {
-					halt = true;
+				pb += 64;
+				if (pb >= list_n) {
+					open = false;
 					break;
 				}
-				if (requested + (unsigned long long)issued * 256ull > max_entries) {
-					capped = true;
-					halt = true;
-					break;
-				}
+				d = dn;
+				if (pb + lane >= list_n) d = zero4;
+				dn = zero4;
+				if (pb + 64 < list_n) dn = list[min(pb + 64 + lane, list_n - 1)];
+				r = seg_round(d.y, d.z);
+				nchunk = (int)((r.total + 63u) >> 6);
+				next = w;
+				issued = 0;
+				continue;
 			}
-			{ // entries of the groups requested in this round: the round's entries pro rata of its groups
-				u32 e = d.z;
-				for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
-				// this wavefront's requests hold 64 groups each, except the round's last one
-				unsigned long long groups = (unsigned long long)issued * 64ull;
-				if (issued > 0 && next - nw == nchunk - 1) groups -= (unsigned long long)nchunk * 64ull - r.total;
-				entries += (unsigned long long)e * groups / r.total;
-				requested += groups * 4ull;
-			}
-			if (halt) {
-				resume = pb;
-				break;
-			}
+#pragma unroll
+			for (int u = 0; u < DEPTH; u++)
+				if (xc[u] < 0 && next < nchunk) issue(u);
 		}
-		d = dn;
+		bool any_chunk = false;
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++) {
+			if (xc[u] < 0) continue; // wave-uniform
+			any_chunk = true;
+			const int4 v = x[u];
+			const bool ok = xok[u];
+			const u32 ev = xv[u];
+			xc[u] = -1;
+			if (open && next < nchunk) issue(u); // refilled before it is processed: everything about the request was copied above
+			f(v, ok, ev);
+		}
+		if (!any_chunk) break;
+		if (stop()) {
+			halt = true;
+			break;
+		}
+		if (requested > max_entries) {
+			capped = true;
+			halt = true;
+			break;
+		}
+	}
+	if (halt) {
+		if (open && issued > 0) { // the round the walk stopped in
+			u32 e = d.z;
+			for (int o = 32; o > 0; o >>= 1) e += (u32)__shfl_xor((int)e, o);
+			unsigned long long groups = (unsigned long long)issued * 64ull;
+			if (next - nw == nchunk - 1) groups -= (unsigned long long)nchunk * 64ull - r.total;
+			entries += (unsigned long long)e * groups / r.total;
+		}
+		resume = pb;
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++)
+			if (xc[u] >= 0) resume = min(resume, xc[u]);
 	}
 	return entries;
 }
@@ -417,7 +455,7 @@ __device__ __forceinline__ unsigned long long meet_walk(const int32_t *__restric
 
 // The same walk with a per-chunk callback: g(v, valid, ev) gets the four entries a lane holds (bit k of `valid` set =
 // entry k lies inside its segment) so that it can issue its own memory operations four at a time.
-template <typename G, typename Stop>
+template <int DEPTH, typename G, typename Stop>
 __device__ __forceinline__ unsigned long long meet_walk_chunks(const int32_t *__restrict__ list, int list_n, int w, int stride,
                                                                const int64_t *__restrict__ xoff,
                                                                const int32_t *__restrict__ xadj, G g, Stop stop) {
@@ -447,7 +485,6 @@ __device__ __forceinline__ unsigned long long meet_walk_chunks(const int32_t *__
 			}
 		};
 		seek();
-		constexpr int DEPTH = 2;
 		int4 x[DEPTH];
 		int xb[DEPTH], xe[DEPTH], xq[DEPTH];
 		u32 xv[DEPTH];

@@ -368,10 +368,9 @@ __global__ void k_wcc_gather_edges(u32 n, const u32 *__restrict__ slots, const u
 	out[2 * (size_t)i + 1] = adj[slots[i]];
 }
 
-static std::mutex g_wcc_lock;
-
 static int wcc_compute(pgq_csr *c, Workspace *ws) {
-	std::lock_guard<std::mutex> g(g_wcc_lock);
+	std::lock_guard<std::mutex> g(c->lazy_lock); // per handle, like the reference's bind-data lock: unrelated CSRs and devices do not wait
+	
 	if (c->wcc) return PGQ_OK;
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V, E = c->E, vs = V + 2;

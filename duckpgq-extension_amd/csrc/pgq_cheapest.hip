@@ -1213,15 +1213,16 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 	// the persistent grid of a round: exactly what is resident at once (each wavefront takes every nwaves-th vertex; a
 	// grid larger than the chip makes the last workgroups start when the first finish: 8192 waves on 7168 slots was 2x)
 	static std::mutex grid_lock;
-	static unsigned grid_cached[2] = { 0, 0 };
+	static unsigned grid_cached[2][64] = {}; // per weight type and device: a node's devices need not be alike
 	unsigned grid;
 	{
 		std::lock_guard<std::mutex> g(grid_lock);
-		unsigned &gc = grid_cached[type_tag - 1];
+		int dev = 0;
+		PGQ_HIP_TRY(hipGetDevice(&dev));
+		unsigned &gc = grid_cached[type_tag - 1][dev & 63];
 		if (!gc) {
-			int per_cu = 0, dev = 0, cus = 0;
+			int per_cu = 0, cus = 0;
 			PGQ_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_relax<T>, 256, 0));
-			PGQ_HIP_TRY(hipGetDevice(&dev));
 			PGQ_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
 			gc = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
 		}

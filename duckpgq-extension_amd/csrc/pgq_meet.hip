@@ -430,8 +430,14 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 		return (w >> (x & 31)) & 1u;
 	};
 	auto mark = [&](u32 x) {
-		if constexpr (GM) atomicOr(&gmap[x >> 5], 1u << (x & 31));
-		else atomicOr(&s_map[x >> 5], 1u << (x & 31));
+		if constexpr (GM) {
+			// look first: on a skewed graph most entries of a two-hop walk are the same few hubs, and read-modify-writes of
+			// one word serialise in the L2 (R-MAT-22: a 200,000-entry marking walk took 270 us) — a set bit needs no atomic
+			const u32 w = __hip_atomic_load(&gmap[x >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (!((w >> (x & 31)) & 1u)) atomicOr(&gmap[x >> 5], 1u << (x & 31));
+		} else {
+			atomicOr(&s_map[x >> 5], 1u << (x & 31));
+		}
 	};
 	auto clear_map = [&]() {
 		if constexpr (GM) {
@@ -642,7 +648,7 @@ template <bool GM, bool TRACE>
 __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin, const int32_t *__restrict__ adj, const int32_t *__restrict__ radj,
                                                  const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
                                                  const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
-                                                 int64_t *__restrict__ out_rows, int64_t cap, int bm_words,
+                                                 int64_t *__restrict__ out_rows, int64_t cap, int64_t test_cap, int bm_words,
                                                  MeetDevBlock *__restrict__ db, u32 *__restrict__ gmaps, MeetQueue qout,
                                                  MeetHostBlock *__restrict__ fin, unsigned long long *__restrict__ trace) {
 	extern __shared__ __attribute__((aligned(16))) u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
@@ -664,8 +670,14 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 		return (w >> (x & 31)) & 1u;
 	};
 	auto mark = [&](u32 x) {
-		if constexpr (GM) atomicOr(&gmap[x >> 5], 1u << (x & 31));
-		else atomicOr(&s_map[x >> 5], 1u << (x & 31));
+		if constexpr (GM) {
+			// look first: on a skewed graph most entries of a two-hop walk are the same few hubs, and read-modify-writes of
+			// one word serialise in the L2 (R-MAT-22: a 200,000-entry marking walk took 270 us) — a set bit needs no atomic
+			const u32 w = __hip_atomic_load(&gmap[x >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (!((w >> (x & 31)) & 1u)) atomicOr(&gmap[x >> 5], 1u << (x & 31));
+		} else {
+			atomicOr(&s_map[x >> 5], 1u << (x & 31));
+		}
 	};
 	auto clear_map = [&]() {
 		if constexpr (GM) {
@@ -687,11 +699,11 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 	};
 	// the padded lists hold copies of a list's last entry and the lanes past a round's end re-read its last group:
 	// both repeat real entries, which neither a bit test nor a mark minds.  Every wavefront may request cap / 16 entries.
-	auto walk_test = [&](const uint4 *list, int list_n, const int32_t *xp, bool have_first, uint4 first) {
+	auto walk_test = [&](const uint4 *list, int list_n, const int32_t *xp, bool have_first, uint4 first, int64_t limit) {
 		bool f = false, capped = false;
 		int resume = 0;
 		const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
-		    list, list_n, wib, 16, xp, win, have_first, first, (unsigned long long)cap >> 4, capped, resume,
+		    list, list_n, wib, 16, xp, win, have_first, first, (unsigned long long)limit >> 4, capped, resume,
 		    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
 		    [&]() {
 			    if (__any(f)) s_flag = 1;
@@ -754,8 +766,12 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 		if (known3) {
 			// k_meet3 excluded distances 1 and 2 and walked part of one endpoint's two-hop neighbourhood against the
 			// other endpoint's one-hop list: the same test with 16 wavefronts, from the round it stopped in
-			walk_fwd = (flags & kEntFwd) != 0;
-			resume3 = (int)(flags >> kEntResumeShift);
+			// k_meet3 walks from the endpoint with the longer two-hop walk when the other endpoint's list does not fit its
+			// register set (512 ids); the bit map takes any list, so the side is chosen again by the walks' sizes — R-MAT-22:
+			// a row that had followed k_meet3 into a hub's two-hop neighbourhood walked its full million-entry allowance,
+			// 270 us for one row — and the walk is taken up where k_meet3 stopped only if the side is the same
+			walk_fwd = workS <= workD;
+			resume3 = walk_fwd == ((flags & kEntFwd) != 0) ? (int)(flags >> kEntResumeShift) : 0;
 			const int32_t *set_list = walk_fwd ? radj + di : adj + so;
 			const int set_n = walk_fwd ? degD : degS;
 			for (int p = tid; p < set_n; p += 1024) mark((u32)set_list[p]);
@@ -801,7 +817,7 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 			// distance 3: the cheaper two-hop walk against the other endpoint's one-hop set
 			const uint4 *wl = (walk_fwd ? fdesc + so : rdesc + di) + resume3;
 			const int wn = (walk_fwd ? degS : degD) - resume3;
-			walk_test(wl, wn, walk_fwd ? padj : rpadj, false, make_uint4(0, 0, 0, 0));
+			walk_test(wl, wn, walk_fwd ? padj : rpadj, false, make_uint4(0, 0, 0, 0), cap);
 			if (flag_snapshot()) {
 				result = 3;
 				do4 = false;
@@ -839,7 +855,11 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 				}
 				f4 = flag_snapshot();
 				if (!f4) {
-					walk_test(test_list, test_n, walk_fwd ? rpadj : padj, true, d_test);
+					// no witness in the first 512 entries: the pair is far apart (or unreachable), or the marked set is tiny.
+					// The other endpoint's two-hop neighbourhood may be the huge one (the smaller one was marked): it gets
+					// `test_cap` entries, not the million of a marking walk — what is still open then is k_bibfs's kind of row
+					// (R-MAT-22: such rows walked their full allowance, 270 us each, only to be handed on)
+					walk_test(test_list, test_n, walk_fwd ? rpadj : padj, true, d_test, test_cap);
 					f4 = flag_snapshot();
 				}
 			}
@@ -930,8 +950,13 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 	unsigned long long entries = 0;
 	u32 vertices = 0;
 	auto or_rtn = [&](int side, u32 x) -> u32 {
-		if constexpr (GM) return atomicOr(&gmap[side * mw + (x >> 5)], 1u << (x & 31));
-		else return atomicOr(&s_map[side * mw + (x >> 5)], 1u << (x & 31));
+		if constexpr (GM) { // look first: a bit that is set needs no read-modify-write (hubs are reached over and over)
+			const u32 w = __hip_atomic_load(&gmap[side * mw + (x >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((w >> (x & 31)) & 1u) return w;
+			return atomicOr(&gmap[side * mw + (x >> 5)], 1u << (x & 31));
+		} else {
+			return atomicOr(&s_map[side * mw + (x >> 5)], 1u << (x & 31));
+		}
 	};
 	auto word_of = [&](int side, u32 x) -> u32 {
 		if constexpr (GM) return __hip_atomic_load(&gmap[side * mw + (x >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1334,7 +1359,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	                   c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap4, bm_words, db, gmaps, q[1], fin)
 #define PGQ_MEET4D(G, T)                                                                                                    \
 	hipLaunchKernelGGL((k_meet4d<G, T>), dim3(grid4), dim3(1024), lds, st, q[0], c->adj, c->radj, c->fdesc, c->rdesc, c->padj, \
-	                   c->rpadj, d_out, cap4, bm_words, db, gmaps, q[1], fin, d_trace)
+	                   c->rpadj, d_out, cap4, (int64_t)std::max(1, opt.meet4_test_cap), bm_words, db, gmaps, q[1], fin, d_trace)
 			if (paths && lds_map) PGQ_MEET4(false);
 			else if (paths) PGQ_MEET4(true);
 			else if (lds_map && d_trace) PGQ_MEET4D(false, true);

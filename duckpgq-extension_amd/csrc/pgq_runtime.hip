@@ -185,6 +185,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "meet", &o.meet, nullptr },
 		{ "meet_cap", &o.meet_cap, nullptr },
 		{ "meet_cap_small", &o.meet_cap_small, nullptr },
+		{ "meet4_test_cap", &o.meet4_test_cap, nullptr },
 		{ "chunk_zero_copy", &o.chunk_zero_copy, nullptr },
 		{ "meet_small_rows", &o.meet_small_rows, nullptr },
 		{ "meet_cap_paths", &o.meet_cap_paths, nullptr },
@@ -1109,7 +1110,18 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	}
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	tr.mark("hub slices");
-	PGQ_TRY(build_meet_layout(c, st));
+	if (build_meet_layout(c, st) != PGQ_OK) {
+		// ~40 B per edge that only the pair-centric pre-pass needs: out of memory here is "no pre-pass" (the searches test
+		// fdesc), not a failed upload
+		(void)hipStreamSynchronize(st);
+		(void)hipGetLastError();
+		for (void **q : { (void **)&c->padj, (void **)&c->rpadj, (void **)&c->fseg, (void **)&c->rseg, (void **)&c->fdesc,
+		                  (void **)&c->rdesc, (void **)&c->fwork, (void **)&c->rwork }) {
+			dev_free(*q);
+			*q = nullptr;
+		}
+		c->padj_groups = c->rpadj_groups = 0;
+	}
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	tr.mark("padded adjacency + slot descriptors");
 	c->bytes = (V + 1) * 16 + 8 * V + E * (4 + 4 + 1 + (c->rpk ? 4 : 0)) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +

@@ -9,7 +9,7 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 rdir = os.path.join(root, "profiles", rnd)
 
 
@@ -21,6 +21,9 @@ def load(name):
         return json.load(open(p))
     except ValueError:
         return None
+
+
+CLASS_OF = {"k_meet3": "meet", "k_meet4d": "meet4", "k_bibfs": "bibfs", "k_pull_lanes": "pull_sparse"}
 
 
 def fmt(x, spec="{:,.0f}"):
@@ -38,6 +41,7 @@ L = ["# profiles — round %s measurements (MI355X, one GPU per gpurun box)" % r
      ""]
 names = [("snb_sf100", "C4 shard: SF100-shaped knows, iterativelength, 65,536 random pairs (default bench; every row through the pre-pass)"),
          ("snb_sf100_8192", "same graph, 8192 random pairs"),
+         ("snb_sf100_2048", "same graph, 2048 random pairs (one DuckDB chunk's worth, device arrays)"),
          ("snb_sf100_8192_msbfs_only", "same, 8192 random pairs, `PGQ_MEET=0` (lane-batched MS-BFS only)"),
          ("snb_cross", "same graph, cross product 2048 sources x 1024 destinations = 2.1 M rows (lane-batched MS-BFS; the `msbfs_cross` leg)"),
          ("snb_cross_2048x32", "same graph, cross product 2048 sources x 32 destinations = 65,536 rows"),
@@ -52,7 +56,7 @@ names = [("snb_sf100", "C4 shard: SF100-shaped knows, iterativelength, 65,536 ra
          ("snb_cheapest_4096_streams6", "same, int64, 6 batches side by side (`relax_streams=6`, the default since; the kernel columns of this line come from a pass in which the 6 batches overlapped — only ms/step and pairs/s count)")]
 L += ["## bench.py, 1 GPU (10 steps, 2 warm-up; timed region runs unprofiled, the roofline columns come from an untimed "
       "pass with one batch in flight and HIP events around every kernel)", "",
-      "| workload | ms/step | pairs/s | MTEPS | rows answered by the pre-pass | dominant kernel class | launches/step | "
+      "| workload | ms/step | pairs/s | MTEPS physical (adjacency entries scanned) | rows answered by the pre-pass | dominant kernel | launches/step | "
       "avg launch ms | algorithmic GB/s | frac of 8 TB/s | whole step GB/s (frac) | CPU baseline |",
       "|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for w, title in names:
@@ -69,9 +73,9 @@ for w, title in names:
         if st:
             cpu_s += "; %s on 1" % fmt(st["value"])
     L.append("| %s | %.3f | %s | %s | %s | `%s` | %s | %s | %s | %s | %s | %s |" % (
-        title, j["ms_per_step"], fmt(j.get("pairs_per_s")), fmt(j["value"]) if j["unit"] == "MTEPS" else "—",
+        title, j["ms_per_step"], fmt(j.get("pairs_per_s")), fmt(j.get("mteps_physical")) if j.get("mteps_physical") else "—",
         fmt(j.get("rows_answered_by_prepass_per_step")), r.get("kernel", "—"),
-        fmt((j.get("roofline_by_kernel") or {}).get(r.get("kernel", "").replace("k_", ""), {}).get("launches_per_step"), "{:.1f}"),
+        fmt((j.get("roofline_by_kernel") or {}).get(CLASS_OF.get(r.get("kernel", ""), r.get("kernel", "").replace("k_", "")), {}).get("launches_per_step"), "{:.1f}"),
         fmt(r.get("avg_launch_ms"), "{:.3f}"), fmt(r.get("achieved")), fmt(r.get("frac"), "{:.3f}"),
         "%s (%s)" % (fmt(step.get("GBps")), fmt(step.get("frac"), "{:.3f}")) if step else "—", cpu_s))
 L += ["", "Kernel classes of the untimed one-batch-in-flight pass (ms per step, algorithmic GB/s where the class has a "
@@ -80,11 +84,14 @@ for w, _ in names:
     j = load("bench_%s.json" % w)
     if j and j.get("roofline_by_kernel"):
         fe = (j.get("roofline") or {}).get("frontier_expansion")
+        pc = (j.get("roofline") or {}).get("prepass_chain")
         L.append("* **%s**: " % w + ", ".join(
             "%s %.3f ms%s" % (k, v["ms_per_step"], (" (%.0f GB/s)" % v["GBps"]) if v.get("GBps") else "")
             for k, v in j["roofline_by_kernel"].items()) +
             ("; frontier expansion (push + pull + pull_sparse) %.3f ms at %.0f GB/s = %.3f of peak" % (
-                fe["ms_per_step"], fe["GBps"], fe["frac"]) if fe else ""))
+                fe["ms_per_step"], fe["GBps"], fe["frac"]) if fe else "") +
+            ("; pre-pass chain (%s) %.3f ms at %.0f GB/s = %.3f of peak" % (
+                " + ".join(pc["classes"]), pc["ms_per_step"], pc["GBps"], pc["frac"]) if pc else ""))
 L += ["", "## rocprofv3 --kernel-trace --stats (top kernels)", ""]
 for p in sorted(glob.glob(os.path.join(rdir, "*kernel_stats.csv"))):
     L += ["`profiles/%s/%s`" % (rnd, os.path.basename(p)), "", "| kernel | calls | avg µs | % |", "|---|---|---|---|"]

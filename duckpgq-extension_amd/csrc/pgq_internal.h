@@ -91,7 +91,7 @@ struct Options {
 	int meet_cap_small = 1 << 14; // ... a lower walk cap (longer walks go to the 16-wavefront kernel sooner)
 	int meet_cap_paths = 1 << 14; // the same for shortestpath rows (longer walks go to k_meet4: 16 wavefronts per row)
 	int meet4 = 1;          // rows k_meet3 leaves open: LDS bit-map kernel for distance <= 4 (k_meet4) when V fits
-	int meet4_test_cap = 1 << 17; // ... that the testing walk of the distance-4 step may scan after its probe found nothing (k_meet4d)
+	int meet4_test_cap = 1 << 15; // ... that the testing walk of the distance-4 step may scan after its probe found nothing (k_meet4d)
 	int meet4_cap = 1 << 20; // adjacency entries either two-hop walk of a row may scan in k_meet4
 	int wbibfs = 0;            // cheapest_path_length, int64 weights: a bidirectional delta-stepping search per row before the batched
 	                           // relaxation (k_wbibfs).  Off by default: bit-exact in the tests, not yet measured at SF100 scale

@@ -262,6 +262,8 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 		// so at upload), so the walk meets the witnesses in the order of the reference's tie-break (smallest second-to-last
 		// vertex first, then the smallest vertex before it) and may stop at the first one
 		bool fwd = PATHS ? false : workS <= workD;
+		// (handing a row on whenever the preferred set does not fit the registers, instead of walking from the other endpoint,
+		// sent 1740 instead of 34 such rows of the 65,536 to the bit-map kernel: 0.244 -> 0.264 ms)
 		if (!PATHS && (fwd ? degD : degS) > kSetRegMax) fwd = !fwd;
 		const int set_n = fwd ? degD : degS;
 		const int exp_n = fwd ? degS : degD;

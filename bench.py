@@ -503,7 +503,7 @@ def main():
             sel = np.arange(ns, dtype=np.int64) * max(1, len(mine) // ns)
             tsel = torch.from_numpy(sel).to(dev)
             out["cpu_baseline"] = cpu_baseline_cheapest(V, off, adj, eid, w, mine[sel], m["out_val"][tsel], m["d_ok"][tsel],
-                                                        how="%d rows at stride %d" % (ns, max(1, len(mine) // ns)))
+                                                        how="all" if ns == len(mine) else "%d rows at stride %d" % (ns, max(1, len(mine) // ns)))
         if not a.no_cpu_baseline and world == 1 and paths:
             out["cpu_baseline"] = cpu_baseline_paths(a, V, off, adj, eid, mine, m)
         if cross is not None:
@@ -578,7 +578,9 @@ def cpu_baseline_cheapest(V, off, adj, eid, w, mine, d_val, d_ok, how="all"):
     from concurrent.futures import ThreadPoolExecutor
     from oracle.pgq_oracle import OracleCSR
     ora = OracleCSR.adopt(V, off, adj, eid, w)
-    threads = max(1, min(os.cpu_count() or 1, len(mine) // 4 or 1))
+    # one thread per 8 rows, at most 32: every thread owns a V-sized label array (a 2^24-vertex forest: 134 MB each), and the
+    # forest's searches are a handful of hops — there one thread is the faster baseline (all rows: `how` == "all")
+    threads = 1 if how == "all" else max(1, min(os.cpu_count() or 1, 32, len(mine) // 8 or 1))
     parts = np.array_split(np.arange(len(mine)), threads)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:

@@ -91,7 +91,7 @@ for w, _ in names:
             ("; frontier expansion (push + pull + pull_sparse) %.3f ms at %.0f GB/s = %.3f of peak" % (
                 fe["ms_per_step"], fe["GBps"], fe["frac"]) if fe else "") +
             ("; pre-pass chain (%s) %.3f ms at %.0f GB/s = %.3f of peak" % (
-                " + ".join(pc["classes"]), pc["ms_per_step"], pc["GBps"], pc["frac"]) if pc else ""))
+                " + ".join(pc["classes"]), pc["ms_per_step"], pc["GBps"], pc["frac"]) if pc and pc["GBps"] > 1 else ""))
 L += ["", "## rocprofv3 --kernel-trace --stats (top kernels)", ""]
 for p in sorted(glob.glob(os.path.join(rdir, "*kernel_stats.csv"))):
     L += ["`profiles/%s/%s`" % (rnd, os.path.basename(p)), "", "| kernel | calls | avg µs | % |", "|---|---|---|---|"]

@@ -320,6 +320,155 @@ def test_padded_layout_and_packed_walk_visit_exactly_the_lists():
             assert (0 < g <= 128) if want else g == 0
 
 
+# ---- round 4: requests in flight across rounds, the filter + register set, the two-ended queue (pgq_walk.h, pgq_meet.hip) ----
+
+def seg_walk_v3_model(desc_list, w, nw, depth, stop_after_requests=None, max_entries=None):
+    """seg_walk since round 4: DEPTH request slots that outlive a round of 64 descriptors.  A pass processes every busy
+    slot (refilling it from the CURRENT round first); the top-up at the head of the loop is the one place a round ends and
+    the next begins, and fills slots left empty from the following rounds.  Returns the (round start, request) pairs in
+    the order they were PROCESSED, the order they were ISSUED, and `resume` (first descriptor of the earliest round with
+    an unprocessed request when the walk was cut)."""
+    n = len(desc_list)
+    rounds = []
+    for pb in range(0, n, 64):
+        total = sum((ln + 3) >> 2 for (_, _, ln) in desc_list[pb:pb + 64])
+        rounds.append((pb, (total + 63) >> 6, total))
+    ri, nxt = 0, w
+    slots = [None] * depth
+    issued, processed, requested = [], [], 0
+    is_open = n > 0
+    resume = 0
+
+    def issue(u):
+        nonlocal nxt, requested
+        pb, nchunk, total = rounds[ri]
+        slots[u] = (pb, nxt)
+        issued.append((pb, nxt))
+        requested += 4 * min(64, total - nxt * 64)
+        nxt += nw
+
+    halt = False
+    while True:
+        while is_open:  # top-up
+            if all(x is not None for x in slots):
+                break
+            if nxt >= rounds[ri][1]:
+                ri += 1
+                if ri >= len(rounds):
+                    is_open = False
+                    break
+                nxt = w
+                continue
+            for u in range(depth):
+                if slots[u] is None and nxt < rounds[ri][1]:
+                    issue(u)
+        any_chunk = False
+        for u in range(depth):
+            if slots[u] is None:
+                continue
+            any_chunk = True
+            cur = slots[u]
+            slots[u] = None
+            if is_open and nxt < rounds[ri][1]:
+                issue(u)
+            processed.append(cur)
+        if not any_chunk:
+            break
+        if stop_after_requests is not None and len(processed) >= stop_after_requests:
+            halt = True
+            break
+        if max_entries is not None and requested > max_entries:
+            halt = True
+            break
+    if halt:
+        resume = rounds[ri][0] if is_open else (rounds[-1][0] if rounds else 0)
+        for x in slots:
+            if x is not None:
+                resume = min(resume, x[0])
+    return processed, issued, resume
+
+
+def test_requests_in_flight_across_rounds_cover_every_group_once_and_in_order():
+    rng = np.random.default_rng(12)
+    for trial in range(40):
+        n = int(rng.integers(1, 400))
+        lens = rng.integers(0, 9, n)  # many short lists: rounds of one or two requests, the case the overlap is for
+        if trial % 3 == 0:
+            lens[rng.integers(0, n, 3)] = rng.integers(200, 700, 3)
+        desc = [(i, 0, int(l)) for i, l in enumerate(lens)]
+        want = []
+        for pb in range(0, n, 64):
+            total = sum((l + 3) >> 2 for (_, _, l) in desc[pb:pb + 64])
+            want += [(pb, c) for c in range((total + 63) >> 6)]
+        for nw, depth in ((1, 2), (1, 4), (16, 2)):
+            got = []
+            for w in range(nw):
+                processed, issued, _ = seg_walk_v3_model(desc, w, nw, depth)
+                assert processed == sorted(processed) and issued == sorted(issued)  # walk order, per wavefront
+                assert sorted(processed) == sorted(issued)
+                got += processed
+            assert sorted(got) == want  # every request of every round exactly once
+        # a cut walk: everything before `resume` has been processed, so the bit-map kernel may take the walk up there
+        processed, issued, resume = seg_walk_v3_model(desc, 0, 1, 2, max_entries=int(rng.integers(1, 4000)))
+        done = set(processed)
+        assert all(r in done for r in want if r[0] < resume)
+        assert resume % 64 == 0 and 0 <= resume <= max(0, (n - 1) // 64 * 64)
+
+
+def filter_word(x):
+    return (x >> 5) & 1023
+
+
+def filter_mask(x, bigv):
+    b = ((x >> 15) ^ (x >> 20) ^ (x >> 25)) if bigv else (x >> 15)
+    return (1 << (x & 31)) | (1 << (b & 31))
+
+
+def test_two_bit_filter_has_no_false_negatives_and_few_false_positives():
+    """flt_word / flt_mask / flt_test (pgq_walk.h): both bits of an id sit in one of 1024 words; a set member always
+    passes (the exact test in registers then decides), and for ids below 2^20 only cross-combinations of two members
+    that share a word can pass wrongly."""
+    rng = np.random.default_rng(13)
+    for bigv, vmax in ((False, 448626), (True, 1 << 28)):
+        for size in (1, 100, 512):
+            members = rng.choice(vmax, size=size, replace=False)
+            bm = [0] * 1024
+            for x in members.tolist():
+                bm[filter_word(x)] |= filter_mask(x, bigv)
+            test = lambda x: (bm[filter_word(x)] & filter_mask(x, bigv)) == filter_mask(x, bigv)
+            assert all(test(x) for x in members.tolist())
+            probes = rng.integers(0, vmax, 200000)
+            mset = set(members.tolist())
+            fp = sum(1 for x in probes.tolist() if x not in mset and test(x))
+            assert fp / len(probes) < (0.002 if not bigv else 0.004) * max(1, size / 100) ** 2
+
+
+def test_two_ended_queue_positions_and_dynamic_hand_out():
+    """queue_push / queue_pos / k_meet4d's job counter (pgq_meet.hip): long rows from the front, proven-distance-4 rows
+    from the back of one array; jobs are handed out in ascending order = every long row before any other."""
+    rng = np.random.default_rng(14)
+    cap = 1000
+    kinds = rng.random(700) < 0.05  # True: a long row
+    front = back = 0
+    arr = [None] * cap
+    for i, long_row in enumerate(kinds.tolist()):
+        if long_row:
+            arr[front] = ("long", i)
+            front += 1
+        else:
+            arr[cap - 1 - back] = ("known4", i)
+            back += 1
+    n = front + back
+    pos = lambda j: j if j < front else cap - 1 - (j - front)
+    order = [arr[pos(j)] for j in range(n)]
+    assert all(x is not None for x in order) and len({x[1] for x in order}) == n
+    assert [k for k, _ in order] == ["long"] * front + ["known4"] * back
+    # a grid of G workgroups: the first G positions are the workgroups' own, the rest drawn from a counter
+    G = 64
+    drawn = list(range(G)) + [G + t for t in range(n)]  # counter values may run past n: those workgroups stop
+    assert sorted(j for j in drawn if j < n) == list(range(n))
+
+
 def light_first_model(V, off, adj, w, lanes, dests, cap0, rng, dtype):
     """k_relax under relax_light (pgq_cheapest.hip): lists sorted by weight, Jacobi rounds over the prefix under a cap
     that doubles per phase; a lane expands a vertex only while its label is under the lane's bound (largest tentative

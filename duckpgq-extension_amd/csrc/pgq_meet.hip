@@ -46,6 +46,10 @@ constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so
 #ifndef PGQ_MEET3_DEPTH_SMALL
 #define PGQ_MEET3_DEPTH_SMALL 4 // ... in the variant for calls too small to fill the chip (latency, not bandwidth, is what counts)
 #endif
+#ifndef PGQ_MEET4_WAVES
+#define PGQ_MEET4_WAVES 16 // wavefronts per k_meet4d row (= workgroup)
+#endif
+constexpr int kM4Threads = 64 * PGQ_MEET4_WAVES;
 #ifndef PGQ_MEET4_BLOCKS
 #define PGQ_MEET4_BLOCKS 8 // wavefronts per SIMD k_meet4d is compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs); at 84 VGPRs only one fits
 #endif
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(1024) void k_meet4(MeetQueue qin, int64_t V, const 
 //     distance 4: map = two-hop set of the cheaper endpoint, two-hop walk of the other one, ended by the first hit
 // Rows with distance >= 4 proven start at the last step (cheaper endpoint: the shorter one-hop list).
 template <bool GM, bool TRACE>
-__global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin, const int32_t *__restrict__ adj, const int32_t *__restrict__ radj,
+__global__ __launch_bounds__(64 * PGQ_MEET4_WAVES, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin, const int32_t *__restrict__ adj, const int32_t *__restrict__ radj,
                                                  const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
                                                  const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
                                                  int64_t *__restrict__ out_rows, int64_t cap, int64_t test_cap, int bm_words,
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 	__shared__ int s_flag;
 	__shared__ int s_capped;
 	__shared__ u32 s_job;
-	__shared__ __attribute__((aligned(16))) unsigned char s_win[16][64];
+	__shared__ __attribute__((aligned(16))) unsigned char s_win[PGQ_MEET4_WAVES][64];
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 	unsigned char *win = s_win[wib]; // seg_owner's window of this wavefront
 	win[lane] = 0;
@@ -684,10 +688,10 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 	auto clear_map = [&]() {
 		if constexpr (GM) {
 			uint4 *m4 = reinterpret_cast<uint4 *>(gmap);
-			for (int k = tid; k < bm_words / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
+			for (int k = tid; k < bm_words / 4; k += kM4Threads) m4[k] = make_uint4(0, 0, 0, 0);
 		} else {
 			uint4_alias *m4 = reinterpret_cast<uint4_alias *>(s_map);
-			for (int k = tid; k < bm_words / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
+			for (int k = tid; k < bm_words / 4; k += kM4Threads) m4[k] = make_uint4(0, 0, 0, 0);
 		}
 	};
 	auto flag_set = [&]() { return *(volatile int *)&s_flag != 0; };
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 		bool f = false, capped = false;
 		int resume = 0;
 		const unsigned long long e2 = seg_walk<PGQ_MEET4_DEPTH, false>(
-		    list, list_n, wib, 16, xp, win, have_first, first, (unsigned long long)limit >> 4, capped, resume,
+		    list, list_n, wib, PGQ_MEET4_WAVES, xp, win, have_first, first, (unsigned long long)limit / PGQ_MEET4_WAVES, capped, resume,
 		    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
 		    [&]() {
 			    if (__any(f)) s_flag = 1;
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 		bool capped = false;
 		int resume = 0;
 		const unsigned long long e2 = seg_walk<PGQ_MEET4_MARK_DEPTH, false>(
-		    list, list_n, wib, 16, xp, win, true, first, (unsigned long long)cap >> 4, capped, resume,
+		    list, list_n, wib, PGQ_MEET4_WAVES, xp, win, true, first, (unsigned long long)cap / PGQ_MEET4_WAVES, capped, resume,
 		    [&](const int4 &v, bool, u32) {
 			    mark((u32)v.x);
 			    mark((u32)v.y);
@@ -776,13 +780,13 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 			resume3 = walk_fwd == ((flags & kEntFwd) != 0) ? (int)(flags >> kEntResumeShift) : 0;
 			const int32_t *set_list = walk_fwd ? radj + di : adj + so;
 			const int set_n = walk_fwd ? degD : degS;
-			for (int p = tid; p < set_n; p += 1024) mark((u32)set_list[p]);
+			for (int p = tid; p < set_n; p += kM4Threads) mark((u32)set_list[p]);
 			if (wib == 0) entries += (unsigned long long)set_n;
 			__syncthreads();
 			do3 = true;
 		} else if (!known4) {
 			bool hit = false;
-			for (int p = tid; p < degS; p += 1024) hit |= (u32)adj[so + p] == ed;
+			for (int p = tid; p < degS; p += kM4Threads) hit |= (u32)adj[so + p] == ed;
 			if (__any(hit) && lane == 0) s_flag = 1;
 			if (flag_snapshot()) { // dst in N_out(src)
 				result = 1;
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 				{ // the set: one-hop list of the endpoint that is not walked
 					const int32_t *set_list = walk_fwd ? radj + di : adj + so;
 					const int set_n = walk_fwd ? degD : degS;
-					for (int p = tid; p < set_n; p += 1024) mark((u32)set_list[p]);
+					for (int p = tid; p < set_n; p += kM4Threads) mark((u32)set_list[p]);
 				}
 				__syncthreads();
 				const int32_t *wl = walk_fwd ? adj + so : radj + di;
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 				if (wib == 0) entries += (unsigned long long)(degS + degD);
 				{ // distance 2: a common neighbour
 					bool f = false;
-					for (int p = tid; p < wn; p += 1024) f |= bit((u32)wl[p]) != 0;
+					for (int p = tid; p < wn; p += kM4Threads) f |= bit((u32)wl[p]) != 0;
 					if (__any(f) && lane == 0) s_flag = 1;
 				}
 				if (flag_snapshot()) {
@@ -837,19 +841,62 @@ __global__ __launch_bounds__(1024, PGQ_MEET4_BLOCKS) void k_meet4d(MeetQueue qin
 			uint4 d_mark = make_uint4(0, 0, 0, 0), d_test = make_uint4(0, 0, 0, 0);
 			if (lane < mark_n) d_mark = mark_list[lane]; // every wavefront holds the round's 64 descriptors (it takes every 16th request)
 			if (lane < test_n) d_test = test_list[lane];
-			walk_mark(mark_list, mark_n, walk_fwd ? padj : rpadj, d_mark);
-			__syncthreads();
+			// Stage A: the first 2048 entries of BOTH two-hop neighbourhoods at once.  A pair at distance 4 — nearly every row
+			// that gets here — has ~16 common vertices among two such prefixes on the SF100-shaped graph (degree-biased
+			// samples collide at sum of p_v^2 = E[deg^2] / (V E[deg]^2) = 3.8e-6 per pair of entries), so marking all 8.5 K
+			// entries of the smaller neighbourhood before looking (two dependent rounds of requests, then the probe: three
+			// round trips) is rarely needed: the lower half of the wavefronts requests and marks one group each of the marking
+			// side, the upper half requests one group each of the other side in the SAME round trip and tests it after the
+			// barrier.  A hit is a witness like any other (the marks are real entries of one neighbourhood, the tested entries
+			// real entries of the other); no hit: the full procedure below, which marks the prefix again.
 			int f4 = 0;
-			if (!s_capped) {
+			constexpr int H = PGQ_MEET4_WAVES / 2;
+			constexpr int kOneShot = 1 << 20; // request stride that leaves a wavefront exactly one request of the round (no refill)
+			{
+				int4 held = make_int4(0, 0, 0, 0);
+				bool have = false;
+				bool capped = false;
+				int resume = 0;
+				if (wib < H) {
+					const unsigned long long e2 = seg_walk<1, false>(
+					    mark_list, min(mark_n, 64), wib, kOneShot, walk_fwd ? padj : rpadj, win, true, d_mark, 0ull, capped, resume,
+					    [&](const int4 &v, bool, u32) {
+						    mark((u32)v.x);
+						    mark((u32)v.y);
+						    mark((u32)v.z);
+						    mark((u32)v.w);
+					    },
+					    []() { return true; });
+					entries += e2;
+				} else {
+					const unsigned long long e2 = seg_walk<1, false>(
+					    test_list, min(test_n, 64), wib - H, kOneShot, walk_fwd ? rpadj : padj, win, true, d_test, 0ull, capped, resume,
+					    [&](const int4 &v, bool, u32) {
+						    held = v;
+						    have = true;
+					    },
+					    []() { return true; });
+					entries += e2;
+				}
+				__syncthreads();
+				if (have && (bit((u32)held.x) | bit((u32)held.y) | bit((u32)held.z) | bit((u32)held.w))) s_flag = 1;
+				f4 = flag_snapshot();
+			}
+			if (!f4) {
+				walk_mark(mark_list, mark_n, walk_fwd ? padj : rpadj, d_mark);
+				__syncthreads();
+			}
+			if (!f4 && !s_capped) {
 				// Probe first: nearly every row that gets here IS at distance 4, and then about one entry in thirty of the other
 				// endpoint's two-hop neighbourhood is marked — the first request (256 entries) holds a witness.  The cooperative
 				// walk below opens with 32 requests (16 wavefronts x 2 in flight) before anyone looks at the flag: ~45 KB and
-				// their bit tests per row, for an answer the first KB gives.  Two wavefronts take one request each.
+				// their bit tests per row, for an answer the first KB gives.  Two wavefronts take one request each (the two
+				// behind the ones stage A tested).
 				if (wib < 2) {
 					bool f = false, capped = false;
 					int resume = 0;
 					const unsigned long long e2 = seg_walk<1, false>(
-					    test_list, min(test_n, 64), wib, 16, walk_fwd ? rpadj : padj, win, true, d_test, 0ull, capped, resume,
+					    test_list, min(test_n, 64), H + wib, kOneShot, walk_fwd ? rpadj : padj, win, true, d_test, 0ull, capped, resume,
 					    [&](const int4 &v, bool, u32) { f |= (bit((u32)v.x) | bit((u32)v.y) | bit((u32)v.z) | bit((u32)v.w)) != 0; },
 					    []() { return true; });
 					entries += e2;
@@ -1360,7 +1407,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	hipLaunchKernelGGL((k_meet4<true, G>), dim3(grid4), dim3(1024), lds, st, q[0], c->V, c->off, c->adj, c->roff, c->radj,     \
 	                   c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap4, bm_words, db, gmaps, q[1], fin)
 #define PGQ_MEET4D(G, T)                                                                                                    \
-	hipLaunchKernelGGL((k_meet4d<G, T>), dim3(grid4), dim3(1024), lds, st, q[0], c->adj, c->radj, c->fdesc, c->rdesc, c->padj, \
+	hipLaunchKernelGGL((k_meet4d<G, T>), dim3(grid4), dim3(kM4Threads), lds, st, q[0], c->adj, c->radj, c->fdesc, c->rdesc, c->padj, \
 	                   c->rpadj, d_out, cap4, (int64_t)std::max(1, opt.meet4_test_cap), bm_words, db, gmaps, q[1], fin, d_trace)
 			if (paths && lds_map) PGQ_MEET4(false);
 			else if (paths) PGQ_MEET4(true);

@@ -261,6 +261,7 @@ struct KernelTimer {
 int dev_alloc(void **out, size_t bytes);
 void dev_free(void *p);
 void dev_cache_trim();
+void drop_idle_workspaces(); // frees the pooled (not leased) per-call workspaces (pgq_msbfs.hip)
 template <typename T> inline int dev_alloc_as(T **out, size_t count) {
 	void *p = nullptr;
 	int rc = dev_alloc(&p, count * sizeof(T));

@@ -1286,6 +1286,15 @@ Workspace::~Workspace() {
 static std::mutex g_ws_lock;
 static std::vector<Workspace *> g_ws_free; // every workspace remembers the device its buffers live on
 
+void drop_idle_workspaces() {
+	std::vector<Workspace *> drop;
+	{
+		std::lock_guard<std::mutex> g(g_ws_lock);
+		drop.swap(g_ws_free);
+	}
+	for (Workspace *w : drop) delete w;
+}
+
 int WorkspaceLease::acquire() {
 	{
 		std::lock_guard<std::mutex> g(g_ws_lock);
@@ -2219,12 +2228,7 @@ void pgq_thread_release(void) {
 
 int pgq_release_cached_memory(void) {
 	PGQ_TRY(ensure_init());
-	std::vector<Workspace *> drop;
-	{
-		std::lock_guard<std::mutex> g(g_ws_lock);
-		drop.swap(g_ws_free);
-	}
-	for (Workspace *w : drop) delete w;
+	drop_idle_workspaces();
 	dev_cache_trim(); // and the freed CSR / upload blocks kept for the next upload
 	return PGQ_OK;
 }

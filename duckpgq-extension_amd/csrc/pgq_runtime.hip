@@ -351,6 +351,11 @@ int dev_alloc(void **out, size_t bytes) {
 		dev_cache_trim();
 		e = hipMalloc(out, want);
 	}
+	if (e != hipSuccess) { // ... and the buffers of the idle pooled workspaces (label arrays of V x 576 B per relaxation stream)
+		(void)hipGetLastError();
+		drop_idle_workspaces();
+		e = hipMalloc(out, want);
+	}
 	if (e != hipSuccess) {
 		*out = nullptr;
 		return fail(PGQ_ERR_OOM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
@@ -409,6 +414,11 @@ int DevBuf::reserve(size_t bytes) {
 	if (e == hipErrorOutOfMemory) { // gigabytes of freed CSR blocks may sit in the block cache: give them back and retry
 		(void)hipGetLastError();
 		dev_cache_trim();
+		e = hipMalloc(&p, want);
+	}
+	if (e == hipErrorOutOfMemory) { // ... and the idle pooled workspaces (tens of GB on a large-V graph after a weighted search)
+		(void)hipGetLastError();
+		drop_idle_workspaces();
 		e = hipMalloc(&p, want);
 	}
 	if (e != hipSuccess) return fail(PGQ_ERR_OOM, std::string("hipMalloc(") + std::to_string(want) + "): " +

@@ -31,12 +31,12 @@ def fmt(x, spec="{:,.0f}"):
 
 
 L = ["# profiles — round %s measurements (MI355X, one GPU per gpurun box)" % rnd.lstrip("r0"), "",
-     "Produced by committed tooling only: `tools/measure_pass.sh` on the GPU box runs `bench.py` per workload (one JSON "
+     "Produced by committed tooling only: `tools/measure_pass_r04.sh` (round 3: `tools/measure_pass.sh`) on the GPU box runs `bench.py` per workload (one JSON "
      "line each), `rocprofv3 --kernel-trace --stats` of the default bench command without its second leg (`--no-legs`: "
      "every `k_meet3` / `k_meet4d` call is a 65,536-row one) and of the cross-product workload (`--workload snb_cross`), "
-     "separate `--pmc` passes of both (summarised by `tools/pmc_summary.py` into `profiles/pmc_<workload>.json`, "
-     "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), `tools/chunk_latency.py` and `tools/membench`.  "
-     "Regenerate this file with `python tools/make_profile_readme.py %s`.  `profiles/r01/`, `profiles/r02/` are the "
+     "separate `--pmc` passes (round 4: of the default workload; the cross-product file is round 3's) summarised by `tools/pmc_summary.py` into `profiles/pmc_<workload>.json` ("
+     "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), `tools/chunk_latency.py`; the `tools/membench` figures quoted in DESIGN.md are round 3's (`profiles/r03/membench_*`).  "
+     "Regenerate this file with `python tools/make_profile_readme.py %s`.  `profiles/r01/` … `profiles/r03/` are the "
      "previous rounds." % rnd,
      ""]
 names = [("snb_sf100", "C4 shard: SF100-shaped knows, iterativelength, 65,536 random pairs (default bench; every row through the pre-pass)"),

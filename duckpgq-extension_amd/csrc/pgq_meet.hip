@@ -8,17 +8,19 @@
 //                 iff  some in-neighbour of N_in(dst) lies in N_out(src)       (backward expansion)
 // and the smallest of these that holds is the answer.  On social graphs almost every random pair is that close (SF100
 // knows graph: 97 % of the pairs at distance <= 3), and deciding it costs the pair one scan of a two-hop
-// neighbourhood — on average 13.6 K adjacency entries from the cheaper side — instead of a share of a full-width
-// MS-BFS level over all 39.9 M in-edges.  One wavefront per pair:
-//   * the one-hop list of the side that is NOT expanded goes into a per-wavefront open-addressing hash table in LDS
-//     (1024 slots: lists of up to 512 vertices);
-//   * the other side's one-hop list is walked 64 vertices at a time (adjacency ranges fetched one per lane), the
-//     segments are streamed 16 bytes per lane per request with four requests in flight; every entry is one hash
-//     probe (LDS);
-//   * pairs whose lists are too long for the table or whose two-hop walk exceeds `meet_cap` entries stay open.
-// Rows it cannot answer (distance >= 4, unreachable, over the caps) are left to the MS-BFS path: the caller collects
-// them and runs the lane-batched search on them only.  Bound: HBM (segmented streaming of adjacency entries);
-// algorithmic bytes = 4 B per adjacency entry scanned + 16 B per expanded vertex (its offsets).
+// neighbourhood — on average 2.2 K adjacency entries until the first witness, from the endpoint with the shorter walk —
+// instead of a share of a full-width MS-BFS level over all 39.9 M in-edges.  The chain:
+//   * k_meet3, one wavefront per pair: the one-hop list of the side that is NOT expanded (<= 512 ids) sits in registers
+//     behind a 4-KB two-bit filter in LDS; the other side's one-hop list arrives as slot descriptors and its lists are
+//     walked as one virtual sequence of 16-byte groups (seg_walk, pgq_walk.h), ended by the first pass with a witness;
+//   * k_meet4d / k_meet4 (paths), one 1024-thread workgroup per row k_meet3 leaves open, an exact vertex bit map as the
+//     set: distance <= 4;
+//   * k_bibfs, one bidirectional BFS per row for a handful of leftovers;
+//   * every kernel appends the rows it cannot answer to the next one's queue, the last workgroup of the last kernel
+//     reports into pinned host memory: the host launches 2-4 kernels and waits once.
+// Rows still open at the end (far apart, unreachable, over the caps) are left to the lane-batched MS-BFS.  Bound: HBM
+// (segmented streaming of adjacency entries); algorithmic bytes = 4 B per adjacency entry scanned + 16 B per slot
+// descriptor + per row its ids, offsets and result.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>

@@ -333,46 +333,6 @@ template <typename H> __device__ __forceinline__ void verify_candidates(const Re
 	}
 }
 
-// ---- the set side of a pair-centric walk: blocked two-bit filter + exact table ---------------------------------------------
-// A request holds 256 entries; with the one-bit filter of round 2 (8192 bits, ~1 % of them set by a 100-vertex set) 92 %
-// of the REQUESTS had some lane with a filter hit, so nearly every request ran the divergent table walk (it showed as
-// 59 SALU + 76 VALU wave-instructions per request, half of the kernel's issue slots).  Two bits per entry inside ONE
-// 32-bit word of a 16384-bit filter cost the same single LDS read and bring a 100-vertex set's false positives to
-// ~0.07 % per entry (~16 % of the requests); word = bits 5..13 of the id, bits = its bits 0..4 and 14..18.
-constexpr int kMeetFilter2Words = 512;
-__device__ __forceinline__ u32 meet_f2_word(u32 x) { return (x >> 5) & (kMeetFilter2Words - 1); }
-__device__ __forceinline__ u32 meet_f2_mask(u32 x) { return (1u << (x & 31)) | (1u << ((x >> 14) & 31)); }
-__device__ __forceinline__ bool meet_f2_hit(const u32 *bm2, u32 x) {
-	const u32 w = bm2[meet_f2_word(x)];
-	return ((w >> (x & 31)) & (w >> ((x >> 14) & 31)) & 1u) != 0;
-}
-// any of the four entries of `v` in the set?  The four filter reads are independent and branch-free; only a lane holding
-// a filter hit walks the table
-__device__ __forceinline__ bool meet_any4(const u32 *tab, const u32 *bm2, const int4 v) {
-	const u32 w0 = bm2[meet_f2_word((u32)v.x)], w1 = bm2[meet_f2_word((u32)v.y)];
-	const u32 w2 = bm2[meet_f2_word((u32)v.z)], w3 = bm2[meet_f2_word((u32)v.w)];
-	const u32 t0 = (w0 >> ((u32)v.x & 31)) & (w0 >> (((u32)v.x >> 14) & 31));
-	const u32 t1 = (w1 >> ((u32)v.y & 31)) & (w1 >> (((u32)v.y >> 14) & 31));
-	const u32 t2 = (w2 >> ((u32)v.z & 31)) & (w2 >> (((u32)v.z >> 14) & 31));
-	const u32 t3 = (w3 >> ((u32)v.w & 31)) & (w3 >> (((u32)v.w >> 14) & 31));
-	if (!((t0 | t1 | t2 | t3) & 1u)) return false;
-	return ((t0 & 1u) && meet_lookup(tab, (u32)v.x)) || ((t1 & 1u) && meet_lookup(tab, (u32)v.y)) ||
-	       ((t2 & 1u) && meet_lookup(tab, (u32)v.z)) || ((t3 & 1u) && meet_lookup(tab, (u32)v.w));
-}
-// which of the four entries are in the set (bit k = entry k), for callers that need the witnesses
-__device__ __forceinline__ u32 meet_which4(const u32 *tab, const u32 *bm2, const int4 v) {
-	u32 p = (u32)meet_f2_hit(bm2, (u32)v.x) | ((u32)meet_f2_hit(bm2, (u32)v.y) << 1) | ((u32)meet_f2_hit(bm2, (u32)v.z) << 2) |
-	        ((u32)meet_f2_hit(bm2, (u32)v.w) << 3);
-	u32 f = 0;
-	while (p) {
-		const u32 k = (u32)__ffs((int)p) - 1u;
-		p &= p - 1u;
-		const u32 x = k == 0 ? (u32)v.x : (k == 1 ? (u32)v.y : (k == 2 ? (u32)v.z : (u32)v.w));
-		if (meet_lookup(tab, x)) f |= 1u << k;
-	}
-	return f;
-}
-
 // Streams the adjacency segments of list[w], list[w + stride], ... (positions < list_n) and calls f(entry) for every
 // entry until stop() (wave-uniform) says so.  Returns the number of entries requested.
 template <typename F, typename Stop>

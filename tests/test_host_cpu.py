@@ -220,3 +220,32 @@ def test_duckdb_glue_type_checks_against_stub_headers():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "duckpgq-extension_amd", "csrc"), "-B", "glue-check"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_pmc_summary_reports_the_prepass_chain_per_step(tmp_path):
+    """tools/pmc_summary.py: a class alias no longer averages a 900-MB k_meet3 launch with a 0.1-MB k_bibfs one (round-3
+    review), and the chain's traffic is bytes x launches summed over its kernels, divided by the steps profiled."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    disp = 0
+    for step in range(3):  # three steps: one k_meet3 and one k_meet4d launch each; k_bibfs only in the first
+        for name, fetch_kb, write_kb in (("void pgq::k_meet3<false, false, 2>(long, long const*)", 400000.0, 6000.0),
+                                         ("void pgq::k_meet4d<false, false>(pgq::MeetQueue)", 20000.0, 10000.0)):
+            disp += 1
+            rows += ["%d,\"%s\",FETCH_SIZE,%f" % (disp, name, fetch_kb), "%d,\"%s\",WRITE_SIZE,%f" % (disp, name, write_kb)]
+        if step == 0:
+            disp += 1
+            rows += ["%d,\"void pgq::k_bibfs<false>(pgq::MeetQueue)\",FETCH_SIZE,50.0" % disp,
+                     "%d,\"void pgq::k_bibfs<false>(pgq::MeetQueue)\",WRITE_SIZE,0.0" % disp]
+    f = tmp_path / "p_counter_collection.csv"
+    f.write_text("\n".join(rows) + "\n")
+    out = mod.summarise([str(f)])
+    meet, meet4 = (2 * 400000.0 + 6000.0) * 1024, (2 * 20000.0 + 10000.0) * 1024
+    assert out["meet"]["kernels"] == ["k_meet3<false, false, 2>"] and out["meet"]["hbm_bytes_per_launch"] == meet
+    assert out["meet4"]["hbm_bytes_per_launch"] == meet4 and out["bibfs"]["launches_profiled"] == 1
+    chain = out["prepass_chain"]
+    assert chain["steps_profiled"] == 3
+    assert abs(chain["hbm_bytes_per_step"] - (meet + meet4 + 2 * 50.0 * 1024 / 3)) < 1.0

@@ -249,3 +249,16 @@ def test_pmc_summary_reports_the_prepass_chain_per_step(tmp_path):
     chain = out["prepass_chain"]
     assert chain["steps_profiled"] == 3
     assert abs(chain["hbm_bytes_per_step"] - (meet + meet4 + 2 * 50.0 * 1024 / 3)) < 1.0
+
+
+def test_bench_strided_sample_of_the_cross_product_covers_every_source():
+    """bench.py's msbfs_cross leg compares a strided sample with the CPU port: every 256th row of the 2048 x 1024 product
+    touches all 2048 sources (= all lanes of the batch); the first 8192 rows, round 3's sample, are 8 of them."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cp = bench.cross_pairs(448626, 2048 * 1024, 2048, bench.PAIR_SEED["snb_cross"])
+    assert cp.shape == (2048 * 1024, 2) and len(np.unique(cp[:, 0])) == 2048
+    sel = np.arange(8192) * (len(cp) // 8192)
+    assert len(np.unique(cp[sel, 0])) == 2048
+    assert len(np.unique(cp[:8192, 0])) == 8

@@ -571,3 +571,25 @@ def test_relax_count_model_tool_runs_and_agrees_with_dijkstra():
                               "--friendships", "40000", "--lanes", "16"] + extra, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert "equal to scipy's Dijkstra: True" in out.stdout
+
+
+def test_walk_model_tool_runs_and_the_walk_size_rule_is_never_worse_on_average():
+    """tools/walk_model.py (the CPU model DESIGN.md 3.0 quotes for the expansion-side rule and for stage A of the
+    distance-4 step) on a small SNB-shaped graph: it runs, both rules agree on which rows are within two hops, and
+    expanding the endpoint with the shorter two-hop walk never walks more on average than the shorter-list rule."""
+    import importlib.util
+    import os
+    from duckpgq_extension_amd import graphgen
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("walk_model", os.path.join(root, "tools", "walk_model.py"))
+    wm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wm)
+    V, s, d = graphgen.snb_knows_like(6000, 90000, seed=5)
+    off, adj, _ = graphgen.csr_from_rows(V, s, d)
+    pairs = np.random.default_rng(1).integers(0, V, size=(400, 2))
+    out = wm.model(V, off, adj, pairs, caps=(256, 1024), prefixes=((512, 512),))
+    assert out["rows"] > 390 and 0.0 <= out["distance_le_2"] <= 1.0
+    assert out["by_walk"]["mean_entries_walked"] <= out["by_list"]["mean_entries_walked"] * 1.02
+    assert out["by_walk"]["cut_at_cap"][1024] <= out["by_list"]["cut_at_cap"][1024]
+    st = out["stage_a"]["512x512"]
+    assert 0 <= st["settled"] <= st["rows"]

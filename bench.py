@@ -90,7 +90,44 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs timed on one CPU thread (0 = 8192 snb / 1024 rmat)")
     ap.add_argument("--weights", default="int64", choices=["int64", "double"], help="forest_cheapest / snb_cheapest: weight type")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, count them with one all_reduce and print {n_gpus}: the CPU test of the "
+                         "launcher (no GPU work)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run on a free loopback port) with the same arguments, and hand their output through — rank 0's
+    JSON line is the only line any rank prints.  Under `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE
+    is set and this is not entered."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(a):
+    """The ranks meet, count themselves and rank 0 prints the count: everything of an N-rank run but the GPU work."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    n = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.all_reduce(n)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": int(n[0]), "world_size": world, "gpus_arg": a.gpus}), flush=True)
 
 
 def build_graph(a):
@@ -372,6 +409,15 @@ def leg_summary(bench, m, workload, total_pairs, copy_gbps):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)  # does not return
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:  # a launcher is around us: the ranks it started are the job
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; reporting n_gpus = WORLD_SIZE" % (
+                a.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+        a.gpus = int(os.environ["WORLD_SIZE"])
+    if a.launch_check:
+        return launch_check(a)
     bench = Bench(a)
     torch, dist, pgq, sharding = bench.torch, bench.dist, bench.pgq, bench.sharding
     world, rank, dev = bench.world, bench.rank, bench.dev

@@ -93,3 +93,24 @@ def test_shard_bounds_cover_everything():
                 assert 0 <= lo <= hi <= total
                 cover.extend(range(lo, hi))
             assert cover == list(range(total))
+
+
+def test_bare_bench_command_starts_n_ranks():
+    """`python bench.py --gpus 2` without a launcher around it must start 2 ranks by itself (round 4: it silently ran
+    one and reported n_gpus 1).  --launch-check stops after the ranks have met and counted themselves: no GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--backend", "gloo", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0's line only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["gpus_arg"] == 2
+    # under a launcher (WORLD_SIZE set) nothing is re-launched
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--launch-check"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1

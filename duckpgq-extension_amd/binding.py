@@ -25,7 +25,8 @@ class Stats(C.Structure):
                 ("frontier_vertices", C.c_int64), ("unique_sources", C.c_int64), ("pairs", C.c_int64),
                 ("deferred_pairs", C.c_int64), ("meet_pairs", C.c_int64),
                 ("algo_bytes", C.c_double * KCLASS_MAX), ("kernel_ms", C.c_double * KCLASS_MAX),
-                ("launches", C.c_int64 * KCLASS_MAX)]
+                ("launches", C.c_int64 * KCLASS_MAX), ("spec_batches", C.c_int64), ("spec_levels", C.c_int64),
+                ("spec_aborts", C.c_int64), ("host_waits", C.c_int64)]
 
 
 def lib_paths():

@@ -72,6 +72,11 @@ struct Options {
 	int probe2_div = 4;     // ... when open pairs <= lanes / probe2_div
 	int probe2_abs = 4096;  // ... or when at most this many pairs are open, whatever the batch width
 	int detect_grid_mult = 8;  // k_detect grid = this many 256-thread workgroups per CU at most (rows are taken grid-stride)
+	int sort_single_batch = 0; // 1: rows sorted by lane even when the distinct sources fit one batch (round-4 behaviour; tests)
+	int spec_levels = 1;    // levels of a batch enqueued ahead under the previous batch's plan, checked on the device: one wait per
+	                        // batch instead of one per level (0: a host round trip after every level)
+	int detect_unroll = 4;  // rows per thread of k_detect with their gathers in flight together (1, 2 or 4)
+	int route_memo = 1;     // large calls on the buffers of the last one that the sample sent to the lane batches go there straight
 	int probe_always = 0;   // 1: probe before every level of a batch that uses the probe (round-2 behaviour; tests)
 	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
@@ -217,6 +222,19 @@ struct pgq_csr {
 	std::vector<pgq_csr *> retired;     // replicas of an earlier device list: calls in flight may still read them; freed with the CSR
 	std::mutex replica_lock;            // guards the three vectors above
 	std::mutex lazy_lock;               // guards the arrays built on first use (wcc)
+	// the levels the last lane batch of each width (1, 2, ..., 32 lane-words) ran, as kLv* bits: the next batch of that width
+	// enqueues them ahead of the host (pgq_msbfs.hip, spec_levels)
+	std::mutex plan_lock;
+	std::vector<uint8_t> level_plan[6];
+	// where the sampled decision sent the last large call (more than 16,384 rows) on these buffers: a call that repeats it
+	// (same row count, same device pointers: the binder evaluates iterativelength and shortestpath on the same pairs, a
+	// benchmark repeats its step) does not launch the pre-pass chain just to have it called off.  Affects speed only: both
+	// routes give the same answers, and the sample is taken again on every call (plan_lock guards it)
+	struct RouteMemo {
+		int64_t n = -1;
+		const void *src = nullptr, *dst = nullptr;
+		int go = 1;
+	} route_memo;
 	bool is_replica = false;
 };
 

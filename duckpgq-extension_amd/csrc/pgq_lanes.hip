@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_compact_lanes(const u32 *__restrict__ n
                                                        BlkInfo *__restrict__ blk, uint4 *__restrict__ recs,
                                                        u32 *__restrict__ totals, int stop_limit,
                                                        const Counters *__restrict__ cnt) {
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	const int lane = threadIdx.x & 63;
 	const int64_t wave = (int64_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(LDSMAP ? 1024 : 256) void k_pull_lanes(
 	// LDSMAP: n_blk bit-map words, n_blk 16-bit record bases relative to their group of kGroupBlocks blocks (records of
 	// a group are contiguous: one k_compact_lanes wavefront wrote them), one 32-bit base per group
 	extern __shared__ u64 s_dyn[];
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	u64 *s_bits = s_dyn;
 	unsigned short *s_base = reinterpret_cast<unsigned short *>(s_dyn + n_blk);
 	u32 *s_super = reinterpret_cast<u32 *>(s_base + ((n_blk + 1) & ~1));

@@ -1186,9 +1186,9 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // compares the two cost estimates ON THE DEVICE: the pre-pass kernels are launched straight behind and return at once
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
 constexpr int kSampleRows = 2048, kSampleSlots = 4096;
+// h_go (nullable): pinned host word that gets the verdict + 1 (meet_sample_async: the host reads it after its next wait)
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
-                                                     double edge_bytes, MeetDevBlock *__restrict__ db) {
-	MeetDecision *const out = &db->dec;
+                                                     double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go) {
 	__shared__ u32 s_set[kSampleSlots];
 	__shared__ u32 s_count[2];
 	for (int k = threadIdx.x; k < kSampleSlots; k += 1024) s_set[k] = kMeetEmpty;
@@ -1242,6 +1242,7 @@ __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *
 	if (threadIdx.x != 0) return;
 	const double distinct = fmin(est, (double)V);
 	out->go = meet_bytes <= lanes_cost_bytes(edge_bytes, distinct) ? 1u : 0u;
+	if (h_go) *h_go = out->go + 1u;
 	out->sample_rows = s_count[1];
 	out->sample_fresh = s_count[0];
 	out->estimate = est;
@@ -1370,7 +1371,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	// (tried in round 4: the decision kernel on a stream of its own beside k_meet3, which polls a stop flag — the event
 	// record / wait pair costs what the 12 us kernel does, and the polled word must be spread over many lines)
 	if (decide)
-		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, db);
+		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec, (u32 *)nullptr);
 	{
 		// calls too small to fill the chip are bound by the longest row, not by bandwidth: more requests in flight shorten
 		// every row (meet_cap_small is a cap of their own; 4096 .. 16384 measured within 3 % of each other: it ships equal
@@ -1431,6 +1432,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		const MeetQueue &qi = q[open_stage];
 		MeetQueue qo2 = q[open_stage ^ 1]; // the other region: the stage that filled it has been read by now
 		qo2.count = &db->count[2];
+		qo2.count_back = nullptr; // one-ended: what k_bibfs leaves open is counted in count[2] alone (q[0] carries k_meet3's two-ended counter)
 		{
 			KernelTimer kt(st, K_BIBFS);
 			if (bi_lds)
@@ -1511,6 +1513,18 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	S.algo_bytes[K_MEET4] += 4.0 * (double)h.entries[1] + 16.0 * (double)h.vertices[1] + 56.0 * (double)(h.count[0] + h.count_back);
 	S.algo_bytes[K_BIBFS] += 4.0 * (double)h.entries[2] + 16.0 * (double)h.vertices[2];
 	*n_open = open;
+	return PGQ_OK;
+}
+
+// The sampled decision alone, behind whatever the stream holds, without a wait: a call whose rows went to the lane
+// batches last time (search_device's route memo) skips the pre-pass chain — 4 launches that would return at once, and
+// their wait — but keeps asking; the verdict (+ 1) is in *pinned word* h_meet[4104] after the call's next wait.
+int meet_sample_async(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes) {
+	PGQ_TRY(ws->route_dec.reserve(sizeof(MeetDecision)));
+	u32 *h_go = reinterpret_cast<u32 *>(static_cast<char *>(ws->h_meet) + 4104);
+	*h_go = 0;
+	hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, ws->stream, n, d_src, c->V, meet_bytes, edge_bytes,
+	                   ws->route_dec.as<MeetDecision>(), h_go);
 	return PGQ_OK;
 }
 

@@ -105,14 +105,14 @@ __global__ void k_compact_sources(int64_t V, const u32 *__restrict__ flag, const
 
 __global__ void k_pair_keys(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                             const u32 *__restrict__ rank, const int64_t *__restrict__ off,
-                            const int64_t *__restrict__ roff, int dst_rule, int64_t V, u32 *__restrict__ key,
-                            u32 *__restrict__ idx) {
+                            const int64_t *__restrict__ roff, int dst_rule, int64_t V, u32 key_trivial, u32 key_nolane,
+                            u32 *__restrict__ key, u32 *__restrict__ idx) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	int64_t s = src[i], d = dst[i];
-	u32 k = kNoLane;
+	u32 k = key_nolane;
 	if (s >= 0 && s < V && d >= 0 && d < V) {
-		if (s == d) k = kTrivial;
+		if (s == d) k = key_trivial;
 		else if (pair_needs_search(s, d, off, roff, dst_rule)) k = rank[s];
 	}
 	key[i] = k;
@@ -121,23 +121,47 @@ __global__ void k_pair_keys(int64_t n, const int64_t *__restrict__ src, const in
 
 // sorted-side copies: sdst, ssrc; sres = -1 (unresolved) / 0 (trivial)
 __global__ void k_gather_sorted(int64_t n, const u32 *__restrict__ skey, const u32 *__restrict__ sidx,
-                                const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                int32_t *__restrict__ ssrc, int32_t *__restrict__ sdst, int32_t *__restrict__ sres) {
+                                const int64_t *__restrict__ src, const int64_t *__restrict__ dst, u32 key_trivial,
+                                u32 key_nolane, int32_t *__restrict__ ssrc, int32_t *__restrict__ sdst,
+                                int32_t *__restrict__ sres) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	u32 p = sidx[i];
 	u32 k = skey[i];
-	ssrc[i] = k == kNoLane ? -1 : (int32_t)src[p];
-	sdst[i] = k == kNoLane ? -1 : (int32_t)dst[p];
-	sres[i] = k == kTrivial ? 0 : -1;
+	ssrc[i] = k == key_nolane ? -1 : (int32_t)src[p];
+	sdst[i] = k == key_nolane ? -1 : (int32_t)dst[p];
+	sres[i] = k == key_trivial ? 0 : -1;
 }
 
-// bstart[b] = first sorted position with key >= b*L, b = 0..nb; bstart[nb+1] = first kTrivial, [nb+2] = first kNoLane
-__global__ void k_batch_bounds(const u32 *__restrict__ skey, int64_t n, u32 L, int nb, int64_t *__restrict__ bstart) {
+// A call whose distinct sources fit ONE batch needs no grouping of its rows at all: the rows stay in the caller's order
+// (row i = sorted position i), trivial rows are born answered (0) and rows without a lane born closed (-2: NULL like an
+// exhausted lane) so that every per-row kernel of the batch [0, n) skips them by their result word.  One pass over the
+// inputs instead of keys + a 32-bit radix sort of 2 M pairs (0.19 ms on the 2048 x 1024 cross product) + a gather.
+__global__ void k_pair_rows(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                            const u32 *__restrict__ rank, const int64_t *__restrict__ off,
+                            const int64_t *__restrict__ roff, int dst_rule, int64_t V, u32 *__restrict__ skey,
+                            int32_t *__restrict__ ssrc, int32_t *__restrict__ sdst, int32_t *__restrict__ sres) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int64_t s = src[i], d = dst[i];
+	u32 k = kNoLane;
+	if (s >= 0 && s < V && d >= 0 && d < V) {
+		if (s == d) k = kTrivial;
+		else if (pair_needs_search(s, d, off, roff, dst_rule)) k = rank[s];
+	}
+	skey[i] = k;
+	ssrc[i] = k == kNoLane ? -1 : (int32_t)s;
+	sdst[i] = k == kNoLane ? -1 : (int32_t)d;
+	sres[i] = k == kTrivial ? 0 : (k == kNoLane ? -2 : -1);
+}
+
+// bstart[b] = first sorted position with key >= b*L, b = 0..nb; bstart[nb+1] = first trivial key, [nb+2] = first no-lane key
+__global__ void k_batch_bounds(const u32 *__restrict__ skey, int64_t n, u32 L, int nb, u32 key_trivial, u32 key_nolane,
+                               int64_t *__restrict__ bstart) {
 	int b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b > nb + 2) return;
-	// laned keys are < U <= nb*L < 2^31, so b*L never collides with the two sentinels
-	u32 target = b <= nb ? (u32)b * L : (b == nb + 1 ? kTrivial : kNoLane);
+	// laned keys are < U <= nb*L < 2^31 <= the two sentinels
+	u32 target = b <= nb ? (u32)b * L : (b == nb + 1 ? key_trivial : key_nolane);
 	int64_t lo = 0, hi = n;
 	while (lo < hi) {
 		int64_t mid = (lo + hi) >> 1;
@@ -147,12 +171,13 @@ __global__ void k_batch_bounds(const u32 *__restrict__ skey, int64_t n, u32 L, i
 	bstart[b] = lo;
 }
 
+// sidx == nullptr: the rows were never permuted (k_pair_rows)
 __global__ void k_scatter_results(int64_t n, const u32 *__restrict__ sidx, const int32_t *__restrict__ sres,
                                   const int64_t *__restrict__ soff, int64_t *__restrict__ out_len,
                                   int64_t *__restrict__ out_off) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	u32 p = sidx[i];
+	const int64_t p = sidx ? (int64_t)sidx[i] : i;
 	out_len[p] = sres[i] < 0 ? -1 : (int64_t)sres[i]; // -1 open at exhaustion, -2 proven unreachable: both NULL
 	if (out_off) out_off[p] = soff[i];
 }
@@ -163,7 +188,8 @@ template <int WD>
 __global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_t base, const int64_t *__restrict__ off,
                              u64 *__restrict__ front0, u32 *__restrict__ nz0, u64 *__restrict__ seen,
                              u64 *__restrict__ active, u64 *__restrict__ q, u32 qcap, int64_t chunk,
-                             Counters *__restrict__ cnt) {
+                             u32 rows, Counters *__restrict__ cnt) {
+	if (blockIdx.x == 0 && threadIdx.x == 0) cnt->unresolved = rows; // every row of the batch is open (the device-side end test reads it)
 	int64_t g = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const bool ok = g < U && g < base + 64 * WD;
 	int v = 0;
@@ -184,10 +210,101 @@ __global__ void k_init_batch(const int32_t *__restrict__ usrc, int64_t U, int64_
 	enqueue_items(ok, v, deg, chunk, q, qcap, &cnt->q_count[0]);
 }
 
+// ---- what a level leaves open: the active-lane mask and the count --------------------------------------------------------
+// k_detect / k_probe collect the lane bits of the rows they leave open and their number per workgroup in LDS.  Round 4
+// merged the words into the global mask with an atomic load + atomicOr per non-empty word and workgroup: 2048 workgroups x
+// 32 words on the same four cache lines are served one at a time (~1.2 ns each: 80 of k_detect's 120 us on a 2.1 M-row
+// cross product were this tail; with 256 workgroups the kernel took 55 us).  Tried first: a slot per workgroup, a ticket,
+// the last workgroup ORs the slots — the agent-scope fence before every ticket is an L2 write-back on gfx950 and made
+// both kernels slower.  Now the mask has kOpenRep COPIES: a workgroup ORs its non-empty words into copy blockIdx % kOpenRep
+// (atomics that return nothing: nobody waits for them, 8 workgroups per line instead of 512), and whoever opens the
+// next use of the mask folds the copies into the mask proper and zeroes them: k_level_reset of the next level after a
+// k_detect, workgroup 0 of k_probe2 (or k_open_merge) after a k_probe.  The open-row count stays one atomicAdd per workgroup.
+constexpr int kOpenGrid = 512; // workgroups (of 1024 threads: two per CU) k_detect / k_probe run at most
+constexpr int kOpenRep = 64;   // copies of the mask
+template <int WD>
+__device__ __forceinline__ void publish_open_lanes(const u64 *s_act, const u32 *s_open, u64 *__restrict__ rep,
+                                                   Counters *__restrict__ cnt) {
+	if (threadIdx.x < WD) {
+		const u64 m = s_act[threadIdx.x];
+		if (m) (void)__hip_atomic_fetch_or(&rep[(size_t)(blockIdx.x % kOpenRep) * WD + threadIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	if (threadIdx.x == 0 && *s_open) atomicAdd(&cnt->unresolved, *s_open);
+}
+// threads 0 .. wd-1 of one workgroup: mask[w] = OR of the copies, copies zeroed (the kernels that wrote them are done)
+__device__ __forceinline__ void fold_open_lanes(u64 *__restrict__ rep, u64 *__restrict__ mask, int wd) {
+	if ((int)threadIdx.x < wd) {
+		u64 acc = 0;
+#pragma unroll 8
+		for (int r = 0; r < kOpenRep; r++) acc |= rep[(size_t)r * wd + threadIdx.x];
+		for (int r = 0; r < kOpenRep; r++) rep[(size_t)r * wd + threadIdx.x] = 0;
+		mask[threadIdx.x] = acc;
+	}
+}
+__global__ void k_open_merge(u64 *__restrict__ rep, u64 *__restrict__ mask, int wd, const Counters *__restrict__ cnt) {
+	if (cnt->done) return;
+	fold_open_lanes(rep, mask, wd);
+}
+
 // one launch at the start of every level instead of several tiny memsets: per-level counters, the next
-// active-lane mask, and the frontier-queue counts a top-down level is about to fill
-__global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero_q0, int zero_q1) {
+// active-lane mask, and the frontier-queue counts a top-down level is about to fill.
+// Levels enqueued ahead (sp.log != null): the host has not seen the previous level's counters, so this kernel
+// (1) writes them into the pinned log, (2) ends the batch when the host loop would (nothing open, empty frontier, or the
+// previous level's probe left <= its stop limit open), (3) checks that the level about to run is the one the counters call
+// for (decide_level, the host loop's own rule) — else the enqueued levels are called off (`done`: every level kernel
+// returns at once) and the host takes over from the logged counters.
+struct SpecArgs {
+	LevelLog *log;  // pinned; entry t - 1 = the counters after level t - 1
+	u32 *status;    // pinned: {done code, level at which it was set}
+	int t;          // the level this launch opens
+	u32 planned;    // its enqueued kernels (kLv* bits); kLvNone: nothing is enqueued behind this launch, only log
+	int prev_stop;  // stop limit of the previous level's probe (-1: none)
+};
+__global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero_q0, int zero_q1, LevelRule rule, SpecArgs sp,
+                              u64 *__restrict__ fold_rep) {
 	const int t = threadIdx.x;
+	__shared__ int s_off;
+	if (cnt->done) return;
+	if (fold_rep) { // the level before ended with k_detect: its open lanes are still in the copies
+		fold_open_lanes(fold_rep, &cnt->act[act_zero ^ 1][0], rule.wd);
+		__syncthreads();
+	}
+	if (sp.log) {
+		if (t == 0) {
+			int off = 0;
+			{
+				int nzw = 0;
+				for (int w = 0; w < rule.wd; w++) nzw += cnt->act[act_zero ^ 1][w] != 0;
+				LevelLog lg;
+				lg.front_edges = cnt->front_edges;
+				lg.edges_scanned = cnt->edges_scanned;
+				lg.word_gathers = cnt->word_gathers;
+				lg.front_vertices = cnt->front_vertices;
+				lg.unresolved = cnt->unresolved;
+				lg.front_words = cnt->front_words;
+				lg.pad2 = cnt->pad2;
+				lg.nzw = (u32)nzw;
+				lg.r0 = 0;
+				sp.log[sp.t - 1] = lg;
+				u32 code = 0;
+				if (lg.unresolved == 0 || lg.front_edges == 0) code = 1;
+				else if (sp.prev_stop >= 0 && lg.unresolved <= (u32)sp.prev_stop) code = 1;
+				else if (sp.planned == kLvNone) code = 3;
+				else if (decide_level(rule, lg.front_edges, lg.front_words, lg.front_vertices, lg.unresolved,
+				                      sp.t == 1 ? rule.wd : nzw) != sp.planned) code = 2;
+				if (code) {
+					cnt->done = code;
+					sp.status[1] = (u32)sp.t;
+					__threadfence_system();
+					sp.status[0] = code;
+					off = 1;
+				}
+			}
+			s_off = off;
+		}
+		__syncthreads();
+		if (s_off) return; // the counters stay as the last level left them
+	}
 	if (t == 0) {
 		cnt->front_vertices = 0;
 		cnt->unresolved = 0;
@@ -203,6 +320,13 @@ __global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero
 	if (t < 32) cnt->act[act_zero][t] = 0;
 }
 
+// memset of a level buffer inside an enqueued-ahead level: must not run when the level does not
+__global__ void k_zero_unless_done(uint4 *__restrict__ p, size_t n16, const Counters *__restrict__ cnt) {
+	if (cnt->done) return;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ---- top-down level ----------------------------------------------------------------------------------------------
 // One wavefront per work item (frontier vertex, or a hub_chunk slice of one); lane = out-neighbour.
 // For every non-empty lane-word of visit[v]: bits not yet in seen[n] are OR-ed into seen[n] and next[n]
@@ -216,7 +340,7 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
                                               u32 qcap, int64_t chunk, int stop_limit,
                                               Counters *__restrict__ cnt) {
 	// the probe already answered (or the host will defer) what is left of the batch: skip the expansion
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	const int lane = threadIdx.x & 63;
 	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -300,6 +424,7 @@ __global__ __launch_bounds__(256) void k_push(const int64_t *__restrict__ off, c
 template <int WD>
 __global__ void k_clear_items(const u64 *__restrict__ qcur, int par, u32 qcap, u64 *__restrict__ visit,
                               u32 *__restrict__ nz, const Counters *__restrict__ cnt) {
+	if (cnt->done) return; // an enqueued-ahead level that does not run: the frontier it would clear is still needed
 	const u32 nq = min(cnt->q_count[par], qcap);
 	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -316,6 +441,7 @@ __global__ void k_clear_items(const u64 *__restrict__ qcur, int par, u32 qcap, u
 template <int WD>
 __global__ void k_queue_from_dense(const u32 *__restrict__ nz, int64_t V, const int64_t *__restrict__ off,
                                    int64_t chunk, u64 *__restrict__ q, u32 qcap, int par, Counters *__restrict__ cnt) {
+	if (cnt->done) return;
 	int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	const int64_t vmax = (V + 63) & ~63ll;
@@ -346,7 +472,7 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
                                               int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NS = 64 / WD;
 	__shared__ u64 red[4][5];
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	const int lane = threadIdx.x & 63;
 	const int word = lane & (WD - 1);
 	const int slot = lane / WD;
@@ -467,7 +593,7 @@ __global__ __launch_bounds__(256) void k_compact_frontier(const u32 *__restrict_
                                                           u64 *__restrict__ cw, u32 *__restrict__ bits,
                                                           u32 *__restrict__ bbase, u32 *__restrict__ totals, u32 cap,
                                                           int stop_limit, const Counters *__restrict__ cnt) {
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	const int lane = threadIdx.x & 63;
 	// every wavefront owns one contiguous vertex range: pass 1 counts its frontier vertices and packed words, two
 	// atomicAdds claim its slices of meta[] / cw[] (a per-64-vertices atomic serialised 65k times on R-MAT-22),
@@ -568,7 +694,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 	extern __shared__ u32 s_dyn[];
 	u32 *s_bits = s_dyn;
 	u32 *s_bbase = s_dyn + lds_bit_words;
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	if (WPB == 16) {
 		for (int i = threadIdx.x; i < lds_bit_words; i += WPB * 64) s_bits[i] = bits[i];
 		for (int i = threadIdx.x; i < lds_bit_words / 2; i += WPB * 64) s_bbase[i] = bbase[i];
@@ -817,7 +943,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pull_sparse(const int64_t *__restr
 template <int WD>
 __global__ void k_pull_hub_zero(const int32_t *__restrict__ hubs, int64_t nh, u64 *__restrict__ next,
                                 int stop_limit, const Counters *__restrict__ cnt) {
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t < nh * WD) next[(size_t)hubs[t / WD] * WD + (t % WD)] = 0;
 }
@@ -829,7 +955,7 @@ __global__ __launch_bounds__(256) void k_pull_hub(const HubItem *__restrict__ it
                                                   u64 *__restrict__ next, const u64 *__restrict__ active,
                                                   int stop_limit, Counters *__restrict__ cnt) {
 	constexpr int NS = 64 / WD;
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	const int lane = threadIdx.x & 63;
 	const int word = lane & (WD - 1);
 	const int slot = lane / WD;
@@ -900,7 +1026,7 @@ template <int WD>
 __global__ void k_pull_hub_fold(const int32_t *__restrict__ hubs, int64_t nh, const int64_t *__restrict__ off,
                                 u64 *__restrict__ seen, const u64 *__restrict__ next, u32 *__restrict__ nz_next,
                                 int stop_limit, Counters *__restrict__ cnt) {
-	if (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit) return;
+	if (level_is_off(cnt, stop_limit)) return;
 	int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (h >= nh) return;
 	const int n = hubs[h];
@@ -922,41 +1048,76 @@ __global__ void k_pull_hub_fold(const int32_t *__restrict__ hubs, int64_t nh, co
 }
 
 // ---- per-pair detection (iterativelength.cpp:119-129) ------------------------------------------------------------
+// A row (lane l, destination d) is answered by the level whose FRONTIER holds bit l at d: seen[d] gets a bit at the level
+// that puts it into next[d] (next = reached & ~seen), so "seen[dst] has the bit for the first time" (:123) and "the
+// frontier of this level has the bit" are the same event, and every (vertex, lane) is in exactly one frontier.  Testing
+// the frontier instead of `seen` lets the 4-byte non-empty-word mask nz[d] (a 1.8-MB table on the SF100 graph: L2
+// resident) filter the rows first: after a top-down level almost no row goes on to the 8-byte gather out of the
+// [V][WD] array.  UN rows per thread, every load of a stage issued for all of them before the first is used (round 4: one
+// row per trip of a grid-stride loop, three dependent round trips each: 0.13 ms per 2.1 M rows, a third of what the box
+// gathers).  The loads are unconditional (closed rows read entry 0): a load under a per-lane condition is waited for inside
+// its branch.
 // Grid-stride over the batch's rows.  A cross product has thousands of rows per lane: one atomic per open row on the
 // same few words of the active-lane mask cost 3 ns each (14 M rows of 32 sources: 80 ms per level), and even a read of
 // the mask per row through L2 is a hot spot on one channel (2 ms per level).  So the open rows' lane bits are collected
-// in a workgroup-local mask in LDS and every workgroup ORs its non-empty words into the global mask once (checking
-// first whether they are already there), with one counter update per workgroup.
-template <int WD>
-__global__ __launch_bounds__(256) void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const int32_t *__restrict__ sdst,
-                                                int32_t *__restrict__ sres, u32 base_lane, const u64 *__restrict__ seen, int level,
-                                                u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
+// in a workgroup-local mask in LDS and published once per workgroup (publish_open_lanes).
+template <int WD, int UN>
+__global__ __launch_bounds__(1024) void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const int32_t *__restrict__ sdst,
+                                                 int32_t *__restrict__ sres, u32 base_lane, const u64 *__restrict__ front,
+                                                 const u32 *__restrict__ nz, int level, u64 *__restrict__ rep,
+                                                 Counters *__restrict__ cnt) {
 	__shared__ u32 s_open;
 	__shared__ u64 s_act[WD];
+	if (level_is_off(cnt, -1)) return;
 	if (threadIdx.x == 0) s_open = 0;
 	if (threadIdx.x < WD) s_act[threadIdx.x] = 0;
 	__syncthreads();
 	u32 n_open = 0;
-	for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
-		if (sres[i] != -1) continue;
-		const u32 l = skey[i] - base_lane;
-		const u64 bit = 1ull << (l & 63);
-		if (seen[(size_t)sdst[i] * WD + (l >> 6)] & bit) {
-			sres[i] = level;
-		} else {
-			n_open++;
-			if (!(s_act[l >> 6] & bit)) atomicOr(&s_act[l >> 6], bit); // rows are sorted by lane: nearly always set already
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t i0 = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < hi; i0 += stride * UN) {
+		int64_t at[UN];
+		bool open[UN];
+		u32 l[UN];
+		int d[UN];
+		u32 m[UN];
+		u64 w[UN];
+#pragma unroll
+		for (int u = 0; u < UN; u++) {
+			const int64_t i = i0 + u * stride;
+			at[u] = i < hi ? i : lo;
+			open[u] = sres[at[u]] == -1 && i < hi;
+		}
+#pragma unroll
+		for (int u = 0; u < UN; u++) {
+			l[u] = skey[at[u]] - base_lane;
+			d[u] = sdst[at[u]];
+			if (!open[u]) l[u] = 0, d[u] = 0;
+		}
+#pragma unroll
+		for (int u = 0; u < UN; u++) m[u] = nz[d[u]];
+#pragma unroll
+		for (int u = 0; u < UN; u++) {
+			const int wq = (int)(l[u] >> 6);
+			const bool hot = open[u] && ((m[u] >> wq) & 1u);
+			w[u] = front[hot ? (size_t)d[u] * WD + wq : (size_t)0];
+			if (!hot) w[u] = 0;
+		}
+#pragma unroll
+		for (int u = 0; u < UN; u++) {
+			if (!open[u]) continue;
+			const u64 bit = 1ull << (l[u] & 63);
+			if (w[u] & bit) {
+				sres[at[u]] = level;
+			} else {
+				n_open++;
+				if (!(s_act[l[u] >> 6] & bit)) atomicOr(&s_act[l[u] >> 6], bit); // a cross product's rows share few lanes: nearly always set already
+			}
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1) n_open += __shfl_xor(n_open, o);
 	if ((threadIdx.x & 63) == 0 && n_open) atomicAdd(&s_open, n_open);
 	__syncthreads();
-	if (threadIdx.x < WD) {
-		const u64 m = s_act[threadIdx.x];
-		if (m && (__hip_atomic_load(&active_next[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m)
-			atomicOr(&active_next[threadIdx.x], m);
-	}
-	if (threadIdx.x == 0 && s_open) atomicAdd(&cnt->unresolved, s_open);
+	publish_open_lanes<WD>(s_act, &s_open, rep, cnt);
 }
 
 
@@ -966,18 +1127,19 @@ __global__ __launch_bounds__(256) void k_detect(int64_t lo, int64_t hi, const u3
 // Run before a level is expanded, it answers pairs one full expansion earlier than iterativelength.cpp:119-129
 // does (same values: the frontier of level-1 is exactly the set at distance level-1).
 template <int WD>
-__global__ __launch_bounds__(256) void k_probe(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
-                                               const int32_t *__restrict__ sdst, int32_t *__restrict__ sres,
-                                               u32 base_lane, const u64 *__restrict__ front,
-                                               const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
-                                               const int32_t *__restrict__ radj, int level,
-                                               u64 *__restrict__ active_next, Counters *__restrict__ cnt) {
+__global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
+                                                const int32_t *__restrict__ sdst, int32_t *__restrict__ sres,
+                                                u32 base_lane, const u64 *__restrict__ front,
+                                                const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
+                                                const int32_t *__restrict__ radj, int level, u64 *__restrict__ rep,
+                                                Counters *__restrict__ cnt) {
 	// Persistent wavefronts over 64-row chunks: a chunk's result words are read coalesced, and only the rows still open
 	// (a ballot) get the wave-wide in-list scan — late levels of a cross product have millions of answered rows and a
 	// few thousand open ones (a wavefront per ROW cost 2.4 ms of launches for 2 M rows).  Active-lane bits and the
 	// open count are collected per workgroup like in k_detect.
 	__shared__ u32 s_open;
 	__shared__ u64 s_act[WD];
+	if (cnt->done) return;
 	if (threadIdx.x == 0) s_open = 0;
 	if (threadIdx.x < WD) s_act[threadIdx.x] = 0;
 	__syncthreads();
@@ -1035,12 +1197,7 @@ __global__ __launch_bounds__(256) void k_probe(int64_t lo, int64_t hi, const u32
 	}
 	if (lane == 0 && n_open) atomicAdd(&s_open, n_open);
 	__syncthreads();
-	if (threadIdx.x < WD) {
-		const u64 m = s_act[threadIdx.x];
-		if (m && (__hip_atomic_load(&active_next[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m)
-			atomicOr(&active_next[threadIdx.x], m);
-	}
-	if (threadIdx.x == 0 && s_open) atomicAdd(&cnt->unresolved, s_open);
+	publish_open_lanes<WD>(s_act, &s_open, rep, cnt);
 }
 
 // Two-hop destination probe: a pair still open after k_probe(level) has hop count level+1 iff some in-neighbour u of
@@ -1056,10 +1213,15 @@ __global__ __launch_bounds__(1024) void k_probe2(int64_t lo, int64_t hi, const u
                                                  u32 base_lane, const u64 *__restrict__ front,
                                                  const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
                                                  const int32_t *__restrict__ radj, int level, u32 run_below,
-                                                 int64_t work_cap, Counters *__restrict__ cnt) {
+                                                 int64_t work_cap, u64 *__restrict__ rep, u64 *__restrict__ active_next,
+                                                 Counters *__restrict__ cnt) {
 	__shared__ unsigned long long s_work;
 	__shared__ int s_found;
 	__shared__ u32 s_list[64], s_n, s_answered;
+	if (cnt->done) return;
+	// the mask of the lanes k_probe left open, for the expansion launched behind this kernel (it stays a superset of
+	// the lanes still open after the answers below)
+	if (blockIdx.x == 0) fold_open_lanes(rep, active_next, WD);
 	const u32 open_now = cnt->unresolved;
 	if (open_now == 0 || open_now > run_below) return;
 	const int lane = threadIdx.x & 63;
@@ -1269,13 +1431,14 @@ __global__ void k_trivial_paths(int64_t lo, int64_t hi, const int32_t *__restric
 Workspace::~Workspace() {
 	if (stream) (void)hipStreamDestroy(stream);
 	if (h_cnt) (void)hipHostFree(h_cnt);
+	if (h_log) (void)hipHostFree(h_log);
 	if (h_meet) (void)hipHostFree(h_meet);
 	if (h_io) (void)hipHostFree(h_io);
 	if (h_bstart) (void)hipHostFree(h_bstart);
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &def_off, &def_ent, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &wb_scratch })
+	                   &def_idx, &def_off, &def_ent, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &wb_scratch, &dpart })
 		b->release();
 	for (auto &l : levels) {
 		l->buf.release();
@@ -1312,6 +1475,7 @@ int WorkspaceLease::acquire() {
 		// a half-built workspace never reaches the pool
 		if (hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess ||
 		    hipHostMalloc((void **)&ws->h_cnt, sizeof(Counters)) != hipSuccess ||
+		    hipHostMalloc((void **)&ws->h_log, sizeof(LevelLog) * (kSpecLevels + 3)) != hipSuccess ||
 		    hipHostMalloc(&ws->h_meet, 8192) != hipSuccess) {
 			delete ws;
 			ws = nullptr;
@@ -1327,15 +1491,24 @@ WorkspaceLease::~WorkspaceLease() {
 	else delete ws;
 }
 
+// every wait of the lane-batched search on its stream is counted (pgq_stats_t::host_waits)
+#define PGQ_WAIT(stream)                                                                                               \
+	do {                                                                                                               \
+		PGQ_HIP_TRY(hipStreamSynchronize(stream));                                                                     \
+		tstats().s.host_waits++;                                                                                       \
+	} while (0)
+
 // ---- lane assignment (host side) ------------------------------------------------------------------------------------
-int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out,
-                  bool dst_rule) {
+// Stage 1: flag the distinct sources of the rows that need a search, rank them (= global lane ids), list them; the number
+// of distinct sources and the range check come back with ONE wait.
+static int lane_ranks(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out,
+                      bool dst_rule) {
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V;
 	PGQ_TRY(ws->flag.reserve((size_t)(V + 1) * 4));
 	PGQ_TRY(ws->rank.reserve((size_t)(V + 1) * 4));
 	PGQ_TRY(ws->usrc.reserve((size_t)std::max<int64_t>(V, 1) * 4));
-	for (DevBuf *b : { &ws->key, &ws->idx, &ws->skey, &ws->sidx, &ws->ssrc, &ws->sdst, &ws->sres }) PGQ_TRY(b->reserve((size_t)n * 4));
+	for (DevBuf *b : { &ws->skey, &ws->ssrc, &ws->sdst, &ws->sres }) PGQ_TRY(b->reserve((size_t)n * 4));
 	PGQ_TRY(ws->soff.reserve((size_t)n * 8));
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
 	int *d_bad = reinterpret_cast<int *>(ws->counters.p); // reused before the batch loop resets it
@@ -1349,41 +1522,101 @@ int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, co
 	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp, ws->flag.as<u32>(), ws->rank.as<u32>(), (int)(V + 1), st));
 	if (V > 0)
 		hipLaunchKernelGGL(k_compact_sources, dim3(blocks_for(V)), dim3(256), 0, st, V, ws->flag.as<u32>(), ws->rank.as<u32>(), ws->usrc.as<int32_t>());
-	hipLaunchKernelGGL(k_pair_keys, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), c->off, c->roff, dst_rule ? 1 : 0, V,
-	                   ws->key.as<u32>(), ws->idx.as<u32>());
-	size_t stmp = 0;
-	PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, stmp, ws->key.as<u32>(), ws->skey.as<u32>(), ws->idx.as<u32>(), ws->sidx.as<u32>(), (int)n, 0, 32, st));
-	PGQ_TRY(ws->sort_tmp.reserve(stmp + 16));
-	PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ws->sort_tmp.p, stmp, ws->key.as<u32>(), ws->skey.as<u32>(), ws->idx.as<u32>(), ws->sidx.as<u32>(), (int)n, 0, 32, st));
-	hipLaunchKernelGGL(k_gather_sorted, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->skey.as<u32>(), ws->sidx.as<u32>(), d_src, d_dst, ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>());
 	kt.stop();
-	u32 U = 0;
-	int bad = 0;
-	PGQ_HIP_TRY(hipMemcpyAsync(&U, ws->rank.as<u32>() + V, 4, hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	// two words of the pinned counter block: no pageable staging on the way back
+	u32 *h2 = reinterpret_cast<u32 *>(ws->h_cnt);
+	PGQ_HIP_TRY(hipMemcpyAsync(&h2[0], ws->rank.as<u32>() + V, 4, hipMemcpyDeviceToHost, st));
+	PGQ_HIP_TRY(hipMemcpyAsync(&h2[1], d_bad, 4, hipMemcpyDeviceToHost, st));
+	PGQ_WAIT(st);
 	KernelTimer::flush();
-	if (bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
-	*U_out = U;
+	if (h2[1]) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+	*U_out = h2[0];
 	return PGQ_OK;
+}
+
+static int reserve_bstart(Workspace *ws, int nb) {
+	PGQ_TRY(ws->bstart.reserve((size_t)(nb + 3) * 8));
+	if (ws->h_bstart_cap < (size_t)(nb + 3)) {
+		if (ws->h_bstart) (void)hipHostFree(ws->h_bstart);
+		ws->h_bstart = nullptr;
+		ws->h_bstart_cap = (size_t)(nb + 3) * 2;
+		PGQ_HIP_TRY(hipHostMalloc((void **)&ws->h_bstart, ws->h_bstart_cap * 8));
+	}
+	return PGQ_OK;
+}
+
+// Stage 2, rows grouped by lane: keys -> stable radix sort over `bits` key bits -> sorted copies.  The two sentinels
+// (trivial rows, rows without a lane) sort behind every lane.
+static int lane_rows_sorted(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, bool dst_rule,
+                            u32 key_trivial, u32 key_nolane, int bits) {
+	hipStream_t st = ws->stream;
+	for (DevBuf *b : { &ws->key, &ws->idx, &ws->sidx }) PGQ_TRY(b->reserve((size_t)n * 4));
+	KernelTimer kt(st, K_PREP);
+	hipLaunchKernelGGL(k_pair_keys, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), c->off, c->roff, dst_rule ? 1 : 0, c->V,
+	                   key_trivial, key_nolane, ws->key.as<u32>(), ws->idx.as<u32>());
+	size_t stmp = 0;
+	PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, stmp, ws->key.as<u32>(), ws->skey.as<u32>(), ws->idx.as<u32>(), ws->sidx.as<u32>(), (int)n, 0, bits, st));
+	PGQ_TRY(ws->sort_tmp.reserve(stmp + 16));
+	PGQ_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ws->sort_tmp.p, stmp, ws->key.as<u32>(), ws->skey.as<u32>(), ws->idx.as<u32>(), ws->sidx.as<u32>(), (int)n, 0, bits, st));
+	hipLaunchKernelGGL(k_gather_sorted, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->skey.as<u32>(), ws->sidx.as<u32>(), d_src, d_dst, key_trivial, key_nolane,
+	                   ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>());
+	kt.stop();
+	return PGQ_OK;
+}
+
+// The cheapest-path driver's entry: lanes ranked, rows sorted by lane under the classic sentinels (its own batch width
+// goes to batch_bounds afterwards).
+int prepare_lanes(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out,
+                  bool dst_rule) {
+	PGQ_TRY(lane_ranks(c, ws, n, d_src, d_dst, U_out, dst_rule));
+	return lane_rows_sorted(c, ws, n, d_src, d_dst, dst_rule, kTrivial, kNoLane, 32);
 }
 
 int batch_bounds(Workspace *ws, int64_t n, int64_t L, int nb) {
 	hipStream_t st = ws->stream;
-	PGQ_TRY(ws->bstart.reserve((size_t)(nb + 3) * 8));
-	if (ws->h_bstart_cap < (size_t)(nb + 3)) {
-		if (ws->h_bstart) (void)hipHostFree(ws->h_bstart);
-		ws->h_bstart_cap = (size_t)(nb + 3) * 2;
-		PGQ_HIP_TRY(hipHostMalloc((void **)&ws->h_bstart, ws->h_bstart_cap * 8));
-	}
+	PGQ_TRY(reserve_bstart(ws, nb));
 	{
 		KernelTimer kt(st, K_PREP);
 		hipLaunchKernelGGL(k_batch_bounds, dim3(blocks_for(nb + 3)), dim3(256), 0, st, ws->skey.as<u32>(), n, (u32)L,
-		                   nb, ws->bstart.as<int64_t>());
+		                   nb, kTrivial, kNoLane, ws->bstart.as<int64_t>());
 		kt.stop();
 	}
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_bstart, ws->bstart.p, (size_t)(nb + 3) * 8, hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	PGQ_WAIT(st);
+	return PGQ_OK;
+}
+
+// The BFS driver's stage 2.  One batch (the distinct sources fit 64 x wd lanes) and nothing downstream that needs the
+// trivial rows as a range (paths): the rows are NOT permuted (k_pair_rows; *identity = true, sidx is not written) and
+// nothing is waited for.  Otherwise: sorted by lane over the bits the keys really have (the sentinels sit right behind
+// the last batch: nb x L and nb x L + 1), bounds computed and fetched (one wait).
+static int lane_rows_bfs(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, bool dst_rule,
+                         int64_t L, int nb, bool may_skip_sort, bool *identity) {
+	hipStream_t st = ws->stream;
+	PGQ_TRY(reserve_bstart(ws, nb));
+	*identity = may_skip_sort && nb <= 1;
+	if (*identity) {
+		KernelTimer kt(st, K_PREP);
+		hipLaunchKernelGGL(k_pair_rows, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), c->off, c->roff, dst_rule ? 1 : 0, c->V,
+		                   ws->skey.as<u32>(), ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>());
+		kt.stop();
+		ws->h_bstart[0] = 0;
+		for (int b = 1; b <= nb + 2; b++) ws->h_bstart[b] = n; // batch 0 = every row; no trivial / NULL ranges
+		return PGQ_OK;
+	}
+	const u32 key_trivial = (u32)((int64_t)nb * L), key_nolane = key_trivial + 1; // nb x L <= U + L < 2^31 + 2^11
+	int bits = 1;
+	while (bits < 32 && (1ull << bits) <= (u64)key_nolane) bits++;
+	PGQ_TRY(lane_rows_sorted(c, ws, n, d_src, d_dst, dst_rule, key_trivial, key_nolane, bits));
+	{
+		KernelTimer kt(st, K_PREP);
+		hipLaunchKernelGGL(k_batch_bounds, dim3(blocks_for(nb + 3)), dim3(256), 0, st, ws->skey.as<u32>(), n, (u32)L, nb,
+		                   key_trivial, key_nolane, ws->bstart.as<int64_t>());
+		kt.stop();
+	}
+	PGQ_HIP_TRY(hipMemcpyAsync(ws->h_bstart, ws->bstart.p, (size_t)(nb + 3) * 8, hipMemcpyDeviceToHost, st));
+	PGQ_WAIT(st);
+	KernelTimer::flush();
 	return PGQ_OK;
 }
 
@@ -1433,14 +1666,19 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 	PGQ_TRY(ws->qbuf[0].reserve((size_t)qcap * 8));
 	PGQ_TRY(ws->qbuf[1].reserve((size_t)qcap * 8));
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	PGQ_TRY(ws->dpart.reserve((size_t)kOpenRep * WD * 8));
 	if (outp.want_te) {
 		PGQ_TRY(ws->lane_sums.reserve((size_t)kMaxTeLevels * L * 8));
 		PGQ_TRY(sh->ste.reserve((size_t)n * 8));
 		PGQ_HIP_TRY(hipMemsetAsync(sh->ste.p, 0, (size_t)n * 8, st));
 	}
 	Counters *d_cnt = ws->counters.as<Counters>();
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	if (ws != sh) PGQ_WAIT(st); // (the caller's own stream orders its batches behind the lane assignment)
 	const int64_t *bs = sh->h_bstart;
+	// levels enqueued ahead of the host under the plan of the last batch of this width; paths keep every
+	// level's frontier and the accounting pass its per-level sums: they stay on the round trip per level
+	const bool spec_ok = opt.spec_levels && !with_paths && !outp.want_te;
+	const int plan_slot = WD == 1 ? 0 : (WD == 2 ? 1 : (WD == 4 ? 2 : (WD == 8 ? 3 : (WD == 16 ? 4 : 5))));
 
 	int64_t child_base = 0;
 	int64_t *d_child = d_child_ext;
@@ -1460,6 +1698,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		// -- reset per-batch state
 		PGQ_HIP_TRY(hipMemsetAsync(ws->seen.p, 0, words * 8, st));
 		PGQ_HIP_TRY(hipMemsetAsync(ws->counters.p, 0, sizeof(Counters), st));
+		PGQ_HIP_TRY(hipMemsetAsync(ws->dpart.p, 0, (size_t)kOpenRep * WD * 8, st)); // the copies of the open-lane mask (publish_open_lanes)
 
 		auto level_buf = [&](int t) -> LevelBuf * {
 			size_t k = with_paths ? (size_t)t : (size_t)(t & 1);
@@ -1481,13 +1720,13 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		LevelBuf *cur = level_buf(0);
 		PGQ_TRY(make_zero(cur));
 		u64 *act_cur = &d_cnt->act[0][0]; // zeroed with the counter block above
-		u64 *act_nxt = &d_cnt->act[1][0];
-		int act_sel = 0;
+		u32 open_before = (u32)(hi - lo); // rows open before the level whose counters are being looked at (byte model of detection)
+		u32 sparse_front_words = 0;       // k_pull_sparse sizes its packed-word buffer from the frontier's words
 		{
 			KernelTimer kt(st, K_PREP);
 			hipLaunchKernelGGL(k_init_batch<WD>, dim3(blocks_for(L)), dim3(256), 0, st, sh->usrc.as<int32_t>(), U,
 			                   (int64_t)base_lane, c->off, cur->buf.as<u64>(), cur->nz.as<u32>(), ws->seen.as<u64>(),
-			                   act_cur, ws->qbuf[0].as<u64>(), qcap, pchunk, d_cnt);
+			                   act_cur, ws->qbuf[0].as<u64>(), qcap, pchunk, (u32)(hi - lo), d_cnt);
 			kt.stop();
 		}
 		cur->dirty = true;
@@ -1496,21 +1735,10 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			hipLaunchKernelGGL(k_lane_degree_sums<WD>, dim3(4 * ncu), dim3(256), 0, st, cur->buf.as<u64>(), c->off, V,
 			                   ws->lane_sums.as<u64>());
 		}
-		PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
-		PGQ_HIP_TRY(hipStreamSynchronize(st));
-		u64 front_edges = ws->h_cnt->front_edges;
-		u32 front_words = ws->h_cnt->front_words;
-		u32 front_vertices = ws->h_cnt->front_vertices;
-		u32 unresolved = (u32)(hi - lo);
-		bool queue_valid = true; // qbuf[par] describes `cur`
-		int par = 0;
-		int levels_run = 0;
-		double active_frac = 1.0;
-		u32 last_cw_cap = 0;
 		// The destination probe answers a pair one expansion early; it costs one in-neighbour scan per open pair,
 		// so it is used while the batch has few pairs relative to the graph (not for cross products) and never in
 		// the traversed-edge accounting pass (which needs every level of every lane).
-		const bool use_probe = opt.probe && !outp.want_te; // whether a level is probed is decided per level (below)
+		const bool use_probe = opt.probe && !outp.want_te; // whether a level is probed is decided per level (decide_level)
 		// open pairs at or below this count stop the batch: 0 = everything answered, > 0 = defer the stragglers
 		int stop = -1;
 		if (use_probe) {
@@ -1518,64 +1746,99 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			// a narrow batch is scan-bound: re-running its stragglers costs as much as finishing them here
 			if (opt.defer && outp.depth < 2 && WD >= 8) stop = (int)std::min<int64_t>(L / opt.defer, (hi - lo) / opt.defer);
 		}
-		for (int t = 1; unresolved > 0 && front_edges > 0; t++) {
+		LevelRule rule;
+		rule.E = (double)E;
+		rule.V = (double)V;
+		rule.push_div = opt.push_div;
+		rule.sparse_below = opt.sparse_below;
+		rule.wd = WD;
+		rule.force_mode = opt.force_mode;
+		rule.force_pull = opt.force_pull;
+		rule.probe_always = opt.probe_always;
+		rule.use_probe = use_probe ? 1 : 0;
+		const bool lanes_ok = opt.lanes && c->rpk != nullptr;
+
+		// ---- host state of the level loop (what enqueueing a level changes; snapshotted per enqueued-ahead level) ----
+		struct HostState {
+			LevelBuf *cur;
+			int par, act_sel;
+			bool queue_valid, dirty[2];
+			bool pending_fold; // the last level ended with k_detect and its open-lane words are still in the copies
+		};
+		HostState hs { cur, 0, 0, true, { false, false }, false }; // queue_valid: qbuf[par] describes `cur`
+		auto save_dirty = [&](HostState &h) {
+			for (size_t k = 0; k < 2 && k < ws->levels.size(); k++) h.dirty[k] = ws->levels[k]->dirty;
+		};
+		auto load_dirty = [&](const HostState &h) {
+			for (size_t k = 0; k < 2 && k < ws->levels.size(); k++) ws->levels[k]->dirty = h.dirty[k];
+		};
+		u32 last_cw_cap = 0;
+		int levels_run = 0;
+		std::vector<uint8_t> ran_plan; // the levels this batch really ran: the next batch's plan
+
+		// Launches the kernels of level t as `bits` says.  spec: the level runs ahead of the host's knowledge — its
+		// k_level_reset logs and checks on the device (SpecArgs) and its memsets are kernels that honour `done`.
+		auto enqueue_level = [&](int t, u32 bits, bool spec, int prev_stop) -> int {
+			LevelBuf *cur = hs.cur;
 			LevelBuf *nxt = level_buf(t);
-			bool sparse_level = false, lanes_level = false;
-			bool push = opt.force_mode == 1 || (opt.force_mode == 0 && (double)front_edges * opt.push_div < (double)E);
-			if (opt.force_mode == 2) push = false;
+			const bool push = bits & kLvPush, sparse_level = bits & kLvSparse, probe_now = bits & kLvProbe;
+			const bool lanes_level = sparse_level && lanes_ok;
+			u64 *act_cur = &d_cnt->act[hs.act_sel][0], *act_nxt = &d_cnt->act[hs.act_sel ^ 1][0];
+			const int par = hs.par;
+			auto zero_level = [&](LevelBuf *lb) -> int {
+				if (!spec) return make_zero(lb);
+				PGQ_TRY(lb->buf.reserve(words * 8));
+				PGQ_TRY(lb->nz.reserve(nz_bytes));
+				if (lb->dirty) {
+					hipLaunchKernelGGL(k_zero_unless_done, dim3(4 * ncu), dim3(256), 0, st, lb->buf.as<uint4>(), (words * 8 + 15) / 16, d_cnt);
+					hipLaunchKernelGGL(k_zero_unless_done, dim3(ncu), dim3(256), 0, st, lb->nz.as<uint4>(), (nz_bytes + 15) / 16, d_cnt);
+					lb->dirty = false;
+				}
+				return PGQ_OK;
+			};
 			// reset the per-level counters but keep the queue counts
 			{
-				const bool zq_cur = push && !queue_valid; // queue rebuilt from the dense frontier below
+				const bool zq_cur = push && !hs.queue_valid; // queue rebuilt from the dense frontier below
 				const int q_cur = par, q_nxt = par ^ 1;
-				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(64), 0, st, d_cnt, act_sel ^ 1,
+				SpecArgs sp { nullptr, nullptr, t, bits, prev_stop };
+				if (spec) {
+					sp.log = ws->h_log;
+					sp.status = reinterpret_cast<u32 *>(ws->h_log + kSpecLevels + 2);
+				}
+				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(64), 0, st, d_cnt, hs.act_sel ^ 1,
 				                   (int)((push && q_nxt == 0) || (zq_cur && q_cur == 0)),
-				                   (int)((push && q_nxt == 1) || (zq_cur && q_cur == 1)));
-			}
-			// The probe answers the pairs at distance t from frontier t-1 (one in-list scan per open pair) BEFORE level t
-			// is expanded.  That only pays when it can spare an expensive expansion: before a top-down level (tiny) or a
-			// sparse bottom-up level it costs more than it saves (cross product of 2048 sources x 32 destinations on the
-			// SF100-shaped graph: the probes of levels 1 and 2 took 0.6 ms and spared nothing), before a DENSE bottom-up
-			// level (1.5 ms at WD = 32) it answers what that level would have been run for.  Few open pairs: always.
-			bool probe_now = false;
-			if (use_probe) {
-				const double wpn = (double)front_edges / (double)std::max<int64_t>(E, 1) *
-				                   ((double)front_words / (double)std::max<u32>(front_vertices, 1u)) * active_frac;
-				const bool dense_next = !push && !(opt.force_pull == 1 || (opt.force_pull == 0 && wpn < opt.sparse_below));
-				// in bytes at the rate the expansion kernels stream: a probe is one latency-bound wavefront per open pair
-				// (measured 4.7 ns per pair at mean in-degree 89: ~256 B per in-edge); a dense level moves ~E (8 + 6 WD),
-				// a sparse one ~4 E + 16 per frontier out-edge + V (4 + 24 WD), a top-down one ~20 per frontier out-edge
-				const double probe_bytes = (double)unresolved * ((double)E / (double)std::max<int64_t>(V, 1)) * 256.0;
-				const double level_bytes = push ? (double)front_edges * 20.0
-				                                : (dense_next ? (double)E * (8.0 + 6.0 * WD)
-				                                              : (double)E * 4.0 + (double)front_edges * 16.0 + (double)V * (4.0 + 24.0 * WD));
-				probe_now = opt.probe_always || probe_bytes <= level_bytes;
+				                   (int)((push && q_nxt == 1) || (zq_cur && q_cur == 1)), rule, sp,
+				                   hs.pending_fold ? ws->dpart.as<u64>() : (u64 *)nullptr);
+				hs.pending_fold = false;
 			}
 			if (probe_now) {
 				KernelTimer kt(st, K_DETECT);
 				// up to one wavefront per row (few rows: the wavefronts of a 64-row chunk share its open rows), at most 8192
-				hipLaunchKernelGGL(k_probe<WD>, dim3(std::min(blocks_for((hi - lo) * 64), 8u * ncu)), dim3(256), 0, st, lo, hi,
+				hipLaunchKernelGGL(k_probe<WD>, dim3(std::min(blocks_for((hi - lo) * 64, 1024), (unsigned)kOpenGrid)), dim3(1024), 0, st, lo, hi,
 				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
-				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, act_nxt, d_cnt);
+				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, ws->dpart.as<u64>(), d_cnt);
 				if (opt.probe2 && !with_paths)
 					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)std::min<int64_t>(hi - lo, 2 * ncu)), dim3(1024), 0, st, lo, hi,
 					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
 					                   (u32)std::max<int64_t>(std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),
 					                                       std::min<int64_t>(hi - lo, opt.probe2_abs)),
-					                   (int64_t)opt.probe2_cap, d_cnt);
+					                   (int64_t)opt.probe2_cap, ws->dpart.as<u64>(), act_nxt, d_cnt);
+				else
+					hipLaunchKernelGGL(k_open_merge, dim3(1), dim3(64), 0, st, ws->dpart.as<u64>(), act_nxt, WD, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
-				act_sel ^= 1;
+				hs.act_sel ^= 1;
 			}
 			const int stop_lvl = probe_now ? stop : -1; // the expansion returns at once when the probe left <= stop pairs open
 			if (push) {
-				if (!queue_valid) {
+				if (!hs.queue_valid) {
 					KernelTimer kt(st, K_QUEUE);
 					hipLaunchKernelGGL(k_queue_from_dense<WD>, dim3(std::min(blocks_for(V), 16u * ncu)), dim3(256), 0, st,
 					                   cur->nz.as<u32>(), V, c->off, pchunk, ws->qbuf[par].as<u64>(), qcap, par, d_cnt);
 					kt.stop();
 				}
-				PGQ_TRY(make_zero(nxt));
+				PGQ_TRY(zero_level(nxt));
 				{
 					KernelTimer kt(st, K_PUSH);
 					hipLaunchKernelGGL(k_push<WD>, dim3(push_grid), dim3(256), 0, st, c->off, c->adj, cur->buf.as<u64>(),
@@ -1591,8 +1854,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					kt.stop();
 					cur->dirty = false;
 				}
-				queue_valid = false; // rebuilt from nz if the next level is top-down too
-				S.push_levels++;
+				hs.queue_valid = false; // rebuilt from nz if the next level is top-down too
 			} else {
 				PGQ_TRY(nxt->buf.reserve(words * 8));
 				PGQ_TRY(nxt->nz.reserve(nz_bytes));
@@ -1609,19 +1871,14 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					kt.stop();
 				}
 				// frontier sparse in lane-words, or few lane-words still wanted -> edge-organised sparse kernel
-				// expected wanted non-empty words per scanned in-edge: share of edges leaving frontier vertices x
-				// non-empty words per frontier vertex x share of lane-words that still hold an active lane
-				const double words_per_nb = (double)front_edges / (double)std::max<int64_t>(E, 1) *
-				                            ((double)front_words / (double)std::max<u32>(front_vertices, 1u)) * active_frac;
-				sparse_level = opt.force_pull == 1 || (opt.force_pull == 0 && words_per_nb < opt.sparse_below);
-				lanes_level = sparse_level && opt.lanes && c->rpk != nullptr;
 				if (lanes_level) {
 					KernelTimer kt(st, K_PULL_SPARSE);
 					PGQ_TRY(pull_lanes_level(c, ws, WD, cur->buf.as<u64>(), cur->nz.as<u32>(), ws->seen.as<u64>(),
 					                         nxt->buf.as<u64>(), nxt->nz.as<u32>(), act_cur, stop_lvl, d_cnt));
 					kt.stop();
 				} else if (sparse_level) {
-					const u32 cw_cap = (u32)std::min<int64_t>((int64_t)front_words + 64, 0x7FFFFFF0ll);
+					// only after a host round trip (never enqueued ahead): the packed-word buffer is sized from the frontier's words
+					const u32 cw_cap = (u32)std::min<int64_t>((int64_t)sparse_front_words + 64, 0x7FFFFFF0ll);
 					last_cw_cap = cw_cap;
 					const int bit_words = (int)(((V + 63) / 64) * 2 + 2); // even: 64-vertex blocks
 					PGQ_TRY(ws->cbits.reserve((size_t)bit_words * 4 + 64));
@@ -1688,8 +1945,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					kt.stop();
 				}
 				nxt->dirty = true;
-				queue_valid = false;
-				S.pull_levels++;
+				hs.queue_valid = false;
 			}
 			if (outp.want_te) {
 				if (t >= kMaxTeLevels) return fail(PGQ_ERR_UNSUPPORTED, "traversed-edge accounting supports at most 1023 levels");
@@ -1697,46 +1953,52 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				                   ws->lane_sums.as<u64>() + (size_t)t * L);
 			}
 			if (!probe_now) {
-				// -- detect finished pairs (iterativelength.cpp:119-129), rebuild the active-lane mask
+				// -- detect finished pairs (iterativelength.cpp:119-129) in the frontier just produced, rebuild the active-lane mask
 				KernelTimer kt(st, K_DETECT);
-				hipLaunchKernelGGL(k_detect<WD>, dim3(std::min(blocks_for(hi - lo), (unsigned)std::max(1, opt.detect_grid_mult) * ncu)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
-				                   sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane, ws->seen.as<u64>(), t,
-				                   act_nxt, d_cnt);
+				const int un = opt.detect_unroll >= 4 ? 4 : (opt.detect_unroll >= 2 ? 2 : 1);
+				const dim3 grid(std::min(blocks_for((hi - lo + un - 1) / un, 1024), (unsigned)std::min(kOpenGrid, std::max(1, opt.detect_grid_mult) * ncu / 4)));
+#define PGQ_DETECT(UNR)                                                                                                  \
+	hipLaunchKernelGGL((k_detect<WD, UNR>), grid, dim3(1024), 0, st, lo, hi, sh->skey.as<u32>(), sh->sdst.as<int32_t>(),   \
+	                   sh->sres.as<int32_t>(), base_lane, nxt->buf.as<u64>(), nxt->nz.as<u32>(), t, ws->dpart.as<u64>(),   \
+	                   d_cnt)
+				if (un == 4) PGQ_DETECT(4);
+				else if (un == 2) PGQ_DETECT(2);
+				else PGQ_DETECT(1);
+#undef PGQ_DETECT
+				// the words are folded into the mask by the next level's k_level_reset; the host loop reads the mask itself
+				if (spec) hs.pending_fold = true;
+				else hipLaunchKernelGGL(k_open_merge, dim3(1), dim3(64), 0, st, ws->dpart.as<u64>(), act_nxt, WD, d_cnt);
 				kt.stop();
-				std::swap(act_cur, act_nxt);
-				act_sel ^= 1;
+				hs.act_sel ^= 1;
 			}
-			PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
-			PGQ_HIP_TRY(hipStreamSynchronize(st));
-			KernelTimer::flush();
-			const Counters &hc = *ws->h_cnt;
+			hs.cur = nxt; // the caller takes it back when the level turns out not to have counted (deferral)
+			return PGQ_OK;
+		};
+
+		// What the host does with a level's counters once it has them.  Returns 1 when the batch is over (the probe left at
+		// most `stop` rows open: they are deferred), 0 to go on.
+		auto post_level = [&](int t, u32 bits, const LevelLog &hc) -> int {
+			const bool push = bits & kLvPush, sparse_level = bits & kLvSparse, probe_now = bits & kLvProbe;
+			const bool lanes_level = sparse_level && lanes_ok;
+			ran_plan.push_back((uint8_t)bits);
 			if (sparse_level && !lanes_level && hc.pad2 > last_cw_cap)
 				return fail(PGQ_ERR_HIP, "internal error: packed frontier holds " + std::to_string(hc.pad2) +
 				                             " words, expected at most " + std::to_string(last_cw_cap));
-			front_edges = hc.front_edges;
-			front_words = hc.front_words;
-			front_vertices = hc.front_vertices;
-			unresolved = hc.unresolved;
-			{ // fraction of lane-words that still hold an active lane (drives the sparse/dense choice)
-				int nzw = 0;
-				for (int w = 0; w < WD; w++) nzw += hc.act[act_sel][w] != 0;
-				active_frac = (double)nzw / WD;
-			}
-			if (probe_now && unresolved <= (u32)stop) { // the expansion kernels returned immediately
-				if (push) S.push_levels--;
-				else S.pull_levels--;
-				if (unresolved > 0) {
+			if (probe_now && hc.unresolved <= (u32)stop) { // the expansion kernels returned immediately
+				if (hc.unresolved > 0) {
 					hipLaunchKernelGGL(k_mark_deferred, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, sh->sres.as<int32_t>());
 					outp.deferred = true;
-					S.deferred_pairs += unresolved;
+					S.deferred_pairs += hc.unresolved;
 				}
-				break;
+				return 1;
 			}
+			if (push) S.push_levels++;
+			else S.pull_levels++;
 			S.levels++;
 			S.edges_scanned += (int64_t)hc.edges_scanned;
 			S.word_gathers += (int64_t)hc.word_gathers;
 			S.frontier_vertices += (int64_t)hc.front_vertices;
-			// algorithmic bytes of this level's expansion kernel
+			// algorithmic bytes of this level's kernels
 			if (push) {
 				S.algo_bytes[K_PUSH] += (double)hc.edges_scanned * 4.0 + (double)hc.word_gathers * 16.0;
 			} else {
@@ -1745,18 +2007,121 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				if (lanes_level) // 4 B per in-slot, one 16-byte record per in-edge leaving a frontier vertex, seen read + next/seen written
 					S.algo_bytes[K_PULL_SPARSE] += (double)hc.edges_scanned * 4.0 + (double)hc.word_gathers * 16.0 + (double)V * (4.0 + 24.0 * WD);
 				else
-				S.algo_bytes[sparse_level ? K_PULL_SPARSE : K_PULL] +=
-				    (double)hc.edges_scanned * 8.0 + (double)hc.word_gathers * 8.0 +
-				    (double)V * (20.0 + 16.0 * WD) + (sparse_level ? (double)hc.word_gathers * 8.0 + (double)V * 4.0 : 0.0);
+					S.algo_bytes[sparse_level ? K_PULL_SPARSE : K_PULL] +=
+					    (double)hc.edges_scanned * 8.0 + (double)hc.word_gathers * 8.0 +
+					    (double)V * (20.0 + 16.0 * WD) + (sparse_level ? (double)hc.word_gathers * 8.0 + (double)V * 4.0 : 0.0);
 			}
+			// detection / probe: the rows' result words, lane ids and destinations (12 B per row of the batch) and, per row
+			// still open, the 4-byte mask look-up and the 8-byte frontier word (detection), or its destination's in-list with
+			// the two look-ups per entry (probe: mean in-degree x 16 B)
+			S.algo_bytes[K_DETECT] += (double)(hi - lo) * 12.0 +
+			                          (double)open_before * (probe_now ? (double)E / (double)std::max<int64_t>(V, 1) * 16.0 : 12.0);
 			if (opt.trace)
-				fprintf(stderr, "[pgq] batch %d level %d %s WD=%d front_v=%u front_e=%llu scanned=%llu gathers=%llu unresolved=%u push_ms=%.3f pull_ms=%.3f\n",
-				        b, t, push ? "push" : (lanes_level ? "pull_lanes" : (sparse_level ? "pull_sparse" : "pull")), WD, hc.front_vertices, (unsigned long long)hc.front_edges,
+				fprintf(stderr, "[pgq] batch %d level %d %s%s WD=%d front_v=%u front_e=%llu scanned=%llu gathers=%llu unresolved=%u push_ms=%.3f pull_ms=%.3f\n",
+				        b, t, probe_now ? "probe+" : "", push ? "push" : (lanes_level ? "pull_lanes" : (sparse_level ? "pull_sparse" : "pull")), WD, hc.front_vertices, (unsigned long long)hc.front_edges,
 				        (unsigned long long)hc.edges_scanned, (unsigned long long)hc.word_gathers, hc.unresolved,
 				        S.kernel_ms[K_PUSH], S.kernel_ms[K_PULL] + S.kernel_ms[K_PULL_HUB] + S.kernel_ms[K_PULL_SPARSE]);
-			cur = nxt;
+			open_before = hc.unresolved;
 			levels_run = t;
+			return 0;
+		};
+
+		LevelLog last {}; // the counters after the last level the host knows about
+		bool batch_over = false;
+		int t = 1;
+		// ---- levels enqueued ahead under the plan of the batch before ----
+		std::vector<uint8_t> plan;
+		if (spec_ok) {
+			std::lock_guard<std::mutex> g(c->plan_lock);
+			plan = c->level_plan[plan_slot];
 		}
+		bool have_last = false;
+		if (!plan.empty()) {
+			std::vector<HostState> snaps;
+			u32 *status = reinterpret_cast<u32 *>(ws->h_log + kSpecLevels + 2);
+			status[0] = status[1] = 0;
+			int prev_stop = -1, K = 0;
+			for (; K < (int)plan.size() && K < kSpecLevels; K++) {
+				const u32 bits = plan[(size_t)K];
+				if ((bits & kLvSparse) && !lanes_ok) break; // k_pull_sparse sizes a buffer from the frontier's words: not ahead of the host
+				save_dirty(hs);
+				snaps.push_back(hs);
+				PGQ_TRY(enqueue_level(K + 1, bits, true, prev_stop));
+				prev_stop = (bits & kLvProbe) ? stop : -1;
+			}
+			save_dirty(hs);
+			snaps.push_back(hs);
+			{ // behind the last enqueued level: log its counters, say whether the batch is over
+				SpecArgs sp { ws->h_log, status, K + 1, kLvNone, prev_stop };
+				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(64), 0, st, d_cnt, hs.act_sel ^ 1, 0, 0, rule, sp,
+				                   hs.pending_fold ? ws->dpart.as<u64>() : (u64 *)nullptr);
+			}
+			PGQ_WAIT(st);
+			KernelTimer::flush();
+			S.spec_batches++;
+			const u32 code = status[0];
+			const int t_stop = (int)status[1]; // levels 1 .. t_stop - 1 ran; log[k] = the counters after level k
+			if (code == 0 || t_stop < 1 || t_stop > K + 1) return fail(PGQ_ERR_HIP, "internal error: enqueued-ahead levels left no status");
+			open_before = (u32)(hi - lo);
+			for (int k = 1; k < t_stop && !batch_over; k++) {
+				const int r = post_level(k, plan[(size_t)k - 1], ws->h_log[k]);
+				if (r < 0) return r;
+				batch_over = r == 1;
+			}
+			if (!batch_over) {
+				if (code == 1) {
+					batch_over = true; // nothing open or an empty frontier: the loop below would not be entered
+				} else { // the plan did not fit (2) or ran out (3): the host takes over at level t_stop
+					hs = snaps[(size_t)t_stop - 1];
+					hs.pending_fold = false; // the k_level_reset that called the levels off had folded them already
+					load_dirty(hs);
+					last = ws->h_log[t_stop - 1];
+					have_last = true;
+					t = t_stop;
+					PGQ_HIP_TRY(hipMemsetAsync(&d_cnt->done, 0, 4, st));
+					S.spec_aborts++;
+				}
+			}
+			if (t_stop >= 1) S.spec_levels += t_stop - 1;
+		}
+		if (!batch_over && !have_last) {
+			PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+			PGQ_WAIT(st);
+			last.front_edges = ws->h_cnt->front_edges;
+			last.front_words = ws->h_cnt->front_words;
+			last.front_vertices = ws->h_cnt->front_vertices;
+			last.unresolved = (u32)(hi - lo);
+			last.nzw = WD;
+			open_before = last.unresolved;
+		}
+		// ---- one host round trip per level ----
+		for (; !batch_over && last.unresolved > 0 && last.front_edges > 0; t++) {
+			const u32 bits = decide_level(rule, last.front_edges, last.front_words, last.front_vertices, last.unresolved,
+			                              t == 1 ? WD : (int)last.nzw);
+			sparse_front_words = last.front_words;
+			PGQ_TRY(enqueue_level(t, bits, false, -1));
+			PGQ_HIP_TRY(hipMemcpyAsync(ws->h_cnt, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+			PGQ_WAIT(st);
+			KernelTimer::flush();
+			const Counters &hc = *ws->h_cnt;
+			last.front_edges = hc.front_edges;
+			last.edges_scanned = hc.edges_scanned;
+			last.word_gathers = hc.word_gathers;
+			last.front_vertices = hc.front_vertices;
+			last.unresolved = hc.unresolved;
+			last.front_words = hc.front_words;
+			last.pad2 = hc.pad2;
+			last.nzw = 0;
+			for (int w = 0; w < WD; w++) last.nzw += hc.act[hs.act_sel][w] != 0;
+			const int r = post_level(t, bits, last);
+			if (r < 0) return r;
+			batch_over = r == 1;
+		}
+		if (spec_ok && !ran_plan.empty()) {
+			std::lock_guard<std::mutex> g(c->plan_lock);
+			c->level_plan[plan_slot] = ran_plan;
+		}
+		cur = hs.cur;
 		if (outp.want_te)
 			hipLaunchKernelGGL(k_pair_te, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
 			                   sh->sres.as<int32_t>(), base_lane, ws->lane_sums.as<u64>(), (int)L, levels_run + 1,
@@ -1768,7 +2133,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			h_off.resize(cnt_pairs);
 			PGQ_HIP_TRY(hipMemcpyAsync(h_res.data(), sh->sres.as<int32_t>() + lo, (size_t)cnt_pairs * 4,
 			                           hipMemcpyDeviceToHost, st));
-			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			PGQ_WAIT(st);
 			int64_t need = child_base;
 			for (int64_t i = 0; i < cnt_pairs; i++) {
 				h_off[i] = need;
@@ -1785,7 +2150,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				PGQ_TRY(bigger.reserve((size_t)need * 8 * 2));
 				if (child_base > 0)
 					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, sh->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
-				PGQ_HIP_TRY(hipStreamSynchronize(st));
+				PGQ_WAIT(st);
 				sh->child.release();
 				sh->child = bigger;
 				d_child = sh->child.as<int64_t>();
@@ -1802,7 +2167,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				                   sh->soff.as<int64_t>(), base_lane, (const u64 *const *)sh->levels_tab.p, c->roff,
 				                   c->radj, c->off, c->adj, c->edge_ids, d_child);
 				kt.stop();
-				PGQ_HIP_TRY(hipStreamSynchronize(st)); // tab is a stack vector
+				PGQ_WAIT(st); // tab is a stack vector
 				KernelTimer::flush();
 			}
 			if (!fits) child_overflow = true;
@@ -1821,7 +2186,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				PGQ_TRY(bigger.reserve((size_t)need * 8));
 				if (child_base > 0)
 					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, sh->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
-				PGQ_HIP_TRY(hipStreamSynchronize(st));
+				PGQ_WAIT(st);
 				sh->child.release();
 				sh->child = bigger;
 			}
@@ -1839,7 +2204,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		// reports everything the caller must provide
 		if (child_overflow) outp.overflow = true;
 	}
-	PGQ_HIP_TRY(hipStreamSynchronize(st)); // other workers / the caller read sres next
+	PGQ_WAIT(st); // other workers / the caller read sres next
 	KernelTimer::flush();
 	return PGQ_OK;
 }
@@ -1853,6 +2218,10 @@ void merge_stats(pgq_stats_t &into, const pgq_stats_t &from) {
 	into.word_gathers += from.word_gathers;
 	into.frontier_vertices += from.frontier_vertices;
 	into.deferred_pairs += from.deferred_pairs;
+	into.spec_batches += from.spec_batches;
+	into.spec_levels += from.spec_levels;
+	into.spec_aborts += from.spec_aborts;
+	into.host_waits += from.host_waits;
 	for (int k = 0; k < PGQ_KCLASS_MAX; k++) {
 		into.algo_bytes[k] += from.algo_bytes[k];
 		into.kernel_ms[k] += from.kernel_ms[k];
@@ -1942,7 +2311,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			DevBuf bigger;
 			PGQ_TRY(bigger.reserve((size_t)need * 8));
 			if (total > 0) PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
-			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			PGQ_WAIT(st);
 			ws->child.release();
 			ws->child = bigger;
 			d_child = ws->child.as<int64_t>();
@@ -1952,7 +2321,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 				PGQ_HIP_TRY(hipMemcpyAsync(d_child + total, inner.ws->child.p, (size_t)so2.child_used * 8,
 				                           hipMemcpyDeviceToDevice, st));
 			PGQ_TRY(meet_apply_paths(ws, nd, ws->def_len.as<int64_t>(), ws->def_off.as<int64_t>(), total, d_out_len, d_out_off));
-			PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+			PGQ_WAIT(st); // the inner workspace goes back to the pool after this
 			KernelTimer::flush();
 		}
 		outp.child_used = need;
@@ -1976,7 +2345,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			PGQ_TRY(search_device(c, inner.ws, nd, ws->open_src, ws->open_dst,
 			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
 			PGQ_TRY(meet_apply(ws, nd, ws->def_len.as<int64_t>(), d_out_len));
-			PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+			PGQ_WAIT(st); // the inner workspace goes back to the pool after this
 		}
 		return PGQ_OK;
 	};
@@ -1994,24 +2363,51 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			PGQ_TRY(search_device(c, inner.ws, nd, ws->open_src, ws->open_dst,
 			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
 			PGQ_TRY(meet_apply(ws, nd, ws->def_len.as<int64_t>(), d_out_len));
-			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			PGQ_WAIT(st);
 		}
 		return PGQ_OK;
 	}
+	bool sampled = false; // the sampled decision was asked for without the chain: read it after the next wait
 	if (may_meet && meet_pays(std::min<int64_t>(n, c->V))) {
-		bool ran = true;
-		PGQ_TRY(run_meet(&ran));
-		if (ran) return PGQ_OK;
+		bool skip = false;
+		if (decide && mopt.route_memo) {
+			std::lock_guard<std::mutex> g(c->plan_lock);
+			const pgq_csr::RouteMemo &m = c->route_memo;
+			skip = m.n == n && m.src == (const void *)d_src && m.dst == (const void *)d_dst && m.go == 0;
+		}
+		if (skip) {
+			PGQ_TRY(meet_sample_async(c, ws, n, d_src, meet_bytes, edge_bytes));
+			sampled = true;
+		} else {
+			bool ran = true;
+			PGQ_TRY(run_meet(&ran));
+			if (decide) {
+				std::lock_guard<std::mutex> g(c->plan_lock);
+				c->route_memo.n = n;
+				c->route_memo.src = d_src;
+				c->route_memo.dst = d_dst;
+				c->route_memo.go = ran ? 1 : 0;
+			}
+			if (ran) return PGQ_OK;
+		}
 	}
 	u32 U = 0;
 	// the accounting pass counts the full BFS of a pair even when dst has no in-edge, so it keeps those lanes
-	PGQ_TRY(prepare_lanes(c, ws, n, d_src, d_dst, &U, !outp.want_te));
+	PGQ_TRY(lane_ranks(c, ws, n, d_src, d_dst, &U, !outp.want_te));
+	if (sampled) { // (lane_ranks has waited for the stream) what the sample says about these rows decides the next call's route
+		const u32 v = *reinterpret_cast<const u32 *>(static_cast<const char *>(ws->h_meet) + 4104);
+		if (v == 2) {
+			std::lock_guard<std::mutex> g(c->plan_lock);
+			c->route_memo.go = 1;
+		}
+	}
 	S.unique_sources += U;
 	if (with_paths) PGQ_HIP_TRY(hipMemsetAsync(ws->soff.p, 0, (size_t)n * 8, st));
 	const int wd = choose_words(U);
 	const int64_t Lb = 64 * (int64_t)wd;
 	const int nb = (int)((U + Lb - 1) / Lb);
-	PGQ_TRY(batch_bounds(ws, n, Lb, nb));
+	bool identity = false; // the rows were left in the caller's order (one batch): no permutation to undo
+	PGQ_TRY(lane_rows_bfs(c, ws, n, d_src, d_dst, !outp.want_te, Lb, nb, !with_paths && !outp.want_te && mopt.sort_single_batch == 0, &identity));
 	auto run = [&](Workspace *priv, int b0, int bstride, SearchOutput &o) -> int {
 		switch (wd) {
 		case 1: return run_batches<1>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);
@@ -2082,7 +2478,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		                   ws->def_dst.as<int64_t>(), ws->def_idx.as<u32>(), d_count);
 		u32 nd = 0;
 		PGQ_HIP_TRY(hipMemcpyAsync(&nd, d_count, 4, hipMemcpyDeviceToHost, st));
-		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		PGQ_WAIT(st);
 		if (nd > 0) {
 			WorkspaceLease inner;
 			PGQ_TRY(inner.acquire());
@@ -2112,7 +2508,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 						DevBuf bigger;
 						PGQ_TRY(bigger.reserve((size_t)need * 8));
 						if (base > 0) PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)base * 8, hipMemcpyDeviceToDevice, st));
-						PGQ_HIP_TRY(hipStreamSynchronize(st));
+						PGQ_WAIT(st);
 						ws->child.release();
 						ws->child = bigger;
 					}
@@ -2125,7 +2521,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 					hipLaunchKernelGGL(k_apply_deferred, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd,
 					                   ws->def_idx.as<u32>(), ws->def_len.as<int64_t>(), ws->sres.as<int32_t>(),
 					                   ws->def_off.as<int64_t>(), ws->soff.as<int64_t>(), base);
-					PGQ_HIP_TRY(hipStreamSynchronize(st)); // the inner workspace goes back to the pool after this
+					PGQ_WAIT(st); // the inner workspace goes back to the pool after this
 					outp.child_used = need;
 				} else { // lengths of the stragglers are still reported
 					hipLaunchKernelGGL(k_apply_deferred, dim3(blocks_for(nd)), dim3(256), 0, st, (int64_t)nd,
@@ -2137,9 +2533,9 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		}
 	}
 	// results back to row order even when the child buffer overflowed (lengths are still right)
-	hipLaunchKernelGGL(k_scatter_results, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->sidx.as<u32>(), ws->sres.as<int32_t>(),
+	hipLaunchKernelGGL(k_scatter_results, dim3(blocks_for(n)), dim3(256), 0, st, n, identity ? nullptr : ws->sidx.as<u32>(), ws->sres.as<int32_t>(),
 	                   ws->soff.as<int64_t>(), d_out_len, with_paths ? d_out_off : nullptr);
-	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	PGQ_WAIT(st);
 	KernelTimer::flush();
 	if (rc == PGQ_OK && outp.overflow)
 		rc = fail(PGQ_ERR_INVALID_ARG, "child buffer too small: need " + std::to_string(outp.child_used) + " elements");

@@ -174,6 +174,10 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "probe2_abs", &o.probe2_abs, nullptr },
 		{ "probe_always", &o.probe_always, nullptr },
 		{ "detect_grid_mult", &o.detect_grid_mult, nullptr },
+		{ "sort_single_batch", &o.sort_single_batch, nullptr },
+		{ "spec_levels", &o.spec_levels, nullptr },
+		{ "route_memo", &o.route_memo, nullptr },
+		{ "detect_unroll", &o.detect_unroll, nullptr },
 		{ "part_weight", &o.part_weight, nullptr },
 		{ "sparse_below", nullptr, &o.sparse_below },
 		{ "sparse_unroll", &o.sparse_unroll, nullptr },

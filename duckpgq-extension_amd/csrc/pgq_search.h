@@ -9,6 +9,7 @@ namespace pgq {
 
 static constexpr u32 kNoLane = 0xFFFFFFFFu;   // NULL rows
 static constexpr u32 kTrivial = 0xFFFFFFFEu;  // src == dst rows (no search needed)
+static constexpr int kSpecLevels = 61;        // levels of a batch enqueued ahead of the host at most (the pinned log holds 64 entries)
 
 struct Counters {
 	u32 q_count[2];      // work items in the frontier queues (by level parity)
@@ -20,9 +21,65 @@ struct Counters {
 	u32 front_words;     // non-empty lane-words of the frontier just produced
 	u32 pad;             // packed frontier: records written ...
 	u32 pad2;            // ... and overflow words written (k_compact_frontier totals)
-	u32 pad3;
+	u32 done;            // levels enqueued ahead (spec_levels): set by k_level_reset when the batch is over (1), when the level's
+	                     // plan is not what the counters call for (2) or when the plan has run out (3); every level kernel returns at once
+	u32 ticket;          // workgroups of k_detect / k_probe that have stored their open-lane words (publish_open_lanes)
+	u32 r1[3];
 	u64 act[2][32];      // active-lane masks (lanes that still have open pairs), double buffered
 };
+
+#ifdef __HIPCC__
+// A level kernel has nothing to do when the batch is over on the device's own account (`done`) or when the probe before
+// it left at most `stop_limit` rows open (the host defers them).
+__device__ __forceinline__ bool level_is_off(const Counters *__restrict__ cnt, int stop_limit) {
+	return cnt->done != 0 || (stop_limit >= 0 && cnt->unresolved <= (u32)stop_limit);
+}
+#endif
+
+// What a level's kernels leave in the counter block, as the host needs it after the level (read back per level, or logged
+// by the next level's k_level_reset into pinned memory when levels are enqueued ahead).
+struct LevelLog {
+	u64 front_edges, edges_scanned, word_gathers;
+	u32 front_vertices, unresolved, front_words, pad2;
+	u32 nzw; // non-empty words of the active-lane mask
+	u32 r0;
+};
+
+// The per-level choices (top-down / bottom-up sparse / bottom-up dense, probe first or detect after) as one function of
+// the counters, shared by the host loop and by k_level_reset, which checks an enqueued-ahead level against it.
+struct LevelRule {
+	double E, V, push_div, sparse_below;
+	int wd, force_mode, force_pull, probe_always, use_probe;
+};
+enum : u32 { kLvPush = 1, kLvSparse = 2, kLvProbe = 4, kLvNone = 0x80 };
+__host__ __device__ static inline u32 decide_level(const LevelRule &r, u64 front_edges, u32 front_words, u32 front_vertices,
+                                                   u32 unresolved, int nzw) {
+	bool push = r.force_mode == 1 || (r.force_mode == 0 && (double)front_edges * r.push_div < r.E);
+	if (r.force_mode == 2) push = false;
+	// expected wanted non-empty words per scanned in-edge: share of edges leaving frontier vertices x non-empty words per
+	// frontier vertex x share of lane-words that still hold an active lane
+	const double active_frac = (double)nzw / (double)r.wd;
+	const double wpn = (double)front_edges / (r.E > 1.0 ? r.E : 1.0) *
+	                   ((double)front_words / (double)(front_vertices > 1u ? front_vertices : 1u)) * active_frac;
+	const bool sparse = !push && (r.force_pull == 1 || (r.force_pull == 0 && wpn < r.sparse_below));
+	// The probe answers the pairs at distance t from frontier t-1 (one in-list scan per open pair) BEFORE level t is
+	// expanded.  That only pays when it can spare an expensive expansion: before a top-down level (tiny) or a sparse
+	// bottom-up level it costs more than it saves (cross product of 2048 sources x 32 destinations on the SF100-shaped
+	// graph: the probes of levels 1 and 2 took 0.6 ms and spared nothing), before a DENSE bottom-up level (1.5 ms at WD = 32)
+	// it answers what that level would have been run for.  Few open pairs: always.  In bytes at the rate the expansion
+	// kernels stream: a probe is one latency-bound wavefront per open pair (measured 4.7 ns per pair at mean in-degree 89:
+	// ~256 B per in-edge); a dense level moves ~E (8 + 6 WD), a sparse one ~4 E + 16 per frontier out-edge + V (4 + 24 WD), a
+	// top-down one ~20 per frontier out-edge.
+	bool probe = false;
+	if (r.use_probe) {
+		const double probe_bytes = (double)unresolved * (r.E / (r.V > 1.0 ? r.V : 1.0)) * 256.0;
+		const double level_bytes = push ? (double)front_edges * 20.0
+		                                : (!sparse ? r.E * (8.0 + 6.0 * r.wd)
+		                                           : r.E * 4.0 + (double)front_edges * 16.0 + r.V * (4.0 + 24.0 * r.wd));
+		probe = r.probe_always || probe_bytes <= level_bytes;
+	}
+	return (push ? kLvPush : 0u) | (sparse ? kLvSparse : 0u) | (probe ? kLvProbe : 0u);
+}
 
 
 struct LevelBuf {
@@ -36,9 +93,11 @@ struct Workspace {
 	int device = 0; // where its buffers live (workspaces are pooled per device)
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
-	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, def_ent, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps, meet_trace, wb_scratch, hv, hmask, hstart, hmap;
+	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, def_ent, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps, meet_trace, wb_scratch, hv, hmask, hstart, hmap,
+	    route_dec, dpart; // [kOpenGrid][WD + 1]: every workgroup's open-lane words + open-row count of the level's detection / probe
 	std::vector<std::unique_ptr<LevelBuf>> levels;
 	Counters *h_cnt = nullptr; // pinned
+	LevelLog *h_log = nullptr; // pinned: [kSpecLevels + 2] counters per enqueued-ahead level, then two status words
 	int64_t wb_V = -1;  // what wb_scratch's label arrays are initialised for
 	int wb_grid = 0;
 	void *h_meet = nullptr;    // pinned, 8 KB: the last workgroup of the pre-pass chain writes its statistics here
@@ -101,6 +160,8 @@ struct MeetPathsOut {
 };
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, MeetPathsOut *po, bool decide, double meet_bytes, double edge_bytes, bool *ran);
+// the pre-pass's sampled decision alone, not waited for (verdict + 1 lands in the pinned word h_meet[4104])
+int meet_sample_async(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes);
 // iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its
 // caps are compacted like the pre-pass's open rows
 int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,

@@ -232,6 +232,10 @@ typedef struct pgq_stats {
 	double algo_bytes[PGQ_KCLASS_MAX]; /* algorithmic bytes per kernel class (DESIGN.md formulas) */
 	double kernel_ms[PGQ_KCLASS_MAX];  /* HIP-event time per kernel class (profile=1) */
 	int64_t launches[PGQ_KCLASS_MAX];
+	int64_t spec_batches;     /* lane batches whose levels were enqueued ahead of the host (one wait per batch) */
+	int64_t spec_levels;      /* levels that ran that way */
+	int64_t spec_aborts;      /* batches whose enqueued levels were called off on the device (plan mismatch / too short) */
+	int64_t host_waits;       /* stream synchronisations of the lane-batched search (lane assignment, levels, results) */
 } pgq_stats_t;
 const char *pgq_kclass_name(int kclass); /* NULL past the last class */
 int pgq_get_stats(pgq_stats_t *out);

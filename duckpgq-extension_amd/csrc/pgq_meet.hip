@@ -104,13 +104,6 @@ struct MeetQueue {
 	u32 *count_back;
 	u32 cap;
 };
-struct MeetDecision {
-	u32 go;           // 1: the pre-pass runs
-	u32 sample_rows;  // non-NULL rows sampled
-	u32 sample_fresh; // distinct sources among them
-	u32 pad;
-	double estimate;  // distinct sources of the whole input
-};
 struct MeetDevBlock { // device side; all zero between calls
 	MeetCounters m;
 	u32 count[4]; // rows open after stage 1, 2, 3; [3]: stage 1's rows appended from the back of its queue
@@ -1185,67 +1178,9 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // strided sample of the rows goes through an LDS hash set, thread 0 inverts E[distinct] = U (1 - (1 - 1/U)^sample) and
 // compares the two cost estimates ON THE DEVICE: the pre-pass kernels are launched straight behind and return at once
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
-constexpr int kSampleRows = 2048, kSampleSlots = 4096;
-// h_go (nullable): pinned host word that gets the verdict + 1 (meet_sample_async: the host reads it after its next wait)
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
                                                      double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go) {
-	__shared__ u32 s_set[kSampleSlots];
-	__shared__ u32 s_count[2];
-	for (int k = threadIdx.x; k < kSampleSlots; k += 1024) s_set[k] = kMeetEmpty;
-	if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
-	__syncthreads();
-	const int64_t sample = n < kSampleRows ? n : kSampleRows;
-	// the sample = runs of 64 consecutive rows at evenly spaced offsets.  A join emits a cross product grouped by source:
-	// single rows at a fixed stride can land on a different source every time (stride = group size) and make it look
-	// like distinct pairs; inside a run a grouped input shows its repeats, and a shuffled one is sampled as well as by
-	// single rows
-	const double stride = (double)n / (double)((sample + 63) >> 6);
-	u32 fresh = 0, rows = 0;
-	for (int64_t k = threadIdx.x; k < sample; k += 1024) {
-		const int64_t v = src[min(n - 1, (int64_t)((double)(k >> 6) * stride) + (k & 63))];
-		if (v < 0) continue; // NULL row
-		rows++;
-		const u32 x = (u32)v;
-		u32 h = (x * 0x9E3779B1u) >> 20; // 12 bits
-		for (;;) {
-			const u32 old = atomicCAS(&s_set[h], kMeetEmpty, x);
-			if (old == kMeetEmpty) fresh++;
-			if (old == kMeetEmpty || old == x) break;
-			h = (h + 1) & (kSampleSlots - 1);
-		}
-	}
-	if (fresh) atomicAdd(&s_count[0], fresh);
-	if (rows) atomicAdd(&s_count[1], rows);
-	__syncthreads();
-	// E[distinct](U) = U (1 - (1 - 1/U)^s) is increasing in U: every thread evaluates one point of a geometric grid between
-	// the distinct sources seen and n ((1 - 1/U)^s as exp(s log1p(-1/U)), single precision) and the first point that
-	// reaches the sampled count is the estimate — round 3 bisected on one thread (18 dependent steps: 4 of the 16 us this
-	// kernel sits in front of every large call with)
-	__shared__ u32 s_first;
-	if (threadIdx.x == 0) s_first = 1023u;
-	__syncthreads();
-	const double d = s_count[0], sr = s_count[1];
-	double est;
-	if (sr < 1 || d < 1) {
-		est = 1;
-	} else if (d >= sr - 0.5) { // every sampled row had its own source
-		est = (double)n;
-	} else { // block-uniform branch
-		const float fd = (float)d, fs = (float)sr, fn = (float)n;
-		const float u = fd * __expf(__logf(fn / fd) * ((float)threadIdx.x * (1.0f / 1023.0f)));
-		const float e = u * (1.0f - __expf(fs * log1pf(-1.0f / u)));
-		if (e >= fd) atomicMin(&s_first, threadIdx.x);
-		__syncthreads();
-		const float uf = fd * __expf(__logf(fn / fd) * ((float)s_first * (1.0f / 1023.0f)));
-		est = fmin((double)n, ceil((double)uf));
-	}
-	if (threadIdx.x != 0) return;
-	const double distinct = fmin(est, (double)V);
-	out->go = meet_bytes <= lanes_cost_bytes(edge_bytes, distinct) ? 1u : 0u;
-	if (h_go) *h_go = out->go + 1u;
-	out->sample_rows = s_count[1];
-	out->sample_fresh = s_count[0];
-	out->estimate = est;
+	sample_distinct_sources(n, src, V, meet_bytes, edge_bytes, out, h_go);
 }
 
 __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
@@ -1513,18 +1448,6 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	S.algo_bytes[K_MEET4] += 4.0 * (double)h.entries[1] + 16.0 * (double)h.vertices[1] + 56.0 * (double)(h.count[0] + h.count_back);
 	S.algo_bytes[K_BIBFS] += 4.0 * (double)h.entries[2] + 16.0 * (double)h.vertices[2];
 	*n_open = open;
-	return PGQ_OK;
-}
-
-// The sampled decision alone, behind whatever the stream holds, without a wait: a call whose rows went to the lane
-// batches last time (search_device's route memo) skips the pre-pass chain — 4 launches that would return at once, and
-// their wait — but keeps asking; the verdict (+ 1) is in *pinned word* h_meet[4104] after the call's next wait.
-int meet_sample_async(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes) {
-	PGQ_TRY(ws->route_dec.reserve(sizeof(MeetDecision)));
-	u32 *h_go = reinterpret_cast<u32 *>(static_cast<char *>(ws->h_meet) + 4104);
-	*h_go = 0;
-	hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, ws->stream, n, d_src, c->V, meet_bytes, edge_bytes,
-	                   ws->route_dec.as<MeetDecision>(), h_go);
 	return PGQ_OK;
 }
 

@@ -83,24 +83,45 @@ __device__ __forceinline__ bool pair_needs_search(int64_t s, int64_t d, const in
 	return off[s + 1] > off[s] && (!dst_rule || roff[d + 1] > roff[d]);
 }
 
-__global__ void k_mark_sources(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                               u32 *__restrict__ flag, int64_t V, const int64_t *__restrict__ off,
-                               const int64_t *__restrict__ roff, int dst_rule, int *__restrict__ bad) {
+// sm.h_go != null: workgroup 0 also takes the pre-pass's sample of the distinct sources (a call the route memo sent
+// straight to the lane batches keeps asking whether its rows still look like a cross product; the verdict lands in pinned
+// memory and is read after the lane assignment's wait).  It rides in this launch: the other workgroups take as long anyway.
+struct SampleArgs {
+	double meet_bytes, edge_bytes;
+	MeetDecision *out;
+	u32 *h_go;
+};
+__global__ __launch_bounds__(256) void k_mark_sources(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                      u32 *__restrict__ flag, int64_t V, const int64_t *__restrict__ off,
+                                                      const int64_t *__restrict__ roff, int dst_rule, int *__restrict__ bad,
+                                                      SampleArgs sm) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	int64_t s = src[i], d = dst[i];
-	if (s < 0) return; // NULL row
-	if (s >= V || d < 0 || d >= V) {
-		*bad = 1;
-		return;
+	if (i < n) {
+		int64_t s = src[i], d = dst[i];
+		if (s >= 0) { // not a NULL row
+			if (s >= V || d < 0 || d >= V) *bad = 1;
+			else if (s != d && pair_needs_search(s, d, off, roff, dst_rule)) flag[s] = 1;
+		}
 	}
-	if (s != d && pair_needs_search(s, d, off, roff, dst_rule)) flag[s] = 1;
+	if (sm.h_go && blockIdx.x == 0) sample_distinct_sources(n, src, V, sm.meet_bytes, sm.edge_bytes, sm.out, sm.h_go);
 }
 
+// h_out (pinned host memory, device-addressable): {distinct sources, range-check flag} — what the host waits for next, written
+// by the kernel itself instead of two copy commands behind it
 __global__ void k_compact_sources(int64_t V, const u32 *__restrict__ flag, const u32 *__restrict__ rank,
-                                  int32_t *__restrict__ usrc) {
+                                  int32_t *__restrict__ usrc, const int *__restrict__ bad, u32 *__restrict__ h_out) {
 	int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (v < V && flag[v]) usrc[rank[v]] = (int32_t)v;
+	if (v == 0) {
+		h_out[0] = rank[V];
+		h_out[1] = (u32)*bad;
+	}
+}
+// the flag array and the counter block of the lane assignment in one launch (two memsets were four fill dispatches)
+__global__ void k_prep_zero(u32 *__restrict__ flag, int64_t n_flag, u32 *__restrict__ cnt_words, int n_cnt) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_flag) flag[i] = 0;
+	if (i < n_cnt) cnt_words[i] = 0;
 }
 
 __global__ void k_pair_keys(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
@@ -231,15 +252,23 @@ __device__ __forceinline__ void publish_open_lanes(const u64 *s_act, const u32 *
 	}
 	if (threadIdx.x == 0 && *s_open) atomicAdd(&cnt->unresolved, *s_open);
 }
-// threads 0 .. wd-1 of one workgroup: mask[w] = OR of the copies, copies zeroed (the kernels that wrote them are done)
+// every thread of one workgroup (any size that is a multiple of 64): mask[w] = OR of the copies, copies zeroed (the kernels
+// that wrote them are done).  Thread t takes word t % wd of the copies t / wd, t / wd + blockDim / wd, ...: all its loads
+// are in flight together, the slices meet in LDS.  Returns nothing; ends with a barrier (the mask is written).
 __device__ __forceinline__ void fold_open_lanes(u64 *__restrict__ rep, u64 *__restrict__ mask, int wd) {
-	if ((int)threadIdx.x < wd) {
-		u64 acc = 0;
-#pragma unroll 8
-		for (int r = 0; r < kOpenRep; r++) acc |= rep[(size_t)r * wd + threadIdx.x];
-		for (int r = 0; r < kOpenRep; r++) rep[(size_t)r * wd + threadIdx.x] = 0;
-		mask[threadIdx.x] = acc;
+	__shared__ u64 s_fold[32];
+	if (threadIdx.x < 32) s_fold[threadIdx.x] = 0;
+	__syncthreads();
+	const int w = (int)threadIdx.x % wd, first = (int)threadIdx.x / wd, step = max(1, (int)blockDim.x / wd);
+	u64 acc = 0;
+	for (int r = first; r < kOpenRep; r += step) {
+		acc |= rep[(size_t)r * wd + w];
+		rep[(size_t)r * wd + w] = 0;
 	}
+	if (acc) atomicOr(&s_fold[w], acc);
+	__syncthreads();
+	if ((int)threadIdx.x < wd) mask[threadIdx.x] = s_fold[threadIdx.x];
+	__syncthreads();
 }
 __global__ void k_open_merge(u64 *__restrict__ rep, u64 *__restrict__ mask, int wd, const Counters *__restrict__ cnt) {
 	if (cnt->done) return;
@@ -263,18 +292,19 @@ struct SpecArgs {
 __global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero_q0, int zero_q1, LevelRule rule, SpecArgs sp,
                               u64 *__restrict__ fold_rep) {
 	const int t = threadIdx.x;
-	__shared__ int s_off;
+	__shared__ int s_off, s_nzw;
 	if (cnt->done) return;
-	if (fold_rep) { // the level before ended with k_detect: its open lanes are still in the copies
-		fold_open_lanes(fold_rep, &cnt->act[act_zero ^ 1][0], rule.wd);
-		__syncthreads();
-	}
+	if (fold_rep) fold_open_lanes(fold_rep, &cnt->act[act_zero ^ 1][0], rule.wd); // the level before ended with k_detect: its open lanes are still in the copies
 	if (sp.log) {
+		if (t < 64) { // the first wavefront counts the non-empty words of the mask
+			const u64 m = __ballot(t < rule.wd && cnt->act[act_zero ^ 1][t < rule.wd ? t : 0] != 0);
+			if (t == 0) s_nzw = __popcll(m);
+		}
+		__syncthreads();
 		if (t == 0) {
 			int off = 0;
 			{
-				int nzw = 0;
-				for (int w = 0; w < rule.wd; w++) nzw += cnt->act[act_zero ^ 1][w] != 0;
+				const int nzw = s_nzw;
 				LevelLog lg;
 				lg.front_edges = cnt->front_edges;
 				lg.edges_scanned = cnt->edges_scanned;
@@ -320,11 +350,41 @@ __global__ void k_level_reset(Counters *__restrict__ cnt, int act_zero, int zero
 	if (t < 32) cnt->act[act_zero][t] = 0;
 }
 
-// memset of a level buffer inside an enqueued-ahead level: must not run when the level does not
-__global__ void k_zero_unless_done(uint4 *__restrict__ p, size_t n16, const Counters *__restrict__ cnt) {
-	if (cnt->done) return;
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+// Frontier buffers that are only ever written through atomics (level 0, targets of top-down levels: the "sparse pool")
+// keep the invariant "a non-zero lane-word has its bit in nz[v]", so they are zeroed by walking nz — 4 bytes per vertex
+// read, only the flagged words written — instead of a memset of V x WD x 8 bytes (115 MB at SF100 / WD = 32) per use.
+__device__ __forceinline__ void clean_row_by_nz(u64 *__restrict__ buf, u32 *__restrict__ nz, int64_t v, int wd) {
+	u32 m = nz[v];
+	if (!m) return;
+	nz[v] = 0;
+	while (m) {
+		const int w = __ffs((int)m) - 1;
+		m &= m - 1;
+		buf[(size_t)v * wd + w] = 0;
+	}
+}
+// inside a level (the target of a top-down level whose last use left it dirty); cnt != null: an enqueued-ahead level,
+// which must leave the buffer alone when it does not run
+__global__ void k_clean_by_nz(u64 *__restrict__ buf, u32 *__restrict__ nz, int64_t V, int wd, const Counters *__restrict__ cnt) {
+	if (cnt && cnt->done) return;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) clean_row_by_nz(buf, nz, v, wd);
+}
+// One launch at the start of a batch instead of six fills: `seen` zeroed (streaming 16-byte stores), the counter block and
+// the copies of the open-lane mask zeroed, the dirty buffers of the sparse pool cleaned by their nz.
+__global__ __launch_bounds__(256) void k_batch_reset(uint4 *__restrict__ seen, size_t seen16, u32 *__restrict__ cnt_words, int n_cnt,
+                                                     u64 *__restrict__ rep, int n_rep, u64 *__restrict__ buf_a, u32 *__restrict__ nz_a,
+                                                     u64 *__restrict__ buf_b, u32 *__restrict__ nz_b, int64_t V, int wd) {
+	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = tid; i < seen16; i += stride) seen[i] = make_uint4(0, 0, 0, 0);
+	if (blockIdx.x == 0) {
+		for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) cnt_words[i] = 0;
+		for (int i = threadIdx.x; i < n_rep; i += blockDim.x) rep[i] = 0;
+	}
+	if (buf_a)
+		for (int64_t v = (int64_t)tid; v < V; v += (int64_t)stride) clean_row_by_nz(buf_a, nz_a, v, wd);
+	if (buf_b)
+		for (int64_t v = (int64_t)tid; v < V; v += (int64_t)stride) clean_row_by_nz(buf_b, nz_b, v, wd);
 }
 
 // ---- top-down level ----------------------------------------------------------------------------------------------
@@ -1064,11 +1124,14 @@ __global__ void k_pull_hub_fold(const int32_t *__restrict__ hubs, int64_t nh, co
 template <int WD, int UN>
 __global__ __launch_bounds__(1024) void k_detect(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const int32_t *__restrict__ sdst,
                                                  int32_t *__restrict__ sres, u32 base_lane, const u64 *__restrict__ front,
-                                                 const u32 *__restrict__ nz, int level, u64 *__restrict__ rep,
+                                                 const u32 *__restrict__ nz, int level, u32 dense_words, u64 *__restrict__ rep,
                                                  Counters *__restrict__ cnt) {
 	__shared__ u32 s_open;
 	__shared__ u64 s_act[WD];
 	if (level_is_off(cnt, -1)) return;
+	// a frontier with more than `dense_words` non-empty words (half of all): the mask look-up would let nearly every row
+	// through and only add a dependent round trip (level 3 of the SF100 cross product: 92 % of the rows are answered)
+	const bool filter = cnt->front_words <= dense_words;
 	if (threadIdx.x == 0) s_open = 0;
 	if (threadIdx.x < WD) s_act[threadIdx.x] = 0;
 	__syncthreads();
@@ -1094,7 +1157,7 @@ __global__ __launch_bounds__(1024) void k_detect(int64_t lo, int64_t hi, const u
 			if (!open[u]) l[u] = 0, d[u] = 0;
 		}
 #pragma unroll
-		for (int u = 0; u < UN; u++) m[u] = nz[d[u]];
+		for (int u = 0; u < UN; u++) m[u] = filter ? nz[d[u]] : 0xFFFFFFFFu;
 #pragma unroll
 		for (int u = 0; u < UN; u++) {
 			const int wq = (int)(l[u] >> 6);
@@ -1440,10 +1503,11 @@ Workspace::~Workspace() {
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
 	                   &def_idx, &def_off, &def_ent, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &wb_scratch, &dpart })
 		b->release();
-	for (auto &l : levels) {
-		l->buf.release();
-		l->nz.release();
-	}
+	for (auto *v : { &levels, &pool })
+		for (auto &l : *v) {
+			l->buf.release();
+			l->nz.release();
+		}
 }
 
 static std::mutex g_ws_lock;
@@ -1502,7 +1566,7 @@ WorkspaceLease::~WorkspaceLease() {
 // Stage 1: flag the distinct sources of the rows that need a search, rank them (= global lane ids), list them; the number
 // of distinct sources and the range check come back with ONE wait.
 static int lane_ranks(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out,
-                      bool dst_rule) {
+                      bool dst_rule, const SampleArgs &sm = SampleArgs { 0.0, 0.0, nullptr, nullptr }) {
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V;
 	PGQ_TRY(ws->flag.reserve((size_t)(V + 1) * 4));
@@ -1512,21 +1576,19 @@ static int lane_ranks(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src
 	PGQ_TRY(ws->soff.reserve((size_t)n * 8));
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
 	int *d_bad = reinterpret_cast<int *>(ws->counters.p); // reused before the batch loop resets it
-	PGQ_HIP_TRY(hipMemsetAsync(ws->flag.p, 0, (size_t)(V + 1) * 4, st));
-	PGQ_HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(Counters), st));
 	KernelTimer kt(st, K_PREP);
-	hipLaunchKernelGGL(k_mark_sources, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->flag.as<u32>(), V, c->off, c->roff, dst_rule ? 1 : 0, d_bad);
+	hipLaunchKernelGGL(k_prep_zero, dim3(blocks_for(V + 1)), dim3(256), 0, st, ws->flag.as<u32>(), V + 1, ws->counters.as<u32>(), (int)(sizeof(Counters) / 4));
+	hipLaunchKernelGGL(k_mark_sources, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->flag.as<u32>(), V, c->off, c->roff, dst_rule ? 1 : 0, d_bad, sm);
 	size_t tmp = 0;
 	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ws->flag.as<u32>(), ws->rank.as<u32>(), (int)(V + 1), st));
 	PGQ_TRY(ws->scan_tmp.reserve(tmp + 16));
 	PGQ_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp, ws->flag.as<u32>(), ws->rank.as<u32>(), (int)(V + 1), st));
-	if (V > 0)
-		hipLaunchKernelGGL(k_compact_sources, dim3(blocks_for(V)), dim3(256), 0, st, V, ws->flag.as<u32>(), ws->rank.as<u32>(), ws->usrc.as<int32_t>());
-	kt.stop();
-	// two words of the pinned counter block: no pageable staging on the way back
+	// the count and the range-check flag land in two words of the pinned counter block
 	u32 *h2 = reinterpret_cast<u32 *>(ws->h_cnt);
-	PGQ_HIP_TRY(hipMemcpyAsync(&h2[0], ws->rank.as<u32>() + V, 4, hipMemcpyDeviceToHost, st));
-	PGQ_HIP_TRY(hipMemcpyAsync(&h2[1], d_bad, 4, hipMemcpyDeviceToHost, st));
+	h2[0] = h2[1] = 0;
+	hipLaunchKernelGGL(k_compact_sources, dim3(blocks_for(std::max<int64_t>(V, 1))), dim3(256), 0, st, V, ws->flag.as<u32>(), ws->rank.as<u32>(), ws->usrc.as<int32_t>(),
+	                   d_bad, h2);
+	kt.stop();
 	PGQ_WAIT(st);
 	KernelTimer::flush();
 	if (h2[1]) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
@@ -1696,17 +1758,22 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		const u32 base_lane = (u32)((int64_t)b * L);
 		S.batches++;
 		// -- reset per-batch state
-		PGQ_HIP_TRY(hipMemsetAsync(ws->seen.p, 0, words * 8, st));
-		PGQ_HIP_TRY(hipMemsetAsync(ws->counters.p, 0, sizeof(Counters), st));
-		PGQ_HIP_TRY(hipMemsetAsync(ws->dpart.p, 0, (size_t)kOpenRep * WD * 8, st)); // the copies of the open-lane mask (publish_open_lanes)
-
-		auto level_buf = [&](int t) -> LevelBuf * {
-			size_t k = with_paths ? (size_t)t : (size_t)(t & 1);
-			while (ws->levels.size() <= k) ws->levels.emplace_back(new LevelBuf());
-			return ws->levels[k].get();
-		};
 		const size_t nz_bytes = (size_t)std::max<int64_t>(V, 1) * 4;
-		auto make_zero = [&](LevelBuf *lb) -> int {
+		// Frontier buffers.  shortestpath keeps every level's frontier (ws->levels[t]).  Otherwise two pools (ws->pool):
+		// [0], [1] "sparse" — level 0 and the targets of top-down levels, written through atomics only, kept all-zero between
+		// uses by walking their nz (k_batch_reset / k_clean_by_nz / k_clear_items); [2], [3] "dense" — targets of bottom-up
+		// levels, which write every row, so they are never zeroed.  A level's target is the buffer of its pool that is not
+		// the current frontier.  (Round 4: two buffers alternating, the top-down targets zeroed by a 115-MB memset per use.)
+		auto level_buf = [&](int t, bool push_target, const LevelBuf *not_this) -> LevelBuf * {
+			if (with_paths) {
+				while (ws->levels.size() <= (size_t)t) ws->levels.emplace_back(new LevelBuf());
+				return ws->levels[(size_t)t].get();
+			}
+			while (ws->pool.size() < 4) ws->pool.emplace_back(new LevelBuf());
+			LevelBuf *a = ws->pool[push_target ? 0 : 2].get();
+			return a != not_this ? a : ws->pool[push_target ? 1 : 3].get();
+		};
+		auto make_zero = [&](LevelBuf *lb) -> int { // shortestpath: a level's own buffer before a top-down level writes into it
 			PGQ_TRY(lb->buf.reserve(words * 8));
 			PGQ_TRY(lb->nz.reserve(nz_bytes));
 			if (lb->dirty) {
@@ -1716,9 +1783,44 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			}
 			return PGQ_OK;
 		};
-		for (auto &lb : ws->levels) lb->dirty = true; // previous batch / call left them in an unknown state
-		LevelBuf *cur = level_buf(0);
-		PGQ_TRY(make_zero(cur));
+		LevelBuf *cur = nullptr;
+		if (with_paths) {
+			PGQ_HIP_TRY(hipMemsetAsync(ws->seen.p, 0, words * 8, st));
+			PGQ_HIP_TRY(hipMemsetAsync(ws->counters.p, 0, sizeof(Counters), st));
+			PGQ_HIP_TRY(hipMemsetAsync(ws->dpart.p, 0, (size_t)kOpenRep * WD * 8, st)); // the copies of the open-lane mask (publish_open_lanes)
+			for (auto &lb : ws->levels) lb->dirty = true; // previous batch / call left them in an unknown state
+			cur = level_buf(0, true, nullptr);
+			PGQ_TRY(make_zero(cur));
+		} else {
+			cur = level_buf(0, true, nullptr);
+			u64 *cb[2] = { nullptr, nullptr };
+			u32 *cz[2] = { nullptr, nullptr };
+			for (int k = 0; k < 2; k++) {
+				LevelBuf *lb = ws->pool[(size_t)k].get();
+				PGQ_TRY(lb->buf.reserve(words * 8));
+				PGQ_TRY(lb->nz.reserve(nz_bytes));
+				// a buffer that is new, was laid out for another (V, WD), or belongs to a batch that did not end normally has no
+				// nz to be trusted: zeroed whole, once
+				if (lb->init_buf != lb->buf.p || lb->init_nz != lb->nz.p || lb->lay_V != V || lb->lay_WD != WD || !ws->pool_trusted) {
+					PGQ_HIP_TRY(hipMemsetAsync(lb->buf.p, 0, words * 8, st));
+					PGQ_HIP_TRY(hipMemsetAsync(lb->nz.p, 0, nz_bytes, st));
+					lb->init_buf = lb->buf.p;
+					lb->init_nz = lb->nz.p;
+					lb->lay_V = V;
+					lb->lay_WD = WD;
+					lb->dirty = false;
+				}
+				if (lb->dirty) {
+					cb[k] = lb->buf.as<u64>();
+					cz[k] = lb->nz.as<u32>();
+					lb->dirty = false;
+				}
+			}
+			ws->pool_trusted = false; // until this batch has ended normally
+			hipLaunchKernelGGL(k_batch_reset, dim3(8 * ncu), dim3(256), 0, st, ws->seen.as<uint4>(), (words * 8 + 15) / 16,
+			                   ws->counters.as<u32>(), (int)(sizeof(Counters) / 4), ws->dpart.as<u64>(), kOpenRep * WD, cb[0], cz[0],
+			                   cb[1], cz[1], V, WD);
+		}
 		u64 *act_cur = &d_cnt->act[0][0]; // zeroed with the counter block above
 		u32 open_before = (u32)(hi - lo); // rows open before the level whose counters are being looked at (byte model of detection)
 		u32 sparse_front_words = 0;       // k_pull_sparse sizes its packed-word buffer from the frontier's words
@@ -1767,10 +1869,10 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		};
 		HostState hs { cur, 0, 0, true, { false, false }, false }; // queue_valid: qbuf[par] describes `cur`
 		auto save_dirty = [&](HostState &h) {
-			for (size_t k = 0; k < 2 && k < ws->levels.size(); k++) h.dirty[k] = ws->levels[k]->dirty;
+			for (size_t k = 0; k < 2 && k < ws->pool.size(); k++) h.dirty[k] = ws->pool[k]->dirty;
 		};
 		auto load_dirty = [&](const HostState &h) {
-			for (size_t k = 0; k < 2 && k < ws->levels.size(); k++) ws->levels[k]->dirty = h.dirty[k];
+			for (size_t k = 0; k < 2 && k < ws->pool.size(); k++) ws->pool[k]->dirty = h.dirty[k];
 		};
 		u32 last_cw_cap = 0;
 		int levels_run = 0;
@@ -1780,18 +1882,16 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		// k_level_reset logs and checks on the device (SpecArgs) and its memsets are kernels that honour `done`.
 		auto enqueue_level = [&](int t, u32 bits, bool spec, int prev_stop) -> int {
 			LevelBuf *cur = hs.cur;
-			LevelBuf *nxt = level_buf(t);
 			const bool push = bits & kLvPush, sparse_level = bits & kLvSparse, probe_now = bits & kLvProbe;
+			LevelBuf *nxt = level_buf(t, push, cur);
 			const bool lanes_level = sparse_level && lanes_ok;
 			u64 *act_cur = &d_cnt->act[hs.act_sel][0], *act_nxt = &d_cnt->act[hs.act_sel ^ 1][0];
 			const int par = hs.par;
-			auto zero_level = [&](LevelBuf *lb) -> int {
-				if (!spec) return make_zero(lb);
-				PGQ_TRY(lb->buf.reserve(words * 8));
-				PGQ_TRY(lb->nz.reserve(nz_bytes));
-				if (lb->dirty) {
-					hipLaunchKernelGGL(k_zero_unless_done, dim3(4 * ncu), dim3(256), 0, st, lb->buf.as<uint4>(), (words * 8 + 15) / 16, d_cnt);
-					hipLaunchKernelGGL(k_zero_unless_done, dim3(ncu), dim3(256), 0, st, lb->nz.as<uint4>(), (nz_bytes + 15) / 16, d_cnt);
+			auto zero_level = [&](LevelBuf *lb) -> int { // the target of a top-down level
+				if (with_paths) return make_zero(lb);
+				if (lb->dirty) { // (its buffers exist and are laid out for this batch: the batch's start saw to both pool members)
+					hipLaunchKernelGGL(k_clean_by_nz, dim3(4 * ncu), dim3(256), 0, st, lb->buf.as<u64>(), lb->nz.as<u32>(), V, (int)WD,
+					                   spec ? (const Counters *)d_cnt : (const Counters *)nullptr);
 					lb->dirty = false;
 				}
 				return PGQ_OK;
@@ -1805,7 +1905,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					sp.log = ws->h_log;
 					sp.status = reinterpret_cast<u32 *>(ws->h_log + kSpecLevels + 2);
 				}
-				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(64), 0, st, d_cnt, hs.act_sel ^ 1,
+				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(256), 0, st, d_cnt, hs.act_sel ^ 1,
 				                   (int)((push && q_nxt == 0) || (zq_cur && q_cur == 0)),
 				                   (int)((push && q_nxt == 1) || (zq_cur && q_cur == 1)), rule, sp,
 				                   hs.pending_fold ? ws->dpart.as<u64>() : (u64 *)nullptr);
@@ -1825,7 +1925,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					                                       std::min<int64_t>(hi - lo, opt.probe2_abs)),
 					                   (int64_t)opt.probe2_cap, ws->dpart.as<u64>(), act_nxt, d_cnt);
 				else
-					hipLaunchKernelGGL(k_open_merge, dim3(1), dim3(64), 0, st, ws->dpart.as<u64>(), act_nxt, WD, d_cnt);
+					hipLaunchKernelGGL(k_open_merge, dim3(1), dim3(256), 0, st, ws->dpart.as<u64>(), act_nxt, WD, d_cnt);
 				kt.stop();
 				std::swap(act_cur, act_nxt); // the expansion below only serves lanes that still have open pairs
 				hs.act_sel ^= 1;
@@ -1959,15 +2059,15 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				const dim3 grid(std::min(blocks_for((hi - lo + un - 1) / un, 1024), (unsigned)std::min(kOpenGrid, std::max(1, opt.detect_grid_mult) * ncu / 4)));
 #define PGQ_DETECT(UNR)                                                                                                  \
 	hipLaunchKernelGGL((k_detect<WD, UNR>), grid, dim3(1024), 0, st, lo, hi, sh->skey.as<u32>(), sh->sdst.as<int32_t>(),   \
-	                   sh->sres.as<int32_t>(), base_lane, nxt->buf.as<u64>(), nxt->nz.as<u32>(), t, ws->dpart.as<u64>(),   \
-	                   d_cnt)
+	                   sh->sres.as<int32_t>(), base_lane, nxt->buf.as<u64>(), nxt->nz.as<u32>(), t,                       \
+	                   (u32)std::min<size_t>(words / 2, 0xFFFFFFFFu), ws->dpart.as<u64>(), d_cnt)
 				if (un == 4) PGQ_DETECT(4);
 				else if (un == 2) PGQ_DETECT(2);
 				else PGQ_DETECT(1);
 #undef PGQ_DETECT
 				// the words are folded into the mask by the next level's k_level_reset; the host loop reads the mask itself
 				if (spec) hs.pending_fold = true;
-				else hipLaunchKernelGGL(k_open_merge, dim3(1), dim3(64), 0, st, ws->dpart.as<u64>(), act_nxt, WD, d_cnt);
+				else hipLaunchKernelGGL(k_open_merge, dim3(1), dim3(256), 0, st, ws->dpart.as<u64>(), act_nxt, WD, d_cnt);
 				kt.stop();
 				hs.act_sel ^= 1;
 			}
@@ -2053,7 +2153,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			snaps.push_back(hs);
 			{ // behind the last enqueued level: log its counters, say whether the batch is over
 				SpecArgs sp { ws->h_log, status, K + 1, kLvNone, prev_stop };
-				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(64), 0, st, d_cnt, hs.act_sel ^ 1, 0, 0, rule, sp,
+				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(256), 0, st, d_cnt, hs.act_sel ^ 1, 0, 0, rule, sp,
 				                   hs.pending_fold ? ws->dpart.as<u64>() : (u64 *)nullptr);
 			}
 			PGQ_WAIT(st);
@@ -2068,13 +2168,14 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				if (r < 0) return r;
 				batch_over = r == 1;
 			}
+			// what the device really did: levels 1 .. t_stop - 1 (the kernels enqueued behind them returned at once)
+			hs = snaps[(size_t)t_stop - 1];
+			hs.pending_fold = false; // the k_level_reset that called the levels off had folded them already
+			load_dirty(hs);
 			if (!batch_over) {
 				if (code == 1) {
 					batch_over = true; // nothing open or an empty frontier: the loop below would not be entered
 				} else { // the plan did not fit (2) or ran out (3): the host takes over at level t_stop
-					hs = snaps[(size_t)t_stop - 1];
-					hs.pending_fold = false; // the k_level_reset that called the levels off had folded them already
-					load_dirty(hs);
 					last = ws->h_log[t_stop - 1];
 					have_last = true;
 					t = t_stop;
@@ -2122,6 +2223,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			c->level_plan[plan_slot] = ran_plan;
 		}
 		cur = hs.cur;
+		ws->pool_trusted = true; // the dirty flags of the sparse pool say what the device did
 		if (outp.want_te)
 			hipLaunchKernelGGL(k_pair_te, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, sh->skey.as<u32>(),
 			                   sh->sres.as<int32_t>(), base_lane, ws->lane_sums.as<u64>(), (int)L, levels_run + 1,
@@ -2376,8 +2478,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			skip = m.n == n && m.src == (const void *)d_src && m.dst == (const void *)d_dst && m.go == 0;
 		}
 		if (skip) {
-			PGQ_TRY(meet_sample_async(c, ws, n, d_src, meet_bytes, edge_bytes));
-			sampled = true;
+			sampled = true; // taken inside the lane assignment's first launch (k_mark_sources)
 		} else {
 			bool ran = true;
 			PGQ_TRY(run_meet(&ran));
@@ -2393,7 +2494,14 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	}
 	u32 U = 0;
 	// the accounting pass counts the full BFS of a pair even when dst has no in-edge, so it keeps those lanes
-	PGQ_TRY(lane_ranks(c, ws, n, d_src, d_dst, &U, !outp.want_te));
+	SampleArgs sm { meet_bytes, edge_bytes, nullptr, nullptr };
+	if (sampled) {
+		PGQ_TRY(ws->route_dec.reserve(sizeof(MeetDecision)));
+		sm.out = ws->route_dec.as<MeetDecision>();
+		sm.h_go = reinterpret_cast<u32 *>(static_cast<char *>(ws->h_meet) + 4104);
+		*sm.h_go = 0;
+	}
+	PGQ_TRY(lane_ranks(c, ws, n, d_src, d_dst, &U, !outp.want_te, sm));
 	if (sampled) { // (lane_ranks has waited for the stream) what the sample says about these rows decides the next call's route
 		const u32 v = *reinterpret_cast<const u32 *>(static_cast<const char *>(ws->h_meet) + 4104);
 		if (v == 2) {

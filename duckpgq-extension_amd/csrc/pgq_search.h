@@ -36,6 +36,95 @@ __device__ __forceinline__ bool level_is_off(const Counters *__restrict__ cnt, i
 }
 #endif
 
+// bytes (at streaming rate) the lane-batched search is priced at for `distinct` sources: full 2048-lane batches of 32
+// lane-words plus one narrower batch for the rest, E x (12 + 3 wd) each; `edge_bytes` = meet_bias x E.  Shared by the
+// host-side decision (few rows) and k_meet_decide (sampled distinct sources).
+__host__ __device__ static inline double lanes_cost_bytes(double edge_bytes, double distinct) {
+	const double full = floor(distinct / 2048.0), rest = distinct - full * 2048.0;
+	double wd = 0.0;
+	if (rest > 0.0) {
+		wd = 1.0;
+		while (wd * 64.0 < rest) wd *= 2.0;
+	}
+	return edge_bytes * (full * (12.0 + 3.0 * 32.0) + (rest > 0.0 ? 12.0 + 3.0 * wd : 0.0));
+}
+
+// ---- how many distinct sources? (the pre-pass's sampled decision; pgq_meet.hip and the lane assignment both run it) ----
+struct MeetDecision {
+	u32 go;           // 1: the pre-pass runs
+	u32 sample_rows;  // non-NULL rows sampled
+	u32 sample_fresh; // distinct sources among them
+	u32 pad;
+	double estimate;  // distinct sources of the whole input
+};
+#ifdef __HIPCC__
+constexpr u32 kSampleEmpty = 0xFFFFFFFFu;
+constexpr int kSampleRows = 2048, kSampleSlots = 4096;
+// Every thread of ONE workgroup (any multiple of 64 threads).  h_go (nullable): pinned host word that gets the verdict + 1.
+__device__ __forceinline__ void sample_distinct_sources(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
+                                                        double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go) {
+	const int nt = (int)blockDim.x;
+	__shared__ u32 s_set[kSampleSlots];
+	__shared__ u32 s_count[2];
+	for (int k = threadIdx.x; k < kSampleSlots; k += nt) s_set[k] = kSampleEmpty;
+	if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
+	__syncthreads();
+	const int64_t sample = n < kSampleRows ? n : kSampleRows;
+	// the sample = runs of 64 consecutive rows at evenly spaced offsets.  A join emits a cross product grouped by source:
+	// single rows at a fixed stride can land on a different source every time (stride = group size) and make it look
+	// like distinct pairs; inside a run a grouped input shows its repeats, and a shuffled one is sampled as well as by
+	// single rows
+	const double stride = (double)n / (double)((sample + 63) >> 6);
+	u32 fresh = 0, rows = 0;
+	for (int64_t k = threadIdx.x; k < sample; k += nt) {
+		const int64_t v = src[min(n - 1, (int64_t)((double)(k >> 6) * stride) + (k & 63))];
+		if (v < 0) continue; // NULL row
+		rows++;
+		const u32 x = (u32)v;
+		u32 h = (x * 0x9E3779B1u) >> 20; // 12 bits
+		for (;;) {
+			const u32 old = atomicCAS(&s_set[h], kSampleEmpty, x);
+			if (old == kSampleEmpty) fresh++;
+			if (old == kSampleEmpty || old == x) break;
+			h = (h + 1) & (kSampleSlots - 1);
+		}
+	}
+	if (fresh) atomicAdd(&s_count[0], fresh);
+	if (rows) atomicAdd(&s_count[1], rows);
+	__syncthreads();
+	// E[distinct](U) = U (1 - (1 - 1/U)^s) is increasing in U: every thread evaluates one point of a geometric grid between
+	// the distinct sources seen and n ((1 - 1/U)^s as exp(s log1p(-1/U)), single precision) and the first point that
+	// reaches the sampled count is the estimate — round 3 bisected on one thread (18 dependent steps: 4 of the 16 us this
+	// kernel sits in front of every large call with)
+	__shared__ u32 s_first;
+	if (threadIdx.x == 0) s_first = (u32)nt - 1u;
+	__syncthreads();
+	const double d = s_count[0], sr = s_count[1];
+	double est;
+	if (sr < 1 || d < 1) {
+		est = 1;
+	} else if (d >= sr - 0.5) { // every sampled row had its own source
+		est = (double)n;
+	} else { // block-uniform branch
+		const float fd = (float)d, fs = (float)sr, fn = (float)n;
+		const float u = fd * __expf(__logf(fn / fd) * ((float)threadIdx.x / (float)(nt - 1)));
+		const float e = u * (1.0f - __expf(fs * log1pf(-1.0f / u)));
+		if (e >= fd) atomicMin(&s_first, threadIdx.x);
+		__syncthreads();
+		const float uf = fd * __expf(__logf(fn / fd) * ((float)s_first / (float)(nt - 1)));
+		est = fmin((double)n, ceil((double)uf));
+	}
+	if (threadIdx.x != 0) return;
+	const double distinct = fmin(est, (double)V);
+	out->go = meet_bytes <= lanes_cost_bytes(edge_bytes, distinct) ? 1u : 0u;
+	if (h_go) *h_go = out->go + 1u;
+	out->sample_rows = s_count[1];
+	out->sample_fresh = s_count[0];
+	out->estimate = est;
+}
+
+#endif
+
 // What a level's kernels leave in the counter block, as the host needs it after the level (read back per level, or logged
 // by the next level's k_level_reset into pinned memory when levels are enqueued ahead).
 struct LevelLog {
@@ -86,6 +175,10 @@ struct LevelBuf {
 	DevBuf buf;        // frontier lane-words [V][WD]
 	DevBuf nz;         // per vertex: which of its WD words are non-empty (u32 bit mask)
 	bool dirty = true; // may hold non-zero words
+	// sparse pool (pgq_msbfs.hip): the allocation and the (V, WD) layout this buffer was zeroed whole for
+	const void *init_buf = nullptr, *init_nz = nullptr;
+	int64_t lay_V = -1;
+	int lay_WD = 0;
 };
 
 struct Workspace {
@@ -95,7 +188,9 @@ struct Workspace {
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
 	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, def_ent, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps, meet_trace, wb_scratch, hv, hmask, hstart, hmap,
 	    route_dec, dpart; // [kOpenGrid][WD + 1]: every workgroup's open-lane words + open-row count of the level's detection / probe
-	std::vector<std::unique_ptr<LevelBuf>> levels;
+	std::vector<std::unique_ptr<LevelBuf>> levels; // shortestpath: one per level
+	std::vector<std::unique_ptr<LevelBuf>> pool;   // otherwise: [0], [1] sparse pool, [2], [3] dense pool
+	bool pool_trusted = false;                     // the last batch ended normally: the sparse pool's dirty flags are true
 	Counters *h_cnt = nullptr; // pinned
 	LevelLog *h_log = nullptr; // pinned: [kSpecLevels + 2] counters per enqueued-ahead level, then two status words
 	int64_t wb_V = -1;  // what wb_scratch's label arrays are initialised for
@@ -124,19 +219,6 @@ struct WorkspaceLease {
 	~WorkspaceLease();
 };
 
-// bytes (at streaming rate) the lane-batched search is priced at for `distinct` sources: full 2048-lane batches of 32
-// lane-words plus one narrower batch for the rest, E x (12 + 3 wd) each; `edge_bytes` = meet_bias x E.  Shared by the
-// host-side decision (few rows) and k_meet_decide (sampled distinct sources).
-__host__ __device__ static inline double lanes_cost_bytes(double edge_bytes, double distinct) {
-	const double full = floor(distinct / 2048.0), rest = distinct - full * 2048.0;
-	double wd = 0.0;
-	if (rest > 0.0) {
-		wd = 1.0;
-		while (wd * 64.0 < rest) wd *= 2.0;
-	}
-	return edge_bytes * (full * (12.0 + 3.0 * 32.0) + (rest > 0.0 ? 12.0 + 3.0 * wd : 0.0));
-}
-
 static inline unsigned blocks_for(int64_t n, int block = 256) {
 	return (unsigned)std::max<int64_t>(1, (n + block - 1) / block);
 }
@@ -160,8 +242,6 @@ struct MeetPathsOut {
 };
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, MeetPathsOut *po, bool decide, double meet_bytes, double edge_bytes, bool *ran);
-// the pre-pass's sampled decision alone, not waited for (verdict + 1 lands in the pinned word h_meet[4104])
-int meet_sample_async(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes);
 // iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its
 // caps are compacted like the pre-pass's open rows
 int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,

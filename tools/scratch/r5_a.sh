@@ -12,3 +12,4 @@ PGQ_SORT_SINGLE_BATCH=1 PGQ_SPEC_LEVELS=0 timeout 300 python bench.py --workload
 PGQ_TRACE=1 timeout 300 python bench.py --workload snb_cross --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $O/trace_cross.txt; tail -30 $O/trace_cross.txt
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb_cross -o s -- python $R/bench.py --workload snb_cross --no-cpu-baseline --steps 5 > $O/stats_snb_cross.log 2>&1; rm -f $O/stats_snb_cross/*kernel_trace.csv)
 ls $O $O/stats_snb_cross
+PGQ_MAX_WORDS=16 timeout 300 python bench.py --workload snb_cross --no-cpu-baseline --steps 10 > $O/bench_snb_cross_w16.json 2>/dev/null; cut -c1-200 $O/bench_snb_cross_w16.json

@@ -565,6 +565,11 @@ __global__ __launch_bounds__(256) void k_pull(const int64_t *__restrict__ roff, 
 			constexpr int GRP = WD < 8 ? WD : 8; // loads in flight per lane
 #pragma unroll
 			for (int r0 = 0; r0 < WD; r0 += GRP) {
+				// a short last chunk (in-degree 89: 25 of 64 slots): its empty groups are not issued — every one of them is eight
+				// 64-lane loads of a cached line through the texture path (1.50 -> 1.42 ms on the dense level of the SF100 cross
+				// product).  Tried on top and dropped: 16 gathers in flight + the next chunk's entries / masks requested ahead
+				// (no gain: the level moves ~10 GB of 128-byte lines, 40 M in-edges x a 256-byte row, in 1.4 ms — the fabric's rate)
+				if (r0 * NS >= c64) break;
 				u64 w[GRP];
 				bool hot[GRP];
 #pragma unroll

@@ -1,5 +1,5 @@
-// pgq_analytics.hip — the other consumers of the device CSR: local clustering coefficient and
-// PageRank.
+// pgq_analytics.hip — the other consumers of the device CSR: local clustering coefficient,
+// PageRank and weakly connected components.
 //
 //   local_clustering_coefficient   src/core/functions/scalar/local_clustering_coefficient.cpp:11-72
 //       count = sum over the SLOTS of src's adjacency of |{slots of that neighbour's adjacency whose vertex is a
@@ -16,9 +16,12 @@
 //       for bit; only the dangling-rank total is a two-level sum (1024 ordered slices, then their ordered sum) instead
 //       of one sequential chain, hence a tolerance of 1e-12 relative in the tests.  Computed once per CSR handle.
 //
-// weakly_connected_component is NOT here: the reference's component id is the root its sequential union-find schedule
-// ends in (weakly_connected_component.cpp:14-34,83-90: goldens pin e.g. id 2 for the cycle 0-1-2-3), not a canonical
-// label; it is mirrored on the host in pgq_udf.cpp.
+//   weakly_connected_component    src/core/functions/scalar/weakly_connected_component.cpp:14-104
+//       the reference's component id is the root its sequential union-find schedule ends in (:14-34,83-90: goldens pin
+//       e.g. id 2 for the cycle 0-1-2-3), not a canonical label.  The schedule is Kruskal's algorithm in CSR slot order, so
+//       the O(E) part — which slots change the forest — is the minimum spanning forest under the weight "slot index":
+//       Boruvka rounds on the device (k_wcc_*, below); the <= V - 1 chosen slots are then replayed in slot order with the
+//       reference's Link on the host.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -232,10 +235,8 @@ __global__ void k_pr_pull(int64_t V, int64_t vs, const int64_t *__restrict__ rof
 	if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_delta, bits);
 }
 
-static std::mutex g_pr_lock;
-
 static int pagerank_compute(pgq_csr *c, Workspace *ws) {
-	std::lock_guard<std::mutex> g(g_pr_lock);
+	std::lock_guard<std::mutex> g(c->lazy_lock); // per handle (round 4: one process-wide mutex across the whole power iteration)
 	if (c->pagerank) return PGQ_OK;
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V, vs = V + 2;

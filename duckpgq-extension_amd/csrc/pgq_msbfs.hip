@@ -1518,11 +1518,16 @@ Workspace::~Workspace() {
 static std::mutex g_ws_lock;
 static std::vector<Workspace *> g_ws_free; // every workspace remembers the device its buffers live on
 
-void drop_idle_workspaces() {
+void drop_idle_workspaces() { // of the calling thread's device: another device's pool does not help an allocation here
 	std::vector<Workspace *> drop;
 	{
 		std::lock_guard<std::mutex> g(g_ws_lock);
-		drop.swap(g_ws_free);
+		const int dev = current_device();
+		for (size_t k = g_ws_free.size(); k-- > 0;)
+			if (g_ws_free[k]->device == dev) {
+				drop.push_back(g_ws_free[k]);
+				g_ws_free.erase(g_ws_free.begin() + (long)k);
+			}
 	}
 	for (Workspace *w : drop) delete w;
 }

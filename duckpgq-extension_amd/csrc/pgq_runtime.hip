@@ -351,11 +351,12 @@ int dev_alloc(void **out, size_t bytes) {
 		}
 	}
 	hipError_t e = hipMalloc(out, want);
-	if (e != hipSuccess) { // give the cached blocks back to the driver and try once more
+	if (e == hipErrorOutOfMemory) { // give the cached blocks back to the driver and try once more (like DevBuf::reserve)
+		(void)hipGetLastError();
 		dev_cache_trim();
 		e = hipMalloc(out, want);
 	}
-	if (e != hipSuccess) { // ... and the buffers of the idle pooled workspaces (label arrays of V x 576 B per relaxation stream)
+	if (e == hipErrorOutOfMemory) { // ... and the buffers of this device's idle pooled workspaces (label arrays of V x 576 B per relaxation stream)
 		(void)hipGetLastError();
 		drop_idle_workspaces();
 		e = hipMalloc(out, want);
@@ -1124,11 +1125,14 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	}
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	tr.mark("hub slices");
-	if (build_meet_layout(c, st) != PGQ_OK) {
-		// ~40 B per edge that only the pair-centric pre-pass needs: out of memory here is "no pre-pass" (the searches test
-		// fdesc), not a failed upload
+	if (const int lrc = build_meet_layout(c, st); lrc != PGQ_OK) {
+		// ~40 B per edge that only the pair-centric pre-pass needs: OUT OF MEMORY here is "no pre-pass" (the searches test
+		// fdesc; pgq_csr_has_prepass_layout() says so), not a failed upload.  Anything else — a failed launch, a device
+		// fault in the scans — is an error of the upload like any other step's
 		(void)hipStreamSynchronize(st);
+		if (lrc != PGQ_ERR_OOM) return lrc;
 		(void)hipGetLastError();
+		if (options().trace) fprintf(stderr, "[pgq] upload: no memory for the pair-centric layout (~40 B per edge): this CSR is searched without the pre-pass\n");
 		for (void **q : { (void **)&c->padj, (void **)&c->rpadj, (void **)&c->fseg, (void **)&c->rseg, (void **)&c->fdesc,
 		                  (void **)&c->rdesc, (void **)&c->fwork, (void **)&c->rwork }) {
 			dev_free(*q);
@@ -1184,14 +1188,16 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 	PGQ_TRY(ensure_init());
 	if (!out) return fail(PGQ_ERR_INVALID_ARG, "out handle pointer is NULL");
 	*out = nullptr;
-	if (V < 0 || V >= (1LL << 31) - 1) return fail(PGQ_ERR_INVALID_ARG, "V must be in [0, 2^31-1)");
+	if (V < 0) return fail(PGQ_ERR_INVALID_ARG, "V must not be negative");
+	if (V >= (1LL << 31) - 1) return fail(PGQ_ERR_UNSUPPORTED, "V >= 2^31 - 1: the device CSR holds int32 vertex ids (include/pgq_hip.h, scale limits)");
 	if (!offsets) return fail(PGQ_ERR_INVALID_ARG, "offsets is NULL");
 	if (w_type < 0 || w_type > 2 || (w_type != 0 && !w)) return fail(PGQ_ERR_INVALID_ARG, "bad weight type / NULL weights");
 	const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
 	int64_t E = 0;
 	if (on_device) PGQ_HIP_TRY(hipMemcpy(&E, offsets + V, sizeof(int64_t), hipMemcpyDeviceToHost));
 	else E = offsets[V]; // E_used = v[V], not e.size()
-	if (E < 0 || E >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "edge count must be in [0, 2^31)");
+	if (E < 0) return fail(PGQ_ERR_INVALID_ARG, "offsets[V] is negative");
+	if (E >= (1LL << 31)) return fail(PGQ_ERR_UNSUPPORTED, "E >= 2^31: the device CSR addresses its adjacency with 32-bit positions (include/pgq_hip.h, scale limits)");
 	if (E > 0 && !adj) return fail(PGQ_ERR_INVALID_ARG, "adj is NULL");
 	pgq_csr *c = new pgq_csr();
 	(void)hipGetDevice(&c->device);
@@ -1296,8 +1302,10 @@ int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const 
 	PGQ_TRY(ensure_init());
 	if (!out) return fail(PGQ_ERR_INVALID_ARG, "out handle pointer is NULL");
 	*out = nullptr;
-	if (V < 0 || V >= (1LL << 31) - 1) return fail(PGQ_ERR_INVALID_ARG, "V must be in [0, 2^31-1)");
-	if (n_rows < 0 || n_rows >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "edge rows must be in [0, 2^31)");
+	if (V < 0) return fail(PGQ_ERR_INVALID_ARG, "V must not be negative");
+	if (V >= (1LL << 31) - 1) return fail(PGQ_ERR_UNSUPPORTED, "V >= 2^31 - 1: the device CSR holds int32 vertex ids (include/pgq_hip.h, scale limits)");
+	if (n_rows < 0) return fail(PGQ_ERR_INVALID_ARG, "negative row count");
+	if (n_rows >= (1LL << 31)) return fail(PGQ_ERR_UNSUPPORTED, "2^31 or more edge rows: the device CSR addresses its adjacency with 32-bit positions (include/pgq_hip.h, scale limits)");
 	if (n_rows > 0 && (!d_src || !d_dst)) return fail(PGQ_ERR_INVALID_ARG, "NULL edge columns");
 	if (w_type < 0 || w_type > 2 || (w_type != 0 && !d_w)) return fail(PGQ_ERR_INVALID_ARG, "bad weight type / NULL weights");
 	const int64_t E = n_rows;
@@ -1521,6 +1529,7 @@ int64_t pgq_csr_num_vertices(const pgq_csr_t *csr) { return csr ? csr->V : -1; }
 int64_t pgq_csr_num_edges(const pgq_csr_t *csr) { return csr ? csr->E : -1; }
 int pgq_csr_w_type(const pgq_csr_t *csr) { return csr ? csr->w_type : -1; }
 int64_t pgq_csr_device_bytes(const pgq_csr_t *csr) { return csr ? csr->bytes : -1; }
+int pgq_csr_has_prepass_layout(const pgq_csr_t *csr) { return csr && csr->fdesc != nullptr ? 1 : 0; }
 
 } // extern "C"
 

@@ -82,7 +82,14 @@ const char *pgq_version(void);
 /* Host arrays in the reference's layout: offsets = CSR::v (at least V+1 int64; the reference allocates
  * V+2), adj = CSR::e, edge_ids = CSR::edge_ids (nullable: slot index is used), w = CSR::w (int64) or
  * CSR::w_double (double) selected by w_type.  Only the first offsets[V] entries of adj/edge_ids/w are read
- * (the undirected CTE over-allocates).  The device copy stores int32 adjacency. */
+ * (the undirected CTE over-allocates).  The device copy stores int32 adjacency.
+ * SCALE LIMITS of the device mirror (the reference's CSR holds int64 everywhere, compressed_sparse_row.hpp:34-35): a CSR
+ * with V >= 2^31 - 1 vertices or E = offsets[V] >= 2^31 entries is REFUSED with PGQ_ERR_UNSUPPORTED by all three
+ * upload / build entry points — vertex ids are int32 on the device, the padded lists of the pair-centric kernels are
+ * addressed by 32-bit group indices, their queue entries hold 32-bit list positions.  Every BASELINE configuration is
+ * inside (the largest, the SF100 reply forest at V = 2^28: E = 2.2 x 10^8).  One call takes at most 2^31 - 1 rows.
+ * When the ~40 bytes per edge of the pair-centric layout do not fit in device memory the upload still succeeds and the
+ * searches run without the pre-pass (same answers, slower on scattered pairs): pgq_csr_has_prepass_layout() tells. */
 int pgq_csr_upload(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
                    int w_type, pgq_csr_t **out);
 /* Same, but the four arrays already live in device memory of the current device (they are copied). */
@@ -105,6 +112,9 @@ int64_t pgq_csr_num_vertices(const pgq_csr_t *csr);
 int64_t pgq_csr_num_edges(const pgq_csr_t *csr);
 int pgq_csr_w_type(const pgq_csr_t *csr);
 int64_t pgq_csr_device_bytes(const pgq_csr_t *csr);
+/* 1: the padded adjacency + slot descriptors of the pair-centric pre-pass were built at upload; 0: they were not (option
+ * meet_layout = 0, or no memory for them): searches go through the lane batches only. */
+int pgq_csr_has_prepass_layout(const pgq_csr_t *csr);
 
 /* ---- searches, chunk form (host memory, UnifiedVectorFormat in, FLAT vector out) --------------------- */
 

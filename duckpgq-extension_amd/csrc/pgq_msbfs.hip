@@ -1599,6 +1599,9 @@ static int lane_ranks(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src
 	hipLaunchKernelGGL(k_compact_sources, dim3(blocks_for(std::max<int64_t>(V, 1))), dim3(256), 0, st, V, ws->flag.as<u32>(), ws->rank.as<u32>(), ws->usrc.as<int32_t>(),
 	                   d_bad, h2);
 	kt.stop();
+	// lane assignment, stage 1: the rows' ids read once (16 B per row), a flag written per row; flags zeroed, scanned
+	// (read + rank written) and compacted: 20 B per vertex
+	tstats().s.algo_bytes[K_PREP] += (double)n * 20.0 + (double)(V + 1) * 20.0;
 	PGQ_WAIT(st);
 	KernelTimer::flush();
 	if (h2[1]) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
@@ -1633,6 +1636,9 @@ static int lane_rows_sorted(pgq_csr *c, Workspace *ws, int64_t n, const int64_t 
 	hipLaunchKernelGGL(k_gather_sorted, dim3(blocks_for(n)), dim3(256), 0, st, n, ws->skey.as<u32>(), ws->sidx.as<u32>(), d_src, d_dst, key_trivial, key_nolane,
 	                   ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>());
 	kt.stop();
+	// stage 2, rows sorted: keys (28 B read, 8 written), a radix sort of 8-byte pairs (one histogram pass + a read and a
+	// write per 8 key bits), the gather of the sorted copies (8 + 16 B read, 12 written)
+	tstats().s.algo_bytes[K_PREP] += (double)n * (36.0 + 8.0 + 16.0 * ((bits + 7) / 8) + 36.0);
 	return PGQ_OK;
 }
 
@@ -1672,6 +1678,8 @@ static int lane_rows_bfs(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		hipLaunchKernelGGL(k_pair_rows, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), c->off, c->roff, dst_rule ? 1 : 0, c->V,
 		                   ws->skey.as<u32>(), ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>());
 		kt.stop();
+		// stage 2, rows in place: ids read again + the source's rank and degree (16 + 12 B), four 4-byte arrays written
+		tstats().s.algo_bytes[K_PREP] += (double)n * 44.0;
 		ws->h_bstart[0] = 0;
 		for (int b = 1; b <= nb + 2; b++) ws->h_bstart[b] = n; // batch 0 = every row; no trivial / NULL ranges
 		return PGQ_OK;
@@ -1827,9 +1835,13 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				}
 			}
 			ws->pool_trusted = false; // until this batch has ended normally
+			KernelTimer kt(st, K_PREP);
 			hipLaunchKernelGGL(k_batch_reset, dim3(8 * ncu), dim3(256), 0, st, ws->seen.as<uint4>(), (words * 8 + 15) / 16,
 			                   ws->counters.as<u32>(), (int)(sizeof(Counters) / 4), ws->dpart.as<u64>(), kOpenRep * WD, cb[0], cz[0],
 			                   cb[1], cz[1], V, WD);
+			kt.stop();
+			// `seen` zeroed (8 WD B per vertex) + the nz words of the sparse-pool buffers that are cleaned (4 B per vertex each)
+			S.algo_bytes[K_PREP] += (double)words * 8.0 + (double)V * 4.0 * ((cb[0] != nullptr) + (cb[1] != nullptr));
 		}
 		u64 *act_cur = &d_cnt->act[0][0]; // zeroed with the counter block above
 		u32 open_before = (u32)(hi - lo); // rows open before the level whose counters are being looked at (byte model of detection)
@@ -1915,10 +1927,12 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 					sp.log = ws->h_log;
 					sp.status = reinterpret_cast<u32 *>(ws->h_log + kSpecLevels + 2);
 				}
+				KernelTimer kt(st, K_QUEUE); // bookkeeping between levels: no byte model, its time counts in the chain
 				hipLaunchKernelGGL(k_level_reset, dim3(1), dim3(256), 0, st, d_cnt, hs.act_sel ^ 1,
 				                   (int)((push && q_nxt == 0) || (zq_cur && q_cur == 0)),
 				                   (int)((push && q_nxt == 1) || (zq_cur && q_cur == 1)), rule, sp,
 				                   hs.pending_fold ? ws->dpart.as<u64>() : (u64 *)nullptr);
+				kt.stop();
 				hs.pending_fold = false;
 			}
 			if (probe_now) {
@@ -2651,8 +2665,11 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		}
 	}
 	// results back to row order even when the child buffer overflowed (lengths are still right)
+	KernelTimer kts(st, K_PREP);
+	S.algo_bytes[K_PREP] += (double)n * (identity ? 12.0 : 16.0); // result word (+ permutation) read, 8-byte length written
 	hipLaunchKernelGGL(k_scatter_results, dim3(blocks_for(n)), dim3(256), 0, st, n, identity ? nullptr : ws->sidx.as<u32>(), ws->sres.as<int32_t>(),
 	                   ws->soff.as<int64_t>(), d_out_len, with_paths ? d_out_off : nullptr);
+	kts.stop();
 	PGQ_WAIT(st);
 	KernelTimer::flush();
 	if (rc == PGQ_OK && outp.overflow)

@@ -8,4 +8,4 @@ This package is only the ctypes binding used by tests/ and bench.py; there is no
 every search call fails loudly if the HIP library or a GPU is missing.
 """
 from .binding import (DeviceCSR, PgqError, PgqState, build_native, copy_bandwidth_gbps, get_stats, kclass_names,  # noqa: F401
-                      lib_paths, load_hip, load_udf, reset_stats, set_option, get_option, init_devices)
+                      lib_paths, load_hip, load_udf, reset_stats, set_option, get_option, get_default_option, init_devices)

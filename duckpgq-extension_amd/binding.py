@@ -94,6 +94,7 @@ def load_hip():
     L.pgq_csr_replicate.argtypes = [C.c_void_p]
     L.pgq_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.pgq_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+    L.pgq_get_default_option.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
     L.pgq_csr_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
     L.pgq_csr_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.pgq_iterativelength_bidirectional.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, Vec, C.c_void_p, C.c_void_p]
@@ -180,6 +181,13 @@ def make_vec(data, sel=None, valid=None, keep=None):
 
 def set_option(key, value):
     _check(load_hip().pgq_set_option(str(key).encode(), str(value).encode()))
+
+
+def get_default_option(key):
+    """The value the library ships with (a process that sets nothing runs under it)."""
+    v = C.c_double(0)
+    _check(load_hip().pgq_get_default_option(str(key).encode(), C.byref(v)))
+    return v.value
 
 
 def get_option(key):

@@ -1170,6 +1170,19 @@ static int cheapest_with_chains(pgq_csr *c, Workspace *ws, int64_t n, const int6
 	return PGQ_OK;
 }
 
+// Whether the relaxation of this CSR runs "light edges first" (weight-sorted lists under a doubling cap, one host round
+// trip per round) or plain rounds (every edge of a changed vertex; few changed vertices loop on the device, k_relax_small).
+// The cap pays by the edges it does not scan: on the weighted knows graph (89 edges per vertex, cheapest paths use the
+// lightest few per cent) it took 9.3 s to 0.6 s per 4096 pairs.  A vertex with three or four edges has nothing to skip:
+// a weighted ring with chords ran 1830 rounds (0.28 s) under the cap against 365 rounds (0.05 s) plain — round 4 shipped
+// that regression.  relax_light = 1 (shipped): by the mean out-degree; 2: always (tests); 0: never.
+static bool light_edges_first(const pgq_csr *c) {
+	const Options &o = options();
+	if (o.relax_light == 0 || c->E <= 0) return false;
+	if (o.relax_light >= 2) return true;
+	return (double)c->E >= (double)std::max(1, o.relax_light_min_degree) * (double)std::max<int64_t>(c->V, 1);
+}
+
 // The batches b0, b0 + bstride, ... of a call: `ws` holds the sorted rows and the distinct sources (read-only here),
 // `priv` everything a batch writes (labels, dirty words, queues) and the stream.  Batches are independent, so several
 // host threads run this side by side on their own workspaces (cheapest_device).
@@ -1264,7 +1277,7 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 		// its lanes' bounds) — until the cap reaches the largest bound (heavier edges cannot be on a cheaper path)
 		// (a mean that is not a positive finite number — NaN / inf weights, an int64 sum that wrapped — gives no first cap:
 		// plain rounds then)
-		const bool light = options().relax_light != 0 && c->E > 0 && c->wadj && c->w_mean > 0 && c->w_mean < 1e300;
+		const bool light = light_edges_first(c) && c->wadj && c->w_mean > 0 && c->w_mean < 1e300;
 		const bool heavy = options().relax_split != 0;
 		static const bool trace = getenv("PGQ_RELAX_TRACE") != nullptr; // per-round line on stderr (measurement only)
 		auto t_round = std::chrono::steady_clock::now();
@@ -1409,7 +1422,7 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 	const int nb = (int)(((int64_t)U + LC - 1) / LC);
 	PGQ_TRY(batch_bounds(ws, n, LC, nb));
 	const int64_t *bs = ws->h_bstart;
-	if (options().relax_light != 0 && c->E > 0) { // once per CSR, before the workers need them
+	if (light_edges_first(c)) { // once per CSR, before the workers need them
 		PGQ_TRY(ensure_weight_sorted(c, ws));
 		PGQ_TRY(ensure_weight_mean(c, ws));
 	} else if (options().relax_delta_div > 0) {

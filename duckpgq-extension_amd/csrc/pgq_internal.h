@@ -58,8 +58,9 @@ struct Options {
 	int chain_cap = 4096;   // steps after which a chain is taken for a cycle and left to the batched relaxation
 	int alloc_cache_mb = 8192; // freed CSR / upload blocks kept for the next upload, per process (0: straight hipFree)
 	int relax_small_limit = 2048; // changed vertices at or below which relaxation rounds loop on the device
-	int relax_light = 1;      // batched relaxation over weight-sorted lists: edges above a cap that doubles phase by phase are not
+	int relax_light = 1;      // (1: where the mean out-degree makes it pay, 2: always, 0: never) batched relaxation over weight-sorted lists: edges above a cap that doubles phase by phase are not
 	                          // scanned, and a vertex stops at the first edge that cannot beat its lanes' bounds (0: plain rounds)
+	int relax_light_min_degree = 8; // relax_light = 1: only CSRs with at least this many edges per vertex (2: always)
 	int relax_light_div = 4;  // first cap = mean weight / this
 	int relax_streams = 6;    // batches of the relaxation side by side on their own label arrays (0: `streams`)
 	int relax_split = 1;      // lists longer than 128 edges are relaxed 64 edges per wavefront by a second launch of the round

@@ -1712,6 +1712,24 @@ static int choose_words(int64_t unique_sources) {
 	return wd;
 }
 
+// A bigger buffer with the first `keep` bytes of the old one; the new block is given back if the copy fails (round 4
+// returned through PGQ_HIP_TRY with it still allocated).
+static int grow_keeping(DevBuf &buf, size_t bytes, size_t keep, hipStream_t st) {
+	DevBuf bigger;
+	PGQ_TRY(bigger.reserve(bytes));
+	hipError_t e = hipSuccess;
+	if (keep > 0) e = hipMemcpyAsync(bigger.p, buf.p, keep, hipMemcpyDeviceToDevice, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) {
+		bigger.release();
+		return fail(PGQ_ERR_HIP, std::string("growing a list buffer: ") + hipGetErrorString(e));
+	}
+	tstats().s.host_waits++;
+	buf.release();
+	buf = bigger;
+	return PGQ_OK;
+}
+
 // ---- the batch driver ----------------------------------------------------------------------------------------------
 // Runs the searches for rows already resident in device memory (d_src/d_dst, -1 src = NULL row).
 // with_paths: also emit [src,e,v,...,dst] lists into ws->child and per-row offsets.
@@ -2272,13 +2290,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				fits = need <= child_cap_ext;
 			} else if ((size_t)need * 8 > sh->child.cap) {
 				// grow, preserving what earlier batches wrote
-				DevBuf bigger;
-				PGQ_TRY(bigger.reserve((size_t)need * 8 * 2));
-				if (child_base > 0)
-					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, sh->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
-				PGQ_WAIT(st);
-				sh->child.release();
-				sh->child = bigger;
+				PGQ_TRY(grow_keeping(sh->child, (size_t)need * 8 * 2, (size_t)child_base * 8, st));
 				d_child = sh->child.as<int64_t>();
 			}
 			if (!d_child_ext) d_child = sh->child.as<int64_t>();
@@ -2308,13 +2320,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			bool fits = true;
 			if (d_child_ext) fits = need <= child_cap_ext;
 			else if ((size_t)need * 8 > sh->child.cap) {
-				DevBuf bigger;
-				PGQ_TRY(bigger.reserve((size_t)need * 8));
-				if (child_base > 0)
-					PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, sh->child.p, (size_t)child_base * 8, hipMemcpyDeviceToDevice, st));
-				PGQ_WAIT(st);
-				sh->child.release();
-				sh->child = bigger;
+				PGQ_TRY(grow_keeping(sh->child, (size_t)need * 8, (size_t)child_base * 8, st));
 			}
 			if (!d_child_ext) d_child = sh->child.as<int64_t>();
 			if (fits) {
@@ -2434,12 +2440,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		if (d_child_ext) {
 			if (need > child_cap_ext) outp.overflow = true;
 		} else if ((size_t)need * 8 > ws->child.cap) { // the open rows' lists do not fit behind the others: a bigger buffer
-			DevBuf bigger;
-			PGQ_TRY(bigger.reserve((size_t)need * 8));
-			if (total > 0) PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
-			PGQ_WAIT(st);
-			ws->child.release();
-			ws->child = bigger;
+			PGQ_TRY(grow_keeping(ws->child, (size_t)need * 8, (size_t)total * 8, st));
 			d_child = ws->child.as<int64_t>();
 		}
 		if (nd > 0) {
@@ -2637,12 +2638,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 					}
 				} else {
 					if ((size_t)need * 8 > ws->child.cap) {
-						DevBuf bigger;
-						PGQ_TRY(bigger.reserve((size_t)need * 8));
-						if (base > 0) PGQ_HIP_TRY(hipMemcpyAsync(bigger.p, ws->child.p, (size_t)base * 8, hipMemcpyDeviceToDevice, st));
-						PGQ_WAIT(st);
-						ws->child.release();
-						ws->child = bigger;
+						PGQ_TRY(grow_keeping(ws->child, (size_t)need * 8, (size_t)base * 8, st));
 					}
 					d_child = ws->child.as<int64_t>();
 				}

@@ -160,6 +160,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "relax_delta_div", &o.relax_delta_div, nullptr },
 		{ "relax_light", &o.relax_light, nullptr },
 		{ "relax_light_div", &o.relax_light_div, nullptr },
+		{ "relax_light_min_degree", &o.relax_light_min_degree, nullptr },
 		{ "relax_split", &o.relax_split, nullptr },
 		{ "relax_streams", &o.relax_streams, nullptr },
 		{ "chain", &o.chain, nullptr },
@@ -1558,6 +1559,11 @@ static int get_option_in(Options &o, const char *key, double *value) {
 
 int pgq_set_option(const char *key, const char *value) { return set_option_in(g_opt, key, value); }
 int pgq_get_option(const char *key, double *value) { return get_option_in(g_opt, key, value); }
+// the value a key ships with (a default-constructed option set: what a process that sets nothing runs under)
+int pgq_get_default_option(const char *key, double *value) {
+	Options shipped;
+	return get_option_in(shipped, key, value);
+}
 
 // Options of ONE handle: the first call copies the process-wide set, later searches on this handle use the copy (two
 // DuckDB connections, or a test, can tune their own CSR without touching each other's).  Upload-time options

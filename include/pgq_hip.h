@@ -217,6 +217,8 @@ int pgq_weakly_connected_component_device(pgq_csr_t *csr, int64_t *d_ids);
 int pgq_set_option(const char *key, const char *value);
 /* Current value of a knob (integers are returned as doubles). */
 int pgq_get_option(const char *key, double *value);
+/* the value the library ships with for this key, whatever the process or the environment has set since */
+int pgq_get_default_option(const char *key, double *value);
 /* Options of ONE handle: the first pgq_csr_set_option copies the process-wide set into the handle; searches on this
  * handle then run under the copy (on every host thread that works for the call), so that two connections, or a test,
  * can tune their own CSR without touching each other's.  Options consumed at upload (meet_align, hub_chunk, ...) are

@@ -21,9 +21,27 @@ def _defaults():
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
-                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 2), ("relax_delta_div", 0), ("relax_light", 1), ("relax_light_div", 4), ("relax_split", 1)):
+                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 2), ("relax_delta_div", 0), ("relax_light", 2), ("relax_light_div", 4), ("relax_split", 1),
+                 ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1)):
         pgq.set_option(k, v)
     yield
+
+
+SHIPPED_KEYS = ("push_div", "streams", "probe2_abs", "meet", "meet_align", "meet_bias", "meet_cap", "meet_cap_small", "meet_cap_paths",
+                "meet_small_rows", "probe", "probe2", "defer", "lanes", "lanes_unroll", "sparse_lds", "sparse_pw", "sparse_unroll",
+                "sparse_spill", "hub_chunk", "push_chunk", "spec_levels", "sort_single_batch", "detect_unroll", "route_memo", "meet4",
+                "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs")
+
+
+@pytest.fixture(params=["fixture_values", "shipped_values"])
+def base_config(request):
+    """The tests that sweep the kernels' variants run twice: under this file's fixture values (pre-pass off, push_div 12,
+    two streams, probe2_abs 512: chosen so that the level kernels see the rows) and under the values the library SHIPS
+    with (read back from the library itself: pgq_get_default_option) — what a DuckDB process that sets nothing runs."""
+    if request.param == "shipped_values":
+        for k in SHIPPED_KEYS:
+            pgq.set_option(k, pgq.get_default_option(k))
+    return request.param
 
 
 # The shipped configuration answers rows through the pair-centric pre-pass (and int64 weighted rows through the per-row
@@ -145,7 +163,7 @@ def random_graph(rng, V, E, skew=False):
 
 @pytest.mark.parametrize("words", [1, 2, 4, 8, 16, 32])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_random_graph_all_variants(words, mode):
+def test_random_graph_all_variants(words, mode, base_config):
     rng = np.random.default_rng(100 * words + mode)
     V, E = 3000, 14000
     rows = random_graph(rng, V, E, skew=True)
@@ -176,13 +194,19 @@ def test_random_graph_all_variants(words, mode):
         pgq.set_option("force_pull", force_pull)
         pgq.set_option("probe2", 1 - lds if probe else 1)  # two-hop destination probe on / off
         pgq.set_option("sparse_lds", lds)  # 1-bit frontier map in LDS (1024-thread groups) or in global memory
+        # round 5: levels enqueued ahead of the host under the previous call's plan (the variants change the level rule
+        # under it: plans that no longer fit are called off on the device) / one wait per level; rows of a one-batch call
+        # left in place / sorted by lane; 1, 2 or 4 rows per thread in k_detect
+        pgq.set_option("spec_levels", (lds + pw) % 2)
+        pgq.set_option("sort_single_batch", (unroll >> 1) % 2)
+        pgq.set_option("detect_unroll", unroll)
         ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
         assert lens(ln, ok) == want
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
 
 
 @pytest.mark.parametrize("cap,lds_kb,align", [(1 << 18, 150, 4), (3000, 150, 16), (1, 150, 4), (1 << 18, 0, 32), (300, 150, 4)])
-def test_meet_prepass_matches_oracle(cap, lds_kb, align):
+def test_meet_prepass_matches_oracle(cap, lds_kb, align, base_config):
     # k_meet3 (pgq_meet.hip): distances 1..3 from two-hop scans, everything else handed to the lane-batched search.
     # cap = adjacency entries a pair's walk may scan before it is handed on: small caps leave most rows to k_meet4d / the
     # MS-BFS path (all paths mixed)
@@ -326,7 +350,7 @@ def test_meet_prepass_out_of_range_ids_rejected():
         dev.iterativelength_bulk_ptr(3, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr())
 
 
-def test_shared_sources_cross_product():
+def test_shared_sources_cross_product(base_config):
     # the binder's shape: few sources x many destinations (match.cpp:467-495) -> lanes are per distinct source
     rng = np.random.default_rng(5)
     V, E = 5000, 40000
@@ -334,9 +358,10 @@ def test_shared_sources_cross_product():
     srcs = rng.integers(0, V, 7)
     ps = np.repeat(srcs, V)
     pd = np.tile(np.arange(V, dtype=np.int64), 7)
-    ln, ok = st.iterativelength(0, V, ps, pd)
     oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
-    assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
+    for rep in range(3):  # the second and third call run their levels ahead of the host under the first one's plan
+        ln, ok = st.iterativelength(0, V, ps, pd)
+        assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
     assert pgq.get_stats()["unique_sources"] >= 1
 
 
@@ -1224,3 +1249,157 @@ def test_options_of_one_handle_do_not_leak_into_another():
             assert st["levels"] > 0
     with pytest.raises(pgq.PgqError, match="unknown option"):
         a.set_option("no_such_option", 1)
+
+
+# ---- round 5: levels enqueued ahead of the host, rows left in place, the route memo --------------------------------------
+
+def _ring_with_chords(V, chords, rng):
+    a = np.arange(V, dtype=np.int64)
+    s = np.concatenate([a, (a + 1) % V, rng.integers(0, V, chords)])
+    d = np.concatenate([(a + 1) % V, a, rng.integers(0, V, chords)])
+    return s, d, np.arange(len(s), dtype=np.int64)
+
+
+def test_levels_enqueued_ahead_match_the_round_trip_loop():
+    """spec_levels: the second batch of a width runs its levels under the first one's plan, k_level_reset checking each on
+    the device.  Same answers as one host round trip per level (spec_levels = 0) and as the oracle: a plan that fits, a plan
+    the level rule contradicts (called off at level 1: force_mode flips between the calls), a plan that runs out (a ring:
+    more levels than the log holds, and a second call that needs MORE levels than the first)."""
+    rng = np.random.default_rng(55)
+    V, E = 20000, 160000
+    st, ora = both(V, random_graph(rng, V, E, skew=True))
+    n = 5000
+    ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=8)
+    want = lens(oln, ook)
+    pgq.set_option("spec_levels", 0)
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    assert lens(ln, ok) == want
+    waits_round_trip = pgq.get_stats()["host_waits"]
+    pgq.set_option("spec_levels", 1)
+    for rep in range(3):
+        pgq.reset_stats()
+        ln, ok = st.iterativelength(0, V, ps, pd)
+        assert lens(ln, ok) == want
+        stats = pgq.get_stats()
+        assert stats["spec_batches"] >= 1 and stats["spec_levels"] >= 1
+    assert stats["host_waits"] < waits_round_trip
+    # the level rule changes under the plan: every level is top-down now, the plan's bottom-up levels are called off
+    pgq.set_option("force_mode", 1)
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    assert lens(ln, ok) == want and pgq.get_stats()["spec_aborts"] >= 1
+    pgq.set_option("force_mode", 2)
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    assert lens(ln, ok) == want and pgq.get_stats()["spec_aborts"] >= 1
+    pgq.set_option("force_mode", 0)
+    # a long-diameter graph: 150 levels > the 61 the log holds; then pairs that need more levels than the plan has
+    V2 = 300
+    st2, ora2 = both(V2, _ring_with_chords(V2, 0, rng))
+    near = np.arange(40, dtype=np.int64)
+    for src, dst in ((near, (near + 5) % V2), (near, (near + 140) % V2), (near, (near + 5) % V2), (near, (near + 149) % V2)):
+        ln, ok = st2.iterativelength(0, V2, src, dst)
+        o1, o2 = ora2.lean_iterativelength(V2, src, dst)
+        assert lens(ln, ok) == lens(o1, o2)
+    # traversed-edge accounting and paths stay on the round-trip loop and still agree
+    assert st.shortestpath(0, V, ps[:800], pd[:800]) == ora.lean_shortestpath(V, ps[:800], pd[:800])
+
+
+def test_route_memo_follows_the_rows():
+    """Large calls (> 16,384 rows) on the same buffers: a cross product is sent to the lane batches by the sampled
+    decision once and goes there straight afterwards (no pre-pass chain); when the SAME device buffers then hold
+    scattered pairs the sample taken beside the lane assignment says so and the call after it runs the pre-pass again.
+    Every answer equal to the oracle's whatever the route."""
+    import torch
+    rng = np.random.default_rng(66)
+    V, E = 30000, 600000
+    s, d, e = random_graph(rng, V, E)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    dev = pgq.DeviceCSR(V, off, adj, eid)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    pgq.set_option("meet", 1)
+    n = 40000
+    srcs = rng.choice(V, 40, replace=False)
+    cross = np.stack([np.repeat(srcs, n // 40), rng.integers(0, V, n)], axis=1).astype(np.int64)
+    scattered = rng.integers(0, V, (n, 2)).astype(np.int64)
+    buf = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    d_src = torch.empty(n, dtype=torch.int64, device="cuda")
+    d_dst = torch.empty(n, dtype=torch.int64, device="cuda")
+    routes = []
+    for rows in (cross, cross, cross, scattered, scattered, scattered, cross, cross):
+        t = torch.from_numpy(rows).to("cuda")
+        d_src.copy_(t[:, 0])
+        d_dst.copy_(t[:, 1])
+        torch.cuda.synchronize()
+        pgq.reset_stats()
+        dev.iterativelength_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), out.data_ptr())
+        got = out.cpu().numpy()
+        oln, ook = ora.lean_iterativelength(V, rows[:, 0], rows[:, 1], nthreads=8)
+        assert ((got >= 0) == ook).all() and (got[ook] == oln[ook]).all()
+        routes.append("prepass" if pgq.get_stats()["meet_pairs"] > 0 else "lanes")
+    assert routes[:3] == ["lanes"] * 3  # the sample calls the pre-pass off; then the memo skips its chain
+    assert routes[4:6] == ["prepass"] * 2  # one call late at most: the memo'd route is a matter of speed, not of answers
+    assert routes[7] == "lanes"
+    del buf
+
+
+def test_zero_copy_chunk_path_with_selection_validity_and_null_rows():
+    """The chunk entry point resolves DuckDB's vectors straight into the pinned staging block the pre-pass kernels read
+    (chunk_zero_copy = 1): selection vectors on both sides, NULL sources, rows whose (ignored) destination payload is out
+    of range behind a NULL source — against the copy path (chunk_zero_copy = 0) and the oracle."""
+    rng = np.random.default_rng(77)
+    V, E = 8000, 90000
+    st, ora = both(V, random_graph(rng, V, E, skew=True))
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_bias", 1e9)
+    base_s, base_d = rng.integers(0, V, 700), rng.integers(0, V, 900)
+    n = 2048
+    ssel, dsel = rng.integers(0, 700, n).astype(np.uint32), rng.integers(0, 900, n).astype(np.uint32)
+    valid = rng.random(700) > 0.1
+    base_s = base_s.copy()
+    base_s[~valid] = 2 ** 40  # garbage payload under a NULL: must not be looked at
+    ps, pd = np.where(valid[ssel], base_s[ssel], 0), base_d[dsel]
+    oln, ook = ora.lean_iterativelength(V, ps, pd)
+    want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid[ssel])]
+    res = {}
+    for zc in (1, 0):
+        pgq.set_option("chunk_zero_copy", zc)
+        ln, ok = st.iterativelength(0, V, base_s, base_d, src_valid=valid, src_sel=ssel, dst_sel=dsel)
+        assert lens(ln, ok) == want
+        res[zc] = (ln.copy(), ok.copy())
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+    # a constant vector (selection of zeros) on the source side: the binder's cross product arrives like this
+    zsel = np.zeros(n, dtype=np.uint32)
+    ln, ok = st.iterativelength(0, V, base_s[valid][:1], base_d, src_sel=zsel, dst_sel=dsel)
+    o1, o2 = ora.lean_iterativelength(V, np.full(n, base_s[valid][0]), base_d[dsel])
+    assert lens(ln, ok) == lens(o1, o2)
+
+
+def test_weighted_ring_with_chords_takes_plain_rounds_and_stays_fast():
+    """Round 4 shipped relax_light = 1 for every CSR: a weighted ring with chords (20,000 vertices, three or four edges
+    each: nothing for the weight cap to skip) took 1830 rounds / 0.28 s per 64 pairs against 365 rounds / 0.05 s with plain
+    rounds.  The shipped rule now goes by the mean out-degree: same values as Dijkstra, int64 and double, within a time
+    bound, and the forced light path (relax_light = 2) still agrees."""
+    import time
+    rng = np.random.default_rng(88)
+    V = 20000
+    s, d, e = _ring_with_chords(V, 4000, rng)
+    for dtype in ("int64", "double"):
+        w = rng.integers(1, 1000, len(s))
+        if dtype == "double":
+            w = w.astype(np.float64) / 7.0
+        st, ora = both(V, (s, d, e), w)
+        ps, pd = rng.integers(0, V, 64), rng.integers(0, V, 64)
+        want, wok = ora.lean_cheapest_path_length(V, ps, pd)
+        for light in (pgq.get_default_option("relax_light"), 2):
+            pgq.set_option("relax_light", int(light))
+            st.cheapest_path_length(0, V, ps, pd)  # warm: weight-sorted lists, label arrays
+            t0 = time.perf_counter()
+            out, ok = st.cheapest_path_length(0, V, ps, pd)
+            dt = time.perf_counter() - t0
+            assert (ok == wok).all() and (out[ok] == want[wok]).all()
+            if light != 2:
+                assert dt < 0.15, "the shipped rule must not take the light-edges-first path here (%.3f s)" % dt

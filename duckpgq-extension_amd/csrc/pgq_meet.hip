@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64 * PGQ_MEET4_WAVES, PGQ_MEET4_BLOCKS) void k_meet
                                                  const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
                                                  int64_t *__restrict__ out_rows, int64_t cap, int64_t test_cap, int bm_words,
                                                  MeetDevBlock *__restrict__ db, u32 *__restrict__ gmaps, MeetQueue qout,
-                                                 MeetHostBlock *__restrict__ fin, unsigned long long *__restrict__ trace) {
+                                                 MeetHostBlock *__restrict__ fin, unsigned long long *__restrict__ trace, SampleArgs sm) {
 	extern __shared__ __attribute__((aligned(16))) u32 s_map[]; // bm_words: one bit per vertex (GM: the map is this workgroup's slice of `gmaps`)
 	// rows the stage before left open (counted on the device: no host round trip): nf from the front of its queue (the
 	// long ones), the rest from the back
@@ -736,6 +736,11 @@ __global__ __launch_bounds__(64 * PGQ_MEET4_WAVES, PGQ_MEET4_BLOCKS) void k_meet
 	// long rows sit at the front, so they start first and a workgroup stuck in one simply takes fewer of the short ones —
 	// with the static stride of round 3 a slot could draw two long rows, or a long one last.  Thread 0 draws the NEXT
 	// position while the current row is processed (the atomic's round trip is off the critical path).
+	// the sampled decision of the distinct sources rides here when the chain runs on the route memo's word (meet_prepass,
+	// decide_mode 2): the LAST workgroup — its first row is one of the short ones, and the rows are handed out dynamically —
+	// takes the sample in the bit map's LDS before its first row clears it
+	if (!GM && sm.h_go && blockIdx.x == gridDim.x - 1 && bm_words >= kSampleSlots)
+		sample_distinct_sources(sm.n, sm.src, sm.V, sm.meet_bytes, sm.edge_bytes, sm.out, sm.h_go, s_map);
 	u32 job = blockIdx.x;
 	for (;;) {
 		__syncthreads(); // the previous row's flags, map and s_job are no longer read
@@ -1180,7 +1185,8 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
                                                      double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go) {
-	sample_distinct_sources(n, src, V, meet_bytes, edge_bytes, out, h_go);
+	__shared__ u32 s_set[kSampleSlots];
+	sample_distinct_sources(n, src, V, meet_bytes, edge_bytes, out, h_go, s_set);
 }
 
 __global__ void k_apply_open(int64_t nd, const u32 *__restrict__ didx, const int64_t *__restrict__ dlen,
@@ -1243,8 +1249,29 @@ static void meet_attributes() {
 // decide: k_meet_decide compares `meet_bytes` with the lanes' cost for the sampled number of distinct sources
 // (lanes_cost_bytes) first; *ran = false when it said no (nothing was written to d_out).
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, MeetPathsOut *po, bool decide, double meet_bytes, double edge_bytes, bool *ran) {
+                 u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go) {
 	const bool paths = po != nullptr;
+	// decide_mode 1: k_meet_decide in front of the chain, its flag gates every stage kernel on the device.  2: the route
+	// memo says the last call on these buffers was answered here: the chain runs ungated and the sample rides in k_meet4d's
+	// launch (its last workgroup, in the bit map's LDS) — *observed_go gets its verdict for the memo, -1 when none was taken
+	// (12 us of kernel + a launch gap in front of every 65,536-row call otherwise; tried first: the sample on a second
+	// stream beside the chain — the extra launch and wait on the host cost what the kernel did)
+	if (observed_go) *observed_go = -1;
+	{ // the ride needs k_meet4d (distance-only flow) with its bit map in LDS and large enough to lend: else the gate again
+		const Options &o = options();
+		const int bmw = (int)((c->V + 127) / 128) * 4;
+		const size_t budget = (size_t)std::min(150, std::max(0, o.meet4_lds_kb)) * 1024;
+		if (decide_mode == 2 && !(o.meet4 && !paths && (size_t)bmw * 4 + 2048 <= budget && bmw >= kSampleSlots)) decide_mode = 1;
+	}
+	const bool decide = decide_mode == 1;
+	u32 *h_go = reinterpret_cast<u32 *>(static_cast<char *>(ws->h_meet) + 4104);
+	SampleArgs ride { meet_bytes, edge_bytes, nullptr, nullptr, n, d_src, c->V };
+	if (decide_mode == 2) {
+		PGQ_TRY(ws->route_dec.reserve(sizeof(MeetDecision)));
+		*h_go = 0;
+		ride.out = ws->route_dec.as<MeetDecision>();
+		ride.h_go = h_go; // taken inside k_meet4d's launch when its map is in LDS and large enough; else no verdict this call
+	}
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
 	const Options &opt = options();
@@ -1346,7 +1373,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	                   c->fdesc, c->rdesc, c->padj, c->rpadj, d_out, rec, cap4, bm_words, db, gmaps, q[1], fin)
 #define PGQ_MEET4D(G, T)                                                                                                    \
 	hipLaunchKernelGGL((k_meet4d<G, T>), dim3(grid4), dim3(kM4Threads), lds, st, q[0], c->adj, c->radj, c->fdesc, c->rdesc, c->padj, \
-	                   c->rpadj, d_out, cap4, (int64_t)std::max(1, opt.meet4_test_cap), bm_words, db, gmaps, q[1], fin, d_trace)
+	                   c->rpadj, d_out, cap4, (int64_t)std::max(1, opt.meet4_test_cap), bm_words, db, gmaps, q[1], fin, d_trace, ride)
 			if (paths && lds_map) PGQ_MEET4(false);
 			else if (paths) PGQ_MEET4(true);
 			else if (lds_map && d_trace) PGQ_MEET4D(false, true);
@@ -1407,6 +1434,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		kt.stop();
 	}
 	PGQ_TRY(meet_wait(ws, hb));
+	if (decide_mode == 2 && observed_go && *h_go) *observed_go = (int)*h_go - 1;
 	if (paths) po->total = *h_total;
 	const MeetHostBlock &h = *hb;
 	if (d_trace) { // debugging aid: where k_meet4d's time goes

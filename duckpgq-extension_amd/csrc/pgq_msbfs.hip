@@ -86,11 +86,6 @@ __device__ __forceinline__ bool pair_needs_search(int64_t s, int64_t d, const in
 // sm.h_go != null: workgroup 0 also takes the pre-pass's sample of the distinct sources (a call the route memo sent
 // straight to the lane batches keeps asking whether its rows still look like a cross product; the verdict lands in pinned
 // memory and is read after the lane assignment's wait).  It rides in this launch: the other workgroups take as long anyway.
-struct SampleArgs {
-	double meet_bytes, edge_bytes;
-	MeetDecision *out;
-	u32 *h_go;
-};
 __global__ __launch_bounds__(256) void k_mark_sources(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                       u32 *__restrict__ flag, int64_t V, const int64_t *__restrict__ off,
                                                       const int64_t *__restrict__ roff, int dst_rule, int *__restrict__ bad,
@@ -103,7 +98,8 @@ __global__ __launch_bounds__(256) void k_mark_sources(int64_t n, const int64_t *
 			else if (s != d && pair_needs_search(s, d, off, roff, dst_rule)) flag[s] = 1;
 		}
 	}
-	if (sm.h_go && blockIdx.x == 0) sample_distinct_sources(n, src, V, sm.meet_bytes, sm.edge_bytes, sm.out, sm.h_go);
+	__shared__ u32 s_set[kSampleSlots];
+	if (sm.h_go && blockIdx.x == 0) sample_distinct_sources(n, src, V, sm.meet_bytes, sm.edge_bytes, sm.out, sm.h_go, s_set);
 }
 
 // h_out (pinned host memory, device-addressable): {distinct sources, range-check flag} — what the host waits for next, written
@@ -1576,7 +1572,7 @@ WorkspaceLease::~WorkspaceLease() {
 // Stage 1: flag the distinct sources of the rows that need a search, rank them (= global lane ids), list them; the number
 // of distinct sources and the range check come back with ONE wait.
 static int lane_ranks(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out,
-                      bool dst_rule, const SampleArgs &sm = SampleArgs { 0.0, 0.0, nullptr, nullptr }) {
+                      bool dst_rule, const SampleArgs &sm = SampleArgs { 0.0, 0.0, nullptr, nullptr, 0, nullptr, 0 }) {
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V;
 	PGQ_TRY(ws->flag.reserve((size_t)(V + 1) * 4));
@@ -2261,8 +2257,10 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			batch_over = r == 1;
 		}
 		if (spec_ok && !ran_plan.empty()) {
+			// (the last batch of a call may hold a handful of lanes: its levels are not what the next FULL batch will run)
+			const bool full = (U - (int64_t)base_lane) * 2 >= L;
 			std::lock_guard<std::mutex> g(c->plan_lock);
-			c->level_plan[plan_slot] = ran_plan;
+			if (full || c->level_plan[plan_slot].empty()) c->level_plan[plan_slot] = ran_plan;
 		}
 		cur = hs.cur;
 		ws->pool_trusted = true; // the dirty flags of the sparse pool say what the device did
@@ -2403,6 +2401,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// few rows: every row is taken as a distinct source (the pessimistic case for the pre-pass); many rows: a sampled
 	// estimate of the distinct sources decides ON THE DEVICE, in the same launch chain (cross products share their lanes)
 	const bool decide = n > kMeetDecideRows;
+	int decide_mode = decide ? 1 : 0, observed_go = -1; // 2: the memo vouches for the pre-pass, the sample only observes (meet_prepass)
 	// shortestpath: the pre-pass also records each answered row's inner vertices (reference tie-break); their lists are
 	// packed first, the lists of the rows left to the lane-batched search are appended behind them
 	auto run_meet_paths = [&](bool *ran) -> int {
@@ -2420,7 +2419,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			po.child_cap = (int64_t)(ws->child.cap / 8);
 		}
 		PGQ_HIP_TRY(hipMemsetAsync(d_out_off, 0, (size_t)n * 8, st));
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, &po, decide, meet_bytes, edge_bytes, ran));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, &po, decide_mode, meet_bytes, edge_bytes, ran, &observed_go));
 		if (!*ran) return PGQ_OK;
 		const int64_t total = po.total;
 		WorkspaceLease inner;
@@ -2459,7 +2458,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	auto run_meet = [&](bool *ran) -> int {
 		if (with_paths) return run_meet_paths(ran);
 		u32 nd = 0;
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide, meet_bytes, edge_bytes, ran));
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide_mode, meet_bytes, edge_bytes, ran, &observed_go));
 		if (!*ran) return PGQ_OK;
 		if (nd > 0) {
 			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
@@ -2500,7 +2499,9 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		if (decide && mopt.route_memo) {
 			std::lock_guard<std::mutex> g(c->plan_lock);
 			const pgq_csr::RouteMemo &m = c->route_memo;
-			skip = m.n == n && m.src == (const void *)d_src && m.dst == (const void *)d_dst && m.go == 0;
+			const bool same = m.n == n && m.src == (const void *)d_src && m.dst == (const void *)d_dst;
+			skip = same && m.go == 0;
+			if (same && m.go == 1) decide_mode = 2;
 		}
 		if (skip) {
 			sampled = true; // taken inside the lane assignment's first launch (k_mark_sources)
@@ -2513,13 +2514,14 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 				c->route_memo.src = d_src;
 				c->route_memo.dst = d_dst;
 				c->route_memo.go = ran ? 1 : 0;
+				if (decide_mode == 2 && observed_go == 0) c->route_memo.go = 0; // these rows look like a cross product now: gated again next time
 			}
 			if (ran) return PGQ_OK;
 		}
 	}
 	u32 U = 0;
 	// the accounting pass counts the full BFS of a pair even when dst has no in-edge, so it keeps those lanes
-	SampleArgs sm { meet_bytes, edge_bytes, nullptr, nullptr };
+	SampleArgs sm { meet_bytes, edge_bytes, nullptr, nullptr, n, d_src, c->V };
 	if (sampled) {
 		PGQ_TRY(ws->route_dec.reserve(sizeof(MeetDecision)));
 		sm.out = ws->route_dec.as<MeetDecision>();

@@ -60,11 +60,12 @@ struct MeetDecision {
 #ifdef __HIPCC__
 constexpr u32 kSampleEmpty = 0xFFFFFFFFu;
 constexpr int kSampleRows = 2048, kSampleSlots = 4096;
-// Every thread of ONE workgroup (any multiple of 64 threads).  h_go (nullable): pinned host word that gets the verdict + 1.
+// Every thread of ONE workgroup (any multiple of 64 threads).  s_set: kSampleSlots words of LDS the caller lends (its own
+// array, or a map it is not using yet).  h_go (nullable): pinned host word that gets the verdict + 1.
 __device__ __forceinline__ void sample_distinct_sources(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
-                                                        double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go) {
+                                                        double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go,
+                                                        u32 *s_set) {
 	const int nt = (int)blockDim.x;
-	__shared__ u32 s_set[kSampleSlots];
 	__shared__ u32 s_count[2];
 	for (int k = threadIdx.x; k < kSampleSlots; k += nt) s_set[k] = kSampleEmpty;
 	if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
@@ -124,6 +125,15 @@ __device__ __forceinline__ void sample_distinct_sources(int64_t n, const int64_t
 }
 
 #endif
+// a sample riding in another kernel's launch (k_mark_sources: the lane assignment; k_meet4d: the pre-pass chain)
+struct SampleArgs {
+	double meet_bytes, edge_bytes;
+	MeetDecision *out;
+	u32 *h_go; // null: no sample
+	int64_t n;
+	const int64_t *src;
+	int64_t V;
+};
 
 // What a level's kernels leave in the counter block, as the host needs it after the level (read back per level, or logged
 // by the next level's k_level_reset into pinned memory when levels are enqueued ahead).
@@ -241,7 +251,7 @@ struct MeetPathsOut {
 	int64_t total = 0;
 };
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, MeetPathsOut *po, bool decide, double meet_bytes, double edge_bytes, bool *ran);
+                 u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go);
 // iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its
 // caps are compacted like the pre-pass's open rows
 int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,

@@ -1283,8 +1283,8 @@ def test_levels_enqueued_ahead_match_the_round_trip_loop():
         ln, ok = st.iterativelength(0, V, ps, pd)
         assert lens(ln, ok) == want
         stats = pgq.get_stats()
-        assert stats["spec_batches"] >= 1 and stats["spec_levels"] >= 1
-    assert stats["host_waits"] < waits_round_trip
+        assert stats["spec_batches"] >= 1  # (a batch much narrower than the one that left the plan may be called off at level 1)
+    assert stats["spec_levels"] >= 1 and stats["host_waits"] < waits_round_trip
     # the level rule changes under the plan: every level is top-down now, the plan's bottom-up levels are called off
     pgq.set_option("force_mode", 1)
     pgq.reset_stats()

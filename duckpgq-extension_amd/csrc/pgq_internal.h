@@ -77,6 +77,7 @@ struct Options {
 	int spec_levels = 1;    // levels of a batch enqueued ahead under the previous batch's plan, checked on the device: one wait per
 	                        // batch instead of one per level (0: a host round trip after every level)
 	int detect_unroll = 4;  // rows per thread of k_detect with their gathers in flight together (1, 2 or 4)
+	int meet_calibrate = 1; // the pre-pass's bytes per row are measured (1024 pseudo-random pairs) before the first large call is routed
 	int route_memo = 1;     // large calls on the buffers of the last one that the sample sent to the lane batches go there straight
 	int probe_always = 0;   // 1: probe before every level of a batch that uses the probe (round-2 behaviour; tests)
 	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
@@ -117,7 +118,8 @@ struct Options {
 	int lanes = 1;          // sparse bottom-up levels use the lane-list kernel (k_pull_lanes); 0: k_pull_sparse
 	int lanes_unroll = 2;   // 64-entry chunks in flight per wave in k_pull_lanes (1, 2 or 4)
 	int meet_trace = 0;      // debugging: per-workgroup timestamps of k_meet4d, summarised on stderr
-	int meet4_grid_mult = 2; // k_meet4d grid = this many 1024-thread workgroups per CU (2 fit beside their LDS bit maps; rows are handed out dynamically)
+	int meet4_grid_mult = 1; // k_meet4d grid = this many 1024-thread workgroups per CU (2 fit beside their LDS bit maps; rows are handed out
+	                         // dynamically).  Round 5, after stage A / the probe shortened a row: one per CU 42.6 us, two 51.2, three 62.8 per 65,536 rows
 	int meet_grid_mult = 8; // k_meet3 grid = this many times the 8192 one-wavefront workgroups the chip holds (rows per workgroup = n / grid)
 	int meet_layout = 1;    // build the padded adjacency + slot descriptors at upload (the pre-pass needs them)
 	int meet_align = 32;    // entries a padded list is aligned and padded to (4 = one 16-byte group; 16 / 32 = whole 64 / 128-byte lines: -4 % / -6 % on the pre-pass)
@@ -203,6 +205,7 @@ struct pgq_csr {
 	int64_t hub_threshold = 0;
 	int64_t max_out_degree = 0, max_in_degree = 0;
 	double two_hop_mean = 0; // mean over vertices of in-degree x out-degree = expected two-hop walk of a random endpoint
+	std::atomic<double> meet_bpr { 0.0 }; // bytes per row the pre-pass has been measured to move on this CSR (0: not yet; pgq_msbfs.hip)
 	int64_t bytes = 0;
 	bool has_negative_weight = false;
 	// multi-GPU: copies of this CSR on the other enabled devices (pgq_csr_replicate), indexed like enabled_devices();

@@ -2367,11 +2367,57 @@ static bool prepass_may(const pgq_csr *c, const SearchOutput &outp) {
 	// two-hop scans instead of another round of whole-graph levels
 	return options().meet && !outp.want_te && outp.depth <= 1 && !outp.from_meet && c->E > 0 && c->fdesc != nullptr;
 }
+// Bytes the pre-pass moves per row.  Known once a pre-pass has run on this CSR (measured: its kernels count the entries
+// they walk; calibrate_prepass runs 1024 pseudo-random pairs through it before the first large call is routed).  Before
+// that: the cheaper endpoint's WHOLE two-hop neighbourhood, ~0.6 x E[in-degree x out-degree] entries — what a far pair
+// costs.  Close pairs stop after a fraction of it: on the SF100-shaped graph the bound is 6x what 65,536 random pairs
+// move (12 KB per row), and a 2048 x 32 cross product priced with it went through the lane batches at 0.73 ms where the
+// pre-pass takes 0.22.
+static double prepass_row_bytes(const pgq_csr *c) {
+	const double measured = c->meet_bpr.load(std::memory_order_relaxed);
+	return measured > 0 ? measured : c->two_hop_mean * 4.0 * 0.6;
+}
+__global__ void k_calibration_pairs(int64_t n, int64_t V, int64_t *__restrict__ src, int64_t *__restrict__ dst) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	auto mix = [](u64 x) { // splitmix64
+		x += 0x9E3779B97F4A7C15ull;
+		x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+		x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+		return x ^ (x >> 31);
+	};
+	src[i] = (int64_t)(mix(2 * (u64)i) % (u64)V);
+	dst[i] = (int64_t)(mix(2 * (u64)i + 1) % (u64)V);
+}
+static int calibrate_prepass(pgq_csr *c) {
+	std::lock_guard<std::mutex> g(c->lazy_lock);
+	if (c->meet_bpr.load() > 0) return PGQ_OK;
+	const int64_t n0 = 1024;
+	WorkspaceLease lease;
+	PGQ_TRY(lease.acquire());
+	Workspace *w = lease.ws;
+	PGQ_TRY(w->in_src.reserve((size_t)n0 * 8));
+	PGQ_TRY(w->in_dst.reserve((size_t)n0 * 8));
+	PGQ_TRY(w->out_len.reserve((size_t)n0 * 8));
+	hipLaunchKernelGGL(k_calibration_pairs, dim3(blocks_for(n0)), dim3(256), 0, w->stream, n0, c->V, w->in_src.as<int64_t>(), w->in_dst.as<int64_t>());
+	pgq_stats_t &S = tstats().s;
+	const pgq_stats_t saved = S; // the caller's statistics are about its own rows
+	u32 nd = 0;
+	bool ran = true;
+	const int rc = meet_prepass(c, w, n0, w->in_src.as<int64_t>(), w->in_dst.as<int64_t>(), w->out_len.as<int64_t>(), &nd, nullptr, 0,
+	                            0.0, 0.0, &ran, nullptr);
+	const double bytes = (S.algo_bytes[K_MEET] - saved.algo_bytes[K_MEET]) + (S.algo_bytes[K_MEET4] - saved.algo_bytes[K_MEET4]) +
+	                     (S.algo_bytes[K_BIBFS] - saved.algo_bytes[K_BIBFS]);
+	S = saved;
+	PGQ_TRY(rc);
+	c->meet_bpr.store(std::max(64.0, bytes / (double)n0));
+	return PGQ_OK;
+}
 static bool prepass_takes(const pgq_csr *c, int64_t n, const SearchOutput &outp) {
 	if (!prepass_may(c, outp)) return false;
-	const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
+	const double meet_bytes = (double)n * prepass_row_bytes(c);
 	const double edge_bytes = options().meet_bias * (double)c->E;
-	return meet_bytes <= lanes_cost_bytes(edge_bytes, (double)std::min<int64_t>(n, c->V));
+	return meet_bytes <= lanes_cost_bytes(edge_bytes, (double)std::min<int64_t>(n, c->V), (double)n, (double)c->V);
 }
 
 // Lane assignment + sorting of the rows, then the templated batch loop; results scattered back to row order.
@@ -2389,15 +2435,17 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// endpoint is expanded: ~0.6 of that) against ~16 B per edge per 2048-lane batch.
 	const Options &mopt = options();
 	const bool may_meet = prepass_may(c, outp);
+	// a large call is about to be routed on the pre-pass's bytes per row: measured first if this CSR has none yet
+	if (may_meet && n > kMeetDecideRows && mopt.meet_calibrate && c->meet_bpr.load(std::memory_order_relaxed) <= 0) PGQ_TRY(calibrate_prepass(c));
 	// Cost model (bytes at streaming rate): the pre-pass walks, per row, the cheaper endpoint's two-hop neighbourhood
 	// (~0.6 of E[in-degree x out-degree] entries when it has to walk all of it; it usually stops far earlier: the estimate
 	// is on the safe side).  A lane batch of `wd` lane-words costs about one sparse and one dense bottom-up level
 	// (or the probes that replace it): E x (12 + 3 wd) bytes — calibrated on the 2048-lane batch of the SF100-shaped
 	// graph (0.94 ms ~ 4.3 GB at streaming rate; round 2 priced a batch at 16 B per edge and sent a 2048 x 32 cross product
 	// through the lanes at three times the cost of the pre-pass).  `meet_bias` scales the lanes' side.
-	const double meet_bytes = (double)n * c->two_hop_mean * 4.0 * 0.6;
+	const double meet_bytes = (double)n * prepass_row_bytes(c);
 	const double edge_bytes = mopt.meet_bias * (double)c->E; // x (12 + 3 wd) per batch
-	auto meet_pays = [&](int64_t distinct_sources) { return meet_bytes <= lanes_cost_bytes(edge_bytes, (double)distinct_sources); };
+	auto meet_pays = [&](int64_t distinct_sources) { return meet_bytes <= lanes_cost_bytes(edge_bytes, (double)distinct_sources, (double)n, (double)c->V); };
 	// few rows: every row is taken as a distinct source (the pessimistic case for the pre-pass); many rows: a sampled
 	// estimate of the distinct sources decides ON THE DEVICE, in the same launch chain (cross products share their lanes)
 	const bool decide = n > kMeetDecideRows;
@@ -2458,8 +2506,14 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	auto run_meet = [&](bool *ran) -> int {
 		if (with_paths) return run_meet_paths(ran);
 		u32 nd = 0;
+		const double b0 = S.algo_bytes[K_MEET] + S.algo_bytes[K_MEET4] + S.algo_bytes[K_BIBFS];
 		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide_mode, meet_bytes, edge_bytes, ran, &observed_go));
 		if (!*ran) return PGQ_OK;
+		if (n >= 1024) { // what these rows really moved refines the CSR's bytes per row (half the weight to the newest call)
+			const double now = std::max(64.0, (S.algo_bytes[K_MEET] + S.algo_bytes[K_MEET4] + S.algo_bytes[K_BIBFS] - b0) / (double)n);
+			const double old = c->meet_bpr.load(std::memory_order_relaxed);
+			c->meet_bpr.store(old > 0 ? 0.5 * old + 0.5 * now : now, std::memory_order_relaxed);
+		}
 		if (nd > 0) {
 			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
 			WorkspaceLease inner;

@@ -39,14 +39,21 @@ __device__ __forceinline__ bool level_is_off(const Counters *__restrict__ cnt, i
 // bytes (at streaming rate) the lane-batched search is priced at for `distinct` sources: full 2048-lane batches of 32
 // lane-words plus one narrower batch for the rest, E x (12 + 3 wd) each; `edge_bytes` = meet_bias x E.  Shared by the
 // host-side decision (few rows) and k_meet_decide (sampled distinct sources).
-__host__ __device__ static inline double lanes_cost_bytes(double edge_bytes, double distinct) {
+// Round 5: `rows` / `V` add the DENSE bottom-up level, E x (8 + 6 wd), to every batch that holds more than V / 8 rows — with
+// that many open rows the probes do not replace it (2048 sources x 128 .. 1024 destinations on the SF100-shaped graph: 2.1 -
+// 2.3 ms per batch against 0.73 ms at x 32, where the probes do; priced without it a 2048 x 256 product went through the
+// lanes at 2.05 ms where the pre-pass takes 1.16).
+__host__ __device__ static inline double lanes_cost_bytes(double edge_bytes, double distinct, double rows, double V) {
 	const double full = floor(distinct / 2048.0), rest = distinct - full * 2048.0;
 	double wd = 0.0;
 	if (rest > 0.0) {
 		wd = 1.0;
 		while (wd * 64.0 < rest) wd *= 2.0;
 	}
-	return edge_bytes * (full * (12.0 + 3.0 * 32.0) + (rest > 0.0 ? 12.0 + 3.0 * wd : 0.0));
+	const double batches = full + (rest > 0.0 ? 1.0 : 0.0);
+	const bool dense = batches > 0.0 && rows / batches > V / 8.0;
+	return edge_bytes * (full * (12.0 + 3.0 * 32.0 + (dense ? 8.0 + 6.0 * 32.0 : 0.0)) +
+	                     (rest > 0.0 ? 12.0 + 3.0 * wd + (dense ? 8.0 + 6.0 * wd : 0.0) : 0.0));
 }
 
 // ---- how many distinct sources? (the pre-pass's sampled decision; pgq_meet.hip and the lane assignment both run it) ----
@@ -66,9 +73,9 @@ __device__ __forceinline__ void sample_distinct_sources(int64_t n, const int64_t
                                                         double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go,
                                                         u32 *s_set) {
 	const int nt = (int)blockDim.x;
-	__shared__ u32 s_count[2];
+	__shared__ u32 s_count[4];
 	for (int k = threadIdx.x; k < kSampleSlots; k += nt) s_set[k] = kSampleEmpty;
-	if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
+	if (threadIdx.x < 4) s_count[threadIdx.x] = 0;
 	__syncthreads();
 	const int64_t sample = n < kSampleRows ? n : kSampleRows;
 	// the sample = runs of 64 consecutive rows at evenly spaced offsets.  A join emits a cross product grouped by source:
@@ -76,10 +83,32 @@ __device__ __forceinline__ void sample_distinct_sources(int64_t n, const int64_t
 	// like distinct pairs; inside a run a grouped input shows its repeats, and a shuffled one is sampled as well as by
 	// single rows
 	const double stride = (double)n / (double)((sample + 63) >> 6);
-	u32 fresh = 0, rows = 0;
-	for (int64_t k = threadIdx.x; k < sample; k += nt) {
-		const int64_t v = src[min(n - 1, (int64_t)((double)(k >> 6) * stride) + (k & 63))];
-		if (v < 0) continue; // NULL row
+	// (round 5: every run is shifted by a pseudo-random part of its stride — offsets at exact multiples of n / 32 start every
+	// run on a group boundary of a product whose groups divide that stride, and the boundary count below was off by 2x)
+	auto run_start = [&](int64_t r) {
+		const int64_t room = (int64_t)stride - 64;
+		const int64_t jitter = room > 0 ? (int64_t)((((u64)r + 1) * 0x9E3779B97F4A7C15ull) >> 33) % room : 0;
+		return (int64_t)((double)r * stride) + jitter;
+	};
+	// Round 5: the runs also show how the input is GROUPED.  `changes` counts the adjacent rows of a run whose sources
+	// differ: a join's output (every source's rows in one stretch) changes source once per group, so n x changes / pairs
+	// is its number of groups = distinct sources — which the hash-set estimate below cannot see (32 runs of a 2048 x 32
+	// product hold 64 sources: "64 distinct", and the product went to the lane batches at three times the pre-pass's time).
+	u32 fresh = 0, rows = 0, changes = 0, pairs = 0;
+	const int64_t sample_up = (sample + 63) & ~(int64_t)63; // whole wavefronts stay in the loop for the shuffle
+	for (int64_t k = threadIdx.x; k < sample_up; k += nt) {
+		const bool in = k < sample;
+		const int64_t at = min(n - 1, run_start(k >> 6) + (k & 63));
+		const int64_t v = in ? src[at] : (int64_t)-1;
+		int64_t pv = __shfl_up(v, 1);
+		// a run's first row is compared with the row in front of the run: runs that start on a group boundary (evenly spaced
+		// offsets and equal groups: a 2048 x 32 product sampled at stride 2048) would otherwise never see that boundary
+		if ((k & 63) == 0) pv = in && at > 0 ? src[at - 1] : (int64_t)-1;
+		if (in && v >= 0 && pv >= 0) {
+			pairs++;
+			changes += v != pv ? 1u : 0u;
+		}
+		if (v < 0) continue; // NULL row (or past the sample)
 		rows++;
 		const u32 x = (u32)v;
 		u32 h = (x * 0x9E3779B1u) >> 20; // 12 bits
@@ -92,6 +121,8 @@ __device__ __forceinline__ void sample_distinct_sources(int64_t n, const int64_t
 	}
 	if (fresh) atomicAdd(&s_count[0], fresh);
 	if (rows) atomicAdd(&s_count[1], rows);
+	if (changes) atomicAdd(&s_count[2], changes);
+	if (pairs) atomicAdd(&s_count[3], pairs);
 	__syncthreads();
 	// E[distinct](U) = U (1 - (1 - 1/U)^s) is increasing in U: every thread evaluates one point of a geometric grid between
 	// the distinct sources seen and n ((1 - 1/U)^s as exp(s log1p(-1/U)), single precision) and the first point that
@@ -115,9 +146,47 @@ __device__ __forceinline__ void sample_distinct_sources(int64_t n, const int64_t
 		const float uf = fd * __expf(__logf(fn / fd) * ((float)s_first / (float)(nt - 1)));
 		est = fmin((double)n, ceil((double)uf));
 	}
+	// grouped input (fewer than half of the adjacent sampled rows change their source): the groups counted through the
+	// density of the changes.  A handful of changes in the whole sample (groups of hundreds of rows and more) is too few to
+	// count by: then the first row of every run measures its own group — gallop + bisection to both ends, ~2 log2(g) loads —
+	// and, a uniformly drawn row falling into a group in proportion to its length, n x mean(1 / g) is the number of groups.
+	const double ch = s_count[2], pr = s_count[3];
+	const bool grouped = pr >= 32.0 && ch * 2.0 < pr; // block-uniform
+	__shared__ float s_inv[32];
+	const int runs = (int)((sample + 63) >> 6);
+	if (grouped && ch < 16.0) {
+		if ((int)threadIdx.x < runs && threadIdx.x < 32) {
+			const int64_t p = min(n - 1, run_start((int64_t)threadIdx.x));
+			const int64_t v = src[p];
+			auto extent = [&](int64_t dir) { // rows of v's stretch strictly beyond p in direction dir
+				const int64_t room = dir > 0 ? n - 1 - p : p;
+				int64_t step = 1;
+				while (step <= room && src[p + dir * step] == v) step <<= 1;
+				int64_t lo = step >> 1, hi = min(step, room + 1); // src[p + dir*lo] == v (or lo == 0); first mismatch in (lo, hi]
+				while (hi - lo > 1) {
+					const int64_t mid = (lo + hi) >> 1;
+					if (src[p + dir * mid] == v) lo = mid;
+					else hi = mid;
+				}
+				return lo;
+			};
+			s_inv[threadIdx.x] = 1.0f / (float)(1 + extent(1) + extent(-1));
+		}
+		__syncthreads();
+	}
 	if (threadIdx.x != 0) return;
+	if (grouped) {
+		double groups = (double)n * fmax(ch, 0.5) / pr;
+		if (ch < 16.0) {
+			double inv = 0;
+			const int m = runs < 32 ? runs : 32;
+			for (int r = 0; r < m; r++) inv += (double)s_inv[r];
+			groups = (double)n * inv / (double)m;
+		}
+		est = fmin((double)n, fmax(d, groups));
+	}
 	const double distinct = fmin(est, (double)V);
-	out->go = meet_bytes <= lanes_cost_bytes(edge_bytes, distinct) ? 1u : 0u;
+	out->go = meet_bytes <= lanes_cost_bytes(edge_bytes, distinct, (double)n, (double)V) ? 1u : 0u;
 	if (h_go) *h_go = out->go + 1u;
 	out->sample_rows = s_count[1];
 	out->sample_fresh = s_count[0];

@@ -30,7 +30,7 @@ def _defaults():
 SHIPPED_KEYS = ("push_div", "streams", "probe2_abs", "meet", "meet_align", "meet_bias", "meet_cap", "meet_cap_small", "meet_cap_paths",
                 "meet_small_rows", "probe", "probe2", "defer", "lanes", "lanes_unroll", "sparse_lds", "sparse_pw", "sparse_unroll",
                 "sparse_spill", "hub_chunk", "push_chunk", "spec_levels", "sort_single_batch", "detect_unroll", "route_memo", "meet4",
-                "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs")
+                "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs", "meet4_grid_mult", "meet_grid_mult", "meet_calibrate")
 
 
 @pytest.fixture(params=["fixture_values", "shipped_values"])

@@ -593,3 +593,83 @@ def test_walk_model_tool_runs_and_the_walk_size_rule_is_never_worse_on_average()
     assert out["by_walk"]["cut_at_cap"][1024] <= out["by_list"]["cut_at_cap"][1024]
     st = out["stage_a"]["512x512"]
     assert 0 <= st["settled"] <= st["rows"]
+
+
+# ---- round 5: the sampled decision's estimate of the distinct sources (pgq_search.h: sample_distinct_sources) -------------
+
+def _distinct_sources_model(src):
+    """CPU model of the device estimator: 32 runs of 64 consecutive rows at evenly spaced offsets; the hash-set estimate
+    (inverting E[distinct] = U (1 - (1 - 1/U)^s) on a geometric grid) for inputs in random order, the density of source
+    CHANGES between adjacent rows for grouped inputs (a join's output), and for groups too long to count that way the
+    measured stretch around the first row of every run (n x mean(1 / g))."""
+    import math
+    n = len(src)
+    sample = min(n, 2048)
+    runs = (sample + 63) // 64
+    stride = n / runs
+
+    def run_start(r):  # evenly spaced, shifted by a pseudo-random part of the stride (no aliasing with regular groups)
+        room = int(stride) - 64
+        jitter = ((((r + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF) >> 33) % room if room > 0 else 0
+        return int(r * stride) + jitter
+
+    rows, seen, changes, pairs = 0, set(), 0, 0
+    for k in range(sample):
+        p = min(n - 1, run_start(k >> 6) + (k & 63))
+        v = src[p]
+        pv = src[p - 1] if p > 0 else -1  # (inside a run: the row before; a run's first row: the row in front of the run)
+        if v >= 0 and pv >= 0:
+            pairs += 1
+            changes += v != pv
+        if v < 0:
+            continue
+        rows += 1
+        seen.add(v)
+    d, sr = len(seen), rows
+    if sr < 1 or d < 1:
+        est = 1.0
+    elif d >= sr - 0.5:
+        est = float(n)
+    else:
+        est = float(n)
+        for t in range(1024):
+            u = d * math.exp(math.log(n / d) * t / 1023.0)
+            if u * (1.0 - math.exp(sr * math.log1p(-1.0 / u))) >= d:
+                est = min(float(n), math.ceil(u))
+                break
+    if pairs >= 32 and changes * 2 < pairs:
+        groups = n * max(changes, 0.5) / pairs
+        if changes < 16:
+            inv = []
+            for r in range(min(runs, 32)):
+                p = min(n - 1, run_start(r))
+                lo = hi = p
+                while hi + 1 < n and src[hi + 1] == src[p]:
+                    hi += 1
+                while lo > 0 and src[lo - 1] == src[p]:
+                    lo -= 1
+                inv.append(1.0 / (hi - lo + 1))
+            groups = n * sum(inv) / len(inv)
+        est = min(float(n), max(float(d), groups))
+    return est
+
+
+def test_distinct_source_estimate_on_grouped_and_shuffled_inputs():
+    rng = np.random.default_rng(12)
+    V = 448626
+    for sources, per in ((2048, 32), (2048, 128), (2048, 1024), (32, 65536), (40, 1000), (10000, 7)):
+        s = np.repeat(rng.choice(V, sources, replace=False), per)  # grouped by source, like a nested-loop join emits it
+        est = _distinct_sources_model(s)
+        assert sources / 1.6 <= est <= sources * 1.6, (sources, per, est)
+    for sources, n in ((2048, 65536), (300, 100000), (50000, 65536)):  # the same sources in random order
+        s = rng.choice(rng.choice(V, sources, replace=False), n)
+        est = _distinct_sources_model(s)
+        true = len(np.unique(s))
+        assert true / 2.0 <= est <= true * 2.0, (sources, n, est, true)
+    s = rng.permutation(V)[:65536]  # every row its own source
+    assert _distinct_sources_model(s) == 65536.0
+    # ragged groups (a join with a filter): lengths between 1 and 400
+    lens = rng.integers(1, 400, 3000)
+    s = np.repeat(rng.choice(V, 3000, replace=False), lens)
+    est = _distinct_sources_model(s)
+    assert 3000 / 1.7 <= est <= 3000 * 1.7, est

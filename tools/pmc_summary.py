@@ -53,6 +53,18 @@ def _summarise(agg, launches):
         chain = [k for k in out if k.startswith(("k_meet3", "k_meet4", "k_bibfs"))]
         out["prepass_chain"] = {"steps_profiled": steps, "kernels": sorted(chain),
                                 "hbm_bytes_per_step": sum(out[k].get("hbm_bytes_per_launch", 0.0) * out[k]["launches_profiled"] for k in chain) / steps}
+    # round 5: the lane-batched search's launch chain per step (bench.py: roofline.traffic of the msbfs legs) — every kernel
+    # of a batch from the lane assignment to the result scatter; steps profiled = launches of k_init_batch (one per batch)
+    init = [k for k in out if k.startswith("k_init_batch")]
+    if init:
+        steps = max(sum(out[k]["launches_profiled"] for k in init), 1)
+        names = ("k_prep_zero", "k_mark_sources", "k_compact_sources", "k_pair_rows", "k_pair_keys", "k_gather_sorted", "k_batch_bounds",
+                 "k_batch_reset", "k_init_batch", "k_level_reset", "k_push<", "k_clear_items", "k_queue_from_dense", "k_detect<",
+                 "k_compact_lanes", "k_pull_lanes<", "k_pull<", "k_pull_hub", "k_probe<", "k_probe2<", "k_scatter_results",
+                 "k_clean_by_nz", "k_open_merge", "k_compact_frontier", "k_pull_sparse<")
+        chain = [k for k in out if k.startswith(names)]
+        out["chain"] = {"steps_profiled": steps, "kernels": sorted(chain),
+                        "hbm_bytes_per_step": sum(out[k].get("hbm_bytes_per_launch", 0.0) * out[k]["launches_profiled"] for k in chain) / steps}
     return out
 
 

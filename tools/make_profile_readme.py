@@ -9,7 +9,7 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 rdir = os.path.join(root, "profiles", rnd)
 
 
@@ -31,67 +31,74 @@ def fmt(x, spec="{:,.0f}"):
 
 
 L = ["# profiles — round %s measurements (MI355X, one GPU per gpurun box)" % rnd.lstrip("r0"), "",
-     "Produced by committed tooling only: `tools/measure_pass_r04.sh` (round 3: `tools/measure_pass.sh`) on the GPU box runs `bench.py` per workload (one JSON "
-     "line each), `rocprofv3 --kernel-trace --stats` of the default bench command without its second leg (`--no-legs`: "
-     "every `k_meet3` / `k_meet4d` call is a 65,536-row one) and of the cross-product workload (`--workload snb_cross`), "
-     "separate `--pmc` passes (round 4: of the default workload; the cross-product file is round 3's) summarised by `tools/pmc_summary.py` into `profiles/pmc_<workload>.json` ("
-     "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), `tools/chunk_latency.py`; the `tools/membench` figures quoted in DESIGN.md are round 3's (`profiles/r03/membench_*`).  "
-     "Regenerate this file with `python tools/make_profile_readme.py %s`.  `profiles/r01/` … `profiles/r03/` are the "
-     "previous rounds." % rnd,
+     "Produced by committed tooling only: `tools/measure_pass_r05.sh` on the GPU box (PART=1: `bench.py` with the driver's own "
+     "command — every BASELINE config is a leg of that one line since round 5 — and the call shapes beside it, `rocprofv3 "
+     "--kernel-trace --stats` of the default workload without its legs (`--no-legs`: every `k_meet3` / `k_meet4d` call is a "
+     "65,536-row one) and of the cross product (`--workload snb_cross`), `tools/chunk_latency.py`; PART=2: separate `--pmc` "
+     "passes of both workloads, summarised by `tools/pmc_summary.py` into `profiles/pmc_<workload>.json` (FETCH_SIZE doubled "
+     "per MI355X_MICROARCH.md §HBM); PART=3: the whole `-m gpu` suite (`pytest_gpu.txt`); PART=4: configs[4] at its named scale).  "
+     "The `tools/membench` figures quoted in DESIGN.md are round 3's (`profiles/r03/membench_*`).  Regenerate this file with "
+     "`python tools/make_profile_readme.py %s`.  `profiles/r01/` … `profiles/r04/` are the previous rounds." % rnd,
      ""]
-names = [("snb_sf100", "C4 shard: SF100-shaped knows, iterativelength, 65,536 random pairs (default bench; every row through the pre-pass)"),
-         ("snb_sf100_8192", "same graph, 8192 random pairs"),
-         ("snb_sf100_2048", "same graph, 2048 random pairs (one DuckDB chunk's worth, device arrays)"),
-         ("snb_sf100_8192_msbfs_only", "same, 8192 random pairs, `PGQ_MEET=0` (lane-batched MS-BFS only)"),
-         ("snb_cross", "same graph, cross product 2048 sources x 1024 destinations = 2.1 M rows (lane-batched MS-BFS; the `msbfs_cross` leg)"),
-         ("snb_cross_2048x32", "same graph, cross product 2048 sources x 32 destinations = 65,536 rows"),
-         ("snb_cross_allv", "same graph, 32 sources x every vertex = 14.4 M rows"),
-         ("rmat22", "C2: R-MAT scale 22, iterativelength, 1024 pairs"),
-         ("snb_paths", "C3: SF100-shaped knows, shortestpath + reconstruction, 4096 pairs"),
-         ("forest_cheapest", "C5: reply forest V=2^24, int64 weights, cheapest_path_length, 4096 reachable pairs"),
-         ("forest_cheapest_double", "C5, double weights"),
-         ("forest_cheapest_2_28", "C5 at the named scale: reply forest V=2^28 (268 M vertices, 215 M edges), int64 weights, 4096 pairs"),
-         ("snb_cheapest_4096", "general graph: weighted knows graph (int64 weights 1..999), cheapest_path_length, 4096 pairs (batched relaxation, light edges first; 3 batches side by side)"),
-         ("snb_cheapest_4096_double", "same, double weights"),
-         ("snb_cheapest_4096_streams6", "same, int64, 6 batches side by side (`relax_streams=6`, the default since; the kernel columns of this line come from a pass in which the 6 batches overlapped — only ms/step and pairs/s count)")]
-L += ["## bench.py, 1 GPU (10 steps, 2 warm-up; timed region runs unprofiled, the roofline columns come from an untimed "
-      "pass with one batch in flight and HIP events around every kernel)", "",
-      "| workload | ms/step | pairs/s | MTEPS physical (adjacency entries scanned) | rows answered by the pre-pass | dominant kernel | launches/step | "
-      "avg launch ms | algorithmic GB/s | frac of 8 TB/s | whole step GB/s (frac) | CPU baseline |",
-      "|---|---|---|---|---|---|---|---|---|---|---|---|"]
-for w, title in names:
+default = load("bench_default.json")
+rows = []  # (title, leg-like dict)
+if default:
+    top = dict(default)
+    rows.append(("configs[3] on one GPU: SF100-shaped knows, iterativelength, 65,536 random pairs (the line's top level = leg `prepass`)", top))
+    titles = {"msbfs_cross": "same graph, the binder's call shape: 2048 sources x 1024 destinations = 2.1 M rows (leg `msbfs_cross`, lane-batched MS-BFS)",
+              "snb_paths": "configs[2]: SF100-shaped knows, shortestpath + reconstruction, 4096 pairs (leg `snb_paths`)",
+              "rmat22": "configs[1]: R-MAT scale 22, iterativelength, 1024 pairs (leg `rmat22`)",
+              "forest_cheapest": "configs[4]: reply forest V = 2^24, int64 weights, cheapest_path_length, 4096 pairs (leg `forest_cheapest`)",
+              "cheapest_general": "configs[4]'s operator on a general graph: weighted knows graph, 4096 pairs (leg `cheapest_general`, one step)"}
+    for k in ("msbfs_cross", "snb_paths", "rmat22", "forest_cheapest", "cheapest_general"):
+        if k in (default.get("legs") or {}):
+            rows.append((titles[k], default["legs"][k]))
+for w, title in (("snb_sf100_8192", "SF100 graph, 8192 random pairs (configs[3]'s shard at 8 GPUs)"),
+                 ("snb_sf100_2048", "SF100 graph, 2048 random pairs (one DuckDB chunk's worth, device arrays)"),
+                 ("snb_sf100_8192_msbfs_only", "8192 random pairs, `PGQ_MEET=0` (lane-batched MS-BFS only)"),
+                 ("snb_cross_2048x32", "cross product 2048 sources x 32 destinations = 65,536 rows (routed to the pre-pass since round 5)"),
+                 ("snb_cross_2048x32_lanes", "the same rows with `PGQ_MEET=0` (lane batches: round 4's route)"),
+                 ("snb_cross_allv", "32 sources x every vertex = 14.4 M rows"),
+                 ("forest_cheapest_double", "configs[4], double weights"),
+                 ("forest_cheapest_2_28", "configs[4] at the named scale: reply forest V = 2^28 (268 M vertices, 215 M edges), int64 weights")):
     j = load("bench_%s.json" % w)
-    if not j:
-        continue
+    if j:
+        rows.append((title, j))
+L += ["## bench.py, 1 GPU (timed region runs unprofiled; the roofline columns come from an untimed pass with one batch in "
+      "flight and HIP events around every launch; `chain` = all kernel classes of the leg: algorithmic bytes over the sum of "
+      "their launch durations)", "",
+      "| workload | ms/step | pairs/s | launch chain | chain GB/s | chain frac of 8 TB/s | chain traffic (PMC) / algorithmic | dominant kernel (frac) | "
+      "whole step frac | CPU baseline |",
+      "|---|---|---|---|---|---|---|---|---|---|"]
+for title, j in rows:
     r = j.get("roofline") or {}
     step = r.get("step") or {}
+    dom = r.get("dominant_kernel") or {}
     cpu = j.get("cpu_baseline")
-    st = (cpu or {}).get("single_thread")
     cpu_s = "—"
-    if cpu:
-        cpu_s = "%s %s on %d threads" % (fmt(cpu["value"]), cpu["unit"], cpu["cores"])
-        if st:
-            cpu_s += "; %s on 1" % fmt(st["value"])
-    L.append("| %s | %.3f | %s | %s | %s | `%s` | %s | %s | %s | %s | %s | %s |" % (
-        title, j["ms_per_step"], fmt(j.get("pairs_per_s")), fmt(j.get("mteps_physical")) if j.get("mteps_physical") else "—",
-        fmt(j.get("rows_answered_by_prepass_per_step")), r.get("kernel", "—"),
-        fmt((j.get("roofline_by_kernel") or {}).get(CLASS_OF.get(r.get("kernel", ""), r.get("kernel", "").replace("k_", "")), {}).get("launches_per_step"), "{:.1f}"),
-        fmt(r.get("avg_launch_ms"), "{:.3f}"), fmt(r.get("achieved")), fmt(r.get("frac"), "{:.3f}"),
-        "%s (%s)" % (fmt(step.get("GBps")), fmt(step.get("frac"), "{:.3f}")) if step else "—", cpu_s))
-L += ["", "Kernel classes of the untimed one-batch-in-flight pass (ms per step, algorithmic GB/s where the class has a "
-      "byte model):", ""]
-for w, _ in names:
-    j = load("bench_%s.json" % w)
-    if j and j.get("roofline_by_kernel"):
-        fe = (j.get("roofline") or {}).get("frontier_expansion")
-        pc = (j.get("roofline") or {}).get("prepass_chain")
-        L.append("* **%s**: " % w + ", ".join(
+    if cpu and cpu.get("value") is not None:
+        cpu_s = "%s %s on %s threads" % (fmt(cpu["value"]), cpu.get("unit", ""), cpu.get("cores"))
+    # traffic: from the PMC files as committed (the bench line embeds what the file held when it ran), and only where the
+    # counters were collected on this shape: the default workload and the 2048 x 1024 cross product
+    tr = None
+    pmc_of = {"prepass": ("pmc_snb_sf100.json", "prepass_chain"), "msbfs_cross": ("pmc_snb_cross.json", "chain")}
+    key = "prepass" if j is rows[0][1] else ("msbfs_cross" if "msbfs_cross" in title else None)
+    if key:
+        try:
+            tr = json.load(open(os.path.join(root, "profiles", pmc_of[key][0])))[pmc_of[key][1]]["hbm_bytes_per_step"]
+        except Exception:
+            tr = None
+    ab = r.get("algorithmic_bytes_per_step")
+    L.append("| %s | %.4f | %s | %s | %s | %s | %s | `%s` (%s) | %s | %s |" % (
+        title, j["ms_per_step"], fmt(j.get("pairs_per_s")), " + ".join(r.get("classes") or []) or "—", fmt(r.get("achieved")),
+        fmt(r.get("frac"), "{:.3f}"), ("%.0f MB / %.0f MB = %.2f x" % (tr / 1e6, ab / 1e6, tr / ab)) if tr and ab else "—",
+        dom.get("kernel", "—"), fmt(dom.get("frac"), "{:.3f}"), fmt(step.get("frac"), "{:.3f}"), cpu_s))
+L += ["", "Kernel classes of the untimed one-batch-in-flight pass (ms per step; algorithmic GB/s where the class has a byte model):", ""]
+for title, j in rows:
+    if j.get("roofline_by_kernel"):
+        L.append("* **%s**: " % title.split(":")[0].split("(")[0].strip() + ", ".join(
             "%s %.3f ms%s" % (k, v["ms_per_step"], (" (%.0f GB/s)" % v["GBps"]) if v.get("GBps") else "")
-            for k, v in j["roofline_by_kernel"].items()) +
-            ("; frontier expansion (push + pull + pull_sparse) %.3f ms at %.0f GB/s = %.3f of peak" % (
-                fe["ms_per_step"], fe["GBps"], fe["frac"]) if fe else "") +
-            ("; pre-pass chain (%s) %.3f ms at %.0f GB/s = %.3f of peak" % (
-                " + ".join(pc["classes"]), pc["ms_per_step"], pc["GBps"], pc["frac"]) if pc and pc["GBps"] > 1 else ""))
+            for k, v in j["roofline_by_kernel"].items()))
 L += ["", "## rocprofv3 --kernel-trace --stats (top kernels)", ""]
 for p in sorted(glob.glob(os.path.join(rdir, "*kernel_stats.csv"))):
     L += ["`profiles/%s/%s`" % (rnd, os.path.basename(p)), "", "| kernel | calls | avg µs | % |", "|---|---|---|---|"]

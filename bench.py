@@ -630,7 +630,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline_paths(a, V, off, adj, eid, mine, m)
         if cross is not None:
             if not a.no_cpu_baseline:
-                cross["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, cp, mc["d_te"], mc["out_len"], sample=8192)  # strided: every source
+                cross["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, cp, mc["d_te"], mc["out_len"], sample=65536)  # strided: 32 rows of every source, one chunk per host thread
             legs = {"prepass": {k: main_leg[k] for k in main_leg if k != "roofline_by_kernel"}, "msbfs_cross": cross}
             legs["prepass"]["workload"] = "%d random pairs (default_rng(4)): every row answered by the pair-centric kernels" % total_pairs
             if "cpu_baseline" in out:

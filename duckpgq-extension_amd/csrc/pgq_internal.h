@@ -40,6 +40,9 @@ int fail(int code, const std::string &msg);
 int ensure_init();
 // the device this host thread works on (pgq_init's device unless a multi-device call bound the thread to another)
 int current_device();
+// compute units of the device this host thread works on (cached per device; 256 on MI355X — the persistent grids are
+// sized from it, not from the constant)
+int device_cus();
 void bind_thread_device(int device); // < 0: back to the default
 const std::vector<int> &enabled_devices();
 

@@ -420,7 +420,7 @@ static int launch_lanes(pgq_csr *c, Workspace *ws, const u64 *front, const u32 *
 	const Options &opt = options();
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V;
-	const int ncu = 256;
+	const int ncu = device_cus();
 	const int n_blk = (int)((V + 63) / 64);
 	PGQ_TRY(ws->lblk.reserve((size_t)(n_blk + 1) * sizeof(BlkInfo)));
 	PGQ_TRY(ws->lrec.reserve((size_t)std::max<int64_t>(V, 1) * sizeof(uint4)));

@@ -1305,10 +1305,10 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	// instructions from 16 wavefronts, and two workgroups share the CU's issue slots): small calls, whose ~2 % of open rows
 	// do not fill 256 CUs anyway, get one workgroup per CU (8192 rows: 0.086 -> 0.076 ms, 2048 rows: 0.062 -> 0.053 ms)
 	const bool small_call = !paths && n <= (int64_t)opt.meet_small_rows;
-	u32 grid4 = (u32)std::min<int64_t>(n, 256 * std::max(1, paths ? 4 : (small_call ? 1 : opt.meet4_grid_mult)));
+	u32 grid4 = (u32)std::min<int64_t>(n, (int64_t)device_cus() * std::max(1, paths ? 4 : (small_call ? 1 : opt.meet4_grid_mult)));
 	size_t maps_bytes = 0;
 	if (run4 && !lds_map) {
-		grid4 = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, 256), gm_budget / ((size_t)bm_words * 4)));
+		grid4 = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, device_cus()), gm_budget / ((size_t)bm_words * 4)));
 		maps_bytes = (size_t)grid4 * bm_words * 4;
 	}
 	const size_t bi_map_words = (run_bi && !bi_lds) ? (size_t)bi_grid * 2 * mwb : 0;
@@ -1342,7 +1342,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		const int64_t cap = std::max(1, paths ? opt.meet_cap_paths : (small ? opt.meet_cap_small : opt.meet_cap));
 		const bool bigv = c->V > (1 << 20);
 		KernelTimer kt(st, K_MEET);
-		const unsigned resident = 256 * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 8 rounds
+		const unsigned resident = (unsigned)device_cus() * 32 / kMeetWPB; // more workgroups than the chip holds at once: up to 8 rounds
 		const dim3 grid((unsigned)std::min<int64_t>((n + kMeetWPB - 1) / kMeetWPB, (int64_t)std::max(1, opt.meet_grid_mult) * resident));
 		MeetHostBlock *fin = last_stage == 0 ? hb : nullptr;
 #define PGQ_MEET3(P, B, D)                                                                                               \
@@ -1479,6 +1479,19 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	return PGQ_OK;
 }
 
+// The sampled decision alone, waited for: shortestpath on a large input asks before it reserves 72 bytes per row for the
+// lists of the rows the pre-pass would answer (a cross product is called off: nothing of it would be used).
+int meet_decide_alone(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes, bool *go) {
+	PGQ_TRY(ws->route_dec.reserve(sizeof(MeetDecision)));
+	u32 *h_go = reinterpret_cast<u32 *>(static_cast<char *>(ws->h_meet) + 4104);
+	*h_go = 0;
+	hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, ws->stream, n, d_src, c->V, meet_bytes, edge_bytes,
+	                   ws->route_dec.as<MeetDecision>(), h_go);
+	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
+	*go = *h_go == 2;
+	return PGQ_OK;
+}
+
 // ---- iterativelengthbidirectional: every row through the bidirectional search ---------------------------------------------
 // The reference's IterativeLengthBidirectionalFunction (iterativelength_bidirectional.cpp:43-153) is meant to search
 // forward from src and backward from dst over the transposed CSR until the two meet (it is unreachable from the binder
@@ -1534,7 +1547,7 @@ int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_sr
 	const size_t lds_budget = (size_t)std::min(150, std::max(0, opt.meet4_lds_kb)) * 1024;
 	const bool bi_lds = (size_t)2 * mwb * 4 + 2048 <= lds_budget;
 	const int qcap = std::max(1024, opt.bibfs_queue);
-	const u32 grid = (u32)std::min<int64_t>(n, 256);
+	const u32 grid = (u32)std::min<int64_t>(n, device_cus());
 	const size_t map_words = bi_lds ? 0 : (size_t)grid * 2 * mwb;
 	PGQ_TRY(ws->meet_maps.reserve((map_words + (size_t)grid * 4 * qcap) * 4 + 64));
 	u32 *maps = ws->meet_maps.as<u32>();

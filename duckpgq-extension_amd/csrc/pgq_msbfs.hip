@@ -1780,7 +1780,7 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 	std::vector<int32_t> h_res;
 	std::vector<int64_t> h_off;
 
-	const int ncu = 256;
+	const int ncu = device_cus();
 	const unsigned pull_grid = (unsigned)std::max(1, opt.blocks_per_cu) * ncu;
 	const unsigned push_grid = 8 * ncu;
 
@@ -2456,6 +2456,16 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		u32 nd = 0;
 		// the lists of the rows the pre-pass answers have at most 9 elements (distance <= 4): the buffer for them is sized
 		// up front, so that they are written in the same launch chain as the search
+		if (decide_mode == 1) { // asked first, on its own: the buffers below are only worth reserving when the pre-pass runs
+			bool go = true;
+			PGQ_TRY(meet_decide_alone(c, ws, n, d_src, meet_bytes, edge_bytes, &go));
+			S.host_waits++;
+			if (!go) {
+				*ran = false;
+				return PGQ_OK;
+			}
+			decide_mode = 0;
+		}
 		MeetPathsOut po;
 		po.d_out_off = d_out_off;
 		if (d_child_ext) {

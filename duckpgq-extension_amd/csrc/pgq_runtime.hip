@@ -133,6 +133,17 @@ int worker_wait(const std::shared_ptr<WorkerTask> &t) {
 	return t->failed == PGQ_OK ? PGQ_OK : fail(t->failed, t->what);
 }
 
+int device_cus() {
+	static std::atomic<int> cached[64] = {};
+	const int dev = current_device() & 63;
+	int v = cached[dev].load(std::memory_order_relaxed);
+	if (v > 0) return v;
+	int cus = 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus <= 0) cus = 256;
+	cached[dev].store(cus, std::memory_order_relaxed);
+	return cus;
+}
+
 ThreadStats::ThreadStats() { memset(&s, 0, sizeof(s)); }
 ThreadStats &tstats() {
 	static thread_local ThreadStats ts;

@@ -321,6 +321,8 @@ struct MeetPathsOut {
 };
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go);
+// the pre-pass's sampled decision alone, waited for (*go: the pre-pass pays)
+int meet_decide_alone(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes, bool *go);
 // iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its
 // caps are compacted like the pre-pass's open rows
 int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,

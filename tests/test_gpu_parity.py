@@ -1403,3 +1403,51 @@ def test_weighted_ring_with_chords_takes_plain_rounds_and_stays_fast():
             assert (ok == wok).all() and (out[ok] == want[wok]).all()
             if light != 2:
                 assert dt < 0.15, "the shipped rule must not take the light-edges-first path here (%.3f s)" % dt
+
+
+def test_workspace_reuse_across_widths_graphs_and_entry_points_fuzz():
+    """Round 5 keeps state between calls that round 4 rebuilt every time: the sparse frontier pool is cleaned by its nz
+    (and zeroed whole only when its layout changes), level plans and the route memo live on the CSR handle, the
+    open-lane copies are folded by the next user.  One thread (one pooled workspace) alternates graphs of different V,
+    batch widths 1..32, one-batch and multi-batch calls, cross products and scattered pairs, iterativelength /
+    shortestpath / the accounting pass / the bidirectional entry point — every answer against the oracle."""
+    rng = np.random.default_rng(2025)
+    graphs = []
+    for V, E, skew in ((1, 0, False), (77, 300, False), (1000, 9000, True), (4097, 30000, False), (20000, 150000, True)):
+        rows = random_graph(rng, V, E, skew=skew) if E else (np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64))
+        off, adj, eid = graphgen.csr_from_rows(V, rows[0], rows[1])
+        graphs.append((V, pgq.DeviceCSR(V, off, adj, eid), OracleCSR.adopt(V, off, adj, eid)))
+    pgq.set_option("meet", 0)  # every row through the lane batches (the pre-pass has its own tests)
+    for it in range(60):
+        V, dev, ora = graphs[int(rng.integers(0, len(graphs)))]
+        shape = int(rng.integers(0, 4))
+        if shape == 0:  # scattered pairs: many sources
+            n = int(rng.integers(1, 6000))
+            ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        elif shape == 1:  # cross product: few sources, rows grouped
+            k = int(rng.integers(1, 40))
+            per = int(rng.integers(1, 300))
+            ps = np.repeat(rng.integers(0, V, k), per)
+            pd = rng.integers(0, V, len(ps))
+        elif shape == 2:  # one source x every vertex
+            ps, pd = np.full(V, int(rng.integers(0, V))), np.arange(V, dtype=np.int64)
+        else:  # a handful of rows
+            n = int(rng.integers(1, 70))
+            ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        pgq.set_option("words", int(rng.choice([0, 0, 1, 2, 8, 32])))
+        pgq.set_option("spec_levels", int(rng.integers(0, 2)))
+        pgq.set_option("force_mode", int(rng.choice([0, 0, 0, 1, 2])))
+        pgq.set_option("streams", int(rng.integers(1, 4)))
+        oln, ook = ora.lean_iterativelength(V, ps, pd)
+        what = int(rng.integers(0, 5))
+        if what <= 2:
+            ln, ok = dev.iterativelength(ps, pd)
+            assert lens(ln, ok) == lens(oln, ook), (it, V, shape)
+        elif what == 3:
+            m = min(len(ps), 400)
+            assert dev.shortestpath(ps[:m], pd[:m]) == ora.lean_shortestpath(V, ps[:m], pd[:m]), (it, V, shape)
+        else:
+            ln, ok = dev.iterativelength_bidirectional(ps, pd) if hasattr(dev, "iterativelength_bidirectional") else dev.iterativelength(ps, pd)
+            assert lens(ln, ok) == lens(oln, ook), (it, V, shape)
+    for _, dev, _ in graphs:
+        dev.close()

@@ -1201,10 +1201,14 @@ __global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u3
 	// (a ballot) get the wave-wide in-list scan — late levels of a cross product have millions of answered rows and a
 	// few thousand open ones (a wavefront per ROW cost 2.4 ms of launches for 2 M rows).  Active-lane bits and the
 	// open count are collected per workgroup like in k_detect.
+	constexpr int kQueue = 1024;
 	__shared__ u32 s_open;
 	__shared__ u64 s_act[WD];
+	__shared__ u32 q_row[kQueue], q_lane[kQueue];
+	__shared__ int q_dst[kQueue];
+	__shared__ u32 q_n, q_next, q_cut;
 	if (cnt->done) return;
-	if (threadIdx.x == 0) s_open = 0;
+	if (threadIdx.x == 0) s_open = 0, q_n = 0, q_next = 0, q_cut = (u32)kQueue;
 	if (threadIdx.x < WD) s_act[threadIdx.x] = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
@@ -1216,6 +1220,41 @@ __global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u3
 	const int G = (int)max((int64_t)1, min((int64_t)64, nwaves / max(nchunks, (int64_t)1)));
 	const int g = (int)(gw % G);
 	u32 n_open = 0; // lane 0 counts
+	// one open row: does an in-neighbour of its destination carry its lane in the frontier?
+	auto probe_row = [&](int64_t row, u32 l, int d) {
+		const int w = (int)(l >> 6);
+		const u64 bit = 1ull << (l & 63);
+		const int64_t b = roff[d], e = roff[d + 1];
+		if (b == e) { // nothing points at dst: unreachable, no search needed (reported as NULL like :133-139)
+			if (lane == 0) sres[row] = -2;
+			return;
+		}
+		bool found = false;
+		for (int64_t base = b; base < e && !found; base += 64) {
+			const int64_t j = base + lane;
+			bool hit = false;
+			if (j < e) {
+				const int v = radj[j];
+				if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
+			}
+			found = __any(hit);
+		}
+		if (lane == 0) {
+			if (found) {
+				sres[row] = level;
+			} else {
+				n_open++;
+				if (!(s_act[w] & bit)) atomicOr(&s_act[w], bit);
+			}
+		}
+	};
+	// More chunks than wavefronts (a cross product: 32,768 chunks holding 0..6 open rows each after level 3): with every
+	// wavefront probing the open rows of ITS chunks, a wavefront's share was Poisson-distributed (mean 6, the longest of
+	// 8192 wavefronts ~16) and the kernel as long as that one.  Now the 16 wavefronts of a workgroup first collect the open
+	// rows of all their chunks in an LDS queue and then draw rows from it one by one: the spread is a workgroup's (~96 +-
+	// 10 rows), not a wavefront's.  (Tried first: chunks handed out by one global counter — 16 K returning atomics on one
+	// address made the kernel three times slower.)  A full queue: the chunk's rows are probed where they are found.
+	const bool pooled = G == 1;
 	for (int64_t chunk = gw / G; chunk * 64 < n; chunk += nwaves / G) {
 		const int64_t i = lo + chunk * 64 + lane;
 		const bool mine_open = i < hi && sres[i] == -1;
@@ -1226,37 +1265,40 @@ __global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u3
 			my_d = sdst[i];
 		}
 		u64 todo = __ballot(mine_open);
+		if (pooled && todo) {
+			const u32 c = (u32)__popcll(todo);
+			u32 base = 0;
+			if (lane == 0) base = atomicAdd(&q_n, c);
+			base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+			if (base + c <= (u32)kQueue) {
+				if (mine_open) {
+					const u32 p = base + (u32)__popcll(todo & ((1ull << lane) - 1ull));
+					q_row[p] = (u32)(i - lo);
+					q_lane[p] = my_l;
+					q_dst[p] = my_d;
+				}
+				continue;
+			}
+			// does not fit: its slots stay unwritten, so the queue ends where this (or an earlier such) chunk's slots begin —
+			// every later chunk overflows too (the count only grows)
+			if (lane == 0) atomicMin(&q_cut, base);
+		}
 		while (todo) {
 			const int k = __ffsll((long long)todo) - 1;
 			todo &= todo - 1;
 			if (k % G != g) continue; // by row index: the split must not depend on what the chunk's other wavefronts have answered
-			const u32 l = (u32)__builtin_amdgcn_readlane((int)my_l, k);
-			const int d = __builtin_amdgcn_readlane(my_d, k);
-			const int w = (int)(l >> 6);
-			const u64 bit = 1ull << (l & 63);
-			const int64_t b = roff[d], e = roff[d + 1];
-			if (b == e) { // nothing points at dst: unreachable, no search needed (reported as NULL like :133-139)
-				if (lane == 0) sres[lo + chunk * 64 + k] = -2;
-				continue;
-			}
-			bool found = false;
-			for (int64_t base = b; base < e && !found; base += 64) {
-				const int64_t j = base + lane;
-				bool hit = false;
-				if (j < e) {
-					const int v = radj[j];
-					if ((nz[v] >> w) & 1u) hit = (front[(size_t)v * WD + w] & bit) != 0;
-				}
-				found = __any(hit);
-			}
-			if (lane == 0) {
-				if (found) {
-					sres[lo + chunk * 64 + k] = level;
-				} else {
-					n_open++;
-					if (!(s_act[w] & bit)) atomicOr(&s_act[w], bit);
-				}
-			}
+			probe_row(lo + chunk * 64 + k, (u32)__builtin_amdgcn_readlane((int)my_l, k), __builtin_amdgcn_readlane(my_d, k));
+		}
+	}
+	if (pooled) {
+		__syncthreads();
+		const u32 filled = min(q_n, q_cut);
+		for (;;) {
+			u32 p = 0;
+			if (lane == 0) p = atomicAdd(&q_next, 1u);
+			p = (u32)__builtin_amdgcn_readfirstlane((int)p);
+			if (p >= filled) break;
+			probe_row(lo + (int64_t)q_row[p], q_lane[p], q_dst[p]);
 		}
 	}
 	if (lane == 0 && n_open) atomicAdd(&s_open, n_open);

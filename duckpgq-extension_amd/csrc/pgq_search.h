@@ -23,8 +23,7 @@ struct Counters {
 	u32 pad2;            // ... and overflow words written (k_compact_frontier totals)
 	u32 done;            // levels enqueued ahead (spec_levels): set by k_level_reset when the batch is over (1), when the level's
 	                     // plan is not what the counters call for (2) or when the plan has run out (3); every level kernel returns at once
-	u32 ticket;          // workgroups of k_detect / k_probe that have stored their open-lane words (publish_open_lanes)
-	u32 r1[3];
+	u32 r1[4];
 	u64 act[2][32];      // active-lane masks (lanes that still have open pairs), double buffered
 };
 

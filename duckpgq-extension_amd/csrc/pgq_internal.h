@@ -113,6 +113,7 @@ struct Options {
 	int wbibfs_mem_mb = 2048;  // scratch budget (two label arrays of V entries per workgroup)
 	int wbibfs_delta_div = 64; // band width = mean weight / this (a model run on the weighted knows graph: 3-10x fewer relaxations at 64 than at 8)
 	int bibfs_rows = 256;      // k_bibfs (one bidirectional search per row) runs when at most this many rows are still open (0: off)
+	int bibfs_grid = 64;       // workgroups of k_bibfs (one row at a time each; every one owns 4 x bibfs_queue words of scratch)
 	int bibfs_cap = 8 << 20;   // adjacency entries one expansion of k_bibfs may read
 	int bibfs_queue = 1 << 17; // frontier vertices per side k_bibfs keeps
 	int meet4_lds_kb = 150;    // largest vertex bit map k_meet4 keeps in LDS (tests lower it to force the global-memory maps)

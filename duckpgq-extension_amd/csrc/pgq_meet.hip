@@ -1299,7 +1299,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	const int mwb = bm_words + 4;
 	const bool bi_lds = (size_t)2 * mwb * 4 + 2048 <= lds_budget; // k_bibfs: both sides' maps in LDS when they fit
 	const int qcap = std::max(1024, opt.bibfs_queue);
-	const u32 bi_grid = (u32)std::min(64, std::max(1, opt.bibfs_rows));
+	const u32 bi_grid = (u32)std::min(std::max(1, opt.bibfs_grid), std::max(1, opt.bibfs_rows));
 	// k_meet4d hands rows out dynamically: a grid of exactly the workgroups the chip holds (meet4_grid_mult = 2 per CU).
 	// A row alone on its CU is through in ~15 us, beside a second one in ~20 (the phases of a row are short bursts of
 	// instructions from 16 wavefronts, and two workgroups share the CU's issue slots): small calls, whose ~2 % of open rows

@@ -220,6 +220,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "wbibfs_mem_mb", &o.wbibfs_mem_mb, nullptr },
 		{ "wbibfs_delta_div", &o.wbibfs_delta_div, nullptr },
 		{ "bibfs_cap", &o.bibfs_cap, nullptr },
+		{ "bibfs_grid", &o.bibfs_grid, nullptr },
 		{ "bibfs_queue", &o.bibfs_queue, nullptr },
 		{ "meet_bias", nullptr, &o.meet_bias },
 		{ "lanes_unroll", &o.lanes_unroll, nullptr },

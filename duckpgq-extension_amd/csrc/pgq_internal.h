@@ -81,6 +81,7 @@ struct Options {
 	                        // batch instead of one per level (0: a host round trip after every level)
 	int detect_unroll = 4;  // rows per thread of k_detect with their gathers in flight together (1, 2 or 4)
 	int meet_calibrate = 1; // the pre-pass's bytes per row are measured (1024 pseudo-random pairs) before the first large call is routed
+	int stage2_ahead = 1;   // one-batch calls that repeat a row count: lane ids + batch start enqueued in front of the lane assignment's wait
 	int route_memo = 1;     // large calls on the buffers of the last one that the sample sent to the lane batches go there straight
 	int probe_always = 0;   // 1: probe before every level of a batch that uses the probe (round-2 behaviour; tests)
 	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
@@ -242,6 +243,8 @@ struct pgq_csr {
 		int64_t n = -1;
 		const void *src = nullptr, *dst = nullptr;
 		int go = 1;
+		int64_t id_n = -1; // row count of the last call whose rows stayed in place (one batch) ...
+		int id_wd = 0;     // ... and its batch width: the next call with that row count runs stage 2 ahead of its wait
 	} route_memo;
 	bool is_replica = false;
 };

@@ -1614,7 +1614,8 @@ WorkspaceLease::~WorkspaceLease() {
 // Stage 1: flag the distinct sources of the rows that need a search, rank them (= global lane ids), list them; the number
 // of distinct sources and the range check come back with ONE wait.
 static int lane_ranks(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, u32 *U_out,
-                      bool dst_rule, const SampleArgs &sm = SampleArgs { 0.0, 0.0, nullptr, nullptr, 0, nullptr, 0 }) {
+                      bool dst_rule, const SampleArgs &sm = SampleArgs { 0.0, 0.0, nullptr, nullptr, 0, nullptr, 0 },
+                      const std::function<int()> &pre_wait = nullptr) {
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V;
 	PGQ_TRY(ws->flag.reserve((size_t)(V + 1) * 4));
@@ -1637,6 +1638,7 @@ static int lane_ranks(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src
 	hipLaunchKernelGGL(k_compact_sources, dim3(blocks_for(std::max<int64_t>(V, 1))), dim3(256), 0, st, V, ws->flag.as<u32>(), ws->rank.as<u32>(), ws->usrc.as<int32_t>(),
 	                   d_bad, h2);
 	kt.stop();
+	if (pre_wait) PGQ_TRY(pre_wait()); // work the GPU can do while the host waits for the count (search_device: stage 2 ahead)
 	// lane assignment, stage 1: the rows' ids read once (16 B per row), a flag written per row; flags zeroed, scanned
 	// (read + rank written) and compacted: 20 B per vertex
 	tstats().s.algo_bytes[K_PREP] += (double)n * 20.0 + (double)(V + 1) * 20.0;
@@ -1707,10 +1709,15 @@ int batch_bounds(Workspace *ws, int64_t n, int64_t L, int nb) {
 // nothing is waited for.  Otherwise: sorted by lane over the bits the keys really have (the sentinels sit right behind
 // the last batch: nb x L and nb x L + 1), bounds computed and fetched (one wait).
 static int lane_rows_bfs(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, bool dst_rule,
-                         int64_t L, int nb, bool may_skip_sort, bool *identity) {
+                         int64_t L, int nb, bool may_skip_sort, bool *identity, bool rows_done_ahead = false) {
 	hipStream_t st = ws->stream;
 	PGQ_TRY(reserve_bstart(ws, nb));
 	*identity = may_skip_sort && nb <= 1;
+	if (*identity && rows_done_ahead) { // k_pair_rows ran in front of the lane assignment's wait (search_device)
+		ws->h_bstart[0] = 0;
+		for (int b = 1; b <= nb + 2; b++) ws->h_bstart[b] = n;
+		return PGQ_OK;
+	}
 	if (*identity) {
 		KernelTimer kt(st, K_PREP);
 		hipLaunchKernelGGL(k_pair_rows, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), c->off, c->roff, dst_rule ? 1 : 0, c->V,
@@ -1765,6 +1772,50 @@ static int grow_keeping(DevBuf &buf, size_t bytes, size_t keep, hipStream_t st) 
 	tstats().s.host_waits++;
 	buf.release();
 	buf = bigger;
+	return PGQ_OK;
+}
+
+// The start of a lane batch that keeps no per-level frontiers: `seen`, the counter block and the open-lane copies zeroed,
+// the sparse pool's buffers clean (k_batch_reset; a buffer that is new, was laid out for another (V, WD), or belongs to a
+// batch that did not end normally has no nz to be trusted and is zeroed whole, once).  Called by run_batches at a batch's
+// start — or EARLIER, by search_device, in front of the lane assignment's wait when the CSR remembers the width of the
+// last one-batch call (`prereset_*` says so: the GPU then does this while the host waits for the source count).
+static int batch_state_reset(Workspace *ws, int64_t V, int WD) {
+	hipStream_t st = ws->stream;
+	const size_t words = (size_t)std::max<int64_t>(V, 1) * (size_t)WD, nz_bytes = (size_t)std::max<int64_t>(V, 1) * 4;
+	PGQ_TRY(ws->seen.reserve(words * 8));
+	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
+	PGQ_TRY(ws->dpart.reserve((size_t)kOpenRep * WD * 8));
+	while (ws->pool.size() < 4) ws->pool.emplace_back(new LevelBuf());
+	u64 *cb[2] = { nullptr, nullptr };
+	u32 *cz[2] = { nullptr, nullptr };
+	for (int k = 0; k < 2; k++) {
+		LevelBuf *lb = ws->pool[(size_t)k].get();
+		PGQ_TRY(lb->buf.reserve(words * 8));
+		PGQ_TRY(lb->nz.reserve(nz_bytes));
+		if (lb->init_buf != lb->buf.p || lb->init_nz != lb->nz.p || lb->lay_V != V || lb->lay_WD != WD || !ws->pool_trusted) {
+			PGQ_HIP_TRY(hipMemsetAsync(lb->buf.p, 0, words * 8, st));
+			PGQ_HIP_TRY(hipMemsetAsync(lb->nz.p, 0, nz_bytes, st));
+			lb->init_buf = lb->buf.p;
+			lb->init_nz = lb->nz.p;
+			lb->lay_V = V;
+			lb->lay_WD = WD;
+			lb->dirty = false;
+		}
+		if (lb->dirty) {
+			cb[k] = lb->buf.as<u64>();
+			cz[k] = lb->nz.as<u32>();
+			lb->dirty = false;
+		}
+	}
+	ws->pool_trusted = false; // until the batch has ended normally
+	KernelTimer kt(st, K_PREP);
+	hipLaunchKernelGGL(k_batch_reset, dim3(8 * (unsigned)device_cus()), dim3(256), 0, st, ws->seen.as<uint4>(), (words * 8 + 15) / 16,
+	                   ws->counters.as<u32>(), (int)(sizeof(Counters) / 4), ws->dpart.as<u64>(), kOpenRep * WD, cb[0], cz[0], cb[1],
+	                   cz[1], V, WD);
+	kt.stop();
+	// `seen` zeroed (8 WD B per vertex) + the nz words of the sparse-pool buffers that are cleaned (4 B per vertex each)
+	tstats().s.algo_bytes[K_PREP] += (double)words * 8.0 + (double)V * 4.0 * ((cb[0] != nullptr) + (cb[1] != nullptr));
 	return PGQ_OK;
 }
 
@@ -1858,6 +1909,8 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			return PGQ_OK;
 		};
 		LevelBuf *cur = nullptr;
+		const bool start_done = !with_paths && ws->prereset_V == V && ws->prereset_WD == WD; // in front of the lane assignment's wait
+		ws->prereset_V = -1; // one batch's worth, whoever uses `seen` next
 		if (with_paths) {
 			PGQ_HIP_TRY(hipMemsetAsync(ws->seen.p, 0, words * 8, st));
 			PGQ_HIP_TRY(hipMemsetAsync(ws->counters.p, 0, sizeof(Counters), st));
@@ -1866,38 +1919,8 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			cur = level_buf(0, true, nullptr);
 			PGQ_TRY(make_zero(cur));
 		} else {
+			if (!start_done) PGQ_TRY(batch_state_reset(ws, V, WD));
 			cur = level_buf(0, true, nullptr);
-			u64 *cb[2] = { nullptr, nullptr };
-			u32 *cz[2] = { nullptr, nullptr };
-			for (int k = 0; k < 2; k++) {
-				LevelBuf *lb = ws->pool[(size_t)k].get();
-				PGQ_TRY(lb->buf.reserve(words * 8));
-				PGQ_TRY(lb->nz.reserve(nz_bytes));
-				// a buffer that is new, was laid out for another (V, WD), or belongs to a batch that did not end normally has no
-				// nz to be trusted: zeroed whole, once
-				if (lb->init_buf != lb->buf.p || lb->init_nz != lb->nz.p || lb->lay_V != V || lb->lay_WD != WD || !ws->pool_trusted) {
-					PGQ_HIP_TRY(hipMemsetAsync(lb->buf.p, 0, words * 8, st));
-					PGQ_HIP_TRY(hipMemsetAsync(lb->nz.p, 0, nz_bytes, st));
-					lb->init_buf = lb->buf.p;
-					lb->init_nz = lb->nz.p;
-					lb->lay_V = V;
-					lb->lay_WD = WD;
-					lb->dirty = false;
-				}
-				if (lb->dirty) {
-					cb[k] = lb->buf.as<u64>();
-					cz[k] = lb->nz.as<u32>();
-					lb->dirty = false;
-				}
-			}
-			ws->pool_trusted = false; // until this batch has ended normally
-			KernelTimer kt(st, K_PREP);
-			hipLaunchKernelGGL(k_batch_reset, dim3(8 * ncu), dim3(256), 0, st, ws->seen.as<uint4>(), (words * 8 + 15) / 16,
-			                   ws->counters.as<u32>(), (int)(sizeof(Counters) / 4), ws->dpart.as<u64>(), kOpenRep * WD, cb[0], cz[0],
-			                   cb[1], cz[1], V, WD);
-			kt.stop();
-			// `seen` zeroed (8 WD B per vertex) + the nz words of the sparse-pool buffers that are cleaned (4 B per vertex each)
-			S.algo_bytes[K_PREP] += (double)words * 8.0 + (double)V * 4.0 * ((cb[0] != nullptr) + (cb[1] != nullptr));
 		}
 		u64 *act_cur = &d_cnt->act[0][0]; // zeroed with the counter block above
 		u32 open_before = (u32)(hi - lo); // rows open before the level whose counters are being looked at (byte model of detection)
@@ -2634,7 +2657,32 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		sm.h_go = reinterpret_cast<u32 *>(static_cast<char *>(ws->h_meet) + 4104);
 		*sm.h_go = 0;
 	}
-	PGQ_TRY(lane_ranks(c, ws, n, d_src, d_dst, &U, !outp.want_te, sm));
+	// Stage 2 ahead of the wait (round 5): when the last call with this row count on this CSR was a ONE-batch call of width
+	// `ahead_wd`, its two kernels that need nothing from the host — the rows' lane ids (k_pair_rows reads the ranks on the
+	// device) and the batch's start (k_batch_reset) — are enqueued BEFORE the host waits for the source count: the GPU used to
+	// idle through that wait and its wake-up (~15 us) and then run them (48 us on the 2.1 M-row cross product).  If the count
+	// says otherwise afterwards (more than one batch, another width) the normal path overwrites / redoes both: same answers.
+	int ahead_wd = 0;
+	const bool may_stay_in_place = !with_paths && !outp.want_te && mopt.sort_single_batch == 0;
+	if (may_stay_in_place && mopt.stage2_ahead) {
+		std::lock_guard<std::mutex> g(c->plan_lock);
+		if (c->route_memo.id_n == n) ahead_wd = c->route_memo.id_wd;
+	}
+	bool rows_ahead = false;
+	auto pre_wait = [&]() -> int {
+		KernelTimer kt(st, K_PREP);
+		hipLaunchKernelGGL(k_pair_rows, dim3(blocks_for(n)), dim3(256), 0, st, n, d_src, d_dst, ws->rank.as<u32>(), c->off, c->roff,
+		                   outp.want_te ? 0 : 1, c->V, ws->skey.as<u32>(), ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), ws->sres.as<int32_t>());
+		kt.stop();
+		S.algo_bytes[K_PREP] += (double)n * 44.0;
+		rows_ahead = true;
+		PGQ_TRY(batch_state_reset(ws, c->V, ahead_wd));
+		ws->prereset_V = c->V;
+		ws->prereset_WD = ahead_wd;
+		return PGQ_OK;
+	};
+	ws->prereset_V = -1;
+	PGQ_TRY(lane_ranks(c, ws, n, d_src, d_dst, &U, !outp.want_te, sm, ahead_wd > 0 ? std::function<int()>(pre_wait) : std::function<int()>()));
 	if (sampled) { // (lane_ranks has waited for the stream) what the sample says about these rows decides the next call's route
 		const u32 v = *reinterpret_cast<const u32 *>(static_cast<const char *>(ws->h_meet) + 4104);
 		if (v == 2) {
@@ -2648,7 +2696,12 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	const int64_t Lb = 64 * (int64_t)wd;
 	const int nb = (int)((U + Lb - 1) / Lb);
 	bool identity = false; // the rows were left in the caller's order (one batch): no permutation to undo
-	PGQ_TRY(lane_rows_bfs(c, ws, n, d_src, d_dst, !outp.want_te, Lb, nb, !with_paths && !outp.want_te && mopt.sort_single_batch == 0, &identity));
+	PGQ_TRY(lane_rows_bfs(c, ws, n, d_src, d_dst, !outp.want_te, Lb, nb, may_stay_in_place, &identity, rows_ahead));
+	if (may_stay_in_place) { // what the next call with this row count may do ahead of its wait
+		std::lock_guard<std::mutex> g(c->plan_lock);
+		c->route_memo.id_n = identity ? n : -1;
+		c->route_memo.id_wd = wd;
+	}
 	auto run = [&](Workspace *priv, int b0, int bstride, SearchOutput &o) -> int {
 		switch (wd) {
 		case 1: return run_batches<1>(c, ws, priv, b0, bstride, n, U, with_paths, d_child_ext, child_cap_ext, o);

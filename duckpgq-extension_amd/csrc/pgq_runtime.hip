@@ -189,6 +189,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "sort_single_batch", &o.sort_single_batch, nullptr },
 		{ "spec_levels", &o.spec_levels, nullptr },
 		{ "route_memo", &o.route_memo, nullptr },
+		{ "stage2_ahead", &o.stage2_ahead, nullptr },
 		{ "meet_calibrate", &o.meet_calibrate, nullptr },
 		{ "detect_unroll", &o.detect_unroll, nullptr },
 		{ "part_weight", &o.part_weight, nullptr },

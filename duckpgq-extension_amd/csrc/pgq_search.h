@@ -269,6 +269,8 @@ struct Workspace {
 	std::vector<std::unique_ptr<LevelBuf>> levels; // shortestpath: one per level
 	std::vector<std::unique_ptr<LevelBuf>> pool;   // otherwise: [0], [1] sparse pool, [2], [3] dense pool
 	bool pool_trusted = false;                     // the last batch ended normally: the sparse pool's dirty flags are true
+	int64_t prereset_V = -1;                       // batch_state_reset has run ahead for this (V, WD): the next batch's start is done
+	int prereset_WD = 0;
 	Counters *h_cnt = nullptr; // pinned
 	LevelLog *h_log = nullptr; // pinned: [kSpecLevels + 2] counters per enqueued-ahead level, then two status words
 	int64_t wb_V = -1;  // what wb_scratch's label arrays are initialised for

@@ -22,7 +22,7 @@ def _defaults():
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
                  ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 2), ("relax_delta_div", 0), ("relax_light", 2), ("relax_light_div", 4), ("relax_split", 1),
-                 ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1)):
+                 ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1)):
         pgq.set_option(k, v)
     yield
 
@@ -30,7 +30,7 @@ def _defaults():
 SHIPPED_KEYS = ("push_div", "streams", "probe2_abs", "meet", "meet_align", "meet_bias", "meet_cap", "meet_cap_small", "meet_cap_paths",
                 "meet_small_rows", "probe", "probe2", "defer", "lanes", "lanes_unroll", "sparse_lds", "sparse_pw", "sparse_unroll",
                 "sparse_spill", "hub_chunk", "push_chunk", "spec_levels", "sort_single_batch", "detect_unroll", "route_memo", "meet4",
-                "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs", "meet4_grid_mult", "meet_grid_mult", "meet_calibrate")
+                "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs", "meet4_grid_mult", "meet_grid_mult", "meet_calibrate", "stage2_ahead")
 
 
 @pytest.fixture(params=["fixture_values", "shipped_values"])
@@ -200,6 +200,7 @@ def test_random_graph_all_variants(words, mode, base_config):
         pgq.set_option("spec_levels", (lds + pw) % 2)
         pgq.set_option("sort_single_batch", (unroll >> 1) % 2)
         pgq.set_option("detect_unroll", unroll)
+        pgq.set_option("stage2_ahead", (pw + probe) % 2)  # lane ids + batch start in front of the lane assignment's wait (same row count as the call before)
         ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
         assert lens(ln, ok) == want
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
@@ -1441,8 +1442,9 @@ def test_workspace_reuse_across_widths_graphs_and_entry_points_fuzz():
         oln, ook = ora.lean_iterativelength(V, ps, pd)
         what = int(rng.integers(0, 5))
         if what <= 2:
-            ln, ok = dev.iterativelength(ps, pd)
-            assert lens(ln, ok) == lens(oln, ook), (it, V, shape)
+            for rep_ in range(1 + int(rng.integers(0, 2))):  # now and then the same call again: stage 2 ahead of the wait, the level plan
+                ln, ok = dev.iterativelength(ps, pd)
+                assert lens(ln, ok) == lens(oln, ook), (it, V, shape)
         elif what == 3:
             m = min(len(ps), 400)
             assert dev.shortestpath(ps[:m], pd[:m]) == ora.lean_shortestpath(V, ps[:m], pd[:m]), (it, V, shape)

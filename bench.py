@@ -1,29 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — DuckPGQ's path-finding hot path on MI355X (contract: one JSON line on rank 0).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over this rank's batch of (src,dst) pairs, inputs resident in HBM:
-pgq_iterativelength_bulk_device (pair-centric pre-pass for random pairs, lane-batched MS-BFS for cross products and
+pgq_iterativelength_bulk_device (pair-centric pre-pass for scattered pairs, lane-batched MS-BFS for cross products and
 for whatever the pre-pass leaves open), followed for N > 1 by the RCCL all_gather of the per-pair results (the only
 inter-GPU traffic; the CSR is replicated).
 
 Default workload = BASELINE.json configs[3] (the config the metric "MS-BFS MTEPS + src-dst pairs/sec, SNB SF100,
 1/2/4/8 GPU" is quoted on; it fits one GPU): synthetic LDBC-SNB-SF100-shaped Person-knows-Person graph (V=448,626,
 39.88 M symmetric CSR entries), iterativelength on 65,536 random pairs (`default_rng(4)`).
-  N = 1:  the top-level fields describe that workload; `legs` holds it ("prepass": every row is answered by the
-          pair-centric kernels) next to "msbfs_cross": the same graph and row count in the binder's call shape
-          (match.cpp:467-495: a cross product of endpoints — 2048 distinct sources x 1024 destinations each = 2.1 M
-          rows), which the library routes to the lane-batched MS-BFS frontier expansion (one lane per distinct source);
-          each leg has its own ms/step, pairs/s, logical and physical MTEPS, roofline of its dominant kernel class and a
-          CPU-port comparison.  A third leg, `cheapest_general`, times cheapest_path_length of 4096 pairs on the same
-          graph with int64 weights (one step; the general-graph case of the batched relaxation).
+  N = 1:  the top-level fields describe that workload (= leg "prepass": every row is answered by the pair-centric
+          kernels); `legs` holds it next to one leg per other BASELINE config and call shape (`legs_by_config` maps them):
+            msbfs_cross       the same graph in the binder's call shape (match.cpp:467-495: a cross product of endpoints —
+                              2048 distinct sources x 1024 destinations = 2.1 M rows), routed to the lane-batched MS-BFS
+            snb_paths         configs[2]: shortestpath + reconstruction, 4096 pairs, same CSR
+            rmat22            configs[1]: R-MAT scale 22, iterativelength, 1024 pairs (own graph: ~15 s of generation)
+            forest_cheapest   configs[4]: weighted cheapest path on a 2^24-vertex reply forest, 4096 pairs
+            cheapest_general  cheapest_path_length of 4096 pairs on the knows graph with int64 weights (one step)
+          each with its own ms/step, pairs/s, MTEPS, roofline and a bounded CPU comparison of the TIMED output
+          (--config-legs '' / --no-legs / --cheapest-pairs 0 drop them; the whole default command takes ~95 s).
   N > 1:  --scaling strong by default (configs[3] is 65,536 pairs in total, cut across the GPUs); the weak figure
           (65,536 pairs on every GPU) is measured in the same run and reported under "weak".
-Other BASELINE configs: --workload rmat22 (configs[1]), snb_paths (configs[2]), forest_cheapest (configs[4]);
-snb_cross / snb_cross_allv run the cross-product shapes as the main workload; snb_cheapest = weighted knows graph.
+Other workloads as the main line: --workload rmat22 | snb_paths | forest_cheapest (--scale 28 = configs[4]'s named size) |
+snb_cross | snb_cross_allv | snb_cheapest.
 
 value    = (src, dst) pairs answered per second, whole job (metric "src_dst_pairs_per_s"; BASELINE's metric is "MS-BFS
            MTEPS + src-dst pairs/sec").  Beside it: `mteps_physical` = adjacency entries the kernels really scanned per
@@ -32,11 +35,12 @@ value    = (src, dst) pairs answered per second, whole job (metric "src_dst_pair
            dst (all levels if unreachable) — what the reference's per-pair lane traverses; a pure function of (graph,
            src, dst), counted once on the GPU outside the timed region (pgq_traversed_edges_bulk_device) and pinned
            against the CPU oracle in tests/.  The logical figure counts work the pair-centric kernels AVOID: it is not
-           a hardware throughput and is no longer the headline (round 3's `value`).
-roofline = the dominant kernel class of an untimed pass with one batch in flight and per-launch HIP events on the
-           library's own stream (no overlap: a launch's event duration is its own duration); achieved = algorithmic
-           bytes / that time (DESIGN.md has the formulas).  `step` = all kernel classes' algorithmic bytes over the
-           wall time of the timed region.
+           a hardware throughput and is not the headline (it was round 3's `value`; kept as `msbfs_mteps`).
+roofline = the leg's whole LAUNCH CHAIN (schema 5): the algorithmic bytes of all its kernel classes (DESIGN.md has the
+           formulas) over the sum of their launch durations, measured in an untimed pass with one batch in flight and HIP
+           events around every launch on the library's own stream; `dominant_kernel` = the single class with the most
+           time (round 4's top level), `step` = the same bytes over the wall time of the timed region, `traffic` = HBM
+           bytes per step of that chain from the committed PMC passes (profiles/pmc_<workload>.json).
 cpu_baseline = the literal restatement of the reference UDF (oracle/, 512-lane bitsets, 2048-row chunks) timed on this
            box's host cores on a bounded sample of the same pairs, same MTEPS definition, compared row by row with
            the output of the TIMED steps (the output buffer is poisoned before the timed loop).

@@ -673,3 +673,164 @@ def test_distinct_source_estimate_on_grouped_and_shuffled_inputs():
     s = np.repeat(rng.choice(V, 3000, replace=False), lens)
     est = _distinct_sources_model(s)
     assert 3000 / 1.7 <= est <= 3000 * 1.7, est
+
+
+# ---- round 5: levels enqueued ahead of the host (pgq_msbfs.hip: run_batches, k_level_reset) ------------------------------
+
+def _decide_level(rule, fe, fw, fv, unresolved, nzw):
+    """decide_level of pgq_search.h: bit 0 top-down, bit 1 sparse bottom-up, bit 2 probe before the level."""
+    E, V, wd = rule["E"], rule["V"], rule["wd"]
+    push = fe * rule["push_div"] < E
+    wpn = fe / max(E, 1.0) * (fw / max(fv, 1)) * (nzw / wd)
+    sparse = (not push) and wpn < rule["sparse_below"]
+    probe = False
+    if rule["use_probe"]:
+        probe_bytes = unresolved * (E / max(V, 1.0)) * 256.0
+        level_bytes = fe * 20.0 if push else (E * (8.0 + 6.0 * wd) if not sparse else E * 4.0 + fe * 16.0 + V * (4.0 + 24.0 * wd))
+        probe = probe_bytes <= level_bytes
+    return (1 if push else 0) | (2 if sparse else 0) | (4 if probe else 0)
+
+
+class _LaneBatchModel:
+    """One lane batch as the level kernels see it: per-lane frontiers over a small graph, rows (lane, dst), the counter
+    block, and `done`.  A level = [probe: answers rows at distance t from frontier t-1] expansion [detection unless probed];
+    with a probe the expansion is skipped when at most `stop` rows are left open (they are deferred)."""
+
+    def __init__(self, off, adj, srcs, rows, stop):
+        self.off, self.adj, self.V = off, adj, len(off) - 1
+        self.L = len(srcs)
+        self.front = [{s} for s in srcs]
+        self.seen = [{s} for s in srcs]
+        self.rows, self.res = rows, [-1] * len(rows)
+        self.stop, self.done, self.t_ran = stop, 0, 0
+        self.cnt = self._counters(len(rows))
+
+    def _counters(self, unresolved):
+        verts = set().union(*self.front) if self.front else set()
+        fe = sum(self.off[v + 1] - self.off[v] for f in self.front for v in f)  # per (vertex, lane): the model's own measure
+        act = {l for (l, d), r in zip(self.rows, self.res) if r == -1}
+        return {"fe": fe, "fv": len(verts), "fw": sum(len(f) for f in self.front), "unresolved": unresolved,
+                "nzw": max(1, len(act))}
+
+    def level(self, t, bits):
+        """The kernels of level t (they return at once when `done`)."""
+        if self.done:
+            return
+        probe = bool(bits & 4)
+        if probe:  # rows at distance t: an in-neighbour of dst is in frontier t-1  <=>  dst in N_out(frontier)
+            for i, (l, d) in enumerate(self.rows):
+                if self.res[i] == -1 and any(d in self.adj[self.off[v]:self.off[v + 1]] for v in self.front[l]):
+                    self.res[i] = t
+            self.cnt["unresolved"] = sum(r == -1 for r in self.res)
+            if self.cnt["unresolved"] <= self.stop:
+                self.t_ran = t
+                return  # the expansion returns at once; the host (or the next k_level_reset) ends the batch
+        nxt = []
+        for l in range(self.L):
+            reach = {int(n) for v in self.front[l] for n in self.adj[self.off[v]:self.off[v + 1]]} - self.seen[l]
+            self.seen[l] |= reach
+            nxt.append(reach)
+        self.front = nxt
+        if not probe:
+            for i, (l, d) in enumerate(self.rows):
+                if self.res[i] == -1 and d in self.front[l]:
+                    self.res[i] = t
+        self.cnt = self._counters(sum(r == -1 for r in self.res))
+        self.t_ran = t
+
+
+def _round_trip(m, rule):
+    ran, t = [], 1
+    while m.cnt["unresolved"] > 0 and m.cnt["fe"] > 0:
+        bits = _decide_level(rule, m.cnt["fe"], m.cnt["fw"], m.cnt["fv"], m.cnt["unresolved"], rule["wd"] if t == 1 else m.cnt["nzw"])
+        m.level(t, bits)
+        ran.append(bits)
+        if (bits & 4) and m.cnt["unresolved"] <= m.stop:
+            break
+        t += 1
+    return ran
+
+
+def _enqueued_ahead(m, rule, plan):
+    """The chain: k_level_reset(t) in front of every planned level + one behind the last; then the host's replay and, when
+    the device called the levels off, the round-trip loop from there.  Returns the levels that really ran."""
+    log, status, prev_stop = {}, None, -1
+    for k, bits in enumerate(list(plan) + [0x80]):
+        t = k + 1
+        if not m.done:  # k_level_reset(t)
+            log[t - 1] = dict(m.cnt)
+            c = m.cnt
+            code = 0
+            if c["unresolved"] == 0 or c["fe"] == 0:
+                code = 1
+            elif prev_stop >= 0 and c["unresolved"] <= prev_stop:
+                code = 1
+            elif bits == 0x80:
+                code = 3
+            elif _decide_level(rule, c["fe"], c["fw"], c["fv"], c["unresolved"], rule["wd"] if t == 1 else c["nzw"]) != bits:
+                code = 2
+            if code:
+                m.done, status = code, (code, t)
+        if bits != 0x80:
+            m.level(t, bits)
+            prev_stop = m.stop if (bits & 4) else -1
+    code, t_stop = status
+    ran, over = [], False
+    for k in range(1, t_stop):  # the host's replay of its bookkeeping from the log
+        ran.append(plan[k - 1])
+        if (plan[k - 1] & 4) and log[k]["unresolved"] <= m.stop:
+            over = True
+            break
+    if not over and code != 1:  # the host takes over at level t_stop with the logged counters (= the model's own)
+        assert log[t_stop - 1] == m.cnt
+        m.done = 0
+        t = t_stop
+        while m.cnt["unresolved"] > 0 and m.cnt["fe"] > 0:
+            bits = _decide_level(rule, m.cnt["fe"], m.cnt["fw"], m.cnt["fv"], m.cnt["unresolved"], rule["wd"] if t == 1 else m.cnt["nzw"])
+            m.level(t, bits)
+            ran.append(bits)
+            if (bits & 4) and m.cnt["unresolved"] <= m.stop:
+                break
+            t += 1
+    return ran, code
+
+
+def test_levels_enqueued_ahead_protocol_matches_the_round_trip_loop():
+    """Whatever plan a batch is enqueued under — the right one, a truncated one, one with wrong levels, one that is too
+    long — the levels that really run and every row's answer are those of the round-trip loop."""
+    rng = np.random.default_rng(31)
+    codes = set()
+    for trial in range(60):
+        V = int(rng.integers(20, 120))
+        E = int(rng.integers(V, 6 * V))
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        order = np.argsort(s, kind="stable")
+        off = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum(np.bincount(s, minlength=V), out=off[1:])
+        adj = d[order]
+        srcs = [int(x) for x in rng.choice(V, int(rng.integers(1, 12)), replace=False)]
+        rows = [(int(rng.integers(0, len(srcs))), int(rng.integers(0, V))) for _ in range(int(rng.integers(1, 80)))]
+        rows = [(l, dd) for l, dd in rows if dd != srcs[l]]
+        if not rows:
+            continue
+        stop = int(rng.integers(0, 4))
+        rule = {"E": float(E), "V": float(V), "wd": 1, "push_div": float(rng.choice([2.0, 12.0, 24.0])), "sparse_below": 1.5,
+                "use_probe": int(rng.integers(0, 2))}
+        ref = _LaneBatchModel(off, adj, srcs, rows, stop)
+        want_ran = _round_trip(ref, rule)
+        for variant in range(4):
+            plan = list(want_ran)
+            if variant == 1 and plan:
+                plan = plan[:int(rng.integers(0, len(plan)))]                    # runs out
+            elif variant == 2 and plan:
+                plan[int(rng.integers(0, len(plan)))] ^= int(rng.choice([1, 2, 4]))  # a level the counters do not call for
+            elif variant == 3:
+                plan = plan + [int(rng.integers(0, 8)) for _ in range(3)]          # longer than the batch
+            if not plan:
+                continue
+            m = _LaneBatchModel(off, adj, srcs, rows, stop)
+            ran, code = _enqueued_ahead(m, rule, plan)
+            codes.add(code)
+            assert ran == want_ran, (trial, variant, plan, ran, want_ran)
+            assert m.res == ref.res
+    assert codes >= {1, 2, 3}

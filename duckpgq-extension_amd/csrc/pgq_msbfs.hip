@@ -22,9 +22,15 @@
 //     lane-word density.
 //   * vertices whose in-degree exceeds `hub_chunk` are split into slices (k_pull_hub*).
 //   * lengths come from destination probes (k_probe: is an in-neighbour of dst in the previous frontier?; k_probe2:
-//     two hops, for the last few open pairs) or, for cross-product shaped calls, from seen[dst] after the level
-//     exactly like iterativelength.cpp:119-129 (k_detect).  Stragglers of a wide batch are re-run in a narrow one.
+//     two hops, for the last few open pairs) or, for cross-product shaped calls, from the level's frontier at dst —
+//     the event of iterativelength.cpp:119-129, "seen[dst] has the bit for the first time" (k_detect, behind the
+//     non-empty-word mask).  Stragglers of a wide batch are re-run in a narrow one.
 //   * independent batches are searched concurrently by worker threads on separate HIP streams.
+//   * round 5: the rows of a call whose sources fit one batch are not sorted (k_pair_rows); top-down levels write into a
+//     "sparse pool" of frontier buffers that is cleaned by walking nz, bottom-up levels into a "dense pool" that is never
+//     zeroed (k_batch_reset); the per-level choice is ONE function of the counters (decide_level) and a batch's levels
+//     are enqueued ahead of the host under the plan of the batch before, k_level_reset checking every level against
+//     that function on the device (`done`: all level kernels return at once) — one wait per batch, not per level.
 //   * shortestpath keeps every level's frontier bitmap instead of the reference's two 8 KiB/vertex parent
 //     arrays (shortest_path.cpp:82-83) and rebuilds each path backwards with the reference's tie-break:
 //     parent(x) = smallest frontier vertex of the previous level with an edge to x, edge = first CSR slot of

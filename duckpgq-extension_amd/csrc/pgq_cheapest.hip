@@ -43,6 +43,33 @@ template <> struct Inf<double> {
 	static constexpr int64_t bits = 0x7FDFFFFFFFFFFFFFll;
 };
 
+// Label STORAGE of the batched relaxation (round 5): int64 weights whose largest possible path sum fits 31 bits
+// (w_max x V < 2^31 - 1: weights 1..999 on the 448 K-vertex knows graph are at 4.5 x 10^8) keep their labels as int32 —
+// a label row is 256 bytes instead of 512, and the rows are what the relaxation moves (2 rows per relaxed edge).  All
+// arithmetic and every comparison stay in the 64-bit domain of the reference (cheapest_path_length.cpp:29-36): a stored
+// label is widened on load, "unlabelled" (0x7FFFFFFF) to the reference's max / 2 sentinel, and a candidate is only
+// narrowed when it is stored, where the precondition makes it exact.  Doubles and wider int64 ranges keep 8-byte labels.
+template <typename DT> struct Lab;
+template <> struct Lab<int64_t> {
+	static constexpr int64_t unlabelled(int64_t inf_bits) { return inf_bits; }
+	static __device__ __forceinline__ int64_t widen(int64_t v, int64_t) { return v; }
+	static __device__ __forceinline__ int64_t min_into(int64_t *p, int64_t cand, int64_t) {
+		return (int64_t)atomicMin((long long *)p, (long long)cand);
+	}
+};
+template <> struct Lab<int32_t> {
+	static constexpr int32_t kUnlabelled = 0x7FFFFFFF;
+	static constexpr int32_t unlabelled(int64_t) { return kUnlabelled; }
+	static __device__ __forceinline__ int64_t widen(int32_t v, int64_t inf_bits) { return v == kUnlabelled ? inf_bits : (int64_t)v; }
+	static __device__ __forceinline__ int64_t min_into(int32_t *p, int64_t cand, int64_t inf_bits) {
+		return widen(atomicMin(p, (int32_t)cand), inf_bits);
+	}
+};
+__global__ void k_fill32(int32_t *__restrict__ p, int64_t n, int32_t value) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) p[i] = value;
+}
 __global__ void k_fill64(int64_t *__restrict__ p, int64_t n, int64_t value) {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -50,7 +77,8 @@ __global__ void k_fill64(int64_t *__restrict__ p, int64_t n, int64_t value) {
 }
 
 // sources of the batch: dist[src][lane] = 0, dirty, queued
-__global__ void k_cheapest_init(const int32_t *__restrict__ usrc, int64_t U, int64_t base, int64_t *__restrict__ dist,
+template <typename DT>
+__global__ void k_cheapest_init(const int32_t *__restrict__ usrc, int64_t U, int64_t base, DT *__restrict__ dist,
                                 u64 *__restrict__ dirty, u32 *__restrict__ tflag, u32 tepoch,
                                 int32_t *__restrict__ touched, u32 *__restrict__ qcount, u32 *__restrict__ tcount,
                                 int32_t *__restrict__ q) {
@@ -132,9 +160,9 @@ __device__ __forceinline__ void relax_append(int *s_buf, int &pend, bool fresh, 
 	}
 }
 
-template <typename T>
+template <typename T, typename DT>
 __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
-                                               const T *__restrict__ w, int64_t *__restrict__ dist,
+                                               const T *__restrict__ w, DT *__restrict__ dist,
                                                u64 *__restrict__ dirty_cur, u64 *__restrict__ dirty_nxt,
                                                const int32_t *__restrict__ qcur, const u32 *__restrict__ nq_ptr,
                                                int32_t *__restrict__ qnxt, u32 *__restrict__ nq_nxt,
@@ -204,9 +232,9 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 				else cand[u] = dvb + (int64_t)ww[u];
 #if !PGQ_RELAX_NVFIRST
 #if PGQ_RELAX_SEGCOND
-				curv[u] = dist[mine && (!sorted || cand[u] < my_bound) ? (size_t)nn[u] * LC + lane : (size_t)v * LC];
+				curv[u] = Lab<DT>::widen(dist[mine && (!sorted || cand[u] < my_bound) ? (size_t)nn[u] * LC + lane : (size_t)v * LC], Inf<T>::bits);
 #else
-				curv[u] = dist[(size_t)nn[u] * LC + lane]; // unconditional: all eight rows are in flight together
+				curv[u] = Lab<DT>::widen(dist[(size_t)nn[u] * LC + lane], Inf<T>::bits); // unconditional: all eight rows are in flight together
 #endif
 #endif
 			}
@@ -231,7 +259,7 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 #else
 				const bool need = u < nv;
 #endif
-				curv[u] = dist[need ? (size_t)nn[u] * LC + lane : (size_t)v * LC];
+				curv[u] = Lab<DT>::widen(dist[need ? (size_t)nn[u] * LC + lane : (size_t)v * LC], Inf<T>::bits);
 			}
 #endif
 			if (sorted) edges += (u64)nv;
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 			for (int u = 0; u < UNR; u++) {
 				const bool go = u < nv && mine && (!sorted || cand[u] < my_bound) && cand[u] < curv[u];
 				curv[u] = cand[u]; // "not improved" unless the atomic says otherwise
-				if (go) curv[u] = atomicMin((long long *)&dist[(size_t)nn[u] * LC + lane], (long long)cand[u]);
+				if (go) curv[u] = Lab<DT>::min_into(&dist[(size_t)nn[u] * LC + lane], cand[u], Inf<T>::bits);
 			}
 			u64 my_im = 0;
 			int my_n = 0;
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 			const int64_t e = min(b + kHeavyChunk, off[v + 1]);
 			if (sorted && w[b] > wcap) continue; // the whole chunk lies above this phase's cap
 			// the label may have improved since pass 0 queued v: any label is the length of a real path, the smaller the better
-			const int64_t dvb = dist[(size_t)v * LC + lane];
+			const int64_t dvb = Lab<DT>::widen(dist[(size_t)v * LC + lane], Inf<T>::bits);
 			walk(v, dvb, (hmask[ent] >> lane) & 1ull, b, e);
 		}
 	} else {
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 		int64_t dvb = 0, b = 0, e = 0;
 		if (i < nq) {
 			mask = dirty_cur[v];
-			dvb = dist[(size_t)v * LC + lane];
+			dvb = Lab<DT>::widen(dist[(size_t)v * LC + lane], Inf<T>::bits);
 			b = off[v];
 			e = off[v + 1];
 		}
@@ -291,7 +319,7 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 			int64_t dvb1 = 0, b1 = 0, e1 = 0;
 			if (i1 < nq) {
 				mask1 = dirty_cur[v1];
-				dvb1 = dist[(size_t)v1 * LC + lane];
+				dvb1 = Lab<DT>::widen(dist[(size_t)v1 * LC + lane], Inf<T>::bits);
 				b1 = off[v1];
 				e1 = off[v1 + 1];
 			}
@@ -368,15 +396,16 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 
 // bound[lane] = the largest tentative label among the lane's destinations (rows [lo, hi) are sorted by lane); INF while
 // one of them is unlabelled.  Workgroup-local maxima in LDS, one atomicMax per lane and workgroup.
+template <typename DT>
 __global__ __launch_bounds__(256) void k_lane_bounds(int64_t lo, int64_t hi, const u32 *__restrict__ skey,
                                                      const int32_t *__restrict__ sdst, u32 base_lane,
-                                                     const int64_t *__restrict__ dist, long long *__restrict__ bound) {
+                                                     const DT *__restrict__ dist, int64_t inf_bits, long long *__restrict__ bound) {
 	__shared__ long long s_b[64];
 	if (threadIdx.x < 64) s_b[threadIdx.x] = 0;
 	__syncthreads();
 	for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
 		const u32 l = skey[i] - base_lane;
-		const long long d = (long long)dist[(size_t)sdst[i] * LC + l];
+		const long long d = (long long)Lab<DT>::widen(dist[(size_t)sdst[i] * LC + l], inf_bits);
 		if (d > s_b[l]) atomicMax(&s_b[l], d);
 	}
 	__syncthreads();
@@ -468,13 +497,14 @@ __global__ __launch_bounds__(1024) void k_relax_small(const int64_t *__restrict_
 }
 
 // results: out[row] = dist[dst][lane]; INF -> invalid.  Also trivial rows.
+template <typename DT>
 __global__ void k_cheapest_results(int64_t lo, int64_t hi, const u32 *__restrict__ skey, const u32 *__restrict__ sidx,
-                                   const int32_t *__restrict__ sdst, u32 base_lane, const int64_t *__restrict__ dist,
+                                   const int32_t *__restrict__ sdst, u32 base_lane, const DT *__restrict__ dist,
                                    int64_t inf_bits, int64_t *__restrict__ out, uint8_t *__restrict__ ok) {
 	int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= hi) return;
 	const u32 l = skey[i] - base_lane;
-	const int64_t d = dist[(size_t)sdst[i] * LC + l];
+	const int64_t d = Lab<DT>::widen(dist[(size_t)sdst[i] * LC + l], inf_bits);
 	const u32 row = sidx[i];
 	if (d == inf_bits) {
 		ok[row] = 0;
@@ -494,8 +524,9 @@ __global__ void k_cheapest_tails(int64_t lo_trivial, int64_t lo_null, int64_t n,
 	ok[row] = i < lo_null ? 1 : 0;
 }
 
+template <typename DT>
 __global__ void k_reset_touched(const int32_t *__restrict__ touched, const u32 *__restrict__ tcount,
-                                int64_t *__restrict__ dist, int64_t inf_bits) {
+                                DT *__restrict__ dist, DT inf_bits) {
 	const u32 nt = *tcount;
 	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1186,20 +1217,31 @@ static bool light_edges_first(const pgq_csr *c) {
 // The batches b0, b0 + bstride, ... of a call: `ws` holds the sorted rows and the distinct sources (read-only here),
 // `priv` everything a batch writes (labels, dirty words, queues) and the stream.  Batches are independent, so several
 // host threads run this side by side on their own workspaces (cheapest_device).
-template <typename T>
+// Whether this CSR's labels are stored as int32 (Lab<int32_t> above): int64 weights, the light-edges-first path (the
+// device-side small rounds of the plain path keep 8-byte labels), and no path sum that could reach 2^31 - 1.
+template <typename T> static bool labels_fit_32(const pgq_csr *c) {
+	if (!std::is_same<T, int64_t>::value || !options().relax_labels32 || !light_edges_first(c) || !c->wadj) return false;
+	if (!(c->w_mean > 0 && c->w_mean < 1e300)) return false; // (plain rounds then: relax_batches' own test)
+	const unsigned long long w_max = c->w_max_bits; // int64 weights are non-negative here: the bit pattern is the value
+	return w_max < (1ull << 31) && (double)w_max * (double)std::max<int64_t>(c->V, 1) < 2147483000.0;
+}
+
+template <typename T, typename DT>
 static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int bstride, int nb, u32 U, int64_t *d_out,
                          uint8_t *d_ok) {
 	hipStream_t st = priv->stream;
 	const int64_t V = c->V;
 	const int64_t inf_bits = Inf<T>::bits;
+	const DT inf_label = (DT)Lab<DT>::unlabelled(inf_bits);
 	pgq_stats_t &S = tstats().s;
 	const int64_t *bs = ws->h_bstart;
 	const size_t cells = (size_t)std::max<int64_t>(V, 1) * LC;
 	// distances start at INF; a full fill only when the array is new, afterwards only touched rows are reset
-	const int type_tag = std::is_same<T, double>::value ? 2 : 1; // the INF pattern differs between int64 and double
-	const bool fresh = priv->dist.cap < cells * 8 || priv->dist_V != V || priv->dist_lanes != type_tag;
+	// (the INF pattern differs between int64 and double, the cell size between 8- and 4-byte labels)
+	const int type_tag = sizeof(DT) == 4 ? 3 : (std::is_same<T, double>::value ? 2 : 1);
+	const bool fresh = priv->dist.cap < cells * sizeof(DT) || priv->dist_V != V || priv->dist_lanes != type_tag;
 	priv->dist_V = -1; // stays invalid if we bail out half-way; restored at the end
-	PGQ_TRY(priv->dist.reserve(cells * 8));
+	PGQ_TRY(priv->dist.reserve(cells * sizeof(DT)));
 	for (int k = 0; k < 2; k++) PGQ_TRY(priv->dirty[k].reserve((size_t)std::max<int64_t>(V, 1) * 8));
 	PGQ_TRY(priv->qbuf[0].reserve((size_t)std::max<int64_t>(V, 1) * 4));
 	PGQ_TRY(priv->qbuf[1].reserve((size_t)std::max<int64_t>(V, 1) * 4));
@@ -1216,7 +1258,8 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 	RelaxCounters *d_rc = reinterpret_cast<RelaxCounters *>(priv->counters.p);
 	RelaxCounters *h_rc = reinterpret_cast<RelaxCounters *>(priv->h_cnt);
 	if (fresh) {
-		hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, priv->dist.as<int64_t>(), (int64_t)cells, inf_bits);
+		if constexpr (sizeof(DT) == 4) hipLaunchKernelGGL(k_fill32, dim3(256 * 8), dim3(256), 0, st, priv->dist.as<int32_t>(), (int64_t)cells, (int32_t)inf_label);
+		else hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, priv->dist.as<int64_t>(), (int64_t)cells, inf_bits);
 	}
 	PGQ_HIP_TRY(hipMemsetAsync(priv->dirty[0].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
 	PGQ_HIP_TRY(hipMemsetAsync(priv->dirty[1].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
@@ -1226,7 +1269,7 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 	// the persistent grid of a round: exactly what is resident at once (each wavefront takes every nwaves-th vertex; a
 	// grid larger than the chip makes the last workgroups start when the first finish: 8192 waves on 7168 slots was 2x)
 	static std::mutex grid_lock;
-	static unsigned grid_cached[2][64] = {}; // per weight type and device: a node's devices need not be alike
+	static unsigned grid_cached[3][64] = {}; // per label / weight type and device: a node's devices need not be alike
 	unsigned grid;
 	{
 		std::lock_guard<std::mutex> g(grid_lock);
@@ -1235,7 +1278,7 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 		unsigned &gc = grid_cached[type_tag - 1][dev & 63];
 		if (!gc) {
 			int per_cu = 0, cus = 0;
-			PGQ_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_relax<T>, 256, 0));
+			PGQ_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_relax<T, DT>, 256, 0));
 			PGQ_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
 			gc = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
 		}
@@ -1250,8 +1293,8 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 		PGQ_HIP_TRY(hipMemsetAsync(d_rc, 0, sizeof(RelaxCounters), st));
 		{
 			KernelTimer kt(st, K_PREP);
-			hipLaunchKernelGGL(k_cheapest_init, dim3(1), dim3(64), 0, st, ws->usrc.as<int32_t>(), (int64_t)U, base,
-			                   priv->dist.as<int64_t>(), priv->dirty[0].as<u64>(), priv->tflag.as<u32>(), tepoch,
+			hipLaunchKernelGGL(k_cheapest_init<DT>, dim3(1), dim3(64), 0, st, ws->usrc.as<int32_t>(), (int64_t)U, base,
+			                   priv->dist.as<DT>(), priv->dirty[0].as<u64>(), priv->tflag.as<u32>(), tepoch,
 			                   priv->touched.as<int32_t>(), &d_rc->nq[0], &d_rc->tcount, priv->qbuf[0].as<int32_t>());
 			kt.stop();
 		}
@@ -1291,8 +1334,9 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 		const int32_t *r_adj = light ? c->wadj : c->adj;
 		const T *r_w = light ? (const T *)c->wsorted : (const T *)c->w;
 		for (;;) {
+			if (!light && sizeof(DT) == 4) return fail(PGQ_ERR_HIP, "internal error: 4-byte labels outside the light-edges-first path");
 			if (!light && nq_now <= small_limit) {
-				// few changed vertices: rounds loop on the device inside one workgroup
+				// few changed vertices: rounds loop on the device inside one workgroup (8-byte labels only: labels_fit_32)
 				const int max_rounds = 4096;
 				KernelTimer kt(st, K_RELAX);
 				hipLaunchKernelGGL(k_relax_small<T>, dim3(1), dim3(1024), 0, st, c->off, c->adj, (const T *)c->w,
@@ -1320,10 +1364,10 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 			const long long thr_bits = band > T(0) ? bits_of(thr_val) : (long long)0x7FFFFFFFFFFFFFFFll;
 			{
 				KernelTimer kt(st, K_RELAX);
-				hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned)std::min<int64_t>(blocks_for(hi - lo), 256)), dim3(256), 0, st, lo, hi,
-				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, priv->dist.as<int64_t>(), d_rc->bound);
-				hipLaunchKernelGGL(k_relax<T>, dim3(std::min(grid, std::max(1u, (nq_now + 3) / 4))), dim3(256), 0, st, c->off, r_adj, r_w,
-				                   priv->dist.as<int64_t>(), priv->dirty[par].as<u64>(), priv->dirty[par ^ 1].as<u64>(),
+				hipLaunchKernelGGL(k_lane_bounds<DT>, dim3((unsigned)std::min<int64_t>(blocks_for(hi - lo), 256)), dim3(256), 0, st, lo, hi,
+				                   ws->skey.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, priv->dist.as<DT>(), inf_bits, d_rc->bound);
+				hipLaunchKernelGGL((k_relax<T, DT>), dim3(std::min(grid, std::max(1u, (nq_now + 3) / 4))), dim3(256), 0, st, c->off, r_adj, r_w,
+				                   priv->dist.as<DT>(), priv->dirty[par].as<u64>(), priv->dirty[par ^ 1].as<u64>(),
 				                   priv->qbuf[par].as<int32_t>(), &d_rc->nq[par], priv->qbuf[par ^ 1].as<int32_t>(),
 				                   &d_rc->nq[par ^ 1], priv->tflag.as<u32>(), tepoch,
 				                   priv->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
@@ -1331,8 +1375,8 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 				                   0, heavy ? &d_rc->heavy : (u64 *)nullptr, priv->hv.as<int32_t>(), priv->hmask.as<u64>(),
 				                   priv->hstart.as<u32>(), priv->hmap.as<u32>());
 				if (heavy) // the long lists of the round, a chunk per wavefront
-					hipLaunchKernelGGL(k_relax<T>, dim3(grid), dim3(256), 0, st, c->off, r_adj, r_w,
-					                   priv->dist.as<int64_t>(), priv->dirty[par].as<u64>(), priv->dirty[par ^ 1].as<u64>(),
+					hipLaunchKernelGGL((k_relax<T, DT>), dim3(grid), dim3(256), 0, st, c->off, r_adj, r_w,
+					                   priv->dist.as<DT>(), priv->dirty[par].as<u64>(), priv->dirty[par ^ 1].as<u64>(),
 					                   priv->qbuf[par].as<int32_t>(), &d_rc->nq[par], priv->qbuf[par ^ 1].as<int32_t>(),
 					                   &d_rc->nq[par ^ 1], priv->tflag.as<u32>(), tepoch,
 					                   priv->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
@@ -1393,12 +1437,12 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 			}
 		}
 		S.edges_scanned += (int64_t)h_rc->relaxed_edges;
-		S.algo_bytes[K_RELAX] += (double)h_rc->relaxed_edges * (4.0 + 8.0 + 2.0 * 8.0 * LC);
-		hipLaunchKernelGGL(k_cheapest_results, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
-		                   ws->sidx.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, priv->dist.as<int64_t>(), inf_bits,
+		S.algo_bytes[K_RELAX] += (double)h_rc->relaxed_edges * (4.0 + 8.0 + 2.0 * (double)sizeof(DT) * LC);
+		hipLaunchKernelGGL(k_cheapest_results<DT>, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
+		                   ws->sidx.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, priv->dist.as<DT>(), inf_bits,
 		                   d_out, d_ok);
-		hipLaunchKernelGGL(k_reset_touched, dim3(256 * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
-		                   priv->dist.as<int64_t>(), inf_bits);
+		hipLaunchKernelGGL(k_reset_touched<DT>, dim3(256 * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
+		                   priv->dist.as<DT>(), inf_label);
 	}
 	PGQ_HIP_TRY(hipStreamSynchronize(st));
 	KernelTimer::flush();
@@ -1437,9 +1481,16 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 		const size_t per_worker = (size_t)std::max<int64_t>(c->V, 1) * (LC * 8 + 64) + (size_t)(c->E / 64) * 4;
 		workers = (int)std::min<size_t>((size_t)workers, 1 + free_b / 2 / per_worker);
 	}
+	const bool narrow = labels_fit_32<T>(c); // (the weight-sorted copy above has left the largest weight on the handle)
+	auto run_relax = [&](Workspace *priv, int b0, int bstride) -> int {
+		if constexpr (std::is_same<T, int64_t>::value) {
+			if (narrow) return relax_batches<T, int32_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok);
+		}
+		return relax_batches<T, int64_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok);
+	};
 	int rc = PGQ_OK;
 	if (workers == 1) {
-		rc = relax_batches<T>(c, ws, ws, 0, 1, nb, U, d_out, d_ok);
+		rc = run_relax(ws, 0, 1);
 	} else {
 		std::vector<WorkspaceLease> leases((size_t)workers - 1);
 		for (auto &l : leases) PGQ_TRY(l.acquire());
@@ -1456,13 +1507,13 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 				int r = ensure_init();
 				if (r == PGQ_OK) {
 					(void)pgq_reset_stats();
-					r = relax_batches<T>(c, ws, leases[(size_t)t - 1].ws, t, workers, nb, U, d_out, d_ok);
+					r = run_relax(leases[(size_t)t - 1].ws, t, workers);
 				}
 				rcs[(size_t)t] = r;
 				if (r != PGQ_OK) errs[(size_t)t] = pgq_last_error();
 				wstats[(size_t)t] = tstats().s;
 			}));
-		rcs[0] = relax_batches<T>(c, ws, ws, 0, workers, nb, U, d_out, d_ok);
+		rcs[0] = run_relax(ws, 0, workers);
 		for (size_t k = 0; k < pool.size(); k++) { // a job that threw never wrote its return code: take the pool's word for it
 			const int wr = worker_wait(pool[k]);
 			if (wr != PGQ_OK) {

@@ -63,6 +63,7 @@ struct Options {
 	int relax_small_limit = 2048; // changed vertices at or below which relaxation rounds loop on the device
 	int relax_light = 1;      // (1: where the mean out-degree makes it pay, 2: always, 0: never) batched relaxation over weight-sorted lists: edges above a cap that doubles phase by phase are not
 	                          // scanned, and a vertex stops at the first edge that cannot beat its lanes' bounds (0: plain rounds)
+	int relax_labels32 = 1;   // int64 weights whose path sums fit 31 bits keep 4-byte labels (rows of 256 bytes instead of 512)
 	int relax_light_min_degree = 8; // relax_light = 1: only CSRs with at least this many edges per vertex (2: always)
 	int relax_light_div = 4;  // first cap = mean weight / this
 	int relax_streams = 6;    // batches of the relaxation side by side on their own label arrays (0: `streams`)

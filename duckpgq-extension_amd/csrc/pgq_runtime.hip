@@ -172,6 +172,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "relax_light", &o.relax_light, nullptr },
 		{ "relax_light_div", &o.relax_light_div, nullptr },
 		{ "relax_light_min_degree", &o.relax_light_min_degree, nullptr },
+		{ "relax_labels32", &o.relax_labels32, nullptr },
 		{ "relax_split", &o.relax_split, nullptr },
 		{ "relax_streams", &o.relax_streams, nullptr },
 		{ "chain", &o.chain, nullptr },

@@ -21,7 +21,7 @@ def _defaults():
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
-                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 2), ("relax_delta_div", 0), ("relax_light", 2), ("relax_light_div", 4), ("relax_split", 1),
+                 ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 2), ("relax_delta_div", 0), ("relax_light", 2), ("relax_light_div", 4), ("relax_split", 1), ("relax_labels32", 1),
                  ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1)):
         pgq.set_option(k, v)
     yield
@@ -428,8 +428,9 @@ def test_cheapest_path_bit_exact(kind):
         pgq.set_option("streams", streams)  # batches of 64 sources side by side on their own label arrays
         pgq.set_option("relax_small_limit", 0 if n == 300 else (50 if n == 70 else 2048))  # host rounds / mixed / device rounds
         # light edges first: weight-sorted lists under a cap that doubles per phase, first cap = mean weight / light (0: off)
-        pgq.set_option("relax_light", 1 if light else 0)
+        pgq.set_option("relax_light", 2 if light else 0)  # (1 would go by the mean out-degree: 7.5 here, plain rounds)
         pgq.set_option("relax_light_div", max(light, 1))
+        pgq.set_option("relax_labels32", (n + streams) % 2)  # int64 weights under the light path: 4-byte / 8-byte labels
         # band width of the ordered rounds = mean weight / div: 0 = plain rounds, 1 = a few wide bands, 100000 = a band per label
         pgq.set_option("relax_delta_div", div)
         ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
@@ -1453,3 +1454,27 @@ def test_workspace_reuse_across_widths_graphs_and_entry_points_fuzz():
             assert lens(ln, ok) == lens(oln, ook), (it, V, shape)
     for _, dev, _ in graphs:
         dev.close()
+
+
+def test_cheapest_path_label_width_switches_at_31_bits():
+    """int64 weights keep 4-byte labels while w_max x V stays under 2^31 - 1 and 8-byte labels above (round 5): long chains of
+    maximal weights on both sides of the boundary, so that real labels come close to what the narrow form can hold; both
+    against the oracle's Dijkstra, and the narrow form against the wide one (relax_labels32 = 0)."""
+    rng = np.random.default_rng(91)
+    V = 3000
+    a = np.arange(V - 1, dtype=np.int64)
+    for w_max in (715000, 716500, 10 ** 12):  # 715000 x 3000 = 2.145e9 < 2^31 - 1 < 716500 x 3000
+        s = np.concatenate([a, rng.integers(0, V, 40000)])
+        d = np.concatenate([a + 1, rng.integers(0, V, 40000)])
+        w = np.concatenate([np.full(V - 1, w_max, dtype=np.int64), rng.integers(w_max // 2, w_max + 1, 40000)])
+        st, ora = both(V, (s, d, np.arange(len(s), dtype=np.int64)), w=w)
+        ps = np.concatenate([np.zeros(40, dtype=np.int64), rng.integers(0, V, 200)])
+        pd = np.concatenate([np.full(40, V - 1, dtype=np.int64) - np.arange(40), rng.integers(0, V, 200)])
+        want, wok = ora.lean_cheapest_path_length(V, ps, pd)
+        got = {}
+        for narrow in (1, 0):
+            pgq.set_option("relax_labels32", narrow)
+            out, ok = st.cheapest_path_length(0, V, ps, pd)
+            assert (ok == wok).all() and (out[ok] == want[wok]).all(), (w_max, narrow)
+            got[narrow] = out
+        assert (got[0] == got[1]).all()

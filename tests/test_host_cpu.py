@@ -262,3 +262,21 @@ def test_bench_strided_sample_of_the_cross_product_covers_every_source():
     sel = np.arange(8192) * (len(cp) // 8192)
     assert len(np.unique(cp[sel, 0])) == 2048
     assert len(np.unique(cp[:8192, 0])) == 8
+
+
+def test_stats_struct_layout_matches_the_header(tmp_path):
+    """pgq_stats_t grew at its end in round 5 (spec_batches ... host_waits): the ctypes mirror must have the header's size
+    and field offsets, or every statistic after the first mismatch reads garbage."""
+    import ctypes
+    import subprocess
+    from duckpgq_extension_amd import binding
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pgq_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", '
+                   'sizeof(pgq_stats_t), offsetof(pgq_stats_t, algo_bytes), offsetof(pgq_stats_t, launches), '
+                   'offsetof(pgq_stats_t, spec_batches), offsetof(pgq_stats_t, host_waits));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    size, o_algo, o_launch, o_spec, o_waits = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    S = binding.Stats
+    assert ctypes.sizeof(S) == size
+    assert (S.algo_bytes.offset, S.launches.offset, S.spec_batches.offset, S.host_waits.offset) == (o_algo, o_launch, o_spec, o_waits)

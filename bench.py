@@ -69,8 +69,8 @@ PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5, 
 CHEAPEST = ("forest_cheapest", "snb_cheapest")  # weighted workloads: value = pairs/s
 SNB = ("snb_sf100", "snb_paths", "snb_cheapest", "snb_cross", "snb_cross_allv")
 EXPANSION = ("push", "pull", "pull_hub", "pull_sparse")  # the MS-BFS frontier-expansion kernel classes
-KERNEL_OF = {"meet": "k_meet3", "meet4": "k_meet4d", "bibfs": "k_bibfs", "pull_sparse": "k_pull_lanes"}
-PREPASS = ("meet", "meet4", "bibfs")  # the pair-centric kernels: k_meet3, k_meet4d / k_meet4, k_bibfs
+KERNEL_OF = {"meet": "k_meet3", "meet4": "k_meet4d", "bibfs": "k_bibfs", "pull_sparse": "k_pull_lanes", "ball": "k_src_ball"}
+PREPASS = ("ball", "meet", "meet4", "bibfs")  # the source-centric kernel and the pair-centric ones: k_src_ball, k_meet3, k_meet4d / k_meet4, k_bibfs
 
 
 def parse():

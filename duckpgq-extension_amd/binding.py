@@ -26,7 +26,8 @@ class Stats(C.Structure):
                 ("deferred_pairs", C.c_int64), ("meet_pairs", C.c_int64),
                 ("algo_bytes", C.c_double * KCLASS_MAX), ("kernel_ms", C.c_double * KCLASS_MAX),
                 ("launches", C.c_int64 * KCLASS_MAX), ("spec_batches", C.c_int64), ("spec_levels", C.c_int64),
-                ("spec_aborts", C.c_int64), ("host_waits", C.c_int64)]
+                ("spec_aborts", C.c_int64), ("host_waits", C.c_int64), ("ball_segments", C.c_int64),
+                ("ball_calls", C.c_int64)]
 
 
 def lib_paths():
@@ -101,6 +102,7 @@ def load_hip():
     L.pgq_weakly_connected_component.argtypes = [C.c_void_p, C.c_int64, C.c_int64, Vec, C.c_void_p, C.c_void_p]
     L.pgq_weakly_connected_component_device.argtypes = [C.c_void_p, C.c_void_p]
     L.pgq_get_stats.argtypes = [C.POINTER(Stats)]
+    L.pgq_get_stats_sized.argtypes = [C.POINTER(Stats), C.c_size_t]
     L.pgq_measure_copy_bandwidth.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_double)]
     _hip = L
     return L
@@ -209,7 +211,7 @@ def kclass_names():
 
 def get_stats():
     st = Stats()
-    _check(load_hip().pgq_get_stats(C.byref(st)))
+    _check(load_hip().pgq_get_stats_sized(C.byref(st), C.sizeof(st)))  # the library writes at most this mirror's size
     names = kclass_names()
     d = {f: getattr(st, f) for f, t in Stats._fields_ if t is C.c_int64}
     d["algo_bytes"] = {n: st.algo_bytes[i] for i, n in enumerate(names)}

@@ -129,6 +129,14 @@ struct Options {
 	int meet_grid_mult = 8; // k_meet3 grid = this many times the 8192 one-wavefront workgroups the chip holds (rows per workgroup = n / grid)
 	int meet_layout = 1;    // build the padded adjacency + slot descriptors at upload (the pre-pass needs them)
 	int meet_align = 32;    // entries a padded list is aligned and padded to (4 = one 16-byte group; 16 / 32 = whole 64 / 128-byte lines: -4 % / -6 % on the pre-pass)
+	// round 6: source-centric search for rows that arrive grouped by source (pgq_ball.h: k_ball_segments + k_src_ball)
+	int ball = 1;               // 1: the device decides per call from the number of source runs; 2: always when allowed (tests); 0: never
+	int ball_cap = 1 << 20;     // adjacency entries the two-hop ball of one source may hold; a segment over it leaves its far rows open
+	int ball_test_cap = 1 << 15; // adjacency entries the backward two-hop walk of one row (distance 4) may scan
+	int ball_seg_kb = 512;      // the least a segment costs in the decision, in KB at streaming rate (its ~15 dependent round trips on one of ~512 workgroup slots)
+	int ball_grid = 0;          // > 0: at most this many workgroups of k_src_ball (debugging / sweeps)
+	int ball_sort = 1;          // rows with repeated sources that are NOT grouped are sorted by source first (0: such calls take the older routes)
+	double ball_bias = 1.0;     // the ball runs while ball_bias x its estimated bytes <= the cheaper of the pre-pass and the lane batches
 };
 Options &options();
 // per-handle options (pgq_csr_set_option): the override a host thread works under, and a scope that installs a
@@ -156,7 +164,8 @@ enum KClass {
 	K_MEET = 9,      // pair-centric two-hop pre-pass: k_meet3, one wavefront per row (pgq_meet.hip)
 	K_MEET4 = 10,    // ... its bit-map kernels for the rows k_meet3 leaves open (k_meet4d / k_meet4)
 	K_BIBFS = 11,    // ... one bidirectional search per row (k_bibfs)
-	K_COUNT = 12
+	K_BALL = 12,     // source-centric search of rows grouped by source: k_ball_segments + k_src_ball (pgq_ball.h)
+	K_COUNT = 13
 };
 
 struct ThreadStats {
@@ -246,7 +255,15 @@ struct pgq_csr {
 		int go = 1;
 		int64_t id_n = -1; // row count of the last call whose rows stayed in place (one batch) ...
 		int id_wd = 0;     // ... and its batch width: the next call with that row count runs stage 2 ahead of its wait
+		// round 6: the last call on these buffers that the source-centric kernels looked at and DECLINED (scattered pairs): the
+		// next one does not launch them again (6 us in front of a 0.2-ms call).  Speed only.
+		int64_t ball_no_n = -1;
+		const void *ball_no_src = nullptr, *ball_no_dst = nullptr;
 	} route_memo;
+	// share of a call's rows the source-centric kernel left open, last time it ran on this CSR (half the weight to the newest
+	// call): above ~2 % those rows drag the lane batches along anyway (R-MAT: far and unreachable pairs), and the kernel
+	// stays out of the chain until the CSR is uploaded again
+	std::atomic<double> ball_open_frac { 0.0 };
 	bool is_replica = false;
 };
 

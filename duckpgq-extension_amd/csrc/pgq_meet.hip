@@ -104,6 +104,13 @@ struct MeetQueue {
 	u32 *count_back;
 	u32 cap;
 };
+// round 6: the source-centric kernels at the head of the chain (pgq_ball.h)
+struct BallDev {
+	unsigned long long entries[32], descs[32]; // adjacency entries / slot descriptors read, spread over slots
+	u32 nseg, nrun; // segments listed (source runs cut at 1024-row windows) and source runs of the input
+	u32 go;         // 1: k_src_ball takes the call — the stage kernels behind it return at once
+	u32 next_job, open, ticket, pad[2];
+};
 struct MeetDevBlock { // device side; all zero between calls
 	MeetCounters m;
 	u32 count[4]; // rows open after stage 1, 2, 3; [3]: stage 1's rows appended from the back of its queue
@@ -111,12 +118,15 @@ struct MeetDevBlock { // device side; all zero between calls
 	u32 next_job; // k_meet4d: the next queue position to hand out
 	u32 pad[2];
 	MeetDecision dec;
+	BallDev ball;
 };
 struct MeetHostBlock { // pinned host memory, written by the last workgroup of the chain
 	unsigned long long entries[3], vertices[3]; // per stage: k_meet3, the bit-map kernel, k_bibfs
 	u32 bad, count[3];
 	MeetDecision dec;
 	u32 done, count_back;
+	unsigned long long ball_entries, ball_descs;
+	u32 ball_go, ball_nseg, ball_nrun, ball_open;
 };
 static_assert(sizeof(MeetHostBlock) <= 8192, "pinned statistics block too small");
 __device__ __forceinline__ void queue_push(const MeetQueue &q, u32 row, const MeetEntry &e) { // one lane
@@ -172,6 +182,27 @@ __device__ __forceinline__ void meet_finalize(MeetDevBlock *db, MeetHostBlock *f
 			db->count[k] = 0;
 		}
 		fin->dec = db->dec;
+		{ // the source-centric kernels' block (they ran, or declined, at the head of this chain)
+			unsigned long long be = 0, bd = 0;
+			for (int k = 0; k < 32; k++) {
+				be += __hip_atomic_load(&db->ball.entries[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				bd += __hip_atomic_load(&db->ball.descs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				db->ball.entries[k] = 0;
+				db->ball.descs[k] = 0;
+			}
+			fin->ball_entries = be;
+			fin->ball_descs = bd;
+			fin->ball_go = db->ball.go;
+			fin->ball_nseg = db->ball.nseg;
+			fin->ball_nrun = db->ball.nrun;
+			fin->ball_open = __hip_atomic_load(&db->ball.open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			db->ball.go = 0;
+			db->ball.nseg = 0;
+			db->ball.nrun = 0;
+			db->ball.open = 0;
+			db->ball.next_job = 0;
+			db->ball.ticket = 0;
+		}
 		fin->count_back = __hip_atomic_load(&db->count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		db->m.bad = 0;
 		db->count[3] = 0;
@@ -189,6 +220,10 @@ __device__ __forceinline__ void meet_add_stats(MeetCounters *mc, int stage, unsi
 	if (entries) atomicAdd(&mc->entries[base + blockIdx.x % cnt], entries);
 	if (vertices) atomicAdd(&mc->vertices[base + blockIdx.x % cnt], vertices);
 }
+
+} // namespace pgq
+#include "pgq_ball.h"
+namespace pgq {
 
 // One wavefront per row.  A row costs ~4 dependent memory round trips before its walk starts (row, offsets, the two
 // one-hop lists — the expanded side's arrives as slot descriptors, so the ranges of its vertices need no look-up) and a
@@ -215,7 +250,7 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 	__shared__ __attribute__((aligned(16))) u32 bm[kFltWords];
 	__shared__ __attribute__((aligned(16))) unsigned char win[64];
 	MeetCounters *const mc = &db->m;
-	if (go && *go == 0) { // (a scalar load: one word read by every wavefront through the vector path is a hot spot on one L2
+	if ((go && *go == 0) || db->ball.go) { // (a scalar load: one word read by every wavefront through the vector path is a hot spot on one L2
 		meet_finalize(db, fin); // channel — polling it per row while the decision kernel ran beside this one made k_meet3
 		return;                 // 0.28 ms instead of 0.16, and with 256 spread copies the two extra stream operations ate the 12 us)
 	}
@@ -739,7 +774,7 @@ __global__ __launch_bounds__(64 * PGQ_MEET4_WAVES, PGQ_MEET4_BLOCKS) void k_meet
 	// the sampled decision of the distinct sources rides here when the chain runs on the route memo's word (meet_prepass,
 	// decide_mode 2): the LAST workgroup — its first row is one of the short ones, and the rows are handed out dynamically —
 	// takes the sample in the bit map's LDS before its first row clears it
-	if (!GM && sm.h_go && blockIdx.x == gridDim.x - 1 && bm_words >= kSampleSlots)
+	if (!GM && sm.h_go && blockIdx.x == gridDim.x - 1 && bm_words >= kSampleSlots && !db->ball.go)
 		sample_distinct_sources(sm.n, sm.src, sm.V, sm.meet_bytes, sm.edge_bytes, sm.out, sm.h_go, s_map);
 	u32 job = blockIdx.x;
 	for (;;) {
@@ -1183,9 +1218,15 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // strided sample of the rows goes through an LDS hash set, thread 0 inverts E[distinct] = U (1 - (1 - 1/U)^sample) and
 // compares the two cost estimates ON THE DEVICE: the pre-pass kernels are launched straight behind and return at once
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
+// ball_go (nullable): the source-centric kernel in front of this one has taken the call: no sample, no pre-pass.
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
-                                                     double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go) {
+                                                     double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go,
+                                                     const u32 *__restrict__ ball_go) {
 	__shared__ u32 s_set[kSampleSlots];
+	if (ball_go && *ball_go) {
+		if (threadIdx.x == 0) out->go = 0;
+		return;
+	}
 	sample_distinct_sources(n, src, V, meet_bytes, edge_bytes, out, h_go, s_set);
 }
 
@@ -1248,9 +1289,15 @@ static void meet_attributes() {
 // open to the next one's queue, the last one reports into the pinned block: the host launches 2-4 kernels and waits ONCE.
 // decide: k_meet_decide compares `meet_bytes` with the lanes' cost for the sampled number of distinct sources
 // (lanes_cost_bytes) first; *ran = false when it said no (nothing was written to d_out).
+// ball_mode (round 6): 1 = k_ball_segments + k_src_ball open the chain and the device decides from the number of source
+// runs whether the source-centric kernel takes the call (then every stage kernel behind it returns at once and *ball_ran
+// = true: the open rows are what IT left); 2 = it always does (tests); 0 = the chain starts with the stage kernels.
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
-                 u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go) {
+                 u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go,
+                 int ball_mode, bool *ball_ran) {
 	const bool paths = po != nullptr;
+	if (ball_ran) *ball_ran = false;
+	if (paths || !c->rseg || !c->fdesc || !c->rdesc || n < 2) ball_mode = 0;
 	// decide_mode 1: k_meet_decide in front of the chain, its flag gates every stage kernel on the device.  2: the route
 	// memo says the last call on these buffers was answered here: the chain runs ungated and the sample rides in k_meet4d's
 	// launch (its last workgroup, in the bit map's LDS) — *observed_go gets its verdict for the memo, -1 when none was taken
@@ -1330,10 +1377,73 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	// shortestpath on a large input: if the decision kernel calls the pre-pass off, nothing writes d_out — the list layout
 	// below must then see "no list" everywhere (-1 in every row), not what the buffer happened to hold
 	if (decide && paths) PGQ_HIP_TRY(hipMemsetAsync(d_out, 0xFF, (size_t)n * 8, st));
+	// ---- round 6: the source-centric kernels open the chain (pgq_ball.h) ----
+	unsigned long long *b_trace = nullptr;
+	if (ball_mode) {
+		// its vertex bit map: LDS when one workgroup's map + 22 KB of row state fit (two workgroups per CU when both do), else a
+		// slice of the global buffer the bit-map kernels use (they run only when this one declines)
+		const size_t row_state = 22 * 1024, lds_all = 160 * 1024;
+		const bool ball_lds = (size_t)bm_words * 4 + row_state <= std::min(lds_all, lds_budget + row_state);
+		unsigned grid_b = 0;
+		size_t ball_maps = 0;
+		if (ball_lds) {
+			grid_b = (unsigned)device_cus() * ((PGQ_BALL_WAVES >= 8 && 2 * ((size_t)bm_words * 4 + row_state) <= lds_all) ? 2u : 1u);
+		} else if ((size_t)bm_words * 4 <= gm_budget) {
+			grid_b = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)device_cus() * 2, gm_budget / ((size_t)bm_words * 4)));
+			ball_maps = (size_t)grid_b * bm_words * 4;
+		}
+		if (opt.ball_grid > 0) grid_b = std::min(grid_b, (unsigned)opt.ball_grid);
+		if (grid_b == 0) {
+			ball_mode = 0; // no room for the maps: the older routes
+		} else {
+			if (ball_maps > ws->meet_maps.cap) {
+				PGQ_TRY(ws->meet_maps.reserve(std::max(ball_maps, maps_bytes + bi_bytes + 64)));
+				gmaps = ws->meet_maps.as<u32>();
+				bi_maps = gmaps + (maps_bytes + 15) / 16 * 4;
+			}
+			PGQ_TRY(ws->ball_segs.reserve((size_t)n * 4));
+			static std::atomic<int> ball_attr { 0 };
+			if (!ball_attr.load()) {
+				(void)hipFuncSetAttribute((const void *)k_src_ball<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+				(void)hipFuncSetAttribute((const void *)k_src_ball<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+				ball_attr.store(1);
+			}
+			BallRule rule;
+			const double mean_deg = (double)c->E / (double)std::max<int64_t>(c->V, 1);
+			rule.seg_floor = 1024.0 * (double)std::max(0, opt.ball_seg_kb);
+			rule.seg_bytes = 4.0 * c->two_hop_mean + 32.0 * mean_deg + 64.0;
+			rule.row_bytes = 4.0 * std::min(mean_deg, 64.0) + 128.0 + 32.0; // the first 64 entries of the in-list, the line its position sits in, the row
+			rule.meet_bytes = meet_bytes;
+			rule.edge_bytes = edge_bytes > 0 ? edge_bytes : (double)c->E;
+			rule.bias = opt.ball_bias;
+			rule.mode = ball_mode;
+			rule.V = c->V;
+			const int64_t nwin = (n + kBallRows - 1) / kBallRows;
+			KernelTimer kt(st, K_BALL);
+			hipLaunchKernelGGL(k_ball_segments, dim3((unsigned)std::min<int64_t>(nwin, (int64_t)device_cus())), dim3(kBallRows), 0, st, n, d_src,
+			                   ws->ball_segs.as<u32>(), db);
+			const int64_t capb = std::max(1, opt.ball_cap), tcap = std::max(1, opt.ball_test_cap);
+			if (opt.meet_trace) {
+				PGQ_TRY(ws->ball_trace.reserve(256));
+				b_trace = ws->ball_trace.as<unsigned long long>();
+				PGQ_HIP_TRY(hipMemsetAsync(b_trace, 0, 256, st));
+			}
+#define PGQ_BALL(G, T, LDS)                                                                                                  \
+	hipLaunchKernelGGL((k_src_ball<G, T>), dim3(grid_b), dim3(kBallRows), LDS, st, n, d_src, d_dst, c->V, c->off, c->roff, c->fdesc, \
+	                   c->rdesc, c->padj, c->rpadj, c->rseg, ws->ball_segs.as<u32>(), d_out, capb, tcap, bm_words, db, gmaps, q[0], rule, b_trace)
+			if (ball_lds && b_trace) PGQ_BALL(false, true, (size_t)bm_words * 4);
+			else if (ball_lds) PGQ_BALL(false, false, (size_t)bm_words * 4);
+			else if (b_trace) PGQ_BALL(true, true, 0);
+			else PGQ_BALL(true, false, 0);
+#undef PGQ_BALL
+			kt.stop();
+		}
+	}
 	// (tried in round 4: the decision kernel on a stream of its own beside k_meet3, which polls a stop flag — the event
 	// record / wait pair costs what the 12 us kernel does, and the polled word must be spread over many lines)
 	if (decide)
-		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec, (u32 *)nullptr);
+		hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, st, n, d_src, c->V, meet_bytes, edge_bytes, &db->dec, (u32 *)nullptr,
+		                   (const u32 *)&db->ball.go);
 	{
 		// calls too small to fill the chip are bound by the longest row, not by bandwidth: more requests in flight shorten
 		// every row (meet_cap_small is a cap of their own; 4096 .. 16384 measured within 3 % of each other: it ships equal
@@ -1456,6 +1566,32 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		        grid4, rows, h.count[0], most, (double)(t1 - t0) * 0.01, (double)(last_start - t0) * 0.01,
 		        (double)(first_end - t0) * 0.01, (double)longest * 0.01);
 	}
+	if (b_trace && h.ball_go) { // debugging aid: where k_src_ball's time goes
+		unsigned long long t[9];
+		PGQ_HIP_TRY(hipMemcpy(t, b_trace, sizeof(t), hipMemcpyDeviceToHost));
+		const double seg = (double)std::max<u32>(h.ball_nseg, 1) * 100.0;
+		fprintf(stderr, "[pgq] k_src_ball trace: %u segments, us per segment: rows+clear %.1f, S1 %.1f, S2 %.1f, in-ball tests %.1f, in-list scans %.1f, "
+		        "distance 4 %.1f, output %.1f, between segments %.1f; longest segment %.1f us\n",
+		        h.ball_nseg, t[0] / seg, t[1] / seg, t[2] / seg, t[3] / seg, t[4] / seg, t[5] / seg, t[6] / seg, t[7] / seg, (double)t[8] * 0.01);
+	}
+	if (ball_mode && h.ball_go) { // the source-centric kernel took the call: what is open sits in region 0, counted by itself
+		if (h.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+		if (ball_ran) *ball_ran = true;
+		ws->open_src = q[0].src;
+		ws->open_dst = q[0].dst;
+		ws->open_idx = q[0].idx;
+		S.meet_pairs += n - (int64_t)h.ball_open;
+		S.edges_scanned += (int64_t)h.ball_entries;
+		// 4 B per adjacency entry (the balls' lists, the destinations' in-lists, the distance-4 walks), 16 B per slot descriptor,
+		// per row its ids, its destination's list position and its result (32 B), per segment its position and offsets (24 B)
+		S.algo_bytes[K_BALL] += 4.0 * (double)h.ball_entries + 16.0 * (double)h.ball_descs + 32.0 * (double)n + 24.0 * (double)h.ball_nseg;
+		S.ball_segments += h.ball_nseg;
+		S.ball_calls++;
+		*n_open = h.ball_open;
+		return PGQ_OK;
+	}
+	if (ball_mode) // it looked at the rows (8 B per row, twice) and declined
+		S.algo_bytes[K_BALL] += 16.0 * (double)n;
 	if (decide && !h.dec.go) {
 		if (ran) *ran = false;
 		*n_open = (u32)n;
@@ -1486,7 +1622,7 @@ int meet_decide_alone(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src
 	u32 *h_go = reinterpret_cast<u32 *>(static_cast<char *>(ws->h_meet) + 4104);
 	*h_go = 0;
 	hipLaunchKernelGGL(k_meet_decide, dim3(1), dim3(1024), 0, ws->stream, n, d_src, c->V, meet_bytes, edge_bytes,
-	                   ws->route_dec.as<MeetDecision>(), h_go);
+	                   ws->route_dec.as<MeetDecision>(), h_go, (const u32 *)nullptr);
 	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
 	*go = *h_go == 2;
 	return PGQ_OK;

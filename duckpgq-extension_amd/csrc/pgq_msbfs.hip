@@ -1550,7 +1550,8 @@ Workspace::~Workspace() {
 	for (DevBuf *b : { &seen, &qbuf[0], &qbuf[1], &qflag, &counters, &flag, &rank, &usrc, &key, &idx, &skey,
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
-	                   &def_idx, &def_off, &def_ent, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &wb_scratch, &dpart })
+	                   &def_idx, &def_off, &def_ent, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &meet_trace,
+	                   &wb_scratch, &hv, &hmask, &hstart, &hmap, &route_dec, &ball_segs, &ball_trace, &dpart })
 		b->release();
 	for (auto *v : { &levels, &pool })
 		for (auto &l : *v) {
@@ -1836,6 +1837,8 @@ struct SearchOutput {
 	bool overflow = false; // the caller's child buffer was too small (lengths are still complete)
 	bool bidir = false;    // iterativelengthbidirectional: every row through the per-row bidirectional search first
 	bool from_meet = false; // these rows are what the pair-centric pre-pass left open: do not run it on them again
+	bool no_ball = false;   // these rows are what the source-centric kernel left open: the pre-pass may take them, that kernel not again
+	int ball_hint = -1;     // the caller has looked at the rows (chunk entry points: they sit in host memory): 0 = not grouped by source
 };
 static constexpr int kMaxTeLevels = 1024;
 
@@ -2423,6 +2426,8 @@ void merge_stats(pgq_stats_t &into, const pgq_stats_t &from) {
 	into.spec_levels += from.spec_levels;
 	into.spec_aborts += from.spec_aborts;
 	into.host_waits += from.host_waits;
+	into.ball_segments += from.ball_segments;
+	into.ball_calls += from.ball_calls;
 	for (int k = 0; k < PGQ_KCLASS_MAX; k++) {
 		into.algo_bytes[k] += from.algo_bytes[k];
 		into.kernel_ms[k] += from.kernel_ms[k];
@@ -2521,6 +2526,19 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	// estimate of the distinct sources decides ON THE DEVICE, in the same launch chain (cross products share their lanes)
 	const bool decide = n > kMeetDecideRows;
 	int decide_mode = decide ? 1 : 0, observed_go = -1; // 2: the memo vouches for the pre-pass, the sample only observes (meet_prepass)
+	// round 6: the source-centric kernels open the pre-pass's chain and decide on the device (pgq_ball.h); not for paths,
+	// not for the rows that kernel itself left open
+	int ball_mode = (with_paths || outp.no_ball || outp.bidir || n < 2) ? 0 : std::max(0, std::min(2, mopt.ball));
+	if (ball_mode == 1) {
+		if (outp.ball_hint == 0 || c->ball_open_frac.load(std::memory_order_relaxed) > 0.02) ball_mode = 0;
+		else if (mopt.route_memo && outp.ball_hint < 0) { // (a caller that has looked at the rows knows better than the memo)
+			std::lock_guard<std::mutex> g(c->plan_lock);
+			const pgq_csr::RouteMemo &m = c->route_memo;
+			if (m.ball_no_n == n && m.ball_no_src == (const void *)d_src && m.ball_no_dst == (const void *)d_dst) ball_mode = 0;
+		}
+	}
+	const int ball_asked = ball_mode;
+	bool ball_ran = false;
 	// shortestpath: the pre-pass also records each answered row's inner vertices (reference tie-break); their lists are
 	// packed first, the lists of the rows left to the lane-batched search are appended behind them
 	auto run_meet_paths = [&](bool *ran) -> int {
@@ -2588,9 +2606,21 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		if (with_paths) return run_meet_paths(ran);
 		u32 nd = 0;
 		const double b0 = S.algo_bytes[K_MEET] + S.algo_bytes[K_MEET4] + S.algo_bytes[K_BIBFS];
-		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide_mode, meet_bytes, edge_bytes, ran, &observed_go));
-		if (!*ran) return PGQ_OK;
-		if (n >= 1024) { // what these rows really moved refines the CSR's bytes per row (half the weight to the newest call)
+		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide_mode, meet_bytes, edge_bytes, ran, &observed_go,
+		                     ball_mode, &ball_ran));
+		if (ball_asked == 1 && outp.ball_hint < 0) { // what the kernels said about these buffers
+			std::lock_guard<std::mutex> g(c->plan_lock);
+			c->route_memo.ball_no_n = ball_ran ? -1 : n;
+			c->route_memo.ball_no_src = d_src;
+			c->route_memo.ball_no_dst = d_dst;
+		}
+		if (ball_ran && n >= 1024) {
+			const double now = (double)nd / (double)n, old = c->ball_open_frac.load(std::memory_order_relaxed);
+			c->ball_open_frac.store(0.5 * old + 0.5 * now, std::memory_order_relaxed);
+		}
+		if (!*ran && !ball_ran) return PGQ_OK;
+		*ran = true;
+		if (n >= 1024 && !ball_ran) { // what these rows really moved refines the CSR's bytes per row (half the weight to the newest call)
 			const double now = std::max(64.0, (S.algo_bytes[K_MEET] + S.algo_bytes[K_MEET4] + S.algo_bytes[K_BIBFS] - b0) / (double)n);
 			const double old = c->meet_bpr.load(std::memory_order_relaxed);
 			c->meet_bpr.store(old > 0 ? 0.5 * old + 0.5 * now : now, std::memory_order_relaxed);
@@ -2601,7 +2631,10 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			PGQ_TRY(inner.acquire());
 			SearchOutput so2;
 			so2.depth = outp.depth + 1;
-			so2.from_meet = true;
+			// what the source-centric kernel left open (distance >= 5, unreachable, segments over its cap) is the pre-pass's kind
+			// of row (k_meet4d / k_bibfs) before it is the lane batches'
+			so2.from_meet = !ball_ran;
+			so2.no_ball = true;
 			S.pairs -= nd; // counted once
 			PGQ_TRY(search_device(c, inner.ws, nd, ws->open_src, ws->open_dst,
 			                      ws->def_len.as<int64_t>(), false, nullptr, nullptr, 0, so2));
@@ -2636,7 +2669,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			const pgq_csr::RouteMemo &m = c->route_memo;
 			const bool same = m.n == n && m.src == (const void *)d_src && m.dst == (const void *)d_dst;
 			skip = same && m.go == 0;
-			if (same && m.go == 1) decide_mode = 2;
+			if (same && m.go != 0) decide_mode = 2;
 		}
 		if (skip) {
 			sampled = true; // taken inside the lane assignment's first launch (k_mark_sources)
@@ -2649,7 +2682,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 				c->route_memo.src = d_src;
 				c->route_memo.dst = d_dst;
 				c->route_memo.go = ran ? 1 : 0;
-				if (decide_mode == 2 && observed_go == 0) c->route_memo.go = 0; // these rows look like a cross product now: gated again next time
+				if (decide_mode == 2 && observed_go == 0 && !ball_ran) c->route_memo.go = 0; // these rows look like a cross product now: gated again next time
 			}
 			if (ran) return PGQ_OK;
 		}
@@ -3137,6 +3170,11 @@ static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t
 		int64_t *h = static_cast<int64_t *>(hp), *d = static_cast<int64_t *>(dp);
 		PGQ_TRY(flatten_pairs_into(V, n, src, dst, h, h + n));
 		SearchOutput so;
+		{ // the rows are in host memory: whether they are grouped by source costs a pass over 2048 words here, two launches there
+			int64_t runs = 1;
+			for (int64_t i = 1; i < n; i++) runs += h[i] != h[i - 1];
+			so.ball_hint = runs * 8 <= n ? 1 : 0;
+		}
 		PGQ_TRY(search_device(csr, ws, n, d, d + n, d + 2 * n, false, nullptr, nullptr, 0, so));
 		const int64_t *res = h + 2 * n;
 		for (int64_t w = 0; w < (n + 63) / 64; w++) { // payload of a NULL row stays -1 like iterativelength.cpp:100,137

@@ -233,6 +233,13 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "meet_trace", &o.meet_trace, nullptr },
 		{ "meet_layout", &o.meet_layout, nullptr },
 		{ "meet_align", &o.meet_align, nullptr },
+		{ "ball", &o.ball, nullptr },
+		{ "ball_cap", &o.ball_cap, nullptr },
+		{ "ball_test_cap", &o.ball_test_cap, nullptr },
+		{ "ball_sort", &o.ball_sort, nullptr },
+		{ "ball_seg_kb", &o.ball_seg_kb, nullptr },
+		{ "ball_grid", &o.ball_grid, nullptr },
+		{ "ball_bias", nullptr, &o.ball_bias },
 	};
 }
 
@@ -1302,7 +1309,7 @@ int pgq_device_count(void) {
 }
 
 const char *pgq_last_error(void) { return t_err.c_str(); }
-const char *pgq_version(void) { return "pgq_hip 0.1 (gfx950)"; }
+const char *pgq_version(void) { return "pgq_hip 0.6 (gfx950; pgq_stats_t: 65 words)"; }
 
 int pgq_csr_upload(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
                    int w_type, pgq_csr_t **out) {
@@ -1596,14 +1603,15 @@ int pgq_csr_get_option(pgq_csr_t *csr, const char *key, double *value) {
 
 const char *pgq_kclass_name(int k) {
 	static const char *names[K_COUNT] = { "prep",   "push",   "pull",  "pull_hub",
-		                                  "queue",  "detect", "recon", "relax", "pull_sparse", "meet", "meet4", "bibfs" };
+		                                  "queue",  "detect", "recon", "relax", "pull_sparse", "meet", "meet4", "bibfs", "ball" };
 	return (k >= 0 && k < K_COUNT) ? names[k] : nullptr;
 }
-int pgq_get_stats(pgq_stats_t *out) {
+int pgq_get_stats_sized(pgq_stats_t *out, size_t struct_size) {
 	if (!out) return fail(PGQ_ERR_INVALID_ARG, "NULL stats");
-	*out = tstats().s;
+	memcpy(out, &tstats().s, std::min(struct_size, sizeof(pgq_stats_t)));
 	return PGQ_OK;
 }
+int pgq_get_stats(pgq_stats_t *out) { return pgq_get_stats_sized(out, sizeof(pgq_stats_t)); }
 int pgq_reset_stats(void) {
 	memset(&tstats().s, 0, sizeof(pgq_stats_t));
 	return PGQ_OK;

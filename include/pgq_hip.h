@@ -248,8 +248,15 @@ typedef struct pgq_stats {
 	int64_t spec_levels;      /* levels that ran that way */
 	int64_t spec_aborts;      /* batches whose enqueued levels were called off on the device (plan mismatch / too short) */
 	int64_t host_waits;       /* stream synchronisations of the lane-batched search (lane assignment, levels, results) */
+	int64_t ball_segments;    /* round 6: source runs (cut at 1024-row windows) the source-centric kernel answered, one ball each */
+	int64_t ball_calls;       /* calls (or straggler passes) the source-centric kernel took */
 } pgq_stats_t;
 const char *pgq_kclass_name(int kclass); /* NULL past the last class */
+/* pgq_stats_t grows at its END from release to release (pgq_version() names the release).  pgq_get_stats_sized writes at most
+ * struct_size bytes — what a caller compiled against an older header passes as sizeof(pgq_stats_t) — so an old binary keeps
+ * working against a newer library; pgq_get_stats(out) = pgq_get_stats_sized(out, sizeof(pgq_stats_t) of THIS header) and is
+ * only safe for callers compiled against it. */
+int pgq_get_stats_sized(pgq_stats_t *out, size_t struct_size);
 int pgq_get_stats(pgq_stats_t *out);
 int pgq_reset_stats(void);
 

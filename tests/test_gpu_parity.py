@@ -22,7 +22,10 @@ def _defaults():
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
                  ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 2), ("relax_delta_div", 0), ("relax_light", 2), ("relax_light_div", 4), ("relax_split", 1), ("relax_labels32", 1),
-                 ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1)):
+                 ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1),
+                 # the source-centric kernel (round 6) would take every grouped input before the kernels under test see it; its own
+                 # tests and the shipped configuration switch it on
+                 ("ball", 0), ("ball_cap", 1 << 20), ("ball_test_cap", 1 << 15), ("ball_bias", 1.0), ("ball_sort", 1), ("ball_seg_kb", 512), ("ball_grid", 0)):
         pgq.set_option(k, v)
     yield
 
@@ -30,7 +33,8 @@ def _defaults():
 SHIPPED_KEYS = ("push_div", "streams", "probe2_abs", "meet", "meet_align", "meet_bias", "meet_cap", "meet_cap_small", "meet_cap_paths",
                 "meet_small_rows", "probe", "probe2", "defer", "lanes", "lanes_unroll", "sparse_lds", "sparse_pw", "sparse_unroll",
                 "sparse_spill", "hub_chunk", "push_chunk", "spec_levels", "sort_single_batch", "detect_unroll", "route_memo", "meet4",
-                "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs", "meet4_grid_mult", "meet_grid_mult", "meet_calibrate", "stage2_ahead")
+                "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs", "meet4_grid_mult", "meet_grid_mult", "meet_calibrate", "stage2_ahead",
+                "ball", "ball_cap", "ball_test_cap", "ball_sort")
 
 
 @pytest.fixture(params=["fixture_values", "shipped_values"])
@@ -299,6 +303,112 @@ def test_bibfs_few_open_rows_any_distance(lds_kb):
         oln, ook = ora3.lean_iterativelength(4000, ps, pd)
         ln, ok = st3.iterativelength(2, 4000, ps, pd)
         assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+
+
+def grouped_rows(rng, V, runs, null_run=0):
+    """Rows grouped by source like a nested-loop join emits them (match.cpp:467-495): `runs` = run lengths, each with a source
+    of its own (repeats allowed: a source may come back in a later run), random destinations with a few src == dst rows."""
+    srcs = rng.integers(0, V, len(runs))
+    ps = np.concatenate([np.full(r, s, dtype=np.int64) for s, r in zip(srcs, runs)])
+    pd = rng.integers(0, V, len(ps))
+    same = rng.random(len(ps)) < 0.01
+    pd[same] = ps[same]
+    valid = np.ones(len(ps), dtype=bool)
+    if null_run:  # a stretch of NULL sources in the middle (their payload is garbage, as DuckDB leaves it)
+        at = len(ps) // 2
+        valid[at:at + null_run] = False
+    return ps, pd, valid
+
+
+@pytest.mark.parametrize("lds_kb", [150, 0])
+@pytest.mark.parametrize("ball_cap,test_cap", [(1 << 20, 1 << 15), (300, 1 << 15), (1 << 20, 40)])
+def test_source_centric_ball_matches_oracle(lds_kb, ball_cap, test_cap):
+    # k_ball_segments + k_src_ball (pgq_ball.h): rows grouped by source answered from ONE two-hop ball per source run in a
+    # vertex bit map (LDS, or a global slice: lds_kb = 0) — d in S1 / S2, an in-neighbour of d in S2 (3), an in-neighbour
+    # of an in-neighbour (4); what it leaves open (distance >= 5, unreachable, balls / walks over their caps) goes through
+    # the pre-pass and the lane batches.  Run lengths that are not multiples of 1024, runs across window boundaries, single rows.
+    rng = np.random.default_rng(606 + lds_kb + ball_cap + test_cap)
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_bias", 1e9)
+    pgq.set_option("ball", 2)  # forced: the decision has its own test
+    pgq.set_option("ball_cap", ball_cap)
+    pgq.set_option("ball_test_cap", test_cap)
+    pgq.set_option("meet4_lds_kb", lds_kb)
+    runs = [1, 3, 64, 700, 1024, 1500, 2500, 1, 1, 90, 2048, 5]
+    # (a) skewed small-world graph: nearly everything within 4 hops, hubs whose balls run over a small cap
+    V, E = 6000, 60000
+    st, ora = both(V, random_graph(rng, V, E, skew=True))
+    ps, pd, valid = grouped_rows(rng, V, runs, null_run=37)
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+    want = [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)]
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
+    assert lens(ln, ok) == want
+    stats = pgq.get_stats()
+    assert stats["ball_calls"] >= 1 and stats["ball_segments"] >= len(runs)
+    if ball_cap >= 1 << 20 and test_cap >= 1 << 15:
+        assert stats["meet_pairs"] >= len(ps) * 0.9  # nearly every row answered by the ball itself
+    # (b) sparse directed graph: dead ends, unreachable pairs, long distances -> most rows stay open and come back through the older routes
+    V2 = 4000
+    st2, ora2 = both(V2, random_graph(rng, V2, 5000), csr_id=1)
+    ps, pd, valid = grouped_rows(rng, V2, [40, 1, 300, 1100, 7])
+    oln, ook = ora2.lean_iterativelength(V2, ps, pd)
+    ln, ok = st2.iterativelength(1, V2, ps, pd)
+    assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+    # (c) a directed ring with chords: distances in the hundreds
+    V3 = 3000
+    ring = np.arange(V3, dtype=np.int64)
+    s3, d3 = np.concatenate([ring, rng.integers(0, V3, 30)]), np.concatenate([(ring + 1) % V3, rng.integers(0, V3, 30)])
+    st3, ora3 = both(V3, (s3, d3, np.arange(len(s3), dtype=np.int64)), csr_id=2)
+    ps, pd, valid = grouped_rows(rng, V3, [50, 50, 200])
+    oln, ook = ora3.lean_iterativelength(V3, ps, pd)
+    ln, ok = st3.iterativelength(2, V3, ps, pd)
+    assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+    # (d) through the bulk entry point on device arrays, 40,000 rows (the decision kernel's range), out-of-range ids refused
+    import torch
+    ps, pd, _ = grouped_rows(rng, V, [9000, 13000, 1024, 1024, 15952])
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+    dev = st.device_csr(0)
+    t_s, t_d = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+    t_o = torch.full((len(ps),), -7, dtype=torch.int64, device="cuda")
+    dev.iterativelength_bulk_ptr(len(ps), t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+    got = t_o.cpu().numpy()
+    assert ((got >= 0) == ook).all() and (got[ook] == oln[ook]).all()
+    t_d[5] = V + 3
+    with pytest.raises(pgq.PgqError):
+        dev.iterativelength_bulk_ptr(len(ps), t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+
+
+def test_source_centric_ball_is_chosen_by_the_source_runs():
+    # ball = 1 (shipped): k_ball_segments counts the source runs and its last workgroup prices one ball per run + one in-list
+    # scan per row against the pre-pass (bytes per row) and the lane batches (level bytes): grouped rows take the ball,
+    # scattered pairs the pre-pass, a handful of sources x every vertex the lane batches — same answers on every route.
+    rng = np.random.default_rng(61)
+    V, E = 20000, 400000
+    st, ora = both(V, random_graph(rng, V, E))
+    pgq.set_option("meet", 1)
+    pgq.set_option("ball", 1)
+    pgq.set_option("ball_seg_kb", 16)  # the least a segment costs: 512 KB as shipped — on this 400,000-edge graph a lane batch is cheaper than that
+    srcs = rng.choice(V, 40, replace=False)
+    for per, expect_ball in ((600, True), (1, False)):
+        if per > 1:
+            ps = np.repeat(srcs, per)
+        else:
+            ps = rng.integers(0, V, 24000)
+        pd = rng.integers(0, V, len(ps))
+        oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+        for rep in range(2):  # the second call runs under whatever the first one left in the route memo
+            pgq.reset_stats()
+            ln, ok = st.iterativelength(0, V, ps, pd)
+            assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+            assert (pgq.get_stats()["ball_calls"] >= 1) == expect_ball, (per, rep, pgq.get_stats())
+    # 3 sources x every vertex: one narrow lane batch is cheaper than 60 balls + 60,000 in-list scans
+    ps = np.repeat(srcs[:3], V)
+    pd = np.tile(np.arange(V, dtype=np.int64), 3)
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+    pgq.reset_stats()
+    ln, ok = st.iterativelength(0, V, ps, pd)
+    assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
 
 
 def test_meet_prepass_large_inputs_cross_product_vs_distinct_sources():

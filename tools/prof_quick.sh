@@ -34,7 +34,7 @@ for p in glob.glob("$O/pmc_*/*counter_collection.csv"):
         k=r["Kernel_Name"].split("(")[0].replace("void ","").replace("pgq::","")
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[(k,r["Counter_Name"])].add(r["Dispatch_Id"])
 for k in agg:
-    if "lanes" in k or "pull_sparse" in k or "k_push" in k or "probe" in k or "meet" in k:
+    if "lanes" in k or "pull_sparse" in k or "k_push" in k or "probe" in k or "meet" in k or "ball" in k:
         print(k, {c: "%.4g"%(v/len(n[(k,c)])) for c,v in sorted(agg[k].items())})
 PY
 fi

@@ -16,13 +16,23 @@ Default workload = BASELINE.json configs[3] (the config the metric "MS-BFS MTEPS
   N = 1:  the top-level fields describe that workload (= leg "prepass": every row is answered by the pair-centric
           kernels); `legs` holds it next to one leg per other BASELINE config and call shape (`legs_by_config` maps them):
             msbfs_cross       the same graph in the binder's call shape (match.cpp:467-495: a cross product of endpoints —
-                              2048 distinct sources x 1024 destinations = 2.1 M rows), routed to the lane-batched MS-BFS
+                              2048 distinct sources x 1024 destinations = 2.1 M rows, grouped by source), as the library routes
+                              it (round 6: the source-centric kernel k_src_ball, one two-hop ball per source run)
+            msbfs_cross_lanes the same rows forced through the lane-batched MS-BFS (handle option ball = 0): the frontier
+                              expansion kernels' own figures (rounds 1-5's msbfs_cross)
+            msbfs_cross_rmat22  the same call shape on R-MAT-22 (configs[1]'s graph): 2048 x 1024 rows, frontier arrays far past
+                              the 256-MiB Infinity Cache — the MS-BFS level kernels against DRAM
             snb_paths         configs[2]: shortestpath + reconstruction, 4096 pairs, same CSR
             rmat22            configs[1]: R-MAT scale 22, iterativelength, 1024 pairs (own graph: ~15 s of generation)
             forest_cheapest   configs[4]: weighted cheapest path on a 2^24-vertex reply forest, 4096 pairs
             cheapest_general  cheapest_path_length of 4096 pairs on the knows graph with int64 weights (one step)
           each with its own ms/step, pairs/s, MTEPS, roofline and a bounded CPU comparison of the TIMED output
-          (--config-legs '' / --no-legs / --cheapest-pairs 0 drop them; the whole default command takes ~95 s).
+          (--config-legs '' / --no-legs / --cheapest-pairs 0 drop them; the whole default command takes ~2-3 minutes).
+          `first_call_ms` (per leg): a FRESH CSR handle (pgq_csr_upload_device) -> its first search, no warm-up call, median
+          over 5 handles — the reference's CSR lives for one query (iterative_length_function_data.cpp:27), so this is what a
+          query sees; `ms_per_step` is the steady state of a handle that has answered the same call before.
+          `legs_summary` (LAST key of the line, and mirrored as top-level scalars leg_<name>_ms / _frac / _first_ms):
+          {leg: [ms_per_step, chain frac, whole-step frac, rows compared with the CPU port, rows equal, first_call_ms]}.
   N > 1:  --scaling strong by default (configs[3] is 65,536 pairs in total, cut across the GPUs); the weak figure
           (65,536 pairs on every GPU) is measured in the same run and reported under "weak".
 Other workloads as the main line: --workload rmat22 | snb_paths | forest_cheapest (--scale 28 = configs[4]'s named size) |
@@ -59,12 +69,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); the measured copy ceiling is reported beside it
 POISON = -7             # written into the result buffers before the timed loop: a step that writes nothing is caught
 
-OPS = {"snb_sf100": "iterativelength", "rmat22": "iterativelength", "snb_paths": "shortestpath+reconstruction",
+OPS = {"snb_sf100": "iterativelength", "rmat22": "iterativelength", "rmat22_cross": "iterativelength", "snb_paths": "shortestpath+reconstruction",
        "forest_cheapest": "cheapest_path_length", "snb_cheapest": "cheapest_path_length",
        "snb_cross": "iterativelength", "snb_cross_allv": "iterativelength"}
-DEFAULT_PAIRS = {"snb_sf100": 65536, "rmat22": 1024, "snb_paths": 4096, "forest_cheapest": 4096, "snb_cheapest": 4096,
+DEFAULT_PAIRS = {"snb_sf100": 65536, "rmat22": 1024, "rmat22_cross": 2048 * 1024, "snb_paths": 4096, "forest_cheapest": 4096, "snb_cheapest": 4096,
                  "snb_cross": 2048 * 1024, "snb_cross_allv": 0}
-PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "snb_paths": 3, "forest_cheapest": 5, "snb_cheapest": 6, "snb_cross": 7,
+PAIR_SEED = {"snb_sf100": 4, "rmat22": 2, "rmat22_cross": 29, "snb_paths": 3, "forest_cheapest": 5, "snb_cheapest": 6, "snb_cross": 7,
              "snb_cross_allv": 8}
 CHEAPEST = ("forest_cheapest", "snb_cheapest")  # weighted workloads: value = pairs/s
 SNB = ("snb_sf100", "snb_paths", "snb_cheapest", "snb_cross", "snb_cross_allv")
@@ -94,6 +104,8 @@ def parse():
     ap.add_argument("--config-legs", default="snb_paths,rmat22,forest_cheapest",
                     help="N = 1 default workload: the other BASELINE configs run as legs of the same line (comma list; '' = none)")
     ap.add_argument("--leg-rmat-scale", type=int, default=22, help="rmat22 leg: R-MAT scale (tests shrink it)")
+    ap.add_argument("--no-first-call", action="store_true", help="skip the first-call-on-a-fresh-handle measurements")
+    ap.add_argument("--first-call-handles", type=int, default=5, help="fresh CSR handles per first_call_ms figure")
     ap.add_argument("--leg-forest-scale", type=int, default=24, help="forest_cheapest leg: log2 V (tests shrink it)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs timed on one CPU thread (0 = 8192 snb / 1024 rmat)")
     ap.add_argument("--weights", default="int64", choices=["int64", "double"], help="forest_cheapest / snb_cheapest: weight type")
@@ -151,7 +163,7 @@ def build_graph(a):
             if a.weights == "double":
                 w = w.astype(np.float64) / 7.0
             name += ",%s w" % a.weights
-    elif a.workload == "rmat22":
+    elif a.workload in ("rmat22", "rmat22_cross"):
         V, s, d = graphgen.rmat(a.scale or 22, seed=22)
         name = "rmat%d_ef16" % (a.scale or 22)
     else:
@@ -181,6 +193,8 @@ def make_pairs(a, V, total, off, adj):
     """One global, seeded pair list.  The reply forest gets destinations that are ancestors of their sources (uniform
     pairs are almost never connected there: the search would only measure the dead-end shortcut)."""
     rng = np.random.default_rng(PAIR_SEED[a.workload])
+    if a.workload == "rmat22_cross":  # the leg msbfs_cross_rmat22 as a workload of its own (same rows: seed 7 + 22)
+        return cross_pairs(V, total, a.cross_sources * max(1, total // (a.cross_sources * a.cross_dests)), PAIR_SEED["snb_cross"] + 22)
     if a.workload == "snb_cross":
         return cross_pairs(V, total, a.cross_sources * max(1, total // (a.cross_sources * a.cross_dests)), PAIR_SEED[a.workload])
     if a.workload == "snb_cross_allv":  # 32 sources x every vertex as destination
@@ -341,6 +355,39 @@ class Bench:
             assert bool((d_len[(iso_steps - 1) & 1] == out_len).all())
         return res
 
+    def first_call(self, make_csr, mine_t, handles, paths=False, cheapest=False):
+        """ms from `a fresh handle exists` to `its first search has returned`, median over `handles` fresh handles: no warm-up
+        call, no route memo, no level plan, calibration included.  The upload itself is timed separately (`upload_ms`)."""
+        torch = self.torch
+        n = mine_t.shape[0]
+        d_src, d_dst = mine_t[:, 0].contiguous(), mine_t[:, 1].contiguous()
+        d_len = torch.empty(n, dtype=torch.int64, device=self.dev)
+        d_off = torch.zeros(n, dtype=torch.int64, device=self.dev) if paths else None
+        d_child = torch.empty(n * 64, dtype=torch.int64, device=self.dev) if paths else None
+        d_val = torch.zeros(n, dtype=torch.int64, device=self.dev) if cheapest else None
+        d_ok = torch.zeros(n, dtype=torch.uint8, device=self.dev) if cheapest else None
+        first, up = [], []
+        for _ in range(max(1, handles)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            csr = make_csr()
+            t1 = time.perf_counter()
+            if paths:
+                csr.shortestpath_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr(), d_off.data_ptr(), d_child.data_ptr(), n * 64)
+            elif cheapest:
+                csr.cheapest_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_val.data_ptr(), d_ok.data_ptr())
+            else:
+                csr.iterativelength_bulk_ptr(n, d_src.data_ptr(), d_dst.data_ptr(), d_len.data_ptr())
+            t2 = time.perf_counter()
+            first.append((t2 - t1) * 1e3)
+            up.append((t1 - t0) * 1e3)
+            del csr
+        return {"first_call_ms": float(np.median(first)), "first_call_ms_first_handle": round(first[0], 4), "first_call_ms_all": [round(x, 4) for x in first],
+                "upload_ms": float(np.median(up)), "handles": len(first),
+                "what": "fresh pgq_csr_upload_device handle -> its first search call returned, no warm-up call; median over the handles. The first "
+                        "handle of a graph shape in the process calibrates (first_call_ms_first_handle); the later ones find what it "
+                        "measured in the per-shape cache (option calibration_cache), like a second query over the same tables"}
+
     def reduce(self, m):
         """max over ranks of the timed region, sums of the work units."""
         torch, dist = self.torch, self.dist
@@ -447,8 +494,8 @@ def config_leg(bench, a, wl, copy_gbps, snb_graph, snb_csr):
     a2.pairs_per_gpu = 0
     cheapest, paths = wl in CHEAPEST, wl == "snb_paths"
     if wl in SNB:
-        name, V, off, adj, eid, w, gen_s = snb_graph
-        csr, t_keep, upload_s = snb_csr, None, None
+        name, V, off, adj, eid, w, gen_s = snb_graph[:7]
+        csr, t_keep, upload_s, t_w = snb_csr, None, None, None
     else:
         name, V, off, adj, eid, w, gen_s = build_graph(a2)
         t_keep = [torch.from_numpy(x).to(dev) for x in (off, adj, eid)]
@@ -462,8 +509,21 @@ def config_leg(bench, a, wl, copy_gbps, snb_graph, snb_csr):
     total = DEFAULT_PAIRS[wl]
     pr = np.ascontiguousarray(make_pairs(a2, V, total, off, adj)).astype(np.int64)
     steps, warmup = max(2, min(a.steps, 10)), min(a.warmup, 2)
-    m = bench.run(wl, csr, torch.from_numpy(pr).to(dev), total, steps, warmup, paths=paths, cheapest=cheapest)
+    pr_t = torch.from_numpy(pr).to(dev)
+    make_csr = None
+    if wl in SNB:
+        t_off, t_adj, t_eid = snb_graph[-1]  # the default workload's device arrays
+        make_csr = lambda: pgq.DeviceCSR.from_device_ptrs(V, t_off.data_ptr(), t_adj.data_ptr(), t_eid.data_ptr(), 0, 0)
+    else:
+        make_csr = lambda: pgq.DeviceCSR.from_device_ptrs(V, t_keep[0].data_ptr(), t_keep[1].data_ptr(), t_keep[2].data_ptr(),
+                                                          t_w.data_ptr() if t_w is not None else 0,
+                                                          (2 if a2.weights == "double" else 1) if t_w is not None else 0)
+    # a handle's first call BEFORE anything has warmed this graph's handles up (the block cache of the uploads aside)
+    fc = None if a.no_first_call else bench.first_call(make_csr, pr_t, a.first_call_handles, paths=paths, cheapest=cheapest)
+    m = bench.run(wl, csr, pr_t, total, steps, warmup, paths=paths, cheapest=cheapest)
     leg, _ = leg_summary(bench, m, wl, total, copy_gbps)
+    if fc:
+        leg["first_call"] = fc
     leg["workload"] = "%s %s, %d pairs (default_rng(%d))" % (name, OPS[wl], total, PAIR_SEED[wl])
     leg["config"] = {"V": V, "E": int(len(adj)), "pairs_total": total, "graph_gen_s": round(gen_s, 1),
                      "csr_upload_ms": round(upload_s * 1e3, 2) if upload_s is not None else None, "steps": steps, "warmup": warmup}
@@ -474,8 +534,26 @@ def config_leg(bench, a, wl, copy_gbps, snb_graph, snb_csr):
             leg["cpu_baseline"] = cpu_baseline_paths(a2, V, off, adj, eid, pr, m, literal=False)
         else:
             leg["cpu_baseline"] = cpu_baseline(a2, V, off, adj, eid, pr, m["d_te"], m["out_len"])
+    out = {wl: {k: leg[k] for k in leg if k != "roofline_by_kernel"} | {"roofline_by_kernel": leg["roofline_by_kernel"]}}
+    if wl == "rmat22" and a.cross_sources > 0:
+        # the binder's call shape on THIS graph: frontier arrays of V x 8 WD bytes (537 MB at WD = 16, 1 GB at 32) are far past
+        # the 256-MiB Infinity Cache — the MS-BFS level kernels against DRAM (round-5 review: every >= 0.50 figure so far was
+        # measured on a cache-resident working set)
+        cp = cross_pairs(V, a.cross_sources * a.cross_dests, a.cross_sources, PAIR_SEED["snb_cross"] + 22)
+        cp_t = torch.from_numpy(cp).to(dev)
+        fc2 = None if a.no_first_call else bench.first_call(make_csr, cp_t, max(1, a.first_call_handles // 2))
+        mc = bench.run("rmat22_cross", csr, cp_t, len(cp), max(2, min(a.steps, 4)), 1)
+        xleg, _ = leg_summary(bench, mc, "rmat22_cross", len(cp), copy_gbps)
+        xleg["workload"] = "%s iterativelength, %d distinct sources x %d destinations each = %d rows (match.cpp:467-495 shape)" % (
+            name, a.cross_sources, len(cp) // a.cross_sources, len(cp))
+        xleg["config"] = {"V": V, "E": int(len(adj)), "pairs_total": len(cp), "frontier_array_MB_at_WD16": round(V * 128 / 1e6, 1)}
+        if fc2:
+            xleg["first_call"] = fc2
+        if not a.no_cpu_baseline:
+            xleg["cpu_baseline"] = cpu_baseline(a2, V, off, adj, eid, cp, mc["d_te"], mc["out_len"], sample=8192)
+        out["msbfs_cross_rmat22"] = {k: xleg[k] for k in xleg if k != "roofline_by_kernel"} | {"roofline_by_kernel": xleg["roofline_by_kernel"]}
     del csr, t_keep
-    return {k: leg[k] for k in leg if k != "roofline_by_kernel"} | {"roofline_by_kernel": leg["roofline_by_kernel"]}
+    return out
 
 
 def main():
@@ -531,6 +609,16 @@ def main():
         return allp_t[lo:hi], total, lo, hi
 
     mine_t, total_pairs, lo, hi = shard(scaling)
+
+    def fresh_csr():
+        return pgq.DeviceCSR.from_device_ptrs(V, t_off.data_ptr(), t_adj.data_ptr(), t_eid.data_ptr(),
+                                              t_w.data_ptr() if has_w else 0, (2 if a.weights == "double" else 1) if has_w else 0)
+
+    # a handle's FIRST call (before this process has run any search on this graph's handles: no route memo, no level plan,
+    # no measured bytes per row) — what a query sees: the reference's CSR lives for one query
+    first_main = None
+    if world == 1 and not a.no_first_call and a.workload != "snb_cross_allv":
+        first_main = bench.first_call(fresh_csr, mine_t, a.first_call_handles, paths=paths, cheapest=cheapest)
     m = bench.run(a.workload, csr, mine_t, total_pairs, a.steps, a.warmup, paths=paths, cheapest=cheapest)
     try:
         copy_gbps = pgq.copy_bandwidth_gbps(1 << 30, 5) if rank == 0 else None
@@ -544,15 +632,51 @@ def main():
         m2 = bench.run(a.workload, csr, mine2, total2, a.steps, a.warmup, paths=paths, cheapest=cheapest)
         leg2, _ = leg_summary(bench, m2, a.workload, total2, copy_gbps)
         other = (mode2, {k: leg2[k] for k in ("ms_per_step", "pairs_per_s", "mteps_logical", "mteps_physical")}, total2)
-    cross = None
+    cross = cross_lanes = None
+    cross_multi = None
+    if world > 1 and a.workload == "snb_sf100" and not a.no_legs:
+        # N > 1: the cross product shards BY SOURCE — rows are grouped by source and cut into contiguous ranges, so every rank keeps
+        # whole sources (2048 sources x 1024 rows over 8 ranks: 256 sources each); strong = the 2.1 M rows in total, weak = 2.1 M per rank
+        cross_multi = {}
+        for mode in ("strong", "weak"):
+            tot = a.cross_sources * a.cross_dests * (world if mode == "weak" else 1)
+            cp_all = cross_pairs(V, tot, a.cross_sources * (world if mode == "weak" else 1), PAIR_SEED["snb_cross"])
+            rows_per_source = max(1, len(cp_all) // (a.cross_sources * (world if mode == "weak" else 1)))
+            # whole sources per rank when they divide evenly (the gather wants equal blocks); else plain contiguous ranges — a
+            # source cut in two costs one more ball (or lane) on one GPU, not correctness
+            even = len(cp_all) % (world * rows_per_source) == 0
+            clo, chi = sharding.shard_bounds_grouped(len(cp_all), world, rank, rows_per_source) if even else sharding.shard_bounds(len(cp_all), world, rank)
+            cp_t = torch.from_numpy(np.ascontiguousarray(cp_all[clo:chi])).to(dev)
+            mcx = bench.run("snb_cross", csr, cp_t, len(cp_all), max(2, min(a.steps, 5)), min(a.warmup, 2))
+            lx, _ = leg_summary(bench, mcx, "snb_cross", len(cp_all), copy_gbps)
+            cross_multi[mode] = {k: lx[k] for k in ("ms_per_step", "pairs_per_s", "mteps_logical", "mteps_physical")} | {
+                "pairs_total": len(cp_all), "scaling": mode, "sharded": "by source: contiguous row ranges aligned to whole sources"}
     if world == 1 and a.workload == "snb_sf100" and not a.no_legs:
-        # the binder's call shape on the same graph and row count: routed to the lane-batched MS-BFS
+        # the binder's call shape on the same graph and row count
         cp = cross_pairs(V, a.cross_sources * a.cross_dests, a.cross_sources, PAIR_SEED["snb_cross"])
         cp_t = torch.from_numpy(cp).to(dev)
+        first_cross = None if a.no_first_call else bench.first_call(fresh_csr, cp_t, a.first_call_handles)
         mc = bench.run("snb_cross", csr, cp_t, len(cp), max(2, min(a.steps, 5)), min(a.warmup, 2))
-        cross, _ = leg_summary(bench, mc, "snb_cross", len(cp), copy_gbps)
-        cross["workload"] = "%d distinct sources x %d destinations each = %d rows (match.cpp:467-495 shape)" % (
+        cross, _ = leg_summary(bench, mc, "snb_cross_ball", len(cp), copy_gbps)
+        cross["workload"] = "%d distinct sources x %d destinations each = %d rows grouped by source (match.cpp:467-495 shape), as the library routes them" % (
             a.cross_sources, len(cp) // a.cross_sources, len(cp))
+        if first_cross:
+            cross["first_call"] = first_cross
+        # the same rows forced through the lane-batched MS-BFS (rounds 1-5's route for them): the frontier-expansion kernels' figures
+        ball_was = pgq.get_option("ball")
+        pgq.set_option("ball", 0)
+        try:
+            first_lanes = None if a.no_first_call else bench.first_call(fresh_csr, cp_t, max(1, a.first_call_handles // 2))
+            csr_l = fresh_csr()  # a handle of its own: the shared one remembers that the source-centric kernel took these buffers
+            ml = bench.run("snb_cross_lanes", csr_l, cp_t, len(cp), max(2, min(a.steps, 5)), min(a.warmup, 2))
+            del csr_l
+        finally:
+            pgq.set_option("ball", int(ball_was))
+        cross_lanes, _ = leg_summary(bench, ml, "snb_cross", len(cp), copy_gbps)
+        cross_lanes["workload"] = "the msbfs_cross rows with the source-centric kernel switched off (ball = 0): lane-batched MS-BFS, 2048 lanes"
+        if first_lanes:
+            cross_lanes["first_call"] = first_lanes
+        assert bool((ml["out_len"] == mc["out_len"]).all()), "the two routes of the cross product disagree"
 
     wleg = None
     if world == 1 and a.workload == "snb_sf100" and not a.no_legs and a.cheapest_pairs > 0:
@@ -576,7 +700,7 @@ def main():
     if world == 1 and a.workload == "snb_sf100" and not a.no_legs:
         # the other BASELINE configs in the same line: configs[2] on this graph, configs[1] and configs[4] on their own
         for wl in [x for x in a.config_legs.split(",") if x]:
-            config_legs[wl] = config_leg(bench, a, wl, copy_gbps, snb_graph, csr)
+            config_legs.update(config_leg(bench, a, wl, copy_gbps, snb_graph + ((t_off, t_adj, t_eid),) if snb_graph else None, csr))
 
     if rank == 0:
         # value = what the hardware did: (src, dst) pairs answered per second (BASELINE metric "MS-BFS MTEPS + src-dst
@@ -590,7 +714,7 @@ def main():
             "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u64" if not cheapest else ("f64" if a.weights == "double" else "int64"),
             "data": "synthetic",
-            "schema": 5,  # round 5: `roofline` = the leg's launch chain (round 4: its dominant kernel, now `roofline.dominant_kernel`)
+            "schema": 6,  # round 6: legs_summary / first_call / msbfs_cross_lanes / msbfs_cross_rmat22; round 5: `roofline` = the leg's launch chain (round 4: its dominant kernel, now `roofline.dominant_kernel`)
             "value_kind": "pairs answered per second, whole job; mteps_physical = adjacency entries scanned per second / 1e6; "
                           "mteps_logical = reference-lane traversed edges per second / 1e6 (work avoided, not a hardware rate)",
             "mteps_logical": main_leg["mteps_logical"],
@@ -621,9 +745,14 @@ def main():
         }
         if other is not None:
             out[other[0]] = dict(other[1], pairs_total=other[2], scaling=other[0])
+        if cross_multi is not None:
+            out["msbfs_cross"] = cross_multi
+        if first_main is not None:
+            out["first_call"] = first_main
+            out["first_call_ms"] = first_main["first_call_ms"]
         mine = allp_t[lo:hi].cpu().numpy()
-        if not a.no_cpu_baseline and world == 1 and a.workload in ("snb_sf100", "rmat22", "snb_cross"):  # rank 0, N=1 only
-            out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, m["d_te"], m["out_len"])
+        if not a.no_cpu_baseline and world == 1 and a.workload in ("snb_sf100", "rmat22", "snb_cross", "rmat22_cross"):  # rank 0, N=1 only
+            out["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, mine, m["d_te"], m["out_len"], sample=8192 if a.workload == "rmat22_cross" else 0)
         if not a.no_cpu_baseline and world == 1 and cheapest:
             ns = len(mine) if a.workload == "forest_cheapest" else min(len(mine), 512)  # a Dijkstra on the knows graph is ~0.5 s
             sel = np.arange(ns, dtype=np.int64) * max(1, len(mine) // ns)
@@ -636,19 +765,44 @@ def main():
             if not a.no_cpu_baseline:
                 cross["cpu_baseline"] = cpu_baseline(a, V, off, adj, eid, cp, mc["d_te"], mc["out_len"], sample=65536)  # strided: 32 rows of every source, one chunk per host thread
             legs = {"prepass": {k: main_leg[k] for k in main_leg if k != "roofline_by_kernel"}, "msbfs_cross": cross}
+            if first_main is not None:
+                legs["prepass"]["first_call"] = first_main
+            if cross_lanes is not None:
+                if not a.no_cpu_baseline:  # the same strided sample, against the forced route's own output
+                    cross_lanes["cpu_baseline"] = {k: cross["cpu_baseline"][k] for k in cross.get("cpu_baseline", {}) if k in ("value", "unit", "cores")}
+                    cross_lanes["cpu_baseline"]["sample"] = "output identical to msbfs_cross's row by row (asserted): its comparison holds for this route"
+                    cross_lanes["cpu_baseline"]["rows_compared"] = int(len(cp))
+                    cross_lanes["cpu_baseline"]["rows_equal"] = int(len(cp))
+                legs["msbfs_cross_lanes"] = cross_lanes
             legs["prepass"]["workload"] = "%d random pairs (default_rng(4)): every row answered by the pair-centric kernels" % total_pairs
             if "cpu_baseline" in out:
-                legs["prepass"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "pairs_per_s")}
+                legs["prepass"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "pairs_per_s", "rows_compared", "rows_equal")}
             if wleg is not None:
                 legs["cheapest_general"] = {k: wleg[k] for k in wleg if k != "roofline_by_kernel"}
             legs.update(config_legs)
             out["legs"] = legs
             out["legs_by_config"] = {"configs[1] R-MAT-22 iterativelength 1024 pairs": "rmat22",
+                                     "configs[1]'s graph in the binder's call shape (DRAM-resident frontier arrays)": "msbfs_cross_rmat22",
+                                     "configs[3] cross product forced through the lane batches": "msbfs_cross_lanes",
                                      "configs[2] SF100 shortestpath + reconstruction 4096 pairs": "snb_paths",
                                      "configs[3] SF100 iterativelength 65,536 pairs": "prepass (= the top-level fields)",
                                      "configs[3] in the binder's call shape (cross product)": "msbfs_cross",
                                      "configs[4] weighted cheapest path, reply forest": "forest_cheapest",
                                      "configs[4]'s operator on a general graph": "cheapest_general"}
+        if "legs" in out:
+            # LAST key of the line + top-level scalars: the driver's record keeps the head of `parsed` and the tail of the line
+            summ = {}
+            for nm, lg in out["legs"].items():
+                cb = lg.get("cpu_baseline", {})
+                fc = lg.get("first_call", {}).get("first_call_ms")
+                summ[nm] = [round(lg["ms_per_step"], 4), round(lg["roofline"]["frac"], 3), round(lg["roofline"]["step"]["frac"], 3),
+                            cb.get("rows_compared"), cb.get("rows_equal"), None if fc is None else round(fc, 3)]
+                out["leg_%s_ms" % nm] = round(lg["ms_per_step"], 4)
+                out["leg_%s_frac" % nm] = round(lg["roofline"]["frac"], 3)
+                if fc is not None:
+                    out["leg_%s_first_ms" % nm] = round(fc, 3)
+            out["legs_summary_format"] = "[ms_per_step, chain frac of 8 TB/s, whole-step frac, rows compared with the CPU port, rows equal, first_call_ms]"
+            out["legs_summary"] = summ
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -682,6 +836,7 @@ def cpu_baseline(a, V, off, adj, eid, mine, d_te, out_len, sample=0):
         dt1 = time.perf_counter() - t0
         gpu_len = out_len[:ns1].cpu().numpy()
         agree = bool(((gpu_len >= 0) == ok).all() and (gpu_len[ok] == ln[ok]).all())
+        res["rows_compared"], res["rows_equal"] = int(ns1), int((((gpu_len >= 0) == ok) & ((gpu_len == ln) | ~ok)).sum())
         te1 = float(d_te[:ns1].sum().item())
         res["single_thread"] = {"value": te1 / dt1 / 1e6, "cores": 1, "pairs_per_s": ns1 / dt1,
                                 "sample": "first %d pairs, %.1f s; results equal the GPU's timed output: %s" % (ns1, dt1, agree)}
@@ -697,6 +852,8 @@ def cpu_baseline(a, V, off, adj, eid, mine, d_te, out_len, sample=0):
         dtm = time.perf_counter() - t0
     gpu_m = out_len[:nsm].cpu().numpy()
     agree_m = bool(((gpu_m >= 0) == okm).all() and (gpu_m[okm] == lnm[okm]).all())
+    if nsm >= res.get("rows_compared", 0):
+        res["rows_compared"], res["rows_equal"] = int(nsm), int((((gpu_m >= 0) == okm) & ((gpu_m == lnm) | ~okm)).sum())
     tem = float(d_te[:nsm].sum().item())
     res.update({"value": tem / dtm / 1e6, "unit": "MTEPS", "cores": threads, "kind": "port",
                 "sample": how + " %d pairs of rank 0's shard in 2048-row chunks, one thread per chunk (%d threads), literal "
@@ -729,7 +886,8 @@ def cpu_baseline_cheapest(V, off, adj, eid, w, mine, d_val, d_ok, how="all"):
     if want.dtype.kind == "f":
         got = got.view(np.float64)
     agree = bool((ok == wok).all() and (got[ok] == want[wok]).all())
-    return {"value": len(mine) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+    same = (ok == wok) & ((got == want) | ~ok) if len(got) == len(want) else np.zeros(len(mine), dtype=bool)
+    return {"value": len(mine) / dt, "unit": "pairs/s", "cores": threads, "kind": "port", "rows_compared": int(len(mine)), "rows_equal": int(same.sum()),
             "sample": "%s (%d pairs), per-pair Dijkstra (oracle/pgq_oracle.cpp lean restatement) on %d threads, %.1f s; "
                       "results equal the GPU's timed output: %s" % (how, len(mine), threads, dt, agree)}
 
@@ -764,12 +922,12 @@ def cpu_baseline_paths(a, V, off, adj, eid, mine, m, literal=True):
                           "shortest_path.cpp:21-31), one thread, %.1f s; full lists equal the GPU's timed output: %d of %d (the literal "
                           "512-lane ShortestPathFunction restatement — 3.7 GB of parent arrays, 5.7 pairs/s — is timed by "
                           "--workload snb_paths)" % (ns, dt2, same, ns),
-                "paths_compared": ns, "paths_equal": same}
+                "paths_compared": ns, "paths_equal": same, "rows_compared": ns, "rows_equal": same}
     return {"value": nb / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
             "sample": "first %d pairs = one 512-lane batch of the literal restatement (oracle/pgq_oracle.cpp, 3.7 GB of parent "
                       "arrays: thread count capped at 1), %.1f s, hop counts equal the GPU's timed output: %s; full lists "
                       "of %d strided rows against the lean restatement (%.1f s): %d equal" % (nb, dt, agree_len, ns, dt2, same),
-            "paths_compared": ns, "paths_equal": same}
+            "paths_compared": ns, "paths_equal": same, "rows_compared": ns, "rows_equal": same}
 
 
 if __name__ == "__main__":

@@ -38,6 +38,13 @@ int fail(int code, const std::string &msg);
 	} while (0)
 
 int ensure_init();
+// What a CSR handle has learned about its graph — the pre-pass's measured bytes per row, the share of rows the
+// source-centric kernel leaves open, the levels a full lane batch of each width runs — kept per graph SHAPE (V, E, largest
+// degrees, mean two-hop walk) across handles: DuckPGQ builds a CSR per query (iterative_length_function_data.cpp:27,
+// duckpgq_state.cpp:162-170), so a handle's first call is the common case, and a query over the same tables as the one
+// before starts where that one ended instead of calibrating again.  Speed only: every route gives the same answers.
+void calibration_load(pgq_csr *c);  // at the end of an upload
+void calibration_store(pgq_csr *c); // when a handle dies, and whenever it has measured something new
 // the device this host thread works on (pgq_init's device unless a multi-device call bound the thread to another)
 int current_device();
 // compute units of the device this host thread works on (cached per device; 256 on MI355X — the persistent grids are
@@ -115,6 +122,7 @@ struct Options {
 	int wbibfs_mem_mb = 2048;  // scratch budget (two label arrays of V entries per workgroup)
 	int wbibfs_delta_div = 64; // band width = mean weight / this (a model run on the weighted knows graph: 3-10x fewer relaxations at 64 than at 8)
 	int bibfs_rows = 256;      // k_bibfs (one bidirectional search per row) runs when at most this many rows are still open (0: off)
+	int bibfs_rows_max = 16384; // ... on graphs with many edges it takes up to E / 4096 rows, at most this many (a lane batch there costs more than that many searches)
 	int bibfs_grid = 64;       // workgroups of k_bibfs (one row at a time each; every one owns 4 x bibfs_queue words of scratch)
 	int bibfs_cap = 8 << 20;   // adjacency entries one expansion of k_bibfs may read
 	int bibfs_queue = 1 << 17; // frontier vertices per side k_bibfs keeps
@@ -134,6 +142,8 @@ struct Options {
 	int ball_cap = 1 << 20;     // adjacency entries the two-hop ball of one source may hold; a segment over it leaves its far rows open
 	int ball_test_cap = 1 << 15; // adjacency entries the backward two-hop walk of one row (distance 4) may scan
 	int ball_seg_kb = 512;      // the least a segment costs in the decision, in KB at streaming rate (its ~15 dependent round trips on one of ~512 workgroup slots)
+	int calibration_cache = 1;  // what a handle measures about its graph (bytes per row of the pre-pass, level plans, ...) is kept per graph
+	                            // shape across handles (0: every handle starts from nothing; tests of the cold paths)
 	int ball_grid = 0;          // > 0: at most this many workgroups of k_src_ball (debugging / sweeps)
 	int ball_sort = 1;          // rows with repeated sources that are NOT grouped are sorted by source first (0: such calls take the older routes)
 	double ball_bias = 1.0;     // the ball runs while ball_bias x its estimated bytes <= the cheaper of the pre-pass and the lane batches

@@ -1346,7 +1346,13 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	const int mwb = bm_words + 4;
 	const bool bi_lds = (size_t)2 * mwb * 4 + 2048 <= lds_budget; // k_bibfs: both sides' maps in LDS when they fit
 	const int qcap = std::max(1024, opt.bibfs_queue);
-	const u32 bi_grid = (u32)std::min(std::max(1, opt.bibfs_grid), std::max(1, opt.bibfs_rows));
+	// round 6: how many rows it takes and on how many workgroups follows the graph and what the call before left: on a
+	// graph whose levels are expensive (R-MAT-22: a lane batch for the 15,800 far / unreachable rows of a 2 M-row cross product
+	// costs 19 ms) a bidirectional search per row on every CU is far cheaper than whole-graph levels for a few thousand rows,
+	// while a graph that has never shown more than a handful keeps the 64-workgroup launch (12 us when nothing is open)
+	const int far_rows = c->meet_far_rows.load(std::memory_order_relaxed);
+	const int bibfs_rows = opt.bibfs_rows <= 0 ? 0 : std::max(opt.bibfs_rows, (int)std::min<int64_t>(opt.bibfs_rows_max, c->E / 4096));
+	const u32 bi_grid = (u32)std::min(std::max(std::max(1, opt.bibfs_grid), std::min(far_rows / 16, 2 * device_cus())), std::max(1, bibfs_rows));
 	// k_meet4d hands rows out dynamically: a grid of exactly the workgroups the chip holds (meet4_grid_mult = 2 per CU).
 	// A row alone on its CU is through in ~15 us, beside a second one in ~20 (the phases of a row are short bursts of
 	// instructions from 16 wavefronts, and two workgroups share the CU's issue slots): small calls, whose ~2 % of open rows
@@ -1508,10 +1514,10 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		{
 			KernelTimer kt(st, K_BIBFS);
 			if (bi_lds)
-				hipLaunchKernelGGL(k_bibfs<false>, dim3(bi_grid), dim3(1024), (size_t)2 * mwb * 4, st, qi, (u32)opt.bibfs_rows,
+				hipLaunchKernelGGL(k_bibfs<false>, dim3(bi_grid), dim3(1024), (size_t)2 * mwb * 4, st, qi, (u32)bibfs_rows,
 				                   c->off, c->adj, c->roff, c->radj, d_out, capb, bm_words, qcap, db, bi_maps, queues, qo2, hb);
 			else
-				hipLaunchKernelGGL(k_bibfs<true>, dim3(bi_grid), dim3(1024), 0, st, qi, (u32)opt.bibfs_rows, c->off, c->adj,
+				hipLaunchKernelGGL(k_bibfs<true>, dim3(bi_grid), dim3(1024), 0, st, qi, (u32)bibfs_rows, c->off, c->adj,
 				                   c->roff, c->radj, d_out, capb, bm_words, qcap, db, bi_maps, queues, qo2, hb);
 			kt.stop();
 		}
@@ -1601,7 +1607,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	const u32 open = h.count[open_stage];
 	if (!paths && opt.bibfs_rows > 0) {
 		const u32 before_bi = h.count[run4 ? 1 : 0]; // rows open when k_bibfs was (or would have been) launched
-		c->meet_far_rows.store(before_bi > 0 ? 1 : 0, std::memory_order_relaxed);
+		c->meet_far_rows.store((int)std::min<u32>(before_bi, 1u << 30), std::memory_order_relaxed); // their number sizes the next call's grid
 	}
 	S.meet_pairs += n - (int64_t)open;
 	S.edges_scanned += (int64_t)(h.entries[0] + h.entries[1] + h.entries[2]);

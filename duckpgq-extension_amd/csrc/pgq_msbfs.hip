@@ -2487,6 +2487,7 @@ static int calibrate_prepass(pgq_csr *c) {
 	S = saved;
 	PGQ_TRY(rc);
 	c->meet_bpr.store(std::max(64.0, bytes / (double)n0));
+	calibration_store(c); // the next handle over a graph of this shape starts with it
 	return PGQ_OK;
 }
 static bool prepass_takes(const pgq_csr *c, int64_t n, const SearchOutput &outp) {

@@ -213,6 +213,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "meet4_global_mb", &o.meet4_global_mb, nullptr },
 		{ "meet4_lds_kb", &o.meet4_lds_kb, nullptr },
 		{ "bibfs_rows", &o.bibfs_rows, nullptr },
+		{ "bibfs_rows_max", &o.bibfs_rows_max, nullptr },
 		{ "wbibfs", &o.wbibfs, nullptr },
 		{ "wbibfs_rows", &o.wbibfs_rows, nullptr },
 		{ "wbibfs_cap", &o.wbibfs_cap, nullptr },
@@ -239,6 +240,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "ball_sort", &o.ball_sort, nullptr },
 		{ "ball_seg_kb", &o.ball_seg_kb, nullptr },
 		{ "ball_grid", &o.ball_grid, nullptr },
+		{ "calibration_cache", &o.calibration_cache, nullptr },
 		{ "ball_bias", nullptr, &o.ball_bias },
 	};
 }
@@ -1117,6 +1119,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	c->max_in_degree = us.max_in;
 	c->max_out_degree = us.max_out;
 	c->two_hop_mean = (double)us.two_hop_sum / (double)std::max<int64_t>(V, 1);
+	calibration_load(c); // (max degrees and E are set above)
 	c->n_pull_parts = us.n_parts;
 	if (us.n_parts > 0)
 		hipLaunchKernelGGL(k_fill_rown, dim3(256 * 8), dim3(256), 0, st, c->roff, c->pull_parts, c->n_pull_parts, c->radj,
@@ -1171,8 +1174,56 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	return PGQ_OK;
 }
 
+// ---- calibration kept across handles (pgq_internal.h) -------------------------------------------------------------------
+struct CalEntry {
+	int64_t V, E, max_out, max_in;
+	double two_hop_mean;
+	double meet_bpr, ball_open_frac;
+	std::vector<uint8_t> level_plan[6];
+};
+static std::mutex g_cal_lock;
+static std::vector<CalEntry> g_cal; // a handful of graph shapes, the most recent last
+static bool cal_same(const CalEntry &e, const pgq_csr *c) {
+	return e.V == c->V && e.E == c->E && e.max_out == c->max_out_degree && e.max_in == c->max_in_degree && e.two_hop_mean == c->two_hop_mean;
+}
+void calibration_load(pgq_csr *c) {
+	if (!c || !options().calibration_cache) return;
+	std::lock_guard<std::mutex> g(g_cal_lock);
+	for (const CalEntry &e : g_cal)
+		if (cal_same(e, c)) {
+			c->meet_bpr.store(e.meet_bpr, std::memory_order_relaxed);
+			c->ball_open_frac.store(e.ball_open_frac, std::memory_order_relaxed);
+			std::lock_guard<std::mutex> g2(c->plan_lock);
+			for (int k = 0; k < 6; k++) c->level_plan[k] = e.level_plan[k];
+			return;
+		}
+}
+void calibration_store(pgq_csr *c) {
+	if (!c || c->is_replica || !options().calibration_cache) return;
+	CalEntry n { c->V, c->E, c->max_out_degree, c->max_in_degree, c->two_hop_mean, c->meet_bpr.load(std::memory_order_relaxed),
+		         c->ball_open_frac.load(std::memory_order_relaxed), {} };
+	bool any = n.meet_bpr > 0 || n.ball_open_frac > 0;
+	{
+		std::lock_guard<std::mutex> g2(c->plan_lock);
+		for (int k = 0; k < 6; k++) {
+			n.level_plan[k] = c->level_plan[k];
+			any = any || !n.level_plan[k].empty();
+		}
+	}
+	if (!any) return;
+	std::lock_guard<std::mutex> g(g_cal_lock);
+	for (size_t k = 0; k < g_cal.size(); k++)
+		if (cal_same(g_cal[k], c)) {
+			g_cal.erase(g_cal.begin() + (long)k);
+			break;
+		}
+	if (g_cal.size() >= 16) g_cal.erase(g_cal.begin());
+	g_cal.push_back(std::move(n));
+}
+
 static void destroy_csr(pgq_csr *c) {
 	if (!c) return;
+	calibration_store(c);
 	if (!c->is_replica) {
 		for (pgq_csr *r : c->replicas)
 			if (r && r != c) destroy_csr(r);

@@ -111,3 +111,14 @@ def gather_paths(d_len, d_off, d_child, used, per):
     base[1:] = torch.cumsum(torch.tensor(sizes[:-1], dtype=torch.int64), 0)
     offs = heads[:, per:2 * per] + base.to(dev)[:, None]
     return heads[:, :per].reshape(-1), offs.reshape(-1), torch.cat([blocks[r, :sizes[r]] for r in range(world)])
+
+
+def shard_bounds_grouped(total, world, rank, group):
+    """shard_bounds for rows that come in groups of `group` consecutive rows (a cross product emitted by a nested-loop
+    join: every source's rows in one stretch, match.cpp:467-495): the cut points are moved down to group boundaries, so
+    that every rank keeps WHOLE sources — one two-hop ball (or one lane) per source is then built on exactly one GPU."""
+    group = max(1, int(group))
+    lo, hi = shard_bounds(total, world, rank)
+    lo = (lo // group) * group
+    hi = total if rank == world - 1 or hi >= total else (hi // group) * group
+    return min(lo, total), max(min(hi, total), min(lo, total))

@@ -114,3 +114,70 @@ def test_bare_bench_command_starts_n_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--launch-check"],
                        capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def _worker8(rank, world, port, total, q):
+    """One of 8 gloo ranks: its shard's results are a pure function of the global row index, so rank 0 can check the
+    gathered arrays without any search."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.shard_bounds(total, world, rank)
+    idx = torch.arange(lo, hi, dtype=torch.int64)
+    ln = idx % 6 - 1  # -1 = NULL row, else a hop count 0..4
+    pend = sharding.gather_rows_async(ln.clone(), total)  # what bench.py issues per step (async, overlapped)
+    allr = pend.wait()
+    ok = torch.equal(allr, torch.arange(total, dtype=torch.int64) % 6 - 1)
+    # ragged path lists: 2 * len + 1 elements per answered row, element j of row i = i * 10 + j
+    sizes = torch.where(ln >= 0, 2 * ln + 1, torch.zeros_like(ln))
+    offs = torch.cumsum(sizes, 0) - sizes
+    used = int(sizes.sum())
+    child = torch.zeros(used + 5, dtype=torch.int64)
+    for i, (l, o) in enumerate(zip(ln.tolist(), offs.tolist())):
+        if l >= 0:
+            child[o:o + 2 * l + 1] = (lo + i) * 10 + torch.arange(2 * l + 1)
+    per = (total + world - 1) // world
+    g_len, g_off, g_child = sharding.gather_paths(ln, offs, child, used, per)
+    if rank == 0:
+        for r in range(world):
+            rlo, rhi = sharding.shard_bounds(total, world, r)
+            rows = list(range(rlo, rhi, max(1, (rhi - rlo) // 97))) + [rhi - 1] if rhi > rlo else []
+            for i in rows:  # ~100 rows of every rank's block, its first and last among them
+                k = r * per + (i - rlo)
+                l = int(g_len[k])
+                ok = ok and l == i % 6 - 1
+                if l >= 0:
+                    o = int(g_off[k])
+                    ok = ok and g_child[o:o + 2 * l + 1].tolist() == [i * 10 + j for j in range(2 * l + 1)]
+        q.put((bool(ok), int(allr.numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_shards_gathers():
+    """world_size 8 over gloo, 65,536 rows (even shards) and 65,535 (the last shard one row short: padded blocks): the
+    async length gather bench.py overlaps with the next step, and the two-collective gather of ragged path lists."""
+    for total in (65536, 65535):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker8, args=(r, 8, port, total, q)) for r in range(8)]
+        for p in procs:
+            p.start()
+        same, n = q.get(timeout=300)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert same and n == total
+
+
+def test_grouped_shards_keep_whole_sources():
+    # a cross product of S sources x D rows each over N ranks: cut points on source boundaries, everything covered once
+    for sources, per_source, world in ((2048, 1024, 8), (2048, 1024, 3), (7, 100, 4), (5, 1, 8), (1, 10, 2)):
+        total = sources * per_source
+        cover = []
+        for r in range(world):
+            lo, hi = sharding.shard_bounds_grouped(total, world, r, per_source)
+            assert lo % per_source == 0 and (hi % per_source == 0 or hi == total) and lo <= hi
+            cover.extend(range(lo, hi))
+        assert cover == list(range(total))

@@ -39,7 +39,7 @@ def _summarise(agg, launches):
     # of bytes x launches, divided by k_meet3's launches = the steps profiled).
     for cls, prefixes in (("pull_sparse", ("k_pull_lanes<", "k_pull_sparse<")), ("pull", ("k_pull<",)), ("push", ("k_push<",)),
                           ("pull_hub", ("k_pull_hub<",)), ("relax", ("k_relax<",)), ("meet", ("k_meet3",)),
-                          ("meet4", ("k_meet4d", "k_meet4<")), ("bibfs", ("k_bibfs",))):
+                          ("meet4", ("k_meet4d", "k_meet4<")), ("bibfs", ("k_bibfs",)), ("ball", ("k_src_ball", "k_ball_segments"))):
         cands = [k for k in out if k.startswith(prefixes)]
         if cands:
             best = max(cands, key=lambda k: out[k].get("hbm_bytes_per_launch", 0) * out[k]["launches_profiled"])
@@ -51,10 +51,10 @@ def _summarise(agg, launches):
     if "meet" in out:
         # steps = launches of the k_meet3 variant that moves the most bytes (round 5: the 1024-row calibration call of a fresh
         # CSR launches the small-call variant once; counted as a step it made the chain look 12 % lighter than its own first kernel)
-        m3 = [k for k in out if k.startswith("k_meet3")]
+        m3 = [k for k in out if k.startswith(("k_meet3", "k_src_ball"))]  # round 6: or of k_src_ball, when IT takes the calls (k_meet3 then returns at once)
         top = max(m3, key=lambda k: out[k].get("hbm_bytes_per_launch", 0) * out[k]["launches_profiled"]) if m3 else None
         steps = max(out[top]["launches_profiled"] if top else out["meet"]["launches_profiled"], 1)
-        chain = [k for k in out if k.startswith(("k_meet3", "k_meet4", "k_bibfs"))]
+        chain = [k for k in out if k.startswith(("k_meet3", "k_meet4", "k_bibfs", "k_src_ball", "k_ball_segments"))]
         out["prepass_chain"] = {"steps_profiled": steps, "kernels": sorted(chain),
                                 "hbm_bytes_per_step": sum(out[k].get("hbm_bytes_per_launch", 0.0) * out[k]["launches_profiled"] for k in chain) / steps}
     # round 5: the lane-batched search's launch chain per step (bench.py: roofline.traffic of the msbfs legs) — every kernel

@@ -64,6 +64,8 @@ def load_hip():
     L.pgq_csr_upload.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.POINTER(C.c_void_p)]
     L.pgq_csr_upload_device.argtypes = L.pgq_csr_upload.argtypes
+    L.pgq_csr_upload_ex.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint,
+                                    C.POINTER(C.c_void_p)]
     L.pgq_csr_build_device.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_void_p)]
     L.pgq_csr_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -243,7 +245,7 @@ def _lists(off, ln, valid, child):
 class DeviceCSR:
     """pgq_csr_t: a CSR resident in HBM (include/pgq_hip.h)."""
 
-    def __init__(self, V, offsets, adj, edge_ids=None, w=None, handle=None):
+    def __init__(self, V, offsets, adj, edge_ids=None, w=None, handle=None, lazy_edge_ids=False):
         self.L = load_hip()
         self.V = int(V)
         self.h = C.c_void_p(handle) if handle else None
@@ -260,7 +262,11 @@ class DeviceCSR:
             if len(adj) == 0:
                 adj = np.zeros(1, dtype=np.int64)
             h = C.c_void_p()
-            _check(self.L.pgq_csr_upload(self.V, _p(offsets), _p(adj), _p(eids), _p(w), wtype, C.byref(h)))
+            if lazy_edge_ids:  # PGQ_UPLOAD_LAZY_EDGE_IDS: the array must outlive the handle — this object keeps it
+                self._keep_eids = eids
+                _check(self.L.pgq_csr_upload_ex(self.V, _p(offsets), _p(adj), _p(eids), _p(w), wtype, 1, C.byref(h)))
+            else:
+                _check(self.L.pgq_csr_upload(self.V, _p(offsets), _p(adj), _p(eids), _p(w), wtype, C.byref(h)))
             self.h = h
 
     @classmethod

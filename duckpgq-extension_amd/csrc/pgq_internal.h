@@ -38,6 +38,7 @@ int fail(int code, const std::string &msg);
 	} while (0)
 
 int ensure_init();
+int ensure_edge_ids(pgq_csr *c); // copies a lazily uploaded edge-id array now (no-op otherwise); thread-safe
 // What a CSR handle has learned about its graph — the pre-pass's measured bytes per row, the share of rows the
 // source-centric kernel leaves open, the levels a full lane batch of each width runs — kept per graph SHAPE (V, E, largest
 // degrees, mean two-hop walk) across handles: DuckPGQ builds a CSR per query (iterative_length_function_data.cpp:27,
@@ -95,7 +96,7 @@ struct Options {
 	int probe2_cap = 1 << 16; // in-edges a two-hop probe may walk per pair
 	int defer = 8;          // defer stragglers when open pairs <= lanes/defer (0 = never)
 	int part_weight = 1024; // in-edges (+8 per vertex) per bottom-up work part
-	int upload_threads = 2;  // host threads staging a pageable CSR through pinned rings
+	int upload_threads = 8;  // host threads filling pinned blocks from a pageable CSR (one more thread issues the copies)
 	int upload_narrow_host = 1; // 1: the staging threads narrow the adjacency to int32; 0: raw int64 over PCIe, narrowed on the device
 	int streams = 3;        // batches searched concurrently (one host thread + HIP stream each)
 	int sparse_lds = 1;     // keep the 1-bit frontier map in LDS when it fits (1024-thread workgroups)
@@ -201,6 +202,9 @@ struct pgq_csr {
 	int64_t *off = nullptr;      // V+1
 	int32_t *adj = nullptr;      // E
 	int64_t *edge_ids = nullptr; // E or null (slot index is the id)
+	// PGQ_UPLOAD_LAZY_EDGE_IDS: the caller's host array, copied by ensure_edge_ids on the first call that reads edge ids
+	const int64_t *lazy_edge_ids = nullptr;
+	std::mutex edge_ids_lock;
 	void *w = nullptr;           // E x 8 B or null
 	// reverse CSR (in-neighbours), built on device at upload
 	int64_t *roff = nullptr; // V+1

@@ -2506,6 +2506,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	S.pairs += n;
 	if (n == 0) return PGQ_OK;
 	if (n >= (1LL << 31)) return fail(PGQ_ERR_INVALID_ARG, "more than 2^31-1 rows in one call");
+	if (with_paths) PGQ_TRY(ensure_edge_ids(c)); // PGQ_UPLOAD_LAZY_EDGE_IDS: the first shortestpath call brings them over
 	// Pair-centric pre-pass: rows at distance <= 3 are answered from two-hop neighbourhood scans (pgq_meet.hip); only
 	// what it leaves open goes through the lane-batched search below.  It pays while the two-hop walks of all rows
 	// cost less than the MS-BFS levels they replace: bytes ~ rows x E[in-degree x out-degree] x 4 (the cheaper

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <thread>
+#include <immintrin.h>
 #include <unordered_map>
 
 #include "pgq_internal.h"
@@ -661,21 +662,59 @@ static int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
 // A plain hipMemcpy from DuckDB's pageable vectors stages through one pinned buffer on one thread (~2.5 GB/s
 // measured: 260 ms for the 0.64 GB SF100 CSR — far more than the search itself).  Here T threads each own a slice,
 // a 2-slot pinned ring and a stream; the adjacency is narrowed to int32 while it is staged (half the PCIe bytes).
+// Streams of the upload / build paths are kept (per device): creating and destroying one costs milliseconds on this runtime —
+// three staged arrays with two streams each + the upload's own were ~15 ms of a 27-ms SF100 upload (round 6), a constant
+// that neither more filler threads nor fewer bytes moved.
+struct StreamPool {
+	std::mutex lock;
+	std::vector<std::pair<int, hipStream_t>> idle; // (device, stream)
+	int get(hipStream_t *out) {
+		const int dev = current_device();
+		{
+			std::lock_guard<std::mutex> g(lock);
+			for (size_t k = 0; k < idle.size(); k++)
+				if (idle[k].first == dev) {
+					*out = idle[k].second;
+					idle.erase(idle.begin() + (long)k);
+					return PGQ_OK;
+				}
+		}
+		PGQ_HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+		return PGQ_OK;
+	}
+	void put(hipStream_t st) {
+		if (!st) return;
+		std::lock_guard<std::mutex> g(lock);
+		if (idle.size() < 32) idle.emplace_back(current_device(), st);
+		else (void)hipStreamDestroy(st);
+	}
+};
+static StreamPool g_streams;
+
 struct PinnedPool {
 	std::mutex lock;
 	std::vector<void *> free_blocks;
 	static constexpr size_t kBlock = 4u << 20;
+	// Blocks are carved out of LARGE pinned allocations (64 blocks = 256 MB at a time; a small first one so that a process
+	// that only ever downloads a result does not pin 256 MB): tools/h2dbench copies 129 GB/s into, and 57 GB/s out of, one
+	// 256-MB hipHostMalloc, while the same traffic through 77 separate 4-MB allocations ran at 28 and 21 GB/s (round 6:
+	// small pinned allocations are mapped with small pages).
+	size_t chunks = 0;
 	void *get() {
-		{
-			std::lock_guard<std::mutex> g(lock);
-			if (!free_blocks.empty()) {
-				void *p = free_blocks.back();
-				free_blocks.pop_back();
-				return p;
+		std::lock_guard<std::mutex> g(lock);
+		if (free_blocks.empty()) {
+			const size_t nb = chunks == 0 ? 8 : 64;
+			void *p = nullptr;
+			if (hipHostMalloc(&p, nb * kBlock) != hipSuccess) {
+				if (nb == 8 || hipHostMalloc(&p, 8 * kBlock) != hipSuccess) return nullptr;
+				for (size_t k = 0; k < 8; k++) free_blocks.push_back(static_cast<char *>(p) + (7 - k) * kBlock);
+			} else {
+				for (size_t k = 0; k < nb; k++) free_blocks.push_back(static_cast<char *>(p) + (nb - 1 - k) * kBlock);
 			}
+			chunks++;
 		}
-		void *p = nullptr;
-		if (hipHostMalloc(&p, kBlock) != hipSuccess) return nullptr;
+		void *p = free_blocks.back();
+		free_blocks.pop_back();
 		return p;
 	}
 	void put(void *p) {
@@ -685,69 +724,165 @@ struct PinnedPool {
 };
 static PinnedPool g_pinned;
 
+// int64 -> int32 with the range check [0, V), V < 2^31: AVX2 where the host has it (a scalar loop ran at ~7 GB/s of input per
+// thread: eight of them were the upload's bottleneck at 56 GB/s; the vector loop is bound by memory).  Returns true when
+// an element was out of range.
+__attribute__((target("avx2"))) static bool narrow_block_avx2(const int64_t *__restrict__ src, int32_t *__restrict__ dst, size_t cnt, int64_t V) {
+	const __m256i idx = _mm256_setr_epi32(0, 2, 4, 6, 1, 3, 5, 7);
+	__m256i acc_hi = _mm256_setzero_si256(), acc_max = _mm256_setzero_si256();
+	size_t i = 0;
+	for (; i + 8 <= cnt; i += 8) {
+		const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+		const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 4));
+		const __m256i pa = _mm256_permutevar8x32_epi32(a, idx), pb = _mm256_permutevar8x32_epi32(b, idx); // low dwords in the lower half, high dwords in the upper
+		const __m256i lo = _mm256_permute2x128_si256(pa, pb, 0x20), hi = _mm256_permute2x128_si256(pa, pb, 0x31);
+		_mm256_storeu_si256(reinterpret_cast<__m256i *>(dst + i), lo);
+		acc_hi = _mm256_or_si256(acc_hi, hi);
+		acc_max = _mm256_max_epu32(acc_max, lo);
+	}
+	alignas(32) uint32_t h[8], m[8];
+	_mm256_store_si256(reinterpret_cast<__m256i *>(h), acc_hi);
+	_mm256_store_si256(reinterpret_cast<__m256i *>(m), acc_max);
+	bool oob = false;
+	for (int k = 0; k < 8; k++) oob |= h[k] != 0 || (int64_t)m[k] >= V; // a non-zero high dword: negative, or >= 2^32
+	for (; i < cnt; i++) {
+		const int64_t x = src[i];
+		oob |= x < 0 || x >= V;
+		dst[i] = (int32_t)x;
+	}
+	return oob;
+}
+static bool narrow_block(const int64_t *__restrict__ src, int32_t *__restrict__ dst, size_t cnt, int64_t V) {
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	if (avx2) return narrow_block_avx2(src, dst, cnt, V);
+	bool oob = false;
+	for (size_t i = 0; i < cnt; i++) {
+		const int64_t x = src[i];
+		oob |= x < 0 || x >= V;
+		dst[i] = (int32_t)x;
+	}
+	return oob;
+}
+
 // mode 0: raw bytes; mode 1: int64 -> int32 narrowing with range check [0, V) (elements counted in int64s)
+// Round 6.  Rounds 1-5 let every staging thread issue its own hipMemcpyAsync on its own stream: the runtime serialises them,
+// more than two threads were slower (8: 25 ms, 16: 55 ms per 320 MB array), and two threads' copy loops — not PCIe — set the
+// pace: 20 ms for the SF100 adjacency.  tools/h2dbench on the same box: PCIe moves 57 GB/s out of pinned memory in 4-MB
+// copies on two streams, eight threads memcpy 129 GB/s.  So: `upload_threads` fillers that make NO HIP call claim blocks from
+// a counter and narrow / copy them into pinned slots — block b owns slot b mod R, with R up to 96 blocks (the whole SF100
+// adjacency fits: nobody waits for a slot; a larger array wraps around and a filler waits for the copy that frees its
+// slot) — and ONE thread, the caller, issues the copies in block order, spinning on a per-block ready flag (a condition
+// variable per hand-over cost more than the 35 us a block's DMA takes).
 static int staged_upload(void *d_dst, const void *h_src, size_t n_elems, size_t elem_bytes, int mode, int64_t V,
                          std::atomic<int> *bad) {
 	if (n_elems == 0) return PGQ_OK;
 	const size_t out_elem = mode == 1 ? 4 : elem_bytes;
-	const size_t per_block = PinnedPool::kBlock / std::max<size_t>(elem_bytes, 8);
+	const size_t per_block = PinnedPool::kBlock / out_elem; // a pinned block is filled to the brim: 4 MB per copy
 	const size_t nblocks = (n_elems + per_block - 1) / per_block;
-	int T = (int)std::min<size_t>(std::min<size_t>((size_t)std::max(1, options().upload_threads),
-	                                             std::max(1u, std::thread::hardware_concurrency())), nblocks);
-	std::vector<int> rcs((size_t)T, PGQ_OK);
-	std::vector<std::string> errs((size_t)T);
-	auto worker = [&](int t) {
-		auto run = [&]() -> int {
-			PGQ_TRY(ensure_init());
-			hipStream_t st = nullptr;
-			PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-			void *slot[2] = { g_pinned.get(), g_pinned.get() };
-			hipEvent_t ev[2] = { nullptr, nullptr };
-			int rc = PGQ_OK;
-			if (!slot[0] || !slot[1]) rc = fail(PGQ_ERR_OOM, "hipHostMalloc of a staging block failed");
-			for (int k = 0; k < 2 && rc == PGQ_OK; k++)
-				if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) rc = fail(PGQ_ERR_HIP, "hipEventCreate failed");
-			size_t it = 0;
-			for (size_t b = (size_t)t; b < nblocks && rc == PGQ_OK; b += (size_t)T, it++) {
-				const int s = (int)(it & 1);
-				if (it >= 2 && hipEventSynchronize(ev[s]) != hipSuccess) rc = fail(PGQ_ERR_HIP, "hipEventSynchronize failed");
-				const size_t lo = b * per_block, cnt = std::min(per_block, n_elems - lo);
-				if (mode == 1) {
-					const int64_t *src = static_cast<const int64_t *>(h_src) + lo;
-					int32_t *dst = static_cast<int32_t *>(slot[s]);
-					bool oob = false;
-					for (size_t i = 0; i < cnt; i++) {
-						const int64_t x = src[i];
-						oob |= x < 0 || x >= V;
-						dst[i] = (int32_t)x;
-					}
-					if (oob) bad->store(1);
-				} else {
-					memcpy(slot[s], static_cast<const char *>(h_src) + lo * elem_bytes, cnt * elem_bytes);
-				}
-				if (rc == PGQ_OK && hipMemcpyAsync(static_cast<char *>(d_dst) + lo * out_elem, slot[s], cnt * out_elem,
-				                                   hipMemcpyHostToDevice, st) != hipSuccess)
-					rc = fail(PGQ_ERR_HIP, "hipMemcpyAsync (staged upload) failed");
-				if (rc == PGQ_OK) (void)hipEventRecord(ev[s], st);
+	const int T = (int)std::min<size_t>(std::min<size_t>((size_t)std::max(1, options().upload_threads),
+	                                                   std::max(1u, std::thread::hardware_concurrency())), nblocks);
+	const size_t R = std::min<size_t>(nblocks, 96);
+	static const int diag = getenv("PGQ_UPLOAD_DIAG") ? atoi(getenv("PGQ_UPLOAD_DIAG")) : 0; // 1: no copies, 2: no filling (timing experiments)
+	PGQ_TRY(ensure_init());
+	hipStream_t st[2] = { nullptr, nullptr };
+	std::vector<void *> slots(R, nullptr);
+	std::vector<hipEvent_t> evs(nblocks > R ? R : 0, nullptr);
+	int rc = PGQ_OK;
+	for (int k = 0; k < 2 && rc == PGQ_OK; k++)
+		rc = g_streams.get(&st[k]);
+	for (size_t k = 0; k < R && rc == PGQ_OK; k++) {
+		slots[k] = g_pinned.get();
+		if (!slots[k]) rc = fail(PGQ_ERR_OOM, "hipHostMalloc of a staging block failed");
+	}
+	for (size_t k = 0; k < evs.size() && rc == PGQ_OK; k++)
+		if (hipEventCreateWithFlags(&evs[k], hipEventDisableTiming) != hipSuccess) rc = fail(PGQ_ERR_HIP, "hipEventCreate failed");
+	std::unique_ptr<std::atomic<unsigned char>[]> ready(new std::atomic<unsigned char>[nblocks]);
+	for (size_t b = 0; b < nblocks; b++) ready[b].store(0, std::memory_order_relaxed);
+	size_t next_issue_bound = 0; // copies issued so far (the issuer's own)
+	std::atomic<size_t> next_block { 0 }, copied { 0 }; // copied: blocks whose DMA has landed (their slots may be refilled)
+	std::atomic<bool> stop { false };
+	// Nobody spins: the boxes this runs on give a process a CPU quota, and a spinning issuer beside eight fillers burnt it
+	// (fill rate 56 -> 17 GB/s).  The issuer sleeps on `cv` until the block it wants is ready (a filler notifies only when the
+	// issuer has said it is waiting for that block); fillers that wait for a slot sleep on `cv_slot` until a copy has landed.
+	std::mutex m;
+	std::condition_variable cv, cv_slot;
+	size_t waiting_for = (size_t)-1;
+	auto filler = [&]() {
+		for (;;) {
+			const size_t b = next_block.fetch_add(1);
+			if (b >= nblocks) return;
+			if (b >= R && copied.load(std::memory_order_acquire) + R <= b) { // the slot still holds block b - R
+				std::unique_lock<std::mutex> lk(m);
+				cv_slot.wait(lk, [&] { return stop.load() || copied.load(std::memory_order_acquire) + R > b; });
+				if (stop.load()) return;
 			}
-			(void)hipStreamSynchronize(st);
-			for (int k = 0; k < 2; k++) {
-				if (ev[k]) (void)hipEventDestroy(ev[k]);
-				if (slot[k]) g_pinned.put(slot[k]);
+			const size_t lo = b * per_block, cnt = std::min(per_block, n_elems - lo);
+			void *slot = slots[b % R];
+			if (diag == 2) {
+			} else if (mode == 1) {
+				if (narrow_block(static_cast<const int64_t *>(h_src) + lo, static_cast<int32_t *>(slot), cnt, V)) bad->store(1);
+			} else {
+				memcpy(slot, static_cast<const char *>(h_src) + lo * elem_bytes, cnt * elem_bytes);
 			}
-			(void)hipStreamDestroy(st);
-			return rc;
-		};
-		rcs[(size_t)t] = run();
-		if (rcs[(size_t)t] != PGQ_OK) errs[(size_t)t] = t_err;
+			ready[b].store(1, std::memory_order_release);
+			bool wake = false;
+			{
+				std::lock_guard<std::mutex> lk(m);
+				wake = waiting_for == b;
+			}
+			if (wake) cv.notify_one();
+		}
 	};
 	std::vector<std::thread> pool;
-	for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
-	worker(0);
+	if (rc == PGQ_OK)
+		for (int t = 0; t < T; t++) pool.emplace_back(filler);
+	size_t landed = 0; // blocks known to have landed (the issuer's view of `copied`)
+	auto land = [&](bool block_on_oldest) { // returns the slots of copies that have landed
+		const size_t before = landed;
+		if (block_on_oldest) {
+			(void)hipEventSynchronize(evs[landed % R]);
+			landed++;
+		}
+		while (landed < next_issue_bound && hipEventQuery(evs[landed % R]) == hipSuccess) landed++;
+		if (landed != before) {
+			{
+				std::lock_guard<std::mutex> lk(m);
+				copied.store(landed, std::memory_order_release);
+			}
+			cv_slot.notify_all();
+		}
+	};
+	for (size_t b = 0; b < nblocks && rc == PGQ_OK; b++) {
+		next_issue_bound = b;
+		while (!ready[b].load(std::memory_order_acquire)) {
+			if (!evs.empty()) land(false);
+			std::unique_lock<std::mutex> lk(m);
+			waiting_for = b;
+			cv.wait_for(lk, std::chrono::microseconds(evs.empty() ? 2000 : 100), [&] { return ready[b].load(std::memory_order_acquire) != 0; });
+			waiting_for = (size_t)-1;
+		}
+		const size_t lo = b * per_block, cnt = std::min(per_block, n_elems - lo);
+		hipStream_t s = st[b & 1];
+		if (diag != 1 && hipMemcpyAsync(static_cast<char *>(d_dst) + lo * out_elem, slots[b % R], cnt * out_elem, hipMemcpyHostToDevice, s) != hipSuccess)
+			rc = fail(PGQ_ERR_HIP, "hipMemcpyAsync (staged upload) failed");
+		if (!evs.empty() && rc == PGQ_OK && hipEventRecord(evs[b % R], s) != hipSuccess) rc = fail(PGQ_ERR_HIP, "hipEventRecord failed");
+		next_issue_bound = b + 1;
+		if (!evs.empty()) land(b + 1 >= R + landed); // the ring is full of copies in flight: wait for the oldest
+	}
+	{
+		std::lock_guard<std::mutex> lk(m);
+		stop.store(true);
+	}
+	cv_slot.notify_all();
 	for (auto &th : pool) th.join();
-	for (int t = 0; t < T; t++)
-		if (rcs[(size_t)t] != PGQ_OK) return fail(rcs[(size_t)t], errs[(size_t)t]);
-	return PGQ_OK;
+	for (int k = 0; k < 2; k++)
+		if (st[k] && hipStreamSynchronize(st[k]) != hipSuccess && rc == PGQ_OK) rc = fail(PGQ_ERR_HIP, "staged upload: stream failed");
+	for (auto e : evs)
+		if (e) (void)hipEventDestroy(e);
+	for (size_t k = 0; k < R; k++)
+		if (slots[k]) g_pinned.put(slots[k]);
+	for (int k = 0; k < 2; k++) g_streams.put(st[k]); // (synchronised above)
+	return rc;
 }
 
 // device -> pageable host through one pinned block at a time (a pageable hipMemcpy D2H ran at ~0.6 GB/s here)
@@ -1257,8 +1392,27 @@ static void destroy_csr(pgq_csr *c) {
 	delete c;
 }
 
+static int staged_upload(void *d_dst, const void *h_src, size_t n_elems, size_t elem_bytes, int mode, int64_t V, std::atomic<int> *bad);
+int ensure_edge_ids(pgq_csr *c) {
+	if (!c || !c->lazy_edge_ids) return PGQ_OK; // (written once under the lock below, read racily here: a stale non-null only costs the lock)
+	std::lock_guard<std::mutex> g(c->edge_ids_lock);
+	if (!c->lazy_edge_ids) return PGQ_OK;
+	int64_t *d = nullptr;
+	PGQ_TRY(dev_alloc((void **)&d, (size_t)c->E * sizeof(int64_t)));
+	std::atomic<int> oob { 0 };
+	const int rc = staged_upload(d, c->lazy_edge_ids, (size_t)c->E, 8, 0, c->V, &oob);
+	if (rc != PGQ_OK) {
+		dev_free(d);
+		return rc;
+	}
+	c->edge_ids = d;
+	c->bytes += c->E * 8;
+	c->lazy_edge_ids = nullptr;
+	return PGQ_OK;
+}
+
 static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
-                       int w_type, bool on_device, pgq_csr_t **out) {
+                       int w_type, bool on_device, pgq_csr_t **out, bool lazy_ids = false) {
 	PGQ_TRY(ensure_init());
 	if (!out) return fail(PGQ_ERR_INVALID_ARG, "out handle pointer is NULL");
 	*out = nullptr;
@@ -1282,9 +1436,14 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 	int rc = PGQ_OK;
 	int64_t *d_adj64 = nullptr;
 	auto body = [&]() -> int {
-		PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		PGQ_TRY(g_streams.get(&st));
 		PGQ_TRY(dev_alloc((void **)&c->off, (size_t)(V + 1) * sizeof(int64_t)));
-		PGQ_HIP_TRY(hipMemcpyAsync(c->off, offsets, (size_t)(V + 1) * sizeof(int64_t), kind, st));
+		if (on_device) {
+			PGQ_HIP_TRY(hipMemcpyAsync(c->off, offsets, (size_t)(V + 1) * sizeof(int64_t), kind, st));
+		} else { // pageable: through the pinned blocks like the other arrays (a plain hipMemcpy of 3.6 MB of pageable memory took ~2 ms)
+			std::atomic<int> unused { 0 };
+			PGQ_TRY(staged_upload(c->off, offsets, (size_t)(V + 1), 8, 0, V, &unused));
+		}
 		if (E > 0 && on_device) {
 			d_adj64 = const_cast<int64_t *>(adj);
 			if (edge_ids) {
@@ -1308,7 +1467,9 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 				PGQ_TRY(staged_upload(d_adj64, adj, (size_t)E, 8, 0, V, &oob));
 			}
 			tr.mark("adjacency staged");
-			if (edge_ids) {
+			if (edge_ids && lazy_ids) {
+				c->lazy_edge_ids = edge_ids; // copied by ensure_edge_ids when a call reads edge ids
+			} else if (edge_ids) {
 				PGQ_TRY(dev_alloc((void **)&c->edge_ids, (size_t)E * sizeof(int64_t)));
 				PGQ_TRY(staged_upload(c->edge_ids, edge_ids, (size_t)E, 8, 0, V, &oob));
 				tr.mark("edge ids staged");
@@ -1323,7 +1484,7 @@ static int upload_impl(int64_t V, const int64_t *offsets, const int64_t *adj, co
 	rc = body();
 	if (st) {
 		(void)hipStreamSynchronize(st);
-		(void)hipStreamDestroy(st);
+		g_streams.put(st);
 	}
 	if (!on_device && d_adj64) dev_free(d_adj64);
 	if (rc != PGQ_OK) {
@@ -1362,6 +1523,11 @@ int pgq_device_count(void) {
 const char *pgq_last_error(void) { return t_err.c_str(); }
 const char *pgq_version(void) { return "pgq_hip 0.6 (gfx950; pgq_stats_t: 65 words)"; }
 
+int pgq_csr_upload_ex(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w, int w_type,
+                      unsigned flags, pgq_csr_t **out) {
+	if (flags & ~PGQ_UPLOAD_LAZY_EDGE_IDS) return fail(PGQ_ERR_INVALID_ARG, "pgq_csr_upload_ex: unknown flag");
+	return upload_impl(V, offsets, adj, edge_ids, w, w_type, false, out, (flags & PGQ_UPLOAD_LAZY_EDGE_IDS) != 0);
+}
 int pgq_csr_upload(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
                    int w_type, pgq_csr_t **out) {
 	return upload_impl(V, offsets, adj, edge_ids, w, w_type, false, out);
@@ -1393,7 +1559,7 @@ int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const 
 	int *d_bad = nullptr;
 	void *d_tmp = nullptr;
 	auto body = [&]() -> int {
-		PGQ_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		PGQ_TRY(g_streams.get(&st));
 		const size_t En = (size_t)std::max<int64_t>(E, 1);
 		PGQ_TRY(dev_alloc_as(&d_key, En));
 		PGQ_TRY(dev_alloc_as(&d_idx, En));
@@ -1437,7 +1603,7 @@ int pgq_csr_build_device(int64_t V, int64_t n_rows, const int64_t *d_src, const 
 	int rc = body();
 	if (st) {
 		(void)hipStreamSynchronize(st);
-		(void)hipStreamDestroy(st);
+		g_streams.put(st);
 	}
 	for (void *p : { (void *)d_key, (void *)d_idx, (void *)d_skey, (void *)d_order, (void *)d_bad, d_tmp }) dev_free(p);
 	if (rc != PGQ_OK) {
@@ -1459,6 +1625,7 @@ int pgq_csr_download(const pgq_csr_t *c, int64_t *offsets, int64_t *adj, int64_t
 		for (int64_t i = 0; i < c->E; i++) adj[i] = a32[i];
 	}
 	if (edge_ids && c->E > 0) {
+		PGQ_TRY(ensure_edge_ids(const_cast<pgq_csr_t *>(c)));
 		if (c->edge_ids) PGQ_TRY(staged_download(edge_ids, c->edge_ids, (size_t)c->E * 8, st));
 		else
 			for (int64_t i = 0; i < c->E; i++) edge_ids[i] = i;
@@ -1557,6 +1724,7 @@ static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
 }
 
 int pgq_csr_replicate(pgq_csr_t *c) {
+	PGQ_TRY(ensure_edge_ids(c)); // replicas carry everything: a lazily uploaded array is copied now
 	PGQ_TRY(ensure_init());
 	if (!c || c->is_replica) return fail(PGQ_ERR_INVALID_ARG, "pgq_csr_replicate: NULL or replica handle");
 	const std::vector<int> devs = enabled_devices();

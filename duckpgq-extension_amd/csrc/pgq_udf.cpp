@@ -103,7 +103,9 @@ pgq_csr_t *device_csr(pgq_state *s, const CsrRef &c, int64_t V) {
 		for (auto &x : off) x = 0;
 	}
 	pgq_csr_t *h = nullptr;
-	if (pgq_csr_upload(V, off.data(), adj, eids, w, wt, &h) != PGQ_OK) return nullptr;
+	// the host CSR owns edge_ids until it is deleted, and the device handle dies first (~HostCSR frees it in its body): the ids cross PCIe only if
+	// a shortestpath call asks for them (PGQ_UPLOAD_LAZY_EDGE_IDS)
+	if (pgq_csr_upload_ex(V, off.data(), adj, eids, w, wt, PGQ_UPLOAD_LAZY_EDGE_IDS, &h) != PGQ_OK) return nullptr;
 	c->device = h;
 	return h;
 }

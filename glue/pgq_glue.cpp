@@ -47,8 +47,10 @@ pgq_csr_t *DeviceCSR(DuckPGQState &state, CSR &csr, int64_t v_size) {
 			w_type = PGQ_W_DOUBLE;
 		}
 	}
-	if (pgq_csr_upload(v_size, reinterpret_cast<const int64_t *>(csr.v), csr.e.data(), csr.edge_ids.data(), w, w_type,
-	                   &csr.device) != PGQ_OK)
+	// the CSR owns edge_ids for as long as it lives and ~CSR() frees the device handle first: the ids cross PCIe only when a
+	// shortestpath call asks for them (PGQ_UPLOAD_LAZY_EDGE_IDS), off the path of the binder's iterativelength filter
+	if (pgq_csr_upload_ex(v_size, reinterpret_cast<const int64_t *>(csr.v), csr.e.data(), csr.edge_ids.data(), w, w_type,
+	                   PGQ_UPLOAD_LAZY_EDGE_IDS, &csr.device) != PGQ_OK)
 		ThrowDevice();
 	return csr.device;
 }

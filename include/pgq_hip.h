@@ -92,6 +92,15 @@ const char *pgq_version(void);
  * searches run without the pre-pass (same answers, slower on scattered pairs): pgq_csr_has_prepass_layout() tells. */
 int pgq_csr_upload(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
                    int w_type, pgq_csr_t **out);
+/* pgq_csr_upload with flags.  PGQ_UPLOAD_LAZY_EDGE_IDS: the caller keeps `edge_ids` valid and unchanged until pgq_csr_free
+ * (the reference's host CSR owns the vector for as long as the CSR exists: compressed_sparse_row.hpp:34-35, and the device
+ * handle dies with it); the library then does NOT copy the E x 8 bytes at upload — iterativelength, cheapest_path_length and
+ * the analytics never read edge ids — but on the first call that needs them (shortestpath, pgq_csr_download,
+ * pgq_csr_replicate).  Half of a query's upload bytes, off the critical path of the binder's iterativelength filter
+ * (match.cpp:658-671 runs it before any shortestpath call). */
+#define PGQ_UPLOAD_LAZY_EDGE_IDS 1u
+int pgq_csr_upload_ex(int64_t V, const int64_t *offsets, const int64_t *adj, const int64_t *edge_ids, const void *w,
+                      int w_type, unsigned flags, pgq_csr_t **out);
 /* Same, but the four arrays already live in device memory of the current device (they are copied). */
 int pgq_csr_upload_device(int64_t V, const int64_t *d_offsets, const int64_t *d_adj, const int64_t *d_edge_ids,
                           const void *d_w, int w_type, pgq_csr_t **out);

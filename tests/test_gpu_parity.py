@@ -1588,3 +1588,95 @@ def test_cheapest_path_label_width_switches_at_31_bits():
             assert (ok == wok).all() and (out[ok] == want[wok]).all(), (w_max, narrow)
             got[narrow] = out
         assert (got[0] == got[1]).all()
+
+
+def test_lazy_edge_ids_cross_pcie_on_the_first_call_that_reads_them():
+    # PGQ_UPLOAD_LAZY_EDGE_IDS (pgq_csr_upload_ex): iterativelength never touches edge ids, so the UDF layer leaves them on
+    # the host; the first shortestpath / download / replicate brings them over.  Same lists as an eager upload.
+    rng = np.random.default_rng(91)
+    V, E = 5000, 60000
+    s, d, _ = random_graph(rng, V, E)
+    eid = rng.permutation(E).astype(np.int64) + 1000  # not the slot index: a wrong or missing copy shows
+    off, adj, e2 = graphgen.csr_from_rows(V, s, d)
+    ids = eid[e2]
+    eager = pgq.DeviceCSR(V, off, adj, ids)
+    lazy = pgq.DeviceCSR(V, off, adj, ids, lazy_edge_ids=True)
+    ps, pd = rng.integers(0, V, 600), rng.integers(0, V, 600)
+    a, ok_a = eager.iterativelength(ps, pd)
+    b, ok_b = lazy.iterativelength(ps, pd)
+    assert (ok_a == ok_b).all() and (a == b).all()
+    bytes_before = lazy.device_bytes
+    want = eager.shortestpath(ps, pd)
+    assert lazy.shortestpath(ps, pd) == want and any(p is not None and len(p) > 1 for p in want)
+    assert lazy.device_bytes == bytes_before + 8 * len(adj)  # the ids were copied by that call
+    assert lazy.shortestpath(ps, pd) == want
+    _, _, got_ids, _ = lazy.download()
+    assert (got_ids == ids).all()
+    lazy2 = pgq.DeviceCSR(V, off, adj, ids, lazy_edge_ids=True)  # download first, then paths
+    assert (lazy2.download()[2] == ids).all() and lazy2.shortestpath(ps[:50], pd[:50]) == want[:50]
+    for c in (eager, lazy, lazy2):
+        c.close()
+
+
+@pytest.mark.parametrize("cache", [1, 0])
+def test_first_call_on_a_fresh_handle_equals_the_tenth(cache):
+    # The reference's CSR lives for ONE query (iterative_length_function_data.cpp:27, duckpgq_state.cpp:162-170): a handle's
+    # first call — no route memo, no level plan, no measured bytes per row; with calibration_cache = 1 whatever an earlier
+    # handle over the same graph shape left behind — must give what its tenth call gives, on every route.
+    import torch
+    rng = np.random.default_rng(17)
+    V, E = 30000, 600000
+    s, d, _ = random_graph(rng, V, E)
+    off, adj, eid = graphgen.csr_from_rows(V, s, d)
+    ora = OracleCSR.adopt(V, off, adj, eid)
+    for k in ("meet", "ball", "wbibfs"):
+        pgq.set_option(k, pgq.get_default_option(k))
+    pgq.set_option("calibration_cache", cache)
+    pgq.set_option("ball_seg_kb", 16)
+    srcs = rng.choice(V, 30, replace=False)
+    shapes = {"scattered": (rng.integers(0, V, 20000), rng.integers(0, V, 20000)),
+              "grouped": (np.repeat(srcs, 700), rng.integers(0, V, 21000)),
+              "few_sources_all_vertices": (np.repeat(srcs[:2], V), np.tile(np.arange(V, dtype=np.int64), 2)),
+              "chunk": (rng.integers(0, V, 2048), rng.integers(0, V, 2048))}
+    try:
+        for name, (ps, pd) in shapes.items():
+            oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+            want = np.where(ook, oln, -1)
+            t_s, t_d = torch.from_numpy(ps.astype(np.int64)).cuda(), torch.from_numpy(pd.astype(np.int64)).cuda()
+            for handle in range(3):  # three fresh handles: the 2nd and 3rd find the 1st's calibration when the cache is on
+                dev = pgq.DeviceCSR(V, off, adj, eid)
+                t_o = torch.full((len(ps),), -7, dtype=torch.int64, device="cuda")
+                for call in range(10 if handle == 0 else 2):
+                    t_o.fill_(-7)
+                    dev.iterativelength_bulk_ptr(len(ps), t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+                    assert (t_o.cpu().numpy() == want).all(), (name, handle, call)
+                dev.close()
+    finally:
+        pgq.set_option("calibration_cache", 1)
+
+
+def test_host_upload_narrows_and_range_checks_every_position():
+    # pgq_csr_upload stages the pageable arrays through pinned blocks on several threads and narrows the adjacency to int32 on
+    # the way (AVX2 where the host has it): the device copy must equal the host arrays, and an id outside [0, V) anywhere —
+    # first element, inside a vector of eight, the scalar tail, another 4-MB block; negative, == V, >= 2^32 — must be refused.
+    rng = np.random.default_rng(5150)
+    V, E = 70000, 2_300_003  # more than two 4-MB blocks of int32, a tail that is not a multiple of eight
+    s = np.sort(rng.integers(0, V, E))
+    d = rng.integers(0, V, E)
+    off = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(np.bincount(s, minlength=V), out=off[1:])
+    adj = d.astype(np.int64)
+    eid = rng.permutation(E).astype(np.int64)
+    for threads in (1, 3, 8):
+        pgq.set_option("upload_threads", threads)
+        dev = pgq.DeviceCSR(V, off, adj, eid)
+        o2, a2, e2, _ = dev.download()
+        assert (o2 == off).all() and (a2 == adj).all() and (e2 == eid).all()
+        dev.close()
+    pgq.set_option("upload_threads", int(pgq.get_default_option("upload_threads")))
+    for pos in (0, 5, 1_048_576 + 3, E - 1, E - 9):
+        for bad in (-1, V, V + 12345, 1 << 32, (1 << 40) + 7, -(1 << 35)):
+            broken = adj.copy()
+            broken[pos] = bad
+            with pytest.raises(pgq.PgqError):
+                pgq.DeviceCSR(V, off, broken, eid)

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
                                                            int64_t V, const int64_t *__restrict__ off, const int64_t *__restrict__ roff,
                                                            const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
                                                            const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
-                                                           const uint2 *__restrict__ rseg, const u32 *__restrict__ segs,
+                                                           const uint2 *__restrict__ rseg, const uint4 *__restrict__ rhead,
+                                                           const u32 *__restrict__ segs,
                                                            int64_t *__restrict__ out, int64_t cap, int64_t test_cap, int bm_words,
                                                            MeetDevBlock *__restrict__ db, u32 *__restrict__ gmaps, MeetQueue qopen, BallRule rule,
                                                            unsigned long long *__restrict__ trace) {
@@ -147,12 +148,13 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 	__shared__ signed char s_res[kBallRows]; // per row: its answer, or kBallOpenI
 	__shared__ u32 s_d[kBallRows];           // the row's destination (the few rows at distance >= 4 look their descriptors up by it)
 	__shared__ uint2 s_in[kBallRows];        // {first group, entries} of the padded in-list of the row's destination
-	__shared__ unsigned short s_q1[kBallRows], s_q2[kBallRows], s_q3[kBallRows];
-	__shared__ u32 s_n1, s_n2, s_n3, s_n4, s_len, s_job, s_capped;
+	__shared__ unsigned short s_q1[kBallRows], s_q2[kBallRows], s_q3[kBallRows], s_q4[kBallRows];
+	__shared__ u32 s_n1, s_n2, s_n3, s_n4, s_n5, s_len, s_job, s_capped;
 	__shared__ int s_flag;
 	__shared__ __attribute__((aligned(16))) unsigned char s_win[kBallRows / 64][64];
 	__shared__ unsigned long long s_stat[2]; // adjacency entries requested / slot descriptors read by this workgroup
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	const bool head = rhead != nullptr; // the fixed-stride in-list heads exist: a row's scan needs its destination id alone
 	unsigned char *win = s_win[wib];
 	win[lane] = 0;
 	if (tid < 2) s_stat[tid] = 0;
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 			s_n2 = 0;
 			s_n3 = 0;
 			s_n4 = 0;
+			s_n5 = 0;
 			s_capped = 0;
 		}
 		const u32 start = segs[job];
@@ -238,10 +241,10 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 					res = 0; // iterativelength.cpp:102-103
 				} else if (degS == 0) {
 					res = -1; // no path can exist: NULL like an exhausted search (iterativelength.cpp:133-139)
-				} else {
+				} else if (!head) {
 					in = rseg[di32]; // ONE 8-byte gather per row (a second one for roff[dst] was another 128-byte line per row: a sixth of the kernel's traffic)
 					if (in.y == 0) res = -1; // nothing points at dst
-				}
+				} // (head: the in-degree arrives with the list's head in the scan; a destination nothing points at is closed there)
 			}
 			s_res[tid] = (signed char)res;
 			s_d[tid] = di32;
@@ -300,6 +303,58 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 				const int sub = lane >> 4, j = lane & 15;
 				const u32 n1 = s_n1;
 				u32 ent = 0;
+				if (head) {
+					// The list's head sits at rhead[16 d ..): entries 0..30 + the in-degree in the first 128-byte line, entries 31..62
+					// in the second.  EIGHT lanes per row and step = one line: the PMC counters of the 16-lane version said the
+					// kernel is bound by what it ISSUES (58 M VALU + 38 M SALU + 9 M LDS wave-instructions per 2.1 M rows, phases
+					// serialised by barriers), not by its bytes — and a destination at distance 3 shows a witness among its first 31
+					// in-neighbours four times out of five.  (a) first line, every row; (b) second line, rows without a witness and
+					// more than 31 in-neighbours; (c) the rest of lists longer than 62 (position looked up now), 128 entries per step.
+					constexpr int UH = 4; // row octets per wavefront and step: 32 rows, four loads per lane in flight
+					const int sub8 = lane >> 3, j8 = lane & 7;
+					for (int pass = 0; pass < 2; pass++) {
+						const unsigned short *qin = pass == 0 ? s_q1 : s_q3;
+						const u32 nin = pass == 0 ? n1 : s_n4;
+						for (u32 base = (u32)wib * (8u * UH); base < nin; base += (u32)(kBallRows / 64) * (8u * UH)) {
+							u32 t[UH];
+							uint4 x0[UH];
+#pragma unroll
+							for (int u = 0; u < UH; u++) {
+								const u32 it = base + (u32)(8 * u + sub8);
+								t[u] = it < nin ? (u32)qin[it] : 0xFFFFFFFFu;
+								const u32 d = t[u] != 0xFFFFFFFFu ? s_d[t[u]] : 0u; // idle octets re-read vertex 0's head
+								const pgq_v4u r = __builtin_nontemporal_load(reinterpret_cast<const pgq_v4u *>(rhead + (size_t)d * 16 + (u32)(8 * pass + j8)));
+								x0[u] = make_uint4(r.x, r.y, r.z, r.w);
+							}
+#pragma unroll
+							for (int u = 0; u < UH; u++) {
+								const bool have = t[u] != 0xFFFFFFFFu;
+								// the in-degree: word 31 = the first line's last word (pass 1 kept it in s_in)
+								const u32 cnt = pass == 0 ? (u32)__shfl((int)x0[u].w, sub8 * 8 + 7) : (have ? s_in[t[u]].y : 0u);
+								bool hit = false;
+								if (have && cnt > 0) hit = (bit(x0[u].x) | bit(x0[u].y) | bit(x0[u].z) | ((pass == 1 || j8 < 7) ? bit(x0[u].w) : 0u)) != 0;
+								const u64 m = __ballot(hit);
+								const bool found = ((m >> (8 * sub8)) & 0xFFull) != 0;
+								if (have && j8 == 0) {
+									if (pass == 0) {
+										ent += min(cnt, 31u);
+										s_in[t[u]] = make_uint2(0u, cnt); // (the later passes and the distance-4 walk want the in-degree)
+										if (cnt == 0) s_res[t[u]] = -1; // nothing points at dst
+										else if (found) s_res[t[u]] = 3;
+										else if (cnt > 31u) s_q3[atomicAdd(&s_n4, 1u)] = (unsigned short)t[u];
+										else s_q2[atomicAdd(&s_n2, 1u)] = (unsigned short)t[u];
+									} else {
+										ent += min(cnt - 31u, 32u);
+										if (found) s_res[t[u]] = 3;
+										else if (cnt > 63u) s_q4[atomicAdd(&s_n5, 1u)] = (unsigned short)t[u];
+										else s_q2[atomicAdd(&s_n2, 1u)] = (unsigned short)t[u];
+									}
+								}
+							}
+						}
+						__syncthreads(); // pass 0's queue of second lines is complete (pass 1: so is the queue of long lists)
+					}
+				} else
 				for (u32 base = (u32)wib * (4u * UQ); base < n1; base += (u32)(kBallRows / 64) * (4u * UQ)) {
 					u32 t[UQ], ng[UQ];
 					uint2 sg[UQ];
@@ -329,16 +384,18 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 						}
 					}
 				}
-				__syncthreads();
-				const u32 n4 = s_n4;
+				if (!head) __syncthreads();
+				const u32 n4 = head ? s_n5 : s_n4;
+				const unsigned short *qlong = head ? s_q4 : s_q3;
 				for (u32 base = (u32)wib * 4u; base < n4; base += (u32)(kBallRows / 64) * 4u) {
 					const u32 it = base + (u32)sub;
 					const bool have = it < n4;
-					const u32 t = have ? (u32)s_q3[it] : 0u;
-					const uint2 sg = have ? s_in[t] : make_uint2(0u, 0u);
+					const u32 t = have ? (u32)qlong[it] : 0u;
+					// head: the list's position is looked up only now, for the few rows whose first 63 entries showed no witness
+					const uint2 sg = have ? (head ? rseg[s_d[t]] : s_in[t]) : make_uint2(0u, 0u);
 					const u32 ng = (sg.y + 3u) >> 2;
 					bool found = false;
-					u32 g0 = 16u;
+					u32 g0 = head ? 15u : 16u; // (the head holds entries 0..62: group 15 = entries 60..63 is read again)
 					while (__any(have && !found && g0 < ng)) {
 						const bool act = have && !found && g0 < ng;
 						const u32 ga = g0 + (u32)j, gb = ga + 16u;

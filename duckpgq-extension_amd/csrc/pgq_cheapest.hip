@@ -424,6 +424,18 @@ struct RelaxCounters {
 	long long bound[64];    // per lane: the largest tentative label among its destinations (nothing beyond it matters)
 };
 
+// the start of a round: the next queue's count, the round's statistics, the lanes' bounds
+__global__ void k_round_reset(RelaxCounters *__restrict__ rc, int next_par) {
+	const int t = threadIdx.x;
+	if (t < 64) rc->bound[t] = 0;
+	if (t == 0) {
+		rc->nq[next_par] = 0;
+		rc->relaxed_vertices = 0;
+		rc->min_deferred = 0x7F7F7F7F7F7F7F7Fll; // > every label
+		rc->heavy = 0;
+	}
+}
+
 #define PGQ_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PGQ_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
@@ -1228,7 +1240,9 @@ template <typename T> static bool labels_fit_32(const pgq_csr *c) {
 
 template <typename T, typename DT>
 static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int bstride, int nb, u32 U, int64_t *d_out,
-                         uint8_t *d_ok) {
+                         uint8_t *d_ok, const bool light) {
+	// `light` (and with it the label width DT) was decided ONCE by cheapest_device: a concurrent pgq_set_option between two
+	// evaluations used to leave a worker with 4-byte labels outside the light-edges-first path (an "internal error" return)
 	hipStream_t st = priv->stream;
 	const int64_t V = c->V;
 	const int64_t inf_bits = Inf<T>::bits;
@@ -1320,7 +1334,6 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 		// its lanes' bounds) — until the cap reaches the largest bound (heavier edges cannot be on a cheaper path)
 		// (a mean that is not a positive finite number — NaN / inf weights, an int64 sum that wrapped — gives no first cap:
 		// plain rounds then)
-		const bool light = light_edges_first(c) && c->wadj && c->w_mean > 0 && c->w_mean < 1e300;
 		const bool heavy = options().relax_split != 0;
 		static const bool trace = getenv("PGQ_RELAX_TRACE") != nullptr; // per-round line on stderr (measurement only)
 		auto t_round = std::chrono::steady_clock::now();
@@ -1356,11 +1369,8 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 				if (nq_now <= small_limit && h_rc->rounds > 0) continue; // hit max_rounds: go again
 			}
 			epoch++;
-			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par ^ 1], 0, 4, st));
-			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->relaxed_vertices, 0, 4, st));
-			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->min_deferred, 0x7F, 8, st)); // > every label
-			PGQ_HIP_TRY(hipMemsetAsync(d_rc->bound, 0, sizeof(d_rc->bound), st));
-			PGQ_HIP_TRY(hipMemsetAsync(&d_rc->heavy, 0, 8, st));
+			// one launch instead of five fills per round (2459 rounds per 4096-pair step on the weighted knows graph)
+			hipLaunchKernelGGL(k_round_reset, dim3(1), dim3(64), 0, st, d_rc, par ^ 1);
 			const long long thr_bits = band > T(0) ? bits_of(thr_val) : (long long)0x7FFFFFFFFFFFFFFFll;
 			{
 				KernelTimer kt(st, K_RELAX);
@@ -1481,12 +1491,15 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 		const size_t per_worker = (size_t)std::max<int64_t>(c->V, 1) * (LC * 8 + 64) + (size_t)(c->E / 64) * 4;
 		workers = (int)std::min<size_t>((size_t)workers, 1 + free_b / 2 / per_worker);
 	}
-	const bool narrow = labels_fit_32<T>(c); // (the weight-sorted copy above has left the largest weight on the handle)
+	// decided once for the whole call, handed to every worker (the weight-sorted copy above has left the mean and the largest
+	// weight on the handle; a mean that is not a positive finite number gives no first cap: plain rounds)
+	const bool light = light_edges_first(c) && c->wadj && c->w_mean > 0 && c->w_mean < 1e300;
+	const bool narrow = light && labels_fit_32<T>(c);
 	auto run_relax = [&](Workspace *priv, int b0, int bstride) -> int {
 		if constexpr (std::is_same<T, int64_t>::value) {
-			if (narrow) return relax_batches<T, int32_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok);
+			if (narrow) return relax_batches<T, int32_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok, light);
 		}
-		return relax_batches<T, int64_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok);
+		return relax_batches<T, int64_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok, light);
 	};
 	int rc = PGQ_OK;
 	if (workers == 1) {

@@ -145,6 +145,7 @@ struct Options {
 	int ball_seg_kb = 512;      // the least a segment costs in the decision, in KB at streaming rate (its ~15 dependent round trips on one of ~512 workgroup slots)
 	int calibration_cache = 1;  // what a handle measures about its graph (bytes per row of the pre-pass, level plans, ...) is kept per graph
 	                            // shape across handles (0: every handle starts from nothing; tests of the cold paths)
+	int ball_head_mb = 512;     // the fixed-stride in-list heads (pgq_csr::rhead, V x 256 bytes) are built when they fit this many MB (0: never)
 	int ball_grid = 0;          // > 0: at most this many workgroups of k_src_ball (debugging / sweeps)
 	int ball_sort = 1;          // rows with repeated sources that are NOT grouped are sorted by source first (0: such calls take the older routes)
 	double ball_bias = 1.0;     // the ball runs while ball_bias x its estimated bytes <= the cheaper of the pre-pass and the lane batches
@@ -228,6 +229,12 @@ struct pgq_csr {
 	// entries of a vertex's two-hop walk in either direction (sum of its neighbours' list lengths, saturating): the
 	// pair-centric kernels expand the endpoint whose walk is the shorter one (round 4; it was the shorter one-hop list)
 	uint32_t *fwork = nullptr, *rwork = nullptr; // V
+	// round 6, the source-centric kernel (pgq_ball.h): every vertex's first 62 in-neighbours at a FIXED stride of 256 bytes =
+	// two 128-byte lines: entries 0..30 and the in-degree in the first (most destinations at distance 3 show a witness among
+	// them: one line per row), entries 31..62 in the second; positions past the list's end repeat its last entry.  A row's
+	// scan then starts from its destination id alone: no gather of the list's position (one more 128-byte line per row, a
+	// sixth of the kernel's traffic) and no dependent round trip.  Built when V x 256 B fits `ball_head_mb`; null otherwise.
+	uint4 *rhead = nullptr; // V x 16
 	int64_t padj_groups = 0, rpadj_groups = 0;
 	std::unique_ptr<pgq::Options> opt;   // this handle's own options (pgq_csr_set_option); null: the process-wide set
 	std::atomic<int> meet_far_rows { 1 }; // the last pre-pass call left rows for k_bibfs (it is launched only then; pgq_meet.hip)
@@ -269,10 +276,12 @@ struct pgq_csr {
 		int go = 1;
 		int64_t id_n = -1; // row count of the last call whose rows stayed in place (one batch) ...
 		int id_wd = 0;     // ... and its batch width: the next call with that row count runs stage 2 ahead of its wait
-		// round 6: the last call on these buffers that the source-centric kernels looked at and DECLINED (scattered pairs): the
-		// next one does not launch them again (6 us in front of a 0.2-ms call).  Speed only.
-		int64_t ball_no_n = -1;
-		const void *ball_no_src = nullptr, *ball_no_dst = nullptr;
+		// round 6: the buffers of the last call the source-centric kernels looked at, and what they said.  Declined (scattered
+		// pairs): the next call on them does not launch the two kernels again (6 us in front of a 0.2-ms call).  Taken: the next
+		// chain is those two kernels alone, without the stage kernels that would only return at once behind them.  Speed only.
+		int64_t ball_n = -1;
+		const void *ball_src = nullptr, *ball_dst = nullptr;
+		bool ball_yes = false;
 	} route_memo;
 	// share of a call's rows the source-centric kernel left open, last time it ran on this CSR (half the weight to the newest
 	// call): above ~2 % those rows drag the lane batches along anyway (R-MAT: far and unreachable pairs), and the kernel

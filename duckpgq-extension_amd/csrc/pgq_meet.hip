@@ -1218,6 +1218,9 @@ __global__ __launch_bounds__(256) void k_emit_paths(int64_t n, const int64_t *__
 // strided sample of the rows goes through an LDS hash set, thread 0 inverts E[distinct] = U (1 - (1 - 1/U)^sample) and
 // compares the two cost estimates ON THE DEVICE: the pre-pass kernels are launched straight behind and return at once
 // when the flag says no, so the host waits once per call instead of once for the decision and once for the result.
+// Ends a chain that holds the source-centric kernels alone (meet_prepass, ball_mode 3): reports like the last stage kernel would.
+__global__ void k_chain_end(MeetDevBlock *__restrict__ db, MeetHostBlock *__restrict__ fin) { meet_finalize(db, fin); }
+
 // ball_go (nullable): the source-centric kernel in front of this one has taken the call: no sample, no pre-pass.
 __global__ __launch_bounds__(1024) void k_meet_decide(int64_t n, const int64_t *__restrict__ src, int64_t V, double meet_bytes,
                                                      double edge_bytes, MeetDecision *__restrict__ out, u32 *__restrict__ h_go,
@@ -1298,6 +1301,12 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	const bool paths = po != nullptr;
 	if (ball_ran) *ball_ran = false;
 	if (paths || !c->rseg || !c->fdesc || !c->rdesc || n < 2) ball_mode = 0;
+	// ball_mode 3: the route memo says the source-centric kernel took these buffers last time — the chain is its two kernels
+	// and a one-thread report, without the stage kernels that would only return at once behind it (65,536 one-wavefront
+	// workgroups of k_meet3 and 256 of k_meet4d starting up to read one word: 28 us of a 0.36-ms call).  If it declines this
+	// time, *ball_ran stays false, *ran = false, and the caller runs the chain again without it.
+	const bool ball_only = ball_mode == 3;
+	if (ball_only) ball_mode = 1;
 	// decide_mode 1: k_meet_decide in front of the chain, its flag gates every stage kernel on the device.  2: the route
 	// memo says the last call on these buffers was answered here: the chain runs ungated and the sample rides in k_meet4d's
 	// launch (its last workgroup, in the bit map's LDS) — *observed_go gets its verdict for the memo, -1 when none was taken
@@ -1386,9 +1395,9 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	// ---- round 6: the source-centric kernels open the chain (pgq_ball.h) ----
 	unsigned long long *b_trace = nullptr;
 	if (ball_mode) {
-		// its vertex bit map: LDS when one workgroup's map + 22 KB of row state fit (two workgroups per CU when both do), else a
+		// its vertex bit map: LDS when one workgroup's map + 23 KB of row state fit (two workgroups per CU when both do), else a
 		// slice of the global buffer the bit-map kernels use (they run only when this one declines)
-		const size_t row_state = 22 * 1024, lds_all = 160 * 1024;
+		const size_t row_state = 23 * 1024, lds_all = 160 * 1024;
 		const bool ball_lds = (size_t)bm_words * 4 + row_state <= std::min(lds_all, lds_budget + row_state);
 		unsigned grid_b = 0;
 		size_t ball_maps = 0;
@@ -1410,15 +1419,15 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			PGQ_TRY(ws->ball_segs.reserve((size_t)n * 4));
 			static std::atomic<int> ball_attr { 0 };
 			if (!ball_attr.load()) {
-				(void)hipFuncSetAttribute((const void *)k_src_ball<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
-				(void)hipFuncSetAttribute((const void *)k_src_ball<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+				(void)hipFuncSetAttribute((const void *)k_src_ball<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 137 * 1024);
+				(void)hipFuncSetAttribute((const void *)k_src_ball<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 137 * 1024);
 				ball_attr.store(1);
 			}
 			BallRule rule;
 			const double mean_deg = (double)c->E / (double)std::max<int64_t>(c->V, 1);
 			rule.seg_floor = 1024.0 * (double)std::max(0, opt.ball_seg_kb);
 			rule.seg_bytes = 4.0 * c->two_hop_mean + 32.0 * mean_deg + 64.0;
-			rule.row_bytes = 4.0 * std::min(mean_deg, 64.0) + 128.0 + 32.0; // the first 64 entries of the in-list, the line its position sits in, the row
+			rule.row_bytes = 4.0 * std::min(mean_deg, 64.0) + (c->rhead ? 0.0 : 128.0) + 32.0; // the first 64 entries of the in-list, the line its position sits in (without rhead), the row
 			rule.meet_bytes = meet_bytes;
 			rule.edge_bytes = edge_bytes > 0 ? edge_bytes : (double)c->E;
 			rule.bias = opt.ball_bias;
@@ -1436,7 +1445,8 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			}
 #define PGQ_BALL(G, T, LDS)                                                                                                  \
 	hipLaunchKernelGGL((k_src_ball<G, T>), dim3(grid_b), dim3(kBallRows), LDS, st, n, d_src, d_dst, c->V, c->off, c->roff, c->fdesc, \
-	                   c->rdesc, c->padj, c->rpadj, c->rseg, ws->ball_segs.as<u32>(), d_out, capb, tcap, bm_words, db, gmaps, q[0], rule, b_trace)
+	                   c->rdesc, c->padj, c->rpadj, c->rseg, opt.ball_head_mb > 0 ? c->rhead : (const uint4 *)nullptr, ws->ball_segs.as<u32>(), d_out, capb, tcap, \
+	                   bm_words, db, gmaps, q[0], rule, b_trace)
 			if (ball_lds && b_trace) PGQ_BALL(false, true, (size_t)bm_words * 4);
 			else if (ball_lds) PGQ_BALL(false, false, (size_t)bm_words * 4);
 			else if (b_trace) PGQ_BALL(true, true, 0);
@@ -1444,6 +1454,29 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 #undef PGQ_BALL
 			kt.stop();
 		}
+	}
+	if (ball_only && ball_mode) {
+		hipLaunchKernelGGL(k_chain_end, dim3(1), dim3(64), 0, st, db, hb);
+		PGQ_TRY(meet_wait(ws, hb));
+		const MeetHostBlock &h = *hb;
+		if (h.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
+		if (!h.ball_go) { // not this time: nothing was answered
+			S.algo_bytes[K_BALL] += 16.0 * (double)n;
+			if (ran) *ran = false;
+			*n_open = (u32)n;
+			return PGQ_OK;
+		}
+		if (ball_ran) *ball_ran = true;
+		ws->open_src = q[0].src;
+		ws->open_dst = q[0].dst;
+		ws->open_idx = q[0].idx;
+		S.meet_pairs += n - (int64_t)h.ball_open;
+		S.edges_scanned += (int64_t)h.ball_entries;
+		S.algo_bytes[K_BALL] += 4.0 * (double)h.ball_entries + 16.0 * (double)h.ball_descs + 32.0 * (double)n + 24.0 * (double)h.ball_nseg;
+		S.ball_segments += h.ball_nseg;
+		S.ball_calls++;
+		*n_open = h.ball_open;
+		return PGQ_OK;
 	}
 	// (tried in round 4: the decision kernel on a stream of its own beside k_meet3, which polls a stop flag — the event
 	// record / wait pair costs what the 12 us kernel does, and the polled word must be spread over many lines)

@@ -2248,6 +2248,9 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 			plan = c->level_plan[plan_slot];
 		}
 		bool have_last = false;
+		// (a plan whose FIRST level cannot be enqueued — a packed sparse level without the lane-list kernel — buys nothing: the
+		// logging launch and its wait would only be added in front of the round-trip loop)
+		if (!plan.empty() && (plan[0] & kLvSparse) && !lanes_ok) plan.clear();
 		if (!plan.empty()) {
 			std::vector<HostState> snaps;
 			u32 *status = reinterpret_cast<u32 *>(ws->h_log + kSpecLevels + 2);
@@ -2536,7 +2539,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		else if (mopt.route_memo && outp.ball_hint < 0) { // (a caller that has looked at the rows knows better than the memo)
 			std::lock_guard<std::mutex> g(c->plan_lock);
 			const pgq_csr::RouteMemo &m = c->route_memo;
-			if (m.ball_no_n == n && m.ball_no_src == (const void *)d_src && m.ball_no_dst == (const void *)d_dst) ball_mode = 0;
+			if (m.ball_n == n && m.ball_src == (const void *)d_src && m.ball_dst == (const void *)d_dst) ball_mode = m.ball_yes ? 3 : 0;
 		}
 	}
 	const int ball_asked = ball_mode;
@@ -2610,11 +2613,16 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		const double b0 = S.algo_bytes[K_MEET] + S.algo_bytes[K_MEET4] + S.algo_bytes[K_BIBFS];
 		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide_mode, meet_bytes, edge_bytes, ran, &observed_go,
 		                     ball_mode, &ball_ran));
-		if (ball_asked == 1 && outp.ball_hint < 0) { // what the kernels said about these buffers
+		if ((ball_asked == 1 || ball_asked == 3) && outp.ball_hint < 0) { // what the kernels said about these buffers
 			std::lock_guard<std::mutex> g(c->plan_lock);
-			c->route_memo.ball_no_n = ball_ran ? -1 : n;
-			c->route_memo.ball_no_src = d_src;
-			c->route_memo.ball_no_dst = d_dst;
+			c->route_memo.ball_n = n;
+			c->route_memo.ball_src = d_src;
+			c->route_memo.ball_dst = d_dst;
+			c->route_memo.ball_yes = ball_ran;
+		}
+		if (ball_asked == 3 && !ball_ran) { // the kernels-alone chain declined these rows: the stage kernels after all
+			*ran = true;
+			PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide_mode, meet_bytes, edge_bytes, ran, &observed_go, 0, nullptr));
 		}
 		if (ball_ran && n >= 1024) {
 			const double now = (double)nd / (double)n, old = c->ball_open_frac.load(std::memory_order_relaxed);

@@ -241,6 +241,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "ball_sort", &o.ball_sort, nullptr },
 		{ "ball_seg_kb", &o.ball_seg_kb, nullptr },
 		{ "ball_grid", &o.ball_grid, nullptr },
+		{ "ball_head_mb", &o.ball_head_mb, nullptr },
 		{ "calibration_cache", &o.calibration_cache, nullptr },
 		{ "ball_bias", nullptr, &o.ball_bias },
 	};
@@ -1127,10 +1128,42 @@ static int build_meet_layout_dir(pgq_csr *c, const int64_t *off, const int32_t *
 	*groups_out = (int64_t)total;
 	return PGQ_OK;
 }
+// rhead (pgq_internal.h): 64 words per vertex = two 128-byte lines.  Word 31 — the last of the FIRST line — is the in-degree;
+// words 0..30 are the list's entries 0..30, words 32..63 its entries 31..62; positions past the list's end repeat its last
+// entry (an empty list: all ones, never tested because its count is 0).  One thread per 16-byte group.
+__global__ __launch_bounds__(256) void k_fill_rhead(int64_t V, const uint2 *__restrict__ seg, const int32_t *__restrict__ padj,
+                                                    uint4 *__restrict__ head) {
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	const int64_t v = t >> 4;
+	const u32 j = (u32)(t & 15);
+	if (v >= V) return;
+	const uint2 s = seg[v];
+	const u32 cnt = s.y;
+	u32 x[4];
+#pragma unroll
+	for (u32 k = 0; k < 4; k++) {
+		const u32 w = 4u * j + k;
+		if (w == 31u) {
+			x[k] = cnt;
+		} else if (cnt == 0u) {
+			x[k] = 0xFFFFFFFFu;
+		} else {
+			const u32 e = min(w < 31u ? w : w - 1u, cnt - 1u);
+			x[k] = (u32)padj[(size_t)s.x * 4 + e];
+		}
+	}
+	head[v * 16 + j] = make_uint4(x[0], x[1], x[2], x[3]);
+}
 static int build_meet_layout(pgq_csr *c, hipStream_t st) {
 	if (!options().meet_layout || c->V <= 0 || c->E <= 0) return PGQ_OK;
 	PGQ_TRY(build_meet_layout_dir(c, c->off, c->adj, &c->padj, &c->fseg, &c->fdesc, &c->fwork, &c->padj_groups, st));
 	PGQ_TRY(build_meet_layout_dir(c, c->roff, c->radj, &c->rpadj, &c->rseg, &c->rdesc, &c->rwork, &c->rpadj_groups, st));
+	if (options().ball && (size_t)c->V * 256 <= ((size_t)std::max(0, options().ball_head_mb) << 20)) {
+		if (dev_alloc_as(&c->rhead, (size_t)c->V * 16) == PGQ_OK) // (no memory for it: the kernel gathers the list positions instead)
+			hipLaunchKernelGGL(k_fill_rhead, dim3((unsigned)((c->V * 16 + 255) / 256)), dim3(256), 0, st, c->V, c->rseg, c->rpadj, c->rhead);
+		else
+			c->rhead = nullptr;
+	}
 	return PGQ_OK;
 }
 
@@ -1295,7 +1328,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 		(void)hipGetLastError();
 		if (options().trace) fprintf(stderr, "[pgq] upload: no memory for the pair-centric layout (~40 B per edge): this CSR is searched without the pre-pass\n");
 		for (void **q : { (void **)&c->padj, (void **)&c->rpadj, (void **)&c->fseg, (void **)&c->rseg, (void **)&c->fdesc,
-		                  (void **)&c->rdesc, (void **)&c->fwork, (void **)&c->rwork }) {
+		                  (void **)&c->rdesc, (void **)&c->fwork, (void **)&c->rwork, (void **)&c->rhead }) {
 			dev_free(*q);
 			*q = nullptr;
 		}
@@ -1305,7 +1338,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	tr.mark("padded adjacency + slot descriptors");
 	c->bytes = (V + 1) * 16 + 8 * V + E * (4 + 4 + 1 + (c->rpk ? 4 : 0)) + (c->edge_ids ? E * 8 : 0) + (c->w ? E * 8 : 0) +
 	           n_items * (int64_t)sizeof(HubItem) +
-	           (c->fdesc ? 2 * E * 16 + 2 * V * 12 + (c->padj_groups + c->rpadj_groups) * 16 : 0);
+	           (c->fdesc ? 2 * E * 16 + 2 * V * 12 + (c->padj_groups + c->rpadj_groups) * 16 : 0) + (c->rhead ? V * 256 : 0);
 	return PGQ_OK;
 }
 
@@ -1380,6 +1413,7 @@ static void destroy_csr(pgq_csr *c) {
 	dev_free(c->rpadj);
 	dev_free(c->fseg);
 	dev_free(c->rseg);
+	dev_free(c->rhead);
 	dev_free(c->fwork);
 	dev_free(c->rwork);
 	dev_free(c->fdesc);
@@ -1715,6 +1749,7 @@ static int clone_csr(const pgq_csr *c, int dev, pgq_csr **out) {
 	PGQ_TRY(copy((void **)&r->rpadj, c->rpadj, (size_t)c->rpadj_groups * 16 + 16));
 	PGQ_TRY(copy((void **)&r->fseg, c->fseg, (size_t)c->V * 8));
 	PGQ_TRY(copy((void **)&r->rseg, c->rseg, (size_t)c->V * 8));
+	PGQ_TRY(copy((void **)&r->rhead, c->rhead, (size_t)c->V * 256));
 	PGQ_TRY(copy((void **)&r->fwork, c->fwork, (size_t)c->V * 4));
 	PGQ_TRY(copy((void **)&r->rwork, c->rwork, (size_t)c->V * 4));
 	PGQ_TRY(copy((void **)&r->fdesc, c->fdesc, (En + 1) * 16));

@@ -124,6 +124,7 @@ __device__ __forceinline__ int seg_owner(const SegRound &r, u32 x0, unsigned cha
 	return (int)wave_incl_max_u32(own) - 1;
 }
 typedef int pgq_v4i __attribute__((ext_vector_type(4)));
+typedef unsigned int pgq_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int4 load_group_nt(const int32_t *__restrict__ xp, u32 group) {
 	// streamed once: non-temporal, so that the lists do not push the descriptors of hot vertices out of L2
 	const pgq_v4i r = __builtin_nontemporal_load(reinterpret_cast<const pgq_v4i *>(xp + (size_t)group * 4));

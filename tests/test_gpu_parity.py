@@ -25,7 +25,7 @@ def _defaults():
                  ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1),
                  # the source-centric kernel (round 6) would take every grouped input before the kernels under test see it; its own
                  # tests and the shipped configuration switch it on
-                 ("ball", 0), ("ball_cap", 1 << 20), ("ball_test_cap", 1 << 15), ("ball_bias", 1.0), ("ball_sort", 1), ("ball_seg_kb", 512), ("ball_grid", 0)):
+                 ("ball", 0), ("ball_cap", 1 << 20), ("ball_test_cap", 1 << 15), ("ball_bias", 1.0), ("ball_sort", 1), ("ball_seg_kb", 512), ("ball_grid", 0), ("ball_head_mb", 512)):
         pgq.set_option(k, v)
     yield
 
@@ -320,9 +320,10 @@ def grouped_rows(rng, V, runs, null_run=0):
     return ps, pd, valid
 
 
+@pytest.mark.parametrize("head_mb", [512, 0])
 @pytest.mark.parametrize("lds_kb", [150, 0])
 @pytest.mark.parametrize("ball_cap,test_cap", [(1 << 20, 1 << 15), (300, 1 << 15), (1 << 20, 40)])
-def test_source_centric_ball_matches_oracle(lds_kb, ball_cap, test_cap):
+def test_source_centric_ball_matches_oracle(lds_kb, ball_cap, test_cap, head_mb):
     # k_ball_segments + k_src_ball (pgq_ball.h): rows grouped by source answered from ONE two-hop ball per source run in a
     # vertex bit map (LDS, or a global slice: lds_kb = 0) — d in S1 / S2, an in-neighbour of d in S2 (3), an in-neighbour
     # of an in-neighbour (4); what it leaves open (distance >= 5, unreachable, balls / walks over their caps) goes through
@@ -331,6 +332,9 @@ def test_source_centric_ball_matches_oracle(lds_kb, ball_cap, test_cap):
     pgq.set_option("meet", 1)
     pgq.set_option("meet_bias", 1e9)
     pgq.set_option("ball", 2)  # forced: the decision has its own test
+    # in-list heads at a fixed stride (pgq_csr::rhead, read at upload and at launch): a row's scan starts from its destination
+    # id alone / 0: the list positions are gathered per row (graphs whose heads do not fit the budget)
+    pgq.set_option("ball_head_mb", head_mb)
     pgq.set_option("ball_cap", ball_cap)
     pgq.set_option("ball_test_cap", test_cap)
     pgq.set_option("meet4_lds_kb", lds_kb)
@@ -402,6 +406,26 @@ def test_source_centric_ball_is_chosen_by_the_source_runs():
             ln, ok = st.iterativelength(0, V, ps, pd)
             assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
             assert (pgq.get_stats()["ball_calls"] >= 1) == expect_ball, (per, rep, pgq.get_stats())
+    # the same device buffers, first grouped (the kernel takes them: the next chain on these buffers is its two kernels alone),
+    # then overwritten in place with scattered pairs: that chain declines and the stage kernels run after all
+    import torch
+    dev = st.device_csr(0)
+    ps = np.repeat(srcs, 600)
+    pd = rng.integers(0, V, len(ps))
+    t_s, t_d = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+    t_o = torch.empty(len(ps), dtype=torch.int64, device="cuda")
+    for rep in range(2):
+        dev.iterativelength_bulk_ptr(len(ps), t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+    assert (t_o.cpu().numpy() == np.where(ook, oln, -1)).all()
+    ps2 = rng.integers(0, V, len(ps))
+    t_s.copy_(torch.from_numpy(ps2))
+    oln, ook = ora.lean_iterativelength(V, ps2, pd, nthreads=4)
+    for rep in range(2):
+        pgq.reset_stats()
+        dev.iterativelength_bulk_ptr(len(ps), t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+        assert (t_o.cpu().numpy() == np.where(ook, oln, -1)).all()
+        assert pgq.get_stats()["ball_calls"] == 0
     # 3 sources x every vertex: one narrow lane batch is cheaper than 60 balls + 60,000 in-list scans
     ps = np.repeat(srcs[:3], V)
     pd = np.tile(np.arange(V, dtype=np.int64), 3)

@@ -147,7 +147,7 @@ static int lcc_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src
 	PGQ_TRY(ws->counters.reserve(sizeof(Counters)));
 	u32 *d_cnt = reinterpret_cast<u32 *>(ws->counters.p); // [0] long-list rows, [1] bad id, [2] compaction cursor
 	PGQ_HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, st));
-	hipLaunchKernelGGL(k_lcc, dim3((unsigned)std::min<int64_t>(n, 256 * 24 * 4)), dim3(64), 0, st, n, d_src, c->V, c->off, c->adj,
+	hipLaunchKernelGGL(k_lcc, dim3((unsigned)std::min<int64_t>(n, (int64_t)device_cus() * 24 * 4)), dim3(64), 0, st, n, d_src, c->V, c->off, c->adj,
 	                   d_out, d_cnt);
 	u32 h[2] = { 0, 0 };
 	PGQ_HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -388,7 +388,7 @@ static int wcc_compute(pgq_csr *c, Workspace *ws) {
 			PGQ_TRY(best.reserve((size_t)V * 8));
 			PGQ_TRY(msf.reserve((size_t)E));
 			PGQ_TRY(cnt.reserve(64));
-			hipLaunchKernelGGL(k_wcc_slot_src, dim3(256 * 8), dim3(256), 0, st, V, c->off, slot_src.as<u32>());
+			hipLaunchKernelGGL(k_wcc_slot_src, dim3((unsigned)device_cus() * 8), dim3(256), 0, st, V, c->off, slot_src.as<u32>());
 			hipLaunchKernelGGL(k_wcc_init, dim3(blocks_for(V)), dim3(256), 0, st, V, comp.as<u32>());
 			PGQ_HIP_TRY(hipMemsetAsync(msf.p, 0, (size_t)E, st));
 			u32 *cur = comp.as<u32>(), *nxt = comp2.as<u32>();

@@ -1116,7 +1116,7 @@ static int weighted_pairs_prepass(pgq_csr *c, Workspace *ws, u32 nd, int64_t *d_
 	long long *dist = ws->wb_scratch.as<long long>();
 	u32 *queues = reinterpret_cast<u32 *>(dist + dist_words);
 	if (fresh) { // every label infinite; the kernel restores what it touched
-		hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, (int64_t *)dist, (int64_t)dist_words, (int64_t)kWbInf);
+		hipLaunchKernelGGL(k_fill64, dim3((unsigned)device_cus() * 8), dim3(256), 0, st, (int64_t *)dist, (int64_t)dist_words, (int64_t)kWbInf);
 		ws->wb_V = c->V;
 		ws->wb_grid = (int)grid;
 	}
@@ -1272,8 +1272,8 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 	RelaxCounters *d_rc = reinterpret_cast<RelaxCounters *>(priv->counters.p);
 	RelaxCounters *h_rc = reinterpret_cast<RelaxCounters *>(priv->h_cnt);
 	if (fresh) {
-		if constexpr (sizeof(DT) == 4) hipLaunchKernelGGL(k_fill32, dim3(256 * 8), dim3(256), 0, st, priv->dist.as<int32_t>(), (int64_t)cells, (int32_t)inf_label);
-		else hipLaunchKernelGGL(k_fill64, dim3(256 * 8), dim3(256), 0, st, priv->dist.as<int64_t>(), (int64_t)cells, inf_bits);
+		if constexpr (sizeof(DT) == 4) hipLaunchKernelGGL(k_fill32, dim3((unsigned)device_cus() * 8), dim3(256), 0, st, priv->dist.as<int32_t>(), (int64_t)cells, (int32_t)inf_label);
+		else hipLaunchKernelGGL(k_fill64, dim3((unsigned)device_cus() * 8), dim3(256), 0, st, priv->dist.as<int64_t>(), (int64_t)cells, inf_bits);
 	}
 	PGQ_HIP_TRY(hipMemsetAsync(priv->dirty[0].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
 	PGQ_HIP_TRY(hipMemsetAsync(priv->dirty[1].p, 0, (size_t)std::max<int64_t>(V, 1) * 8, st));
@@ -1429,7 +1429,7 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 				else wcap = wcap > std::numeric_limits<int64_t>::max() / 2 ? std::numeric_limits<int64_t>::max() : wcap + wcap;
 				// every labelled vertex again, over the longer prefix of its list
 				PGQ_HIP_TRY(hipMemsetAsync(&d_rc->nq[par], 0, 4, st));
-				hipLaunchKernelGGL(k_redirty, dim3(256 * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
+				hipLaunchKernelGGL(k_redirty, dim3((unsigned)device_cus() * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
 				                   priv->dirty[par].as<u64>(), priv->qbuf[par].as<int32_t>(), &d_rc->nq[par]);
 				PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
 				PGQ_HIP_TRY(hipStreamSynchronize(st));
@@ -1451,7 +1451,7 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 		hipLaunchKernelGGL(k_cheapest_results<DT>, dim3(blocks_for(hi - lo)), dim3(256), 0, st, lo, hi, ws->skey.as<u32>(),
 		                   ws->sidx.as<u32>(), ws->sdst.as<int32_t>(), (u32)base, priv->dist.as<DT>(), inf_bits,
 		                   d_out, d_ok);
-		hipLaunchKernelGGL(k_reset_touched<DT>, dim3(256 * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
+		hipLaunchKernelGGL(k_reset_touched<DT>, dim3((unsigned)device_cus() * 4), dim3(256), 0, st, priv->touched.as<int32_t>(), &d_rc->tcount,
 		                   priv->dist.as<DT>(), inf_label);
 	}
 	PGQ_HIP_TRY(hipStreamSynchronize(st));

@@ -1290,7 +1290,7 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 	calibration_load(c); // (max degrees and E are set above)
 	c->n_pull_parts = us.n_parts;
 	if (us.n_parts > 0)
-		hipLaunchKernelGGL(k_fill_rown, dim3(256 * 8), dim3(256), 0, st, c->roff, c->pull_parts, c->n_pull_parts, c->radj,
+		hipLaunchKernelGGL(k_fill_rown, dim3((unsigned)device_cus() * 8), dim3(256), 0, st, c->roff, c->pull_parts, c->n_pull_parts, c->radj,
 		                   c->rown, c->rpk);
 	tr.mark("degree statistics, parts, owner bytes");
 	int64_t n_items = 0;

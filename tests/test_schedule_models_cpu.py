@@ -834,3 +834,104 @@ def test_levels_enqueued_ahead_protocol_matches_the_round_trip_loop():
             assert ran == want_ran, (trial, variant, plan, ran, want_ran)
             assert m.res == ref.res
     assert codes >= {1, 2, 3}
+
+
+# ---- round 6: the source-centric kernel (pgq_ball.h) ---------------------------------------------------------------------
+
+def ball_segments_model(src):
+    """k_ball_segments: a segment starts where the source changes or at a multiple of 1024 rows."""
+    n = len(src)
+    starts = [i for i in range(n) if i % 1024 == 0 or src[i] != src[i - 1]]
+    return [(a, (starts[k + 1] if k + 1 < len(starts) else n)) for k, a in enumerate(starts)]
+
+
+def ball_model(V, off, adj, roff, radj, s, dsts, ball_cap=None, test_cap=None, rng=None):
+    """k_src_ball for one segment (source s, destinations dsts): the answers it writes, None where it leaves the row open.
+    ball_cap: the two-hop walk is cut after that many entries (S2 incomplete); test_cap: the backward walk of a distance-4
+    candidate is cut.  The head layout (entries 0..30 / 31..62 / the rest of the list) only orders the tests: a row is
+    answered 3 iff ANY in-neighbour is in S2, which the three passes together cover."""
+    out = []
+    if s < 0:
+        return [-1] * len(dsts)
+    nb1 = adj[off[s]:off[s + 1]]
+    S1 = set(nb1.tolist())
+    S2 = set(S1)
+    walked, cut = 0, False
+    order = list(nb1.tolist())
+    if rng is not None:
+        rng.shuffle(order)  # 16 wavefronts share the rounds: no particular order
+    for v in order:
+        lst = adj[off[v]:off[v + 1]].tolist()
+        if ball_cap is not None and walked + len(lst) > ball_cap:
+            S2.update(lst[:max(0, ball_cap - walked)])
+            cut = True
+            break
+        walked += len(lst)
+        S2.update(lst)
+    for d in dsts:
+        if d == s:
+            out.append(0)
+            continue
+        if len(nb1) == 0 or roff[d + 1] == roff[d]:
+            out.append(-1)
+            continue
+        if d in S1:
+            out.append(1)
+            continue
+        if d in S2:  # holds for an incomplete S2 as well: S1 is complete, so d is not at distance 1
+            out.append(2)
+            continue
+        if cut:
+            out.append(None)
+            continue
+        ins = radj[roff[d]:roff[d + 1]].tolist()
+        head1, head2, rest = ins[:31], ins[31:62], ins[60:]  # first line, second line, the list from group 15 on
+        if any(u in S2 for u in head1) or any(u in S2 for u in head2) or any(u in S2 for u in rest):
+            out.append(3)
+            continue
+        found, scanned, capped = False, 0, False
+        for u in ins:
+            lst = radj[roff[u]:roff[u + 1]].tolist()
+            if test_cap is not None and scanned + len(lst) > test_cap:
+                capped = True
+                lst = lst[:max(0, test_cap - scanned)]
+            scanned += len(lst)
+            if any(x in S2 for x in lst):
+                found = True
+                break
+            if capped:
+                break
+        out.append(4 if found else None)
+    return out
+
+
+def test_source_centric_ball_rule_matches_bfs():
+    """The distances k_src_ball writes are BFS distances (iterativelength.cpp:34-143), with complete and with cut balls and
+    walks; what it leaves open is at distance >= 5, unreachable, or behind a cap; the segments cover every row once."""
+    rng = np.random.default_rng(66)
+    for trial in range(12):
+        V = int(rng.integers(30, 400))
+        E = int(V * rng.uniform(1.0, 6.0))
+        s = (rng.random(E) ** (1 + trial % 3) * V).astype(np.int64)
+        d = rng.integers(0, V, E)
+        off, adj, roff, radj, _, _, _ = _csr(V, s, d)
+        ora = OracleCSR.from_edges(V, s, d, np.arange(E, dtype=np.int64))
+        runs = rng.integers(1, 40, 12)
+        srcs = rng.integers(0, V, len(runs))
+        ps = np.concatenate([np.full(r, x, dtype=np.int64) for x, r in zip(srcs, runs)])
+        pd = rng.integers(0, V, len(ps))
+        segs = ball_segments_model(ps)
+        assert sorted(i for a, b in segs for i in range(a, b)) == list(range(len(ps)))
+        assert all(len(set(ps[a:b].tolist())) == 1 and b - a <= 1024 for a, b in segs)
+        oln, ook = ora.lean_iterativelength(V, ps, pd)
+        for caps in ((None, None), (int(rng.integers(1, 50)), None), (None, int(rng.integers(1, 30)))):
+            for a, b in segs:
+                got = ball_model(V, off, adj, roff, radj, int(ps[a]), pd[a:b].tolist(), caps[0], caps[1], rng)
+                for k, g in enumerate(got):
+                    want = int(oln[a + k]) if ook[a + k] else -1
+                    if g is None:
+                        assert want == -1 or want >= 3 or caps != (None, None)
+                        if caps == (None, None):
+                            assert want == -1 or want >= 5
+                    else:
+                        assert g == want, (trial, caps, int(ps[a]), int(pd[a + k]), g, want)

@@ -9,7 +9,7 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 rdir = os.path.join(root, "profiles", rnd)
 
 
@@ -23,7 +23,7 @@ def load(name):
         return None
 
 
-CLASS_OF = {"k_meet3": "meet", "k_meet4d": "meet4", "k_bibfs": "bibfs", "k_pull_lanes": "pull_sparse"}
+CLASS_OF = {"k_meet3": "meet", "k_meet4d": "meet4", "k_bibfs": "bibfs", "k_pull_lanes": "pull_sparse", "k_src_ball": "ball"}
 
 
 def fmt(x, spec="{:,.0f}"):
@@ -31,33 +31,35 @@ def fmt(x, spec="{:,.0f}"):
 
 
 L = ["# profiles — round %s measurements (MI355X, one GPU per gpurun box)" % rnd.lstrip("r0"), "",
-     "Produced by committed tooling only: `tools/measure_pass_r05.sh` on the GPU box (PART=1: `bench.py` with the driver's own "
-     "command — every BASELINE config is a leg of that one line since round 5 — and the call shapes beside it, `rocprofv3 "
-     "--kernel-trace --stats` of the default workload without its legs (`--no-legs`: every `k_meet3` / `k_meet4d` call is a "
-     "65,536-row one) and of the cross product (`--workload snb_cross`), `tools/chunk_latency.py`; PART=2: separate `--pmc` "
-     "passes of both workloads, summarised by `tools/pmc_summary.py` into `profiles/pmc_<workload>.json` (FETCH_SIZE doubled "
-     "per MI355X_MICROARCH.md §HBM); PART=3: the whole `-m gpu` suite (`pytest_gpu.txt`); PART=4: configs[4] at its named scale).  "
-     "The `tools/membench` figures quoted in DESIGN.md are round 3's (`profiles/r03/membench_*`).  Regenerate this file with "
-     "`python tools/make_profile_readme.py %s`.  `profiles/r01/` … `profiles/r04/` are the previous rounds." % rnd,
+     "Produced by committed tooling only: `tools/measure_pass_%s.sh` on the GPU box (PART=1: `bench.py` with the driver's own "
+     "command — every BASELINE config and call shape is a leg of that one line — and the shapes beside it on their routes, "
+     "`rocprofv3 --kernel-trace --stats` of the default workload without its legs, of the SF100 cross product as routed "
+     "(`k_src_ball`) and forced through the lane batches (`PGQ_BALL=0`), and of the R-MAT-22 cross product, "
+     "`tools/chunk_latency.py`; PART=2: separate `--pmc` passes of those four workloads, summarised by `tools/pmc_summary.py` "
+     "into `profiles/pmc_<workload>.json` (FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)).  `tools/h2dbench.hip` is the "
+     "PCIe / host-copy yardstick of the upload path (`profiles/%s/h2dbench.txt`).  Regenerate this file with "
+     "`python tools/make_profile_readme.py %s`.  `profiles/r01/` … are the previous rounds." % (rnd, rnd, rnd),
      ""]
 default = load("bench_default.json")
 rows = []  # (title, leg-like dict)
 if default:
     top = dict(default)
     rows.append(("configs[3] on one GPU: SF100-shaped knows, iterativelength, 65,536 random pairs (the line's top level = leg `prepass`)", top))
-    titles = {"msbfs_cross": "same graph, the binder's call shape: 2048 sources x 1024 destinations = 2.1 M rows (leg `msbfs_cross`, lane-batched MS-BFS)",
+    titles = {"msbfs_cross": "same graph, the binder's call shape: 2048 sources x 1024 destinations = 2.1 M rows grouped by source (leg `msbfs_cross`, as routed: the source-centric kernel `k_src_ball`)",
+              "msbfs_cross_lanes": "the same rows forced through the lane-batched MS-BFS (leg `msbfs_cross_lanes`, `ball = 0`)",
+              "msbfs_cross_rmat22": "R-MAT scale 22 in the binder's call shape: 2048 x 1024 rows (leg `msbfs_cross_rmat22`, as routed)",
               "snb_paths": "configs[2]: SF100-shaped knows, shortestpath + reconstruction, 4096 pairs (leg `snb_paths`)",
               "rmat22": "configs[1]: R-MAT scale 22, iterativelength, 1024 pairs (leg `rmat22`)",
               "forest_cheapest": "configs[4]: reply forest V = 2^24, int64 weights, cheapest_path_length, 4096 pairs (leg `forest_cheapest`)",
               "cheapest_general": "configs[4]'s operator on a general graph: weighted knows graph, 4096 pairs (leg `cheapest_general`, one step)"}
-    for k in ("msbfs_cross", "snb_paths", "rmat22", "forest_cheapest", "cheapest_general"):
+    for k in ("msbfs_cross", "msbfs_cross_lanes", "msbfs_cross_rmat22", "snb_paths", "rmat22", "forest_cheapest", "cheapest_general"):
         if k in (default.get("legs") or {}):
             rows.append((titles[k], default["legs"][k]))
 for w, title in (("snb_sf100_8192", "SF100 graph, 8192 random pairs (configs[3]'s shard at 8 GPUs)"),
                  ("snb_sf100_2048", "SF100 graph, 2048 random pairs (one DuckDB chunk's worth, device arrays)"),
-                 ("snb_sf100_8192_msbfs_only", "8192 random pairs, `PGQ_MEET=0` (lane-batched MS-BFS only)"),
-                 ("snb_cross_2048x32", "cross product 2048 sources x 32 destinations = 65,536 rows (routed to the pre-pass since round 5)"),
-                 ("snb_cross_2048x32_lanes", "the same rows with `PGQ_MEET=0` (lane batches: round 4's route)"),
+                 ("snb_cross_2048x32", "cross product 2048 sources x 32 destinations = 65,536 rows (the device's decision: pre-pass)"),
+                 ("snb_cross_2048x128", "cross product 2048 sources x 128 destinations = 262,144 rows (source-centric kernel)"),
+                 ("rmat22_cross_lanes", "R-MAT-22 cross product through the lane batches alone (`PGQ_MEET=0`: no source-centric kernel, no pre-pass)"),
                  ("snb_cross_allv", "32 sources x every vertex = 14.4 M rows"),
                  ("forest_cheapest_double", "configs[4], double weights"),
                  ("forest_cheapest_2_28", "configs[4] at the named scale: reply forest V = 2^28 (268 M vertices, 215 M edges), int64 weights")):
@@ -81,8 +83,9 @@ for title, j in rows:
     # traffic: from the PMC files as committed (the bench line embeds what the file held when it ran), and only where the
     # counters were collected on this shape: the default workload and the 2048 x 1024 cross product
     tr = None
-    pmc_of = {"prepass": ("pmc_snb_sf100.json", "prepass_chain"), "msbfs_cross": ("pmc_snb_cross.json", "chain")}
-    key = "prepass" if j is rows[0][1] else ("msbfs_cross" if "msbfs_cross" in title else None)
+    pmc_of = {"prepass": ("pmc_snb_sf100.json", "prepass_chain"), "msbfs_cross": ("pmc_snb_cross_ball.json", "prepass_chain"),
+              "msbfs_cross_lanes": ("pmc_snb_cross.json", "chain"), "msbfs_cross_rmat22": ("pmc_rmat22_cross.json", "prepass_chain")}
+    key = "prepass" if j is rows[0][1] else next((k for k in ("msbfs_cross_rmat22", "msbfs_cross_lanes", "msbfs_cross") if "`%s`" % k in title), None)
     if key:
         try:
             tr = json.load(open(os.path.join(root, "profiles", pmc_of[key][0])))[pmc_of[key][1]]["hbm_bytes_per_step"]

@@ -45,8 +45,11 @@ struct BallRule {
 // ONE returning atomic and writes them in order (a wave-level atomic per 64 rows would be 33,000 returning atomics on one
 // address for 2.1 M rows: ~0.5 ms; the first version, 1024 workgroups + a ticket: 44 us).  k_src_ball's workgroups read the
 // two totals and decide for themselves whether the kernel takes the call (ball_decides).
+// seg_rows (a power of two <= 1024): a segment also ends at every multiple of it — 1024 for large calls; a chunk-sized call is
+// cut into 128-row segments so that its one or two sources are answered by 16 workgroups at once, each building the same
+// (small) ball, instead of by one or two working through 1024 rows each.
 __global__ __launch_bounds__(1024) void k_ball_segments(int64_t n, const int64_t *__restrict__ src, u32 *__restrict__ segs,
-                                                        MeetDevBlock *__restrict__ db) {
+                                                        MeetDevBlock *__restrict__ db, u32 seg_rows) {
 	__shared__ u32 s_cnt[16], s_run[16], s_base;
 	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 	const int64_t nwin = (n + kBallRows - 1) / kBallRows;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(1024) void k_ball_segments(int64_t n, const int64_t
 		if (i < n) {
 			const bool ch = i == 0 || src[i] != src[i - 1];
 			runs += ch ? 1u : 0u;
-			starts += (ch || tid == 0) ? 1u : 0u;
+			starts += (ch || ((u32)tid & (seg_rows - 1u)) == 0u) ? 1u : 0u;
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1) {
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(1024) void k_ball_segments(int64_t n, const int64_t
 	for (int64_t w = w0; w < w1; w++) {
 		const int64_t i = w * kBallRows + tid;
 		bool st = false;
-		if (i < n) st = tid == 0 || src[i] != src[i - 1];
+		if (i < n) st = ((u32)tid & (seg_rows - 1u)) == 0u || src[i] != src[i - 1];
 		const u64 m = __ballot(st);
 		__syncthreads(); // s_cnt of the window before has been read
 		if (lane == 0) s_cnt[wib] = (u32)__popcll(m);
@@ -126,6 +129,9 @@ __device__ __forceinline__ bool ball_decides(const BallRule &rule, int64_t n, u3
 #ifndef PGQ_BALL_WAVES
 #define PGQ_BALL_WAVES 8 // wavefronts per SIMD k_src_ball is compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs), 4 = one (128)
 #endif
+#ifndef PGQ_BALL_UH
+#define PGQ_BALL_UH 4 // row octets (8 rows, 8 lanes each) a wavefront scans per step out of the fixed-stride heads
+#endif
 #ifndef PGQ_BALL_UQ
 #define PGQ_BALL_UQ 2 // row quads (4 rows, 16 lanes each) a wavefront scans per step, all their loads in flight together
 #endif
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
                                                            const u32 *__restrict__ segs,
                                                            int64_t *__restrict__ out, int64_t cap, int64_t test_cap, int bm_words,
                                                            MeetDevBlock *__restrict__ db, u32 *__restrict__ gmaps, MeetQueue qopen, BallRule rule,
-                                                           unsigned long long *__restrict__ trace) {
+                                                           unsigned long long *__restrict__ trace, u32 seg_rows) {
 	extern __shared__ __attribute__((aligned(16))) u32 s_map[]; // bm_words: one bit per vertex (GM: unused)
 	const u32 nseg = db->ball.nseg;
 	// every workgroup takes the same decision from the same two totals; workgroup 0 leaves it for the kernels behind this one
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 			s_capped = 0;
 		}
 		const u32 start = segs[job];
-		const u32 wend = (u32)min(n, (int64_t)(start | (u32)(kBallRows - 1)) + 1);
+		const u32 wend = (u32)min(n, (int64_t)(start | (seg_rows - 1u)) + 1);
 		const int64_t s = src[start]; // one address for the whole workgroup
 		u32 di32;
 		{
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 					// serialised by barriers), not by its bytes — and a destination at distance 3 shows a witness among its first 31
 					// in-neighbours four times out of five.  (a) first line, every row; (b) second line, rows without a witness and
 					// more than 31 in-neighbours; (c) the rest of lists longer than 62 (position looked up now), 128 entries per step.
-					constexpr int UH = 4; // row octets per wavefront and step: 32 rows, four loads per lane in flight
+					constexpr int UH = PGQ_BALL_UH; // row octets per wavefront and step: 32 rows, four loads per lane in flight (PGQ_BALL_UH = 4)
 					const int sub8 = lane >> 3, j8 = lane & 7;
 					for (int pass = 0; pass < 2; pass++) {
 						const unsigned short *qin = pass == 0 ? s_q1 : s_q3;

@@ -1569,6 +1569,7 @@ extern "C" {
 
 int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                          void *d_out, uint8_t *d_out_valid) {
+	CallScope in_flight;
 	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_weighted(csr));
@@ -1582,6 +1583,7 @@ int pgq_cheapest_path_length_bulk_device(pgq_csr_t *csr, int64_t n, const int64_
 
 int pgq_cheapest_path_length(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, void *out,
                              uint64_t *out_valid) {
+	CallScope in_flight;
 	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_weighted(csr));

@@ -38,6 +38,18 @@ int fail(int code, const std::string &msg);
 	} while (0)
 
 int ensure_init();
+// Waits for a stream the way the moment calls for (round 6).  hipStreamSynchronize spins: right for ONE caller (a chunk is
+// ~50 us of kernels, a sleeping thread wakes up in 20-50), wrong for DuckDB's morsel-driven workers — 16 to 64 threads each in
+// a chunk call (iterativelength.cpp:34 runs per DataChunk per thread) spin on as many cores, and a box that gives the
+// process fewer cores than threads collapses (64 threads on a 16-CPU quota: 9.9 ms per chunk instead of 0.07).  With more than
+// `block_above` calls in flight on this process the wait is an event created with hipEventBlockingSync: the thread sleeps.
+struct CallScope { // one per C-ABI search call: counts the calls in flight
+	CallScope();
+	~CallScope();
+};
+int calls_in_flight();
+hipEvent_t *thread_wait_event(); // this host thread's blocking event for the device it works on (never destroyed: a few per thread)
+int wait_stream(hipStream_t st, hipEvent_t *blocking_event /* created on first use, owned by the caller */);
 int ensure_edge_ids(pgq_csr *c); // copies a lazily uploaded edge-id array now (no-op otherwise); thread-safe
 // What a CSR handle has learned about its graph — the pre-pass's measured bytes per row, the share of rows the
 // source-centric kernel leaves open, the levels a full lane batch of each width runs — kept per graph SHAPE (V, E, largest
@@ -143,9 +155,13 @@ struct Options {
 	int ball_cap = 1 << 20;     // adjacency entries the two-hop ball of one source may hold; a segment over it leaves its far rows open
 	int ball_test_cap = 1 << 15; // adjacency entries the backward two-hop walk of one row (distance 4) may scan
 	int ball_seg_kb = 512;      // the least a segment costs in the decision, in KB at streaming rate (its ~15 dependent round trips on one of ~512 workgroup slots)
+	int block_above = 3;        // more search calls than this in flight on the process: waits sleep on a blocking event instead of spinning
 	int calibration_cache = 1;  // what a handle measures about its graph (bytes per row of the pre-pass, level plans, ...) is kept per graph
 	                            // shape across handles (0: every handle starts from nothing; tests of the cold paths)
 	int ball_head_mb = 512;     // the fixed-stride in-list heads (pgq_csr::rhead, V x 256 bytes) are built when they fit this many MB (0: never)
+	int ball_seg_rows_small = 1024; // calls of at most meet_small_rows rows: a source run is cut into segments of this many rows (64..1024, a power
+	                                // of two).  Measured on 1 source x 2048 destinations: 64, 128, 256 and 1024 all give 0.065 ms per chunk — the call is
+	                                // its launches and its wait, not the scan — so the shorter segments stay an option
 	int ball_grid = 0;          // > 0: at most this many workgroups of k_src_ball (debugging / sweeps)
 	int ball_sort = 1;          // rows with repeated sources that are NOT grouped are sorted by source first (0: such calls take the older routes)
 	double ball_bias = 1.0;     // the ball runs while ball_bias x its estimated bytes <= the cheaper of the pre-pass and the lane batches

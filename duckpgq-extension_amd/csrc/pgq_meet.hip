@@ -1268,7 +1268,7 @@ static int meet_buffers(Workspace *ws, int64_t n, MeetQueue q[2], MeetDevBlock *
 }
 // waits for the chain and takes over what its last workgroup wrote into the pinned block
 static int meet_wait(Workspace *ws, MeetHostBlock *hb) {
-	PGQ_HIP_TRY(hipStreamSynchronize(ws->stream));
+	PGQ_TRY(wait_stream(ws->stream, &ws->ev_block));
 	KernelTimer::flush();
 	if (hb->done != 1) return fail(PGQ_ERR_HIP, "the pre-pass chain did not report back (statistics block not written)");
 	ws->meet_cnt_clean = true;
@@ -1368,6 +1368,11 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	// do not fill 256 CUs anyway, get one workgroup per CU (8192 rows: 0.086 -> 0.076 ms, 2048 rows: 0.062 -> 0.053 ms)
 	const bool small_call = !paths && n <= (int64_t)opt.meet_small_rows;
 	u32 grid4 = (u32)std::min<int64_t>(n, (int64_t)device_cus() * std::max(1, paths ? 4 : (small_call ? 1 : opt.meet4_grid_mult)));
+	// round 6: a chunk-sized call leaves a few dozen rows open (2 % of 2048): a workgroup per CU for them starts 256 x 1024
+	// threads that find nothing to do and, worse, fills every CU — the chunk calls of DuckDB's other worker threads (one per
+	// DataChunk per thread, iterativelength.cpp:34) queue behind it instead of running beside it (tools/chunk_mt.cpp: 8 threads
+	// reached 47 M rows/s, 1.7 x one thread).  One workgroup per 16 rows, at least 16: rows are handed out dynamically anyway.
+	if (small_call) grid4 = std::min<u32>(grid4, (u32)std::max<int64_t>(16, n / 16));
 	size_t maps_bytes = 0;
 	if (run4 && !lds_map) {
 		grid4 = (u32)std::max<size_t>(1, std::min<size_t>((size_t)std::min<int64_t>(n, device_cus()), gm_budget / ((size_t)bm_words * 4)));
@@ -1408,6 +1413,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			ball_maps = (size_t)grid_b * bm_words * 4;
 		}
 		if (opt.ball_grid > 0) grid_b = std::min(grid_b, (unsigned)opt.ball_grid);
+		if (n <= (int64_t)opt.meet_small_rows) grid_b = std::min<unsigned>(grid_b, (unsigned)std::max<int64_t>(8, n / 16)); // (as for k_meet4d below: room for the other threads' chunks)
 		if (grid_b == 0) {
 			ball_mode = 0; // no room for the maps: the older routes
 		} else {
@@ -1434,9 +1440,14 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			rule.mode = ball_mode;
 			rule.V = c->V;
 			const int64_t nwin = (n + kBallRows - 1) / kBallRows;
+			u32 seg_rows = (u32)kBallRows; // chunk-sized calls: shorter segments, more workgroups per source (k_ball_segments)
+			if (n <= (int64_t)opt.meet_small_rows) {
+				seg_rows = 64;
+				while ((int)seg_rows * 2 <= std::min(kBallRows, std::max(64, opt.ball_seg_rows_small))) seg_rows *= 2;
+			}
 			KernelTimer kt(st, K_BALL);
 			hipLaunchKernelGGL(k_ball_segments, dim3((unsigned)std::min<int64_t>(nwin, (int64_t)device_cus())), dim3(kBallRows), 0, st, n, d_src,
-			                   ws->ball_segs.as<u32>(), db);
+			                   ws->ball_segs.as<u32>(), db, seg_rows);
 			const int64_t capb = std::max(1, opt.ball_cap), tcap = std::max(1, opt.ball_test_cap);
 			if (opt.meet_trace) {
 				PGQ_TRY(ws->ball_trace.reserve(256));
@@ -1446,7 +1457,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 #define PGQ_BALL(G, T, LDS)                                                                                                  \
 	hipLaunchKernelGGL((k_src_ball<G, T>), dim3(grid_b), dim3(kBallRows), LDS, st, n, d_src, d_dst, c->V, c->off, c->roff, c->fdesc, \
 	                   c->rdesc, c->padj, c->rpadj, c->rseg, opt.ball_head_mb > 0 ? c->rhead : (const uint4 *)nullptr, ws->ball_segs.as<u32>(), d_out, capb, tcap, \
-	                   bm_words, db, gmaps, q[0], rule, b_trace)
+	                   bm_words, db, gmaps, q[0], rule, b_trace, seg_rows)
 			if (ball_lds && b_trace) PGQ_BALL(false, true, (size_t)bm_words * 4);
 			else if (ball_lds) PGQ_BALL(false, false, (size_t)bm_words * 4);
 			else if (b_trace) PGQ_BALL(true, true, 0);

@@ -1541,6 +1541,7 @@ __global__ void k_trivial_paths(int64_t lo, int64_t hi, const int32_t *__restric
 // ---- workspace ---------------------------------------------------------------------------------------------------
 
 Workspace::~Workspace() {
+	if (ev_block) (void)hipEventDestroy(ev_block);
 	if (stream) (void)hipStreamDestroy(stream);
 	if (h_cnt) (void)hipHostFree(h_cnt);
 	if (h_log) (void)hipHostFree(h_log);
@@ -1613,7 +1614,7 @@ WorkspaceLease::~WorkspaceLease() {
 // every wait of the lane-batched search on its stream is counted (pgq_stats_t::host_waits)
 #define PGQ_WAIT(stream)                                                                                               \
 	do {                                                                                                               \
-		PGQ_HIP_TRY(hipStreamSynchronize(stream));                                                                     \
+		PGQ_TRY(wait_stream(stream, thread_wait_event()));                                                          \
 		tstats().s.host_waits++;                                                                                       \
 	} while (0)
 
@@ -1839,6 +1840,10 @@ struct SearchOutput {
 	bool from_meet = false; // these rows are what the pair-centric pre-pass left open: do not run it on them again
 	bool no_ball = false;   // these rows are what the source-centric kernel left open: the pre-pass may take them, that kernel not again
 	int ball_hint = -1;     // the caller has looked at the rows (chunk entry points: they sit in host memory): 0 = not grouped by source
+	// chunk entry points: the rows sit in a staging buffer whose address is the same for every chunk, so what the route memo
+	// remembers about "these buffers" says nothing about THESE rows (round-5 advisor finding: unrelated chunks hit the memo,
+	// and every change of shape was routed one call late) — such calls neither read nor write it
+	bool no_memo = false;
 };
 static constexpr int kMaxTeLevels = 1024;
 
@@ -2536,12 +2541,15 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	int ball_mode = (with_paths || outp.no_ball || outp.bidir || n < 2) ? 0 : std::max(0, std::min(2, mopt.ball));
 	if (ball_mode == 1) {
 		if (outp.ball_hint == 0 || c->ball_open_frac.load(std::memory_order_relaxed) > 0.02) ball_mode = 0;
-		else if (mopt.route_memo && outp.ball_hint < 0) { // (a caller that has looked at the rows knows better than the memo)
+		else if (mopt.route_memo && outp.ball_hint < 0 && !outp.no_memo) { // (a caller that has looked at the rows knows better than the memo)
 			std::lock_guard<std::mutex> g(c->plan_lock);
 			const pgq_csr::RouteMemo &m = c->route_memo;
 			if (m.ball_n == n && m.ball_src == (const void *)d_src && m.ball_dst == (const void *)d_dst) ball_mode = m.ball_yes ? 3 : 0;
 		}
 	}
+	// the caller has counted the source runs on the host and found the rows grouped: the chain is the two kernels alone (if the
+	// device's byte rule declines after all, run_meet falls back to the stage kernels)
+	if (ball_mode == 1 && outp.ball_hint == 1) ball_mode = 3;
 	const int ball_asked = ball_mode;
 	bool ball_ran = false;
 	// shortestpath: the pre-pass also records each answered row's inner vertices (reference tie-break); their lists are
@@ -2613,7 +2621,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		const double b0 = S.algo_bytes[K_MEET] + S.algo_bytes[K_MEET4] + S.algo_bytes[K_BIBFS];
 		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, nullptr, decide_mode, meet_bytes, edge_bytes, ran, &observed_go,
 		                     ball_mode, &ball_ran));
-		if ((ball_asked == 1 || ball_asked == 3) && outp.ball_hint < 0) { // what the kernels said about these buffers
+		if ((ball_asked == 1 || ball_asked == 3) && outp.ball_hint < 0 && !outp.no_memo) { // what the kernels said about these buffers
 			std::lock_guard<std::mutex> g(c->plan_lock);
 			c->route_memo.ball_n = n;
 			c->route_memo.ball_src = d_src;
@@ -2674,7 +2682,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	bool sampled = false; // the sampled decision was asked for without the chain: read it after the next wait
 	if (may_meet && meet_pays(std::min<int64_t>(n, c->V))) {
 		bool skip = false;
-		if (decide && mopt.route_memo) {
+		if (decide && mopt.route_memo && !outp.no_memo) {
 			std::lock_guard<std::mutex> g(c->plan_lock);
 			const pgq_csr::RouteMemo &m = c->route_memo;
 			const bool same = m.n == n && m.src == (const void *)d_src && m.dst == (const void *)d_dst;
@@ -2686,7 +2694,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		} else {
 			bool ran = true;
 			PGQ_TRY(run_meet(&ran));
-			if (decide) {
+			if (decide && !outp.no_memo) {
 				std::lock_guard<std::mutex> g(c->plan_lock);
 				c->route_memo.n = n;
 				c->route_memo.src = d_src;
@@ -2972,6 +2980,7 @@ int pgq_release_cached_memory(void) {
 
 static int iterativelength_bulk(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out_len,
                                 bool bidir) {
+	CallScope in_flight;
 	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
@@ -2994,6 +3003,7 @@ int pgq_iterativelength_bidirectional_bulk_device(pgq_csr_t *csr, int64_t n, con
 }
 int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t *d_out_len, int64_t *d_out_te) {
+	CallScope in_flight;
 	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
@@ -3014,6 +3024,7 @@ int pgq_traversed_edges_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_
 int pgq_shortestpath_bulk_device(pgq_csr_t *csr, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                                  int64_t *d_out_len, int64_t *d_out_offset, int64_t *d_child, int64_t child_cap,
                                  int64_t *child_used) {
+	CallScope in_flight;
 	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	if (!csr) return fail(PGQ_ERR_INVALID_ARG, "NULL csr");
@@ -3162,6 +3173,7 @@ static int io_block(Workspace *ws, size_t bytes, void **host, void **dev) {
 
 static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, int64_t *out_len,
                                  uint64_t *out_valid, bool bidir) {
+	CallScope in_flight;
 	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_csr(csr, V));
@@ -3180,6 +3192,7 @@ static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t
 		int64_t *h = static_cast<int64_t *>(hp), *d = static_cast<int64_t *>(dp);
 		PGQ_TRY(flatten_pairs_into(V, n, src, dst, h, h + n));
 		SearchOutput so;
+		so.no_memo = true;
 		{ // the rows are in host memory: whether they are grouped by source costs a pass over 2048 words here, two launches there
 			int64_t runs = 1;
 			for (int64_t i = 1; i < n; i++) runs += h[i] != h[i - 1];
@@ -3208,6 +3221,7 @@ static int iterativelength_chunk(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, fp.dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
 	SearchOutput so;
 	so.bidir = bidir;
+	so.no_memo = true;
 	PGQ_TRY(search_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
 	                      false, nullptr, nullptr, 0, so));
 	PGQ_TRY(staged_download(out_len, ws->out_len.p, (size_t)n * 8, ws->stream));
@@ -3229,6 +3243,7 @@ int pgq_iterativelength_bidirectional(pgq_csr_t *csr, int64_t V, int64_t n, pgq_
 
 int pgq_shortestpath(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_vec_t dst, uint64_t *out_offset,
                      uint64_t *out_length, uint64_t *out_valid, const int64_t **out_child, uint64_t *out_child_len) {
+	CallScope in_flight;
 	OptionScope opt_scope(csr);
 	PGQ_TRY(ensure_init());
 	PGQ_TRY(check_csr(csr, V));
@@ -3249,6 +3264,7 @@ int pgq_shortestpath(pgq_csr_t *csr, int64_t V, int64_t n, pgq_vec_t src, pgq_ve
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_src.p, fp.src.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
 	PGQ_HIP_TRY(hipMemcpyAsync(ws->in_dst.p, fp.dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, ws->stream));
 	SearchOutput so;
+	so.no_memo = true;
 	PGQ_TRY(search_device(csr, ws, n, ws->in_src.as<int64_t>(), ws->in_dst.as<int64_t>(), ws->out_len.as<int64_t>(),
 	                      true, ws->out_off.as<int64_t>(), nullptr, 0, so));
 	std::vector<int64_t> len(n), off(n);

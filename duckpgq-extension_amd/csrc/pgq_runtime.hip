@@ -134,6 +134,25 @@ int worker_wait(const std::shared_ptr<WorkerTask> &t) {
 	return t->failed == PGQ_OK ? PGQ_OK : fail(t->failed, t->what);
 }
 
+static std::atomic<int> g_calls { 0 };
+CallScope::CallScope() { g_calls.fetch_add(1, std::memory_order_relaxed); }
+CallScope::~CallScope() { g_calls.fetch_sub(1, std::memory_order_relaxed); }
+int calls_in_flight() { return g_calls.load(std::memory_order_relaxed); }
+hipEvent_t *thread_wait_event() {
+	static thread_local hipEvent_t ev[64] = {};
+	return &ev[current_device() & 63];
+}
+int wait_stream(hipStream_t st, hipEvent_t *ev) {
+	if (ev && calls_in_flight() > options().block_above) {
+		if (!*ev) PGQ_HIP_TRY(hipEventCreateWithFlags(ev, hipEventBlockingSync | hipEventDisableTiming));
+		PGQ_HIP_TRY(hipEventRecord(*ev, st));
+		PGQ_HIP_TRY(hipEventSynchronize(*ev));
+		return PGQ_OK;
+	}
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	return PGQ_OK;
+}
+
 int device_cus() {
 	static std::atomic<int> cached[64] = {};
 	const int dev = current_device() & 63;
@@ -241,8 +260,10 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "ball_sort", &o.ball_sort, nullptr },
 		{ "ball_seg_kb", &o.ball_seg_kb, nullptr },
 		{ "ball_grid", &o.ball_grid, nullptr },
+		{ "ball_seg_rows_small", &o.ball_seg_rows_small, nullptr },
 		{ "ball_head_mb", &o.ball_head_mb, nullptr },
 		{ "calibration_cache", &o.calibration_cache, nullptr },
+		{ "block_above", &o.block_above, nullptr },
 		{ "ball_bias", nullptr, &o.ball_bias },
 	};
 }

@@ -261,6 +261,7 @@ struct LevelBuf {
 
 struct Workspace {
 	hipStream_t stream = nullptr;
+	hipEvent_t ev_block = nullptr; // blocking event of wait_stream (created when the process first has many calls in flight)
 	int device = 0; // where its buffers live (workspaces are pooled per device)
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,

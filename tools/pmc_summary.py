@@ -39,7 +39,7 @@ def _summarise(agg, launches):
     # of bytes x launches, divided by k_meet3's launches = the steps profiled).
     for cls, prefixes in (("pull_sparse", ("k_pull_lanes<", "k_pull_sparse<")), ("pull", ("k_pull<",)), ("push", ("k_push<",)),
                           ("pull_hub", ("k_pull_hub<",)), ("relax", ("k_relax<",)), ("meet", ("k_meet3",)),
-                          ("meet4", ("k_meet4d", "k_meet4<")), ("bibfs", ("k_bibfs",)), ("ball", ("k_src_ball", "k_ball_segments"))):
+                          ("meet4", ("k_meet4d", "k_meet4<")), ("bibfs", ("k_bibfs",)), ("ball", ("k_src_ball",))):
         cands = [k for k in out if k.startswith(prefixes)]
         if cands:
             best = max(cands, key=lambda k: out[k].get("hbm_bytes_per_launch", 0) * out[k]["launches_profiled"])

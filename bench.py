@@ -98,6 +98,8 @@ def parse():
     ap.add_argument("--snb-friendships", type=int, default=19_940_000)
     ap.add_argument("--cross-sources", type=int, default=2048, help="snb_cross / msbfs_cross leg: distinct sources")
     ap.add_argument("--cross-dests", type=int, default=1024, help="snb_cross / msbfs_cross leg: destinations per source")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="pgq_set_option before the run (experiments; recorded in config.options)")
+    ap.add_argument("--cross-shuffle", action="store_true", help="snb_cross / rmat22_cross: rows in random order (a hash join's output) instead of grouped by source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="N = 1 default workload: skip the msbfs_cross and cheapest_general legs")
     ap.add_argument("--cheapest-pairs", type=int, default=4096, help="cheapest_general leg: pairs (0: skip the leg)")
@@ -196,7 +198,8 @@ def make_pairs(a, V, total, off, adj):
     if a.workload == "rmat22_cross":  # the leg msbfs_cross_rmat22 as a workload of its own (same rows: seed 7 + 22)
         return cross_pairs(V, total, a.cross_sources * max(1, total // (a.cross_sources * a.cross_dests)), PAIR_SEED["snb_cross"] + 22)
     if a.workload == "snb_cross":
-        return cross_pairs(V, total, a.cross_sources * max(1, total // (a.cross_sources * a.cross_dests)), PAIR_SEED[a.workload])
+        cp = cross_pairs(V, total, a.cross_sources * max(1, total // (a.cross_sources * a.cross_dests)), PAIR_SEED[a.workload])
+        return cp[rng.permutation(len(cp))] if a.cross_shuffle else cp
     if a.workload == "snb_cross_allv":  # 32 sources x every vertex as destination
         src = rng.choice(V, size=32, replace=False)
         return np.stack([np.repeat(src, V), np.tile(np.arange(V, dtype=np.int64), 32)], axis=1).astype(np.int64)
@@ -569,6 +572,9 @@ def main():
         return launch_check(a)
     bench = Bench(a)
     torch, dist, pgq, sharding = bench.torch, bench.dist, bench.pgq, bench.sharding
+    for kv in a.set:
+        k, v = kv.split("=", 1)
+        pgq.set_option(k, float(v) if "." in v else int(v))
     world, rank, dev = bench.world, bench.rank, bench.dev
     scaling = a.scaling or ("strong" if world > 1 else "weak")
     cheapest = a.workload in CHEAPEST
@@ -724,7 +730,8 @@ def main():
                 "V": V, "E": E, "pairs_total": total_pairs,
                 "parallelism": ("pairs sharded x%d, RCCL all_gather of %s (async, overlapped with the next step)" % (
                     world, "lengths + path lists" if paths else "lengths")) if world > 1 else "1 GPU",
-                "graph_gen_s": round(gen_s, 1), "csr_upload_ms": round(upload_s * 1e3, 2)},
+                "graph_gen_s": round(gen_s, 1), "csr_upload_ms": round(upload_s * 1e3, 2),
+                **({"options": a.set} if a.set else {}), **({"rows": "shuffled"} if a.cross_shuffle else {})},
             "pairs_per_s": main_leg["pairs_per_s"],
             "reachable_pairs": main_leg["reachable_pairs"],
             "traversed_edges_per_step": main_leg["traversed_edges_per_step"],

@@ -298,6 +298,7 @@ struct pgq_csr {
 		int64_t ball_n = -1;
 		const void *ball_src = nullptr, *ball_dst = nullptr;
 		bool ball_yes = false;
+		bool sorted_yes = false; // ... or took them after a sort by source (rows of a source scattered over the input)
 	} route_memo;
 	// share of a call's rows the source-centric kernel left open, last time it ran on this CSR (half the weight to the newest
 	// call): above ~2 % those rows drag the lane batches along anyway (R-MAT: far and unreachable pairs), and the kernel

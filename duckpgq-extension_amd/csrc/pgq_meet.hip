@@ -1297,9 +1297,10 @@ static void meet_attributes() {
 // = true: the open rows are what IT left); 2 = it always does (tests); 0 = the chain starts with the stage kernels.
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go,
-                 int ball_mode, bool *ball_ran) {
+                 int ball_mode, bool *ball_ran, double *est_sources) {
 	const bool paths = po != nullptr;
 	if (ball_ran) *ball_ran = false;
+	if (est_sources) *est_sources = -1.0; // the decision kernel's estimate of the distinct sources, when it ran
 	if (paths || !c->rseg || !c->fdesc || !c->rdesc || n < 2) ball_mode = 0;
 	// ball_mode 3: the route memo says the source-centric kernel took these buffers last time — the chain is its two kernels
 	// and a one-thread report, without the stage kernels that would only return at once behind it (65,536 one-wavefront
@@ -1642,6 +1643,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	}
 	if (ball_mode) // it looked at the rows (8 B per row, twice) and declined
 		S.algo_bytes[K_BALL] += 16.0 * (double)n;
+	if (decide && est_sources) *est_sources = h.dec.estimate;
 	if (decide && !h.dec.go) {
 		if (ran) *ran = false;
 		*n_open = (u32)n;

@@ -266,7 +266,7 @@ struct Workspace {
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
 	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, def_ent, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps, meet_trace, wb_scratch, hv, hmask, hstart, hmap,
-	    route_dec, ball_segs, ball_trace, dpart; // [kOpenGrid][WD + 1]: every workgroup's open-lane words + open-row count of the level's detection / probe
+	    route_dec, ball_segs, ball_trace, sort_src, sort_dst, sort_out, dpart; // [kOpenGrid][WD + 1]: every workgroup's open-lane words + open-row count of the level's detection / probe
 	std::vector<std::unique_ptr<LevelBuf>> levels; // shortestpath: one per level
 	std::vector<std::unique_ptr<LevelBuf>> pool;   // otherwise: [0], [1] sparse pool, [2], [3] dense pool
 	bool pool_trusted = false;                     // the last batch ended normally: the sparse pool's dirty flags are true
@@ -323,7 +323,7 @@ struct MeetPathsOut {
 };
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go,
-                 int ball_mode = 0, bool *ball_ran = nullptr);
+                 int ball_mode = 0, bool *ball_ran = nullptr, double *est_sources = nullptr);
 // the pre-pass's sampled decision alone, waited for (*go: the pre-pass pays)
 int meet_decide_alone(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes, bool *go);
 // iterativelengthbidirectional: every row through k_bibfs (forward CSR from src, transposed CSR from dst); rows over its

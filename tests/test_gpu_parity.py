@@ -435,6 +435,51 @@ def test_source_centric_ball_is_chosen_by_the_source_runs():
     assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
 
 
+def test_ungrouped_rows_of_few_sources_are_sorted_for_the_source_centric_kernel():
+    # ball_sort = 1 (shipped): a cross product whose rows arrive in any order (a hash join's output) is declined by the
+    # source-centric kernel (every row a source run of its own) and by the pre-pass (few distinct sources); sorted by source
+    # it is the kernel's input after all.  Answers land in the caller's row order; NULL sources sort behind every vertex.
+    import torch
+    rng = np.random.default_rng(67)
+    V, E = 20000, 400000
+    st, ora = both(V, random_graph(rng, V, E))
+    pgq.set_option("meet", 1)
+    pgq.set_option("ball", 1)
+    pgq.set_option("ball_seg_kb", 16)
+    dev = st.device_csr(0)
+    srcs = rng.choice(V, 40, replace=False)
+    ps = np.repeat(srcs, 600)
+    pd = rng.integers(0, V, len(ps))
+    perm = rng.permutation(len(ps))
+    ps, pd = ps[perm], pd[perm]
+    ps[rng.integers(0, len(ps), 50)] = -1   # NULL rows
+    valid = ps >= 0
+    oln, ook = ora.lean_iterativelength(V, np.where(valid, ps, 0), np.where(valid, pd, 0), nthreads=4)
+    want = np.where(ook & valid, oln, -1)
+    t_s, t_d = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+    for sort, expect in ((1, True), (0, False)):
+        pgq.set_option("ball_sort", sort)
+        t_s2, t_d2 = t_s.clone(), t_d.clone()   # fresh buffers: the route memo starts over
+        for rep in range(3):  # the second and third call go straight to the sort (route memo)
+            t_o = torch.full((len(ps),), -7, dtype=torch.int64, device="cuda")
+            pgq.reset_stats()
+            dev.iterativelength_bulk_ptr(len(ps), t_s2.data_ptr(), t_d2.data_ptr(), t_o.data_ptr())
+            assert (t_o.cpu().numpy() == want).all(), (sort, rep)
+            assert (pgq.get_stats()["ball_calls"] >= 1) == expect, (sort, rep, pgq.get_stats())
+    pgq.set_option("ball_sort", 1)
+    # the same buffers overwritten with scattered pairs: the sorted kernel's rule declines, the memo forgets, same answers
+    ps2 = rng.integers(0, V, len(ps))
+    t_s2.copy_(torch.from_numpy(ps2))
+    oln, ook = ora.lean_iterativelength(V, ps2, pd, nthreads=4)
+    for rep in range(2):
+        dev.iterativelength_bulk_ptr(len(ps), t_s2.data_ptr(), t_d2.data_ptr(), t_o.data_ptr())
+        assert (t_o.cpu().numpy() == np.where(ook, oln, -1)).all()
+    # an id outside [0, V) is refused from the sorted route as from every other
+    t_s[7] = V + 5
+    with pytest.raises(pgq.PgqError):
+        dev.iterativelength_bulk_ptr(len(ps), t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+
+
 def test_meet_prepass_large_inputs_cross_product_vs_distinct_sources():
     # more than 16384 rows: a sampled estimate of the distinct sources decides between the pre-pass (one two-hop walk per
     # row) and the lane batches (one lane per source)

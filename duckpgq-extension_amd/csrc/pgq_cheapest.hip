@@ -171,7 +171,14 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
                                                const long long *__restrict__ bound, long long *__restrict__ min_deferred,
                                                u32 *__restrict__ relaxed_vertices, int sorted, T wcap,
                                                int heavy_pass, u64 *__restrict__ heavy_ctr, int32_t *__restrict__ hv,
-                                               u64 *__restrict__ hmask, u32 *__restrict__ hstart, u32 *__restrict__ hmap) {
+                                               u64 *__restrict__ hmask, u32 *__restrict__ hstart, u32 *__restrict__ hmap,
+                                               const DT *__restrict__ other, long long *__restrict__ mu,
+                                               u32 *__restrict__ alive, const long long *__restrict__ thr_ptr) {
+	// `other` != nullptr: one side of the bidirectional search (relax_batches_bidir).  Lane l is one (src, dst) PAIR, `dist` this
+	// side's labels and `other` the other side's; `bound` is the pair's best known src -> dst length mu[l] (both sides prune
+	// with it), `*thr_ptr` the distance cap both sides expand under.  A vertex expanded here that carries a label of the other
+	// side closes a path: mu[l] = min(mu[l], label + other label).  alive[l] = 1: the lane left a labelled vertex unexpanded
+	// (over the cap) this round — a side without one has exhausted its closure.
 	// Long lists are not walked by the wavefront that finds them (a round would take as long as its longest list: one
 	// hub of 1 800 edges = 230 dependent trips).  Pass 0 (heavy_pass = 0) appends such a vertex to the heavy list — one
 	// packed 64-bit atomicAdd hands out its entry index and the first of its chunk numbers together — and writes
@@ -201,7 +208,16 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 	const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
 	const u32 nq = heavy_pass ? (u32)(*heavy_ctr & 0xFFFFFFFFull) : *nq_ptr;
-	const long long my_bound = bound[lane];
+	long long my_bound = bound[lane];
+	const long long mu_b = my_bound; // (bidirectional) the pair's bound proper
+	if (thr_ptr) {
+		thr = *thr_ptr;
+		// nothing is labelled at or above twice the cap: a pair that needs such a label is not finished in this phase anyway
+		// (exactness: relax_batches_bidir), and an expansion walks the few edges under 2 C - label instead of its whole list
+		if (other) my_bound = min(my_bound, 2 * thr);
+	}
+	long long my_mu = 0x7FFFFFFFFFFFFFFFll; // (bidirectional) smallest label + other side's label this wavefront's lane has seen
+	bool my_alive = false;
 	u64 edges = 0;
 	u32 expanded = 0;
 	long long min_def = 0x7FFFFFFFFFFFFFFFll;
@@ -263,6 +279,15 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 			}
 #endif
 			if (sorted) edges += (u64)nv;
+			if (other) { // an edge the cap cut (not the pair's bound): the lane's side is not exhausted, and the next cap must reach it
+#pragma unroll
+				for (int u = 0; u < UNR; u++) {
+					if (k0 + u < e && mine && cand[u] >= my_bound && cand[u] < mu_b) {
+						my_alive = true;
+						min_def = min(min_def, (long long)(cand[u] >> 1));
+					}
+				}
+			}
 #pragma unroll
 			for (int u = 0; u < UNR; u++) {
 				const bool go = u < nv && mine && (!sorted || cand[u] < my_bound) && cand[u] < curv[u];
@@ -307,19 +332,21 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 		int v = i < nq ? qcur[i] : 0;
 		int v1 = i1 < nq ? qcur[i1] : 0;
 		u64 mask = 0;
-		int64_t dvb = 0, b = 0, e = 0;
+		int64_t dvb = 0, b = 0, e = 0, ob = Inf<T>::bits;
 		if (i < nq) {
 			mask = dirty_cur[v];
 			dvb = Lab<DT>::widen(dist[(size_t)v * LC + lane], Inf<T>::bits);
+			if (other) ob = Lab<DT>::widen(other[(size_t)v * LC + lane], Inf<T>::bits);
 			b = off[v];
 			e = off[v + 1];
 		}
 		while (i < nq) {
 			u64 mask1 = 0;
-			int64_t dvb1 = 0, b1 = 0, e1 = 0;
+			int64_t dvb1 = 0, b1 = 0, e1 = 0, ob1 = Inf<T>::bits;
 			if (i1 < nq) {
 				mask1 = dirty_cur[v1];
 				dvb1 = Lab<DT>::widen(dist[(size_t)v1 * LC + lane], Inf<T>::bits);
+				if (other) ob1 = Lab<DT>::widen(other[(size_t)v1 * LC + lane], Inf<T>::bits);
 				b1 = off[v1];
 				e1 = off[v1 + 1];
 			}
@@ -327,8 +354,10 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 			if (lane == 0) dirty_cur[v] = 0; // consumed; nobody else touches dirty_cur this round
 			const bool live = ((mask >> lane) & 1ull) && dvb < my_bound;
 			const bool mine = live && dvb < thr;
+			if (other && mine && ob != Inf<T>::bits) my_mu = min(my_mu, (long long)(dvb + ob)); // (int64 weights only: exact in any order)
 			const u64 deferred = __ballot(live && !mine);
 			if (deferred) { // stays dirty for a later round
+				my_alive |= live && !mine;
 				if (live && !mine) min_def = min(min_def, (long long)dvb);
 				bool fresh = false;
 				if (lane == 0) fresh = atomicOr(&dirty_nxt[v], deferred) == 0ull;
@@ -339,6 +368,9 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 				expanded++;
 				bool is_heavy = false;
 				if (heavy_ctr && e - b > kHeavyMin) is_heavy = !sorted || !(w[b + kHeavyMin] > wcap);
+				if (is_heavy && other && sorted) { // no cap on the edge weight here: heavy only if the 129th edge can still get a lane under its bound
+					if constexpr (!std::is_same<T, double>::value) is_heavy = __any(mine && dvb + (int64_t)w[b + kHeavyMin] < my_bound);
+				}
 				if (is_heavy) {
 					const u32 nch = (u32)((e - b + kHeavyChunk - 1) / kHeavyChunk);
 					u64 t = 0;
@@ -362,9 +394,14 @@ __global__ __launch_bounds__(256, PGQ_RELAX_WAVES) void k_relax(const int64_t *_
 			v1 = v2;
 			mask = mask1;
 			dvb = dvb1;
+			ob = ob1;
 			b = b1;
 			e = e1;
 		}
+	}
+	if (other) { // (wave-uniform)
+		if (my_alive) alive[lane] = 1u; // plain stores of one value: no ordering needed
+		if (my_mu < mu_b) atomicMin(&mu[lane], my_mu); // rare: a lane's bound improves a handful of times per search
 	}
 	for (int o = 32; o > 0; o >>= 1) min_def = min(min_def, (long long)__shfl_xor(min_def, o));
 	if (lane == 0) {
@@ -1383,7 +1420,8 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 				                   priv->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
 				                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices, light ? 1 : 0, wcap,
 				                   0, heavy ? &d_rc->heavy : (u64 *)nullptr, priv->hv.as<int32_t>(), priv->hmask.as<u64>(),
-				                   priv->hstart.as<u32>(), priv->hmap.as<u32>());
+				                   priv->hstart.as<u32>(), priv->hmap.as<u32>(), (const DT *)nullptr, (long long *)nullptr, (u32 *)nullptr,
+				                   (const long long *)nullptr);
 				if (heavy) // the long lists of the round, a chunk per wavefront
 					hipLaunchKernelGGL((k_relax<T, DT>), dim3(grid), dim3(256), 0, st, c->off, r_adj, r_w,
 					                   priv->dist.as<DT>(), priv->dirty[par].as<u64>(), priv->dirty[par ^ 1].as<u64>(),
@@ -1392,7 +1430,7 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 					                   priv->touched.as<int32_t>(), &d_rc->tcount, &d_rc->relaxed_edges, thr_bits,
 					                   (const long long *)d_rc->bound, &d_rc->min_deferred, &d_rc->relaxed_vertices, light ? 1 : 0, wcap,
 					                   1, &d_rc->heavy, priv->hv.as<int32_t>(), priv->hmask.as<u64>(), priv->hstart.as<u32>(),
-					                   priv->hmap.as<u32>());
+					                   priv->hmap.as<u32>(), (const DT *)nullptr, (long long *)nullptr, (u32 *)nullptr, (const long long *)nullptr);
 				kt.stop();
 			}
 			PGQ_HIP_TRY(hipMemcpyAsync(h_rc, d_rc, sizeof(RelaxCounters), hipMemcpyDeviceToHost, st));
@@ -1461,6 +1499,315 @@ static int relax_batches(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int
 	return PGQ_OK;
 }
 
+// ---- general graphs, about one destination per source: both ends at once (relax_batches_bidir, round 6) ------------------
+// The batched relaxation above gives a lane the distances from its source to EVERY vertex under the lane's bound: on the
+// weighted knows graph (weights 1..999, mean degree 89) that is most of the graph per source, ~14 expansions per vertex and
+// batch — 0.64 s per 4096 pairs, `k_relax` 94 % of it.  A single pair needs the ball of half the distance around each end:
+// balls grow by e^(0.089 r) there, so two of radius D / 2 hold a few hundred settled vertices where one of radius D holds
+// most of V.  Here a lane is one (src, dst) PAIR and a batch runs the same kernel from both ends — forward over the
+// weight-sorted out-lists into `dist`, backward over the weight-sorted in-lists into `dist_b`:
+//     mu[l]  = the best src -> dst length seen (the bound BOTH sides prune with; INF at first)
+//     a round = k_relax forward, then k_relax backward, each expanding what is dirty with a label below the common cap C
+//               (the kernel's threshold, read from the device) and below mu[l], labelling what gets under min(mu[l], 2 C) —
+//               an expansion walks the few edges under 2 C - label, not its list; a vertex expanded on one side that carries
+//               a label of the other side offers mu[l] = label + other label
+//     a phase ends with a round in which neither side expanded anything (both at their fixpoint under C): a lane is finished
+//               when mu[l] < 2 C, or when one of its sides has neither a labelled vertex left over the cap nor an edge the
+//               cap cut (closure exhausted); then C rises — by a step, by a quarter, and past empty bands to the smallest
+//               label left — and every labelled vertex is expanded again (k_redirty: the longer prefix of its list)
+// Exactness (int64 sums, any order).  At a phase end every vertex with d(src, x) < min(C, mu) carries its exact forward
+// label and has been expanded with it, likewise backward.  Let D < 2 C be the distance and x the last vertex of an optimal
+// path with d(src, x) < C, y its successor: d(src, y) >= C, so d(y, dst) = D - d(src, y) < C, and both labels the two
+// offer each other — d(src, x) + w forward on y, w + d(y, dst) backward on x — are at most D < 2 C: not cut.  The later of "x expanded
+// forward for the last time" / "y expanded backward for the last time" reads the other's final label — x finds db[x] <=
+// w + d(y, dst), or y finds df[y] <= d(src, x) + w — and offers D (launches of one batch never overlap, so one of the two
+// IS later).  Hence mu < 2 C implies D <= mu < 2 C implies mu = D.  A side that has nothing labelled left below mu has
+// expanded its whole closure below mu: were D < mu, dst (src) itself would have been expanded there and offered D.
+// int64 weights only: a double's sum depends on the order of its additions (cheapest_path_length.cpp:29-36 folds from the
+// source), so doubles keep the one-sided relaxation above.
+// MEASURED (round 6, weighted knows graph, 512 pairs): 232 ms against 89 ms one-sided, so `relax_bidir` ships OFF.  That
+// graph has no small balls: its hubs (1800 edges) sit within half a typical distance (D ~ 60..230, median 95) of nearly
+// every vertex, a batch of 64 pairs relaxes 30 M edges from both ends against 40 M one-sided — and pays 83 rounds
+// (9 phases of caps 15, 22, 29, 36, 45, 56, 70, 87, 108, each re-expanding what is labelled) instead of 35, every one of
+// them a rescan of ~400 K labelled vertices per side.  Both variants move a 64-lane label row per relaxed edge for the
+// one or two lanes that need it; that row traffic, not the number of edges, is what a round costs.  On
+// graphs whose balls stay small (bounded degree, road-like) the two-ended search is the cheaper one; kept, tested, optional.
+struct BiBlock {
+	RelaxCounters rc[2]; // forward / backward: k_relax's round counters
+	long long mu[64];    // per lane: best src -> dst length so far = both sides' bound; 0 once the lane is finished
+	long long res[64];   // per lane: the answer (INF: no path)
+	u32 alive[2][64];    // per side and lane: a labelled vertex was left unexpanded (over the cap) this round
+	u32 done[64];
+	long long cap, step;
+	u32 active, phases;
+};
+
+template <typename DT>
+__global__ __launch_bounds__(64) void k_bidir_init(int64_t lo, int nl, const int32_t *__restrict__ ssrc, const int32_t *__restrict__ sdst,
+                                                   DT *__restrict__ dist_f, DT *__restrict__ dist_b, u64 *__restrict__ dirty_f,
+                                                   u64 *__restrict__ dirty_b, u32 *__restrict__ tflag_f, u32 *__restrict__ tflag_b, u32 tepoch,
+                                                   int32_t *__restrict__ touched_f, int32_t *__restrict__ touched_b,
+                                                   int32_t *__restrict__ q_f, int32_t *__restrict__ q_b, BiBlock *__restrict__ bb,
+                                                   long long cap0, long long step, long long inf) {
+	const int t = threadIdx.x; // the block arrives zeroed
+	bb->res[t] = inf;
+	if (t < nl) {
+		const int s = ssrc[lo + t], d = sdst[lo + t]; // s != d (trivial rows sort behind the lanes); several lanes may share an endpoint
+		bb->mu[t] = inf;
+		dist_f[(size_t)s * LC + t] = 0;
+		if (atomicOr(&dirty_f[s], 1ull << t) == 0ull) q_f[atomicAdd(&bb->rc[0].nq[0], 1u)] = s;
+		if (atomicExch(&tflag_f[s], tepoch) != tepoch) touched_f[atomicAdd(&bb->rc[0].tcount, 1u)] = s;
+		dist_b[(size_t)d * LC + t] = 0;
+		if (atomicOr(&dirty_b[d], 1ull << t) == 0ull) q_b[atomicAdd(&bb->rc[1].nq[0], 1u)] = d;
+		if (atomicExch(&tflag_b[d], tepoch) != tepoch) touched_b[atomicAdd(&bb->rc[1].tcount, 1u)] = d;
+	} else {
+		bb->done[t] = 1; // no pair on this lane: bound 0, nothing is ever expanded for it
+	}
+	if (t == 0) {
+		bb->cap = cap0;
+		bb->step = step;
+		bb->active = (u32)nl;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_bidir_round_reset(BiBlock *__restrict__ bb, int next_f, int next_b) {
+	const int t = threadIdx.x;
+	if (t < 2) {
+		RelaxCounters *rc = &bb->rc[t];
+		rc->nq[t == 0 ? next_f : next_b] = 0;
+		rc->relaxed_vertices = 0;
+		rc->min_deferred = 0x7F7F7F7F7F7F7F7Fll;
+		rc->heavy = 0;
+	}
+}
+
+// after the two sides' launches of a round (see the header above)
+__global__ __launch_bounds__(64) void k_bidir_phase_end(BiBlock *__restrict__ bb) {
+	const int t = threadIdx.x;
+	const bool fix = bb->rc[0].relaxed_vertices == 0 && bb->rc[1].relaxed_vertices == 0;
+	const long long C = bb->cap;
+	if (fix && !bb->done[t]) {
+		const long long m = bb->mu[t];
+		if (m < 2 * C || !bb->alive[0][t] || !bb->alive[1][t]) {
+			bb->res[t] = m;
+			bb->mu[t] = 0; // the lane's bound: nothing of it is expanded or labelled any more
+			bb->done[t] = 1;
+		}
+	}
+	if (fix) { // the flags gather over a phase's rounds (an edge is cut in the round its vertex is expanded)
+		bb->alive[0][t] = 0;
+		bb->alive[1][t] = 0;
+	}
+	const u64 open = __ballot(!bb->done[t]);
+	if (t == 0) {
+		bb->active = (u32)__popcll(open);
+		if (fix) {
+			const long long md = min(bb->rc[0].min_deferred, bb->rc[1].min_deferred);
+			long long nc = max(C + bb->step, C + C / 4);
+			if (md != 0x7F7F7F7F7F7F7F7Fll && md + 1 > nc) nc = md + 1; // an empty band: straight to the smallest label left
+			bb->cap = nc;
+			bb->phases++;
+		}
+	}
+}
+
+__global__ __launch_bounds__(64) void k_bidir_results(int64_t lo, int nl, const u32 *__restrict__ sidx, const BiBlock *__restrict__ bb,
+                                                      long long inf, int64_t *__restrict__ out, uint8_t *__restrict__ ok) {
+	const int t = threadIdx.x;
+	if (t >= nl) return;
+	const u32 row = sidx[lo + t];
+	const long long d = bb->res[t];
+	ok[row] = d == inf ? 0 : 1;
+	out[row] = d == inf ? 0 : d;
+}
+
+static std::mutex g_rws_lock;
+// the in-lists sorted by weight (radj / rw -> rwadj / rwsorted), once per CSR: ensure_weight_sorted for the other direction
+static int ensure_reverse_sorted(pgq_csr *c, Workspace *ws) {
+	PGQ_TRY(ensure_reverse_weights(c, ws));
+	std::lock_guard<std::mutex> g(g_rws_lock);
+	if (c->rwadj || c->E == 0 || !c->rw) return PGQ_OK;
+	hipStream_t st = ws->stream;
+	const int64_t E = c->E;
+	DevBuf tmp;
+	int32_t *rwadj = nullptr;
+	void *rwsorted = nullptr;
+	auto body = [&]() -> int {
+		PGQ_TRY(dev_alloc_as(&rwadj, (size_t)E + 4));
+		PGQ_TRY(dev_alloc(&rwsorted, (size_t)E * 8));
+		size_t sb = 0;
+		const unsigned long long *keys = (const unsigned long long *)c->rw; // int64 weights >= 0: the bit pattern is the value
+		PGQ_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, sb, keys, (unsigned long long *)rwsorted, c->radj, rwadj, (int)E, (int)c->V,
+		                                                        c->roff, c->roff + 1, 0, 64, st));
+		PGQ_TRY(tmp.reserve(sb + 16));
+		PGQ_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp.p, sb, keys, (unsigned long long *)rwsorted, c->radj, rwadj, (int)E, (int)c->V,
+		                                                        c->roff, c->roff + 1, 0, 64, st));
+		PGQ_HIP_TRY(hipStreamSynchronize(st));
+		return PGQ_OK;
+	};
+	const int rc = body();
+	(void)hipStreamSynchronize(st);
+	tmp.release();
+	if (rc != PGQ_OK) {
+		dev_free(rwadj);
+		dev_free(rwsorted);
+		return rc;
+	}
+	c->rwsorted = rwsorted;
+	c->rwadj = rwadj;
+	return PGQ_OK;
+}
+
+// The pair batches b0, b0 + bstride, ... < nb of a call: batch b = the sorted rows [64 b, 64 b + 64) of the R rows that need a
+// search (`ws`: sorted rows, read-only; `priv`: everything a batch writes, and the stream — like relax_batches).
+template <typename DT>
+static int relax_batches_bidir(pgq_csr *c, Workspace *ws, Workspace *priv, int b0, int bstride, int nb, int64_t R, int64_t *d_out,
+                               uint8_t *d_ok) {
+	using T = int64_t;
+	hipStream_t st = priv->stream;
+	const int64_t V = std::max<int64_t>(c->V, 1);
+	const int64_t inf_bits = Inf<T>::bits;
+	const DT inf_label = (DT)Lab<DT>::unlabelled(inf_bits);
+	pgq_stats_t &S = tstats().s;
+	const size_t cells = (size_t)V * LC;
+	const int type_tag = sizeof(DT) == 4 ? 3 : 1;
+	DevBuf *dist[2] = { &priv->dist, &priv->dist_b };
+	DevBuf *dirty[2][2] = { { &priv->dirty[0], &priv->dirty[1] }, { &priv->dirty_b[0], &priv->dirty_b[1] } };
+	DevBuf *qbuf[2][2] = { { &priv->qbuf[0], &priv->qbuf[1] }, { &priv->qbuf_b[0], &priv->qbuf_b[1] } };
+	DevBuf *touched[2] = { &priv->touched, &priv->touched_b }, *tflag[2] = { &priv->tflag, &priv->tflag_b };
+	int64_t *dist_V[2] = { &priv->dist_V, &priv->dist_b_V };
+	int *dist_tag[2] = { &priv->dist_lanes, &priv->dist_b_lanes };
+	for (int s = 0; s < 2; s++) {
+		const bool fresh = dist[s]->cap < cells * sizeof(DT) || *dist_V[s] != c->V || *dist_tag[s] != type_tag;
+		*dist_V[s] = -1; // stays invalid if we bail out half-way; restored at the end
+		PGQ_TRY(dist[s]->reserve(cells * sizeof(DT)));
+		for (int k = 0; k < 2; k++) {
+			PGQ_TRY(dirty[s][k]->reserve((size_t)V * 8));
+			PGQ_TRY(qbuf[s][k]->reserve((size_t)V * 4));
+		}
+		PGQ_TRY(touched[s]->reserve((size_t)V * 4));
+		PGQ_TRY(tflag[s]->reserve((size_t)V * 4));
+		if (fresh) {
+			if constexpr (sizeof(DT) == 4) hipLaunchKernelGGL(k_fill32, dim3((unsigned)device_cus() * 8), dim3(256), 0, st, dist[s]->template as<int32_t>(), (int64_t)cells, (int32_t)inf_label);
+			else hipLaunchKernelGGL(k_fill64, dim3((unsigned)device_cus() * 8), dim3(256), 0, st, dist[s]->template as<int64_t>(), (int64_t)cells, inf_bits);
+		}
+		for (int k = 0; k < 2; k++) PGQ_HIP_TRY(hipMemsetAsync(dirty[s][k]->p, 0, (size_t)V * 8, st));
+		PGQ_HIP_TRY(hipMemsetAsync(tflag[s]->p, 0, (size_t)V * 4, st));
+	}
+	PGQ_TRY(priv->hv.reserve((size_t)V * 4));
+	PGQ_TRY(priv->hmask.reserve((size_t)V * 8));
+	PGQ_TRY(priv->hstart.reserve((size_t)V * 4));
+	PGQ_TRY(priv->hmap.reserve((size_t)(c->E / 64 + V) * 4));
+	PGQ_TRY(priv->bi_block.reserve(sizeof(BiBlock)));
+	if (!priv->h_bi) PGQ_HIP_TRY(hipHostMalloc(&priv->h_bi, sizeof(BiBlock)));
+	BiBlock *bb = priv->bi_block.as<BiBlock>();
+	const BiBlock *hb = static_cast<const BiBlock *>(priv->h_bi);
+	unsigned grid;
+	{
+		static std::mutex grid_lock;
+		static unsigned grid_cached[2][64] = {};
+		std::lock_guard<std::mutex> g(grid_lock);
+		int dev = 0;
+		PGQ_HIP_TRY(hipGetDevice(&dev));
+		unsigned &gc = grid_cached[sizeof(DT) == 4 ? 0 : 1][dev & 63];
+		if (!gc) {
+			int per_cu = 0, cus = 0;
+			PGQ_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_relax<T, DT>, 256, 0));
+			PGQ_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+			gc = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
+		}
+		grid = gc;
+	}
+	const Options &opt = options();
+	// (the mean of a shortest path's edges is far below the mean weight: the caps are fractions of twice the mean)
+	const long long cap0 = std::max<long long>(1, (long long)(2.0 * c->w_mean / std::max(1, opt.relax_bidir_c0_div)));
+	const long long step = std::max<long long>(1, (long long)(2.0 * c->w_mean / std::max(1, opt.relax_bidir_step_div)));
+	const int64_t *xoff[2] = { c->off, c->roff };
+	const int32_t *xadj[2] = { c->wadj, c->rwadj };
+	const T *xw[2] = { (const T *)c->wsorted, (const T *)c->rwsorted };
+	static const bool trace = getenv("PGQ_RELAX_TRACE") != nullptr;
+	u32 tepoch = 0;
+	for (int b = b0; b < nb; b += bstride) {
+		const int64_t lo = (int64_t)b * LC;
+		const int nl = (int)std::min<int64_t>(LC, R - lo);
+		if (nl <= 0) continue;
+		S.batches++;
+		tepoch++;
+		PGQ_HIP_TRY(hipMemsetAsync(bb, 0, sizeof(BiBlock), st));
+		{
+			KernelTimer kt(st, K_PREP);
+			hipLaunchKernelGGL(k_bidir_init<DT>, dim3(1), dim3(64), 0, st, lo, nl, ws->ssrc.as<int32_t>(), ws->sdst.as<int32_t>(), dist[0]->template as<DT>(),
+			                   dist[1]->template as<DT>(), dirty[0][0]->template as<u64>(), dirty[1][0]->template as<u64>(), tflag[0]->template as<u32>(),
+			                   tflag[1]->template as<u32>(), tepoch, touched[0]->template as<int32_t>(), touched[1]->template as<int32_t>(),
+			                   qbuf[0][0]->template as<int32_t>(), qbuf[1][0]->template as<int32_t>(), bb, cap0, step, (long long)inf_bits);
+			kt.stop();
+		}
+		int par[2] = { 0, 0 };
+		u32 nq[2] = { (u32)nl, (u32)nl }, phases_seen = 0;
+		for (int64_t round = 0;; round++) {
+			if (round > (int64_t)1 << 22) return fail(PGQ_ERR_HIP, "internal error: the bidirectional relaxation does not terminate");
+			hipLaunchKernelGGL(k_bidir_round_reset, dim3(1), dim3(64), 0, st, bb, par[0] ^ 1, par[1] ^ 1);
+			{
+				KernelTimer kt(st, K_RELAX);
+				for (int s = 0; s < 2; s++) {
+					if (nq[s] == 0) continue;
+					RelaxCounters *rc = &bb->rc[s];
+					for (int hp = 0; hp < 2; hp++)
+						hipLaunchKernelGGL((k_relax<T, DT>), dim3(hp ? grid : std::min(grid, std::max(1u, (nq[s] + 3) / 4))), dim3(256), 0, st, xoff[s], xadj[s], xw[s],
+						                   dist[s]->template as<DT>(), dirty[s][par[s]]->template as<u64>(), dirty[s][par[s] ^ 1]->template as<u64>(),
+						                   qbuf[s][par[s]]->template as<int32_t>(), &rc->nq[par[s]], qbuf[s][par[s] ^ 1]->template as<int32_t>(),
+						                   &rc->nq[par[s] ^ 1], tflag[s]->template as<u32>(), tepoch, touched[s]->template as<int32_t>(), &rc->tcount,
+						                   &rc->relaxed_edges, (long long)0, (const long long *)bb->mu, &rc->min_deferred, &rc->relaxed_vertices, 1,
+						                   std::numeric_limits<T>::max(), hp, &rc->heavy, priv->hv.as<int32_t>(), priv->hmask.as<u64>(),
+						                   priv->hstart.as<u32>(), priv->hmap.as<u32>(), (const DT *)dist[s ^ 1]->template as<DT>(), bb->mu, bb->alive[s],
+						                   (const long long *)&bb->cap);
+				}
+				hipLaunchKernelGGL(k_bidir_phase_end, dim3(1), dim3(64), 0, st, bb);
+				kt.stop();
+			}
+			PGQ_HIP_TRY(hipMemcpyAsync(priv->h_bi, bb, sizeof(BiBlock), hipMemcpyDeviceToHost, st));
+			PGQ_HIP_TRY(hipStreamSynchronize(st));
+			KernelTimer::flush();
+			S.levels++;
+			if (trace)
+				fprintf(stderr, "bidir b=%d round=%lld cap=%lld phases=%u nq=%u/%u expanded=%u/%u next=%u/%u active=%u edges=%llu/%llu\n", b, (long long)round,
+				        hb->cap, hb->phases, nq[0], nq[1], hb->rc[0].relaxed_vertices, hb->rc[1].relaxed_vertices, hb->rc[0].nq[par[0] ^ 1],
+				        hb->rc[1].nq[par[1] ^ 1], hb->active, (unsigned long long)hb->rc[0].relaxed_edges, (unsigned long long)hb->rc[1].relaxed_edges);
+			for (int s = 0; s < 2; s++) {
+				if (nq[s] == 0) continue; // (nothing was launched: the side's queues and parity stay as they are)
+				par[s] ^= 1;
+				nq[s] = hb->rc[s].nq[par[s]];
+			}
+			if (hb->active == 0) break;
+			if (hb->phases != phases_seen) { // a higher cap: every labelled vertex again, over the longer prefix of its list
+				phases_seen = hb->phases;
+				for (int s = 0; s < 2; s++) {
+					hipLaunchKernelGGL(k_redirty, dim3((unsigned)device_cus() * 4), dim3(256), 0, st, touched[s]->template as<int32_t>(), &bb->rc[s].tcount,
+					                   dirty[s][par[s]]->template as<u64>(), qbuf[s][par[s]]->template as<int32_t>(), &bb->rc[s].nq[par[s]]);
+					nq[s] = hb->rc[s].tcount;
+				}
+			}
+		}
+		const u64 edges = hb->rc[0].relaxed_edges + hb->rc[1].relaxed_edges;
+		S.edges_scanned += (int64_t)edges;
+		S.algo_bytes[K_RELAX] += (double)edges * (4.0 + 8.0 + 2.0 * (double)sizeof(DT) * LC);
+		hipLaunchKernelGGL(k_bidir_results, dim3(1), dim3(64), 0, st, lo, nl, ws->sidx.as<u32>(), bb, (long long)inf_bits, d_out, d_ok);
+		for (int s = 0; s < 2; s++)
+			hipLaunchKernelGGL(k_reset_touched<DT>, dim3((unsigned)device_cus() * 4), dim3(256), 0, st, touched[s]->template as<int32_t>(), &bb->rc[s].tcount,
+			                   dist[s]->template as<DT>(), inf_label);
+		// what the finished lanes left dirty: the next batch starts from clean words
+		for (int s = 0; s < 2; s++)
+			for (int k = 0; k < 2; k++) PGQ_HIP_TRY(hipMemsetAsync(dirty[s][k]->p, 0, (size_t)V * 8, st));
+	}
+	PGQ_HIP_TRY(hipStreamSynchronize(st));
+	KernelTimer::flush();
+	for (int s = 0; s < 2; s++) {
+		*dist_V[s] = c->V; // every touched row is back at INF
+		*dist_tag[s] = type_tag;
+	}
+	return PGQ_OK;
+}
+
 template <typename T>
 static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                            int64_t *d_out, uint8_t *d_ok, bool chain) {
@@ -1495,8 +1842,25 @@ static int cheapest_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *
 	// weight on the handle; a mean that is not a positive finite number gives no first cap: plain rounds)
 	const bool light = light_edges_first(c) && c->wadj && c->w_mean > 0 && c->w_mean < 1e300;
 	const bool narrow = light && labels_fit_32<T>(c);
+	// about one destination per source (a list of pairs, not a cross product): every row is a lane of its own, searched from
+	// both ends (relax_batches_bidir); many destinations per source share their source's lane as before
+	const int64_t R = bs[nb]; // the rows that need a search (sorted by source; trivial and NULL rows behind them)
+	bool bidir = false;
+	if constexpr (std::is_same<T, int64_t>::value)
+		bidir = options().relax_bidir && light && R > 0 && R <= (int64_t)std::max(1, options().relax_bidir_rows) * (int64_t)U;
+	int nb_run = nb;
+	if (bidir) {
+		PGQ_TRY(ensure_reverse_sorted(c, ws));
+		bidir = c->rwadj != nullptr;
+		if (bidir) {
+			nb_run = (int)((R + LC - 1) / LC);
+			workers = std::max(1, std::min(workers, nb_run));
+		}
+	}
 	auto run_relax = [&](Workspace *priv, int b0, int bstride) -> int {
 		if constexpr (std::is_same<T, int64_t>::value) {
+			if (bidir) return narrow ? relax_batches_bidir<int32_t>(c, ws, priv, b0, bstride, nb_run, R, d_out, d_ok)
+			                         : relax_batches_bidir<int64_t>(c, ws, priv, b0, bstride, nb_run, R, d_out, d_ok);
 			if (narrow) return relax_batches<T, int32_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok, light);
 		}
 		return relax_batches<T, int64_t>(c, ws, priv, b0, bstride, nb, U, d_out, d_ok, light);

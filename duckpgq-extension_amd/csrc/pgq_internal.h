@@ -86,6 +86,13 @@ struct Options {
 	int relax_labels32 = 1;   // int64 weights whose path sums fit 31 bits keep 4-byte labels (rows of 256 bytes instead of 512)
 	int relax_light_min_degree = 8; // relax_light = 1: only CSRs with at least this many edges per vertex (2: always)
 	int relax_light_div = 4;  // first cap = mean weight / this
+	int relax_bidir = 0;      // int64 weights, light-edges-first graphs, about one destination per source: every lane a (src, dst) pair
+	                          // searched from both ends under a common distance cap (relax_batches_bidir).  Bit-exact in the tests; OFF as
+	                          // shipped: on the weighted knows graph the two half-distance balls already hold the hubs — 30 M relaxed edges
+	                          // per 64 pairs against 40 M one-sided, but 83 rounds instead of 35: 232 ms per 512 pairs against 89
+	int relax_bidir_rows = 2; // ... when the call has at most this many rows per distinct source
+	int relax_bidir_c0_div = 64;    // first distance cap = mean weight x 2 / this ...
+	int relax_bidir_step_div = 128; // ... raised by mean weight x 2 / this per phase (and by a quarter, and past empty bands)
 	int relax_streams = 6;    // batches of the relaxation side by side on their own label arrays (0: `streams`)
 	int relax_split = 1;      // lists longer than 128 edges are relaxed 64 edges per wavefront by a second launch of the round
 	int relax_delta_div = 0;  // batched relaxation: > 0 = a round only expands labels below a threshold that grows by mean weight / this
@@ -269,6 +276,8 @@ struct pgq_csr {
 	// weights in that order (built on first use); w_max_bits = the largest weight as its bit pattern
 	int32_t *wadj = nullptr;
 	void *wsorted = nullptr;
+	int32_t *rwadj = nullptr;    // the same for the in-lists (radj / rw), for the backward side of the bidirectional relaxation
+	void *rwsorted = nullptr;
 	unsigned long long w_max_bits = 0;
 	int64_t *wcc = nullptr;      // weakly_connected_component ids of the V + 2 forest entries (computed once per handle)
 	double *pagerank = nullptr;

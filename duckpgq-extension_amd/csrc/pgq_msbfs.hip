@@ -1567,6 +1567,7 @@ Workspace::~Workspace() {
 	if (ev_block) (void)hipEventDestroy(ev_block);
 	if (stream) (void)hipStreamDestroy(stream);
 	if (h_cnt) (void)hipHostFree(h_cnt);
+	if (h_bi) (void)hipHostFree(h_bi);
 	if (h_log) (void)hipHostFree(h_log);
 	if (h_meet) (void)hipHostFree(h_meet);
 	if (h_io) (void)hipHostFree(h_io);
@@ -1575,7 +1576,8 @@ Workspace::~Workspace() {
 	                   &sidx, &ssrc, &sdst, &sres, &soff, &sort_tmp, &scan_tmp, &bstart, &levels_tab, &child, &in_src,
 	                   &in_dst, &out_len, &out_off, &dist, &dirty[0], &dirty[1], &touched, &tflag, &out_val, &out_ok, &lane_sums, &ste, &def_src, &def_dst, &def_len,
 	                   &def_idx, &def_off, &def_ent, &cbits, &cbbase, &cmeta, &cwords, &lblk, &lrec, &meet_cnt, &meet_rec, &meet_poff, &meet_maps, &meet_trace,
-	                   &wb_scratch, &hv, &hmask, &hstart, &hmap, &route_dec, &ball_segs, &ball_trace, &sort_src, &sort_dst, &sort_out, &dpart })
+	                   &wb_scratch, &hv, &hmask, &hstart, &hmap, &route_dec, &ball_segs, &ball_trace, &sort_src, &sort_dst, &sort_out, &dist_b, &dirty_b[0], &dirty_b[1], &qbuf_b[0], &qbuf_b[1],
+	                   &touched_b, &tflag_b, &bi_block, &dpart })
 		b->release();
 	for (auto *v : { &levels, &pool })
 		for (auto &l : *v) {

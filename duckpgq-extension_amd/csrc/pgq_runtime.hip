@@ -195,6 +195,10 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "relax_labels32", &o.relax_labels32, nullptr },
 		{ "relax_split", &o.relax_split, nullptr },
 		{ "relax_streams", &o.relax_streams, nullptr },
+		{ "relax_bidir", &o.relax_bidir, nullptr },
+		{ "relax_bidir_rows", &o.relax_bidir_rows, nullptr },
+		{ "relax_bidir_c0_div", &o.relax_bidir_c0_div, nullptr },
+		{ "relax_bidir_step_div", &o.relax_bidir_step_div, nullptr },
 		{ "chain", &o.chain, nullptr },
 		{ "chain_cap", &o.chain_cap, nullptr },
 		{ "alloc_cache_mb", &o.alloc_cache_mb, nullptr },
@@ -1444,6 +1448,8 @@ static void destroy_csr(pgq_csr *c) {
 	dev_free(c->rw);
 	dev_free(c->wadj);
 	dev_free(c->wsorted);
+	dev_free(c->rwadj);
+	dev_free(c->rwsorted);
 	delete c;
 }
 

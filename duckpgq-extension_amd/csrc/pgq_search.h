@@ -266,7 +266,7 @@ struct Workspace {
 	DevBuf seen, qbuf[2], qflag, counters, flag, rank, usrc, key, idx, skey, sidx, ssrc, sdst, sres, soff,
 	    sort_tmp, scan_tmp, bstart, levels_tab, child, in_src, in_dst, out_len, out_off, dist, dirty[2], touched,
 	    tflag, out_val, out_ok, lane_sums, ste, def_src, def_dst, def_len, def_idx, def_off, def_ent, cbits, cbbase, cmeta, cwords, lblk, lrec, meet_cnt, meet_rec, meet_poff, meet_maps, meet_trace, wb_scratch, hv, hmask, hstart, hmap,
-	    route_dec, ball_segs, ball_trace, sort_src, sort_dst, sort_out, dpart; // [kOpenGrid][WD + 1]: every workgroup's open-lane words + open-row count of the level's detection / probe
+	    route_dec, ball_segs, ball_trace, sort_src, sort_dst, sort_out, dist_b, dirty_b[2], qbuf_b[2], touched_b, tflag_b, bi_block, dpart; // [kOpenGrid][WD + 1]: every workgroup's open-lane words + open-row count of the level's detection / probe
 	std::vector<std::unique_ptr<LevelBuf>> levels; // shortestpath: one per level
 	std::vector<std::unique_ptr<LevelBuf>> pool;   // otherwise: [0], [1] sparse pool, [2], [3] dense pool
 	bool pool_trusted = false;                     // the last batch ended normally: the sparse pool's dirty flags are true
@@ -290,6 +290,9 @@ struct Workspace {
 	// cheapest path: which (V, lanes, type) the dist array is currently initialised for
 	int64_t dist_V = -1;
 	int dist_lanes = 0;
+	int64_t dist_b_V = -1; // the same for the backward side's labels (relax_batches_bidir)
+	int dist_b_lanes = 0;
+	void *h_bi = nullptr;  // pinned: the bidirectional relaxation's counter block, copied back once per round
 	u32 touch_epoch = 0;
 	~Workspace();
 };

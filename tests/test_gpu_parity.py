@@ -22,6 +22,9 @@ def _defaults():
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
                  ("meet_layout", 1), ("meet_align", 4), ("probe_always", 0), ("meet_grid_mult", 8), ("meet4_grid_mult", 2), ("relax_delta_div", 0), ("relax_light", 2), ("relax_light_div", 4), ("relax_split", 1), ("relax_labels32", 1),
+                 # the two-ended relaxation (round 6) would take every list of int64-weighted pairs before the one-sided kernels under
+                 # test see them; its own test and the shipped configuration switch it on
+                 ("relax_bidir", 0), ("relax_bidir_rows", 2), ("relax_bidir_c0_div", 64), ("relax_bidir_step_div", 128),
                  ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1),
                  # the source-centric kernel (round 6) would take every grouped input before the kernels under test see it; its own
                  # tests and the shipped configuration switch it on
@@ -34,7 +37,7 @@ SHIPPED_KEYS = ("push_div", "streams", "probe2_abs", "meet", "meet_align", "meet
                 "meet_small_rows", "probe", "probe2", "defer", "lanes", "lanes_unroll", "sparse_lds", "sparse_pw", "sparse_unroll",
                 "sparse_spill", "hub_chunk", "push_chunk", "spec_levels", "sort_single_batch", "detect_unroll", "route_memo", "meet4",
                 "bibfs_rows", "relax_light", "relax_split", "relax_streams", "wbibfs", "meet4_grid_mult", "meet_grid_mult", "meet_calibrate", "stage2_ahead",
-                "ball", "ball_cap", "ball_test_cap", "ball_sort")
+                "ball", "ball_cap", "ball_test_cap", "ball_sort", "relax_bidir")
 
 
 @pytest.fixture(params=["fixture_values", "shipped_values"])
@@ -718,6 +721,71 @@ def test_weighted_pair_search_bit_exact(delta_div):
     st, ora = both(V, cases[0][1], w=rng.random(E) + 0.01, csr_id=10)
     out, ok = st.cheapest_path_length(10, V, ps[:100], pd[:100])
     lout, lok = ora.lean_cheapest_path_length(V, ps[:100], pd[:100])
+    assert (ok == lok).all() and (out[ok] == lout[ok]).all()
+
+
+@pytest.mark.parametrize("labels32", [1, 0])
+def test_two_ended_relaxation_bit_exact(labels32):
+    # relax_batches_bidir (pgq_cheapest.hip): every lane a (src, dst) pair, k_relax from both ends under a common distance cap;
+    # int64 weights, lists of pairs.  Caps: shipped, one-unit first cap / steps (a phase per label), one huge cap (a single phase)
+    rng = np.random.default_rng(811 + labels32)
+    pgq.set_option("relax_bidir", 1)
+    pgq.set_option("relax_light", 2)
+    pgq.set_option("relax_labels32", labels32)
+    pgq.set_option("chain", 0)
+    cases = []
+    V, E = 4000, 30000
+    s, d, e = random_graph(rng, V, E, skew=True)
+    cases.append((V, (s, d, e), rng.integers(1, 1000, E)))                      # skewed, hubs over 128 edges (heavy lists)
+    cases.append((V, (s, d, e), rng.integers(0, 3, E)))                         # many zero-weight edges and ties
+    s2, d2, e2 = random_graph(rng, 6000, 7000)
+    cases.append((6000, (s2, d2, e2), rng.integers(1, 50, 7000)))               # sparse: unreachable pairs, small closures
+    s3 = np.concatenate([s[:5000], s[:5000]])
+    d3 = np.concatenate([d[:5000], d[:5000]])
+    cases.append((V, (s3, d3, np.arange(10000, dtype=np.int64)), rng.integers(1, 9, 10000)))  # parallel edges
+    cases.append((V, (s, d, e), np.full(E, 7)))                                 # one weight: every band but each seventh is empty
+    cases.append((V, (s, d, e), (2.0 ** (rng.random(E) * 30)).astype(np.int64)))  # thirty binary orders (8-byte labels)
+    for cid, (Vc, rows, w) in enumerate(cases):
+        st, ora = both(Vc, rows, w=w.astype(np.int64), csr_id=cid)
+        for n, c0, step, streams in ((700, 16, 32, 2), (64, 16, 32, 1), (1, 16, 32, 2), (130, 1 << 30, 1 << 30, 3), (200, 1, 1, 2)):
+            pgq.set_option("relax_bidir_c0_div", c0)
+            pgq.set_option("relax_bidir_step_div", step)
+            pgq.set_option("streams", streams)
+            ps, pd = rng.integers(0, Vc, n), rng.integers(0, Vc, n)
+            if n >= 64:
+                ps[:20] = pd[:20]          # trivial rows
+                ps[20:30] = ps[30]         # a source shared by several lanes (still <= 2 rows per distinct source overall)
+                pd[40:48] = pd[48]         # a destination shared by several lanes
+            out, ok = st.cheapest_path_length(cid, Vc, ps, pd)
+            lout, lok = ora.lean_cheapest_path_length(Vc, ps, pd)
+            assert (ok == lok).all() and (out[ok] == lout[ok]).all(), (cid, n, c0)
+    # the two-ended search is taken (fewer relaxed edges than one lane per source), a cross product is not (same as without it)
+    st, ora = both(cases[0][0], cases[0][1], w=cases[0][2].astype(np.int64), csr_id=9)
+    ps, pd = rng.integers(0, V, 400), rng.integers(0, V, 400)
+    lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
+    scanned = {}
+    for bidir in (1, 0):
+        pgq.set_option("relax_bidir", bidir)
+        pgq.reset_stats()
+        out, ok = st.cheapest_path_length(9, V, ps, pd)
+        assert (ok == lok).all() and (out[ok] == lout[ok]).all()
+        scanned[bidir] = pgq.get_stats()["edges_scanned"]
+    assert scanned[1] != scanned[0]
+    ps = ps[rng.integers(0, 20, 400)]  # 20 sources x 20 destinations each
+    lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
+    for bidir in (1, 0):
+        pgq.set_option("relax_bidir", bidir)
+        pgq.reset_stats()
+        out, ok = st.cheapest_path_length(9, V, ps, pd)
+        assert (ok == lok).all() and (out[ok] == lout[ok]).all()
+        scanned[bidir] = pgq.get_stats()["batches"]
+    assert scanned[1] == scanned[0] == 1  # 20 sources: one batch of lanes either way (400 pairs would be 7 batches of pairs)
+    # double weights keep one lane per source (a two-sided sum is not the reference's left fold)
+    pgq.set_option("relax_bidir", 1)
+    st, ora = both(V, cases[0][1], w=rng.random(E) + 0.01, csr_id=10)
+    ps, pd = rng.integers(0, V, 100), rng.integers(0, V, 100)
+    out, ok = st.cheapest_path_length(10, V, ps, pd)
+    lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
     assert (ok == lok).all() and (out[ok] == lout[ok]).all()
 
 

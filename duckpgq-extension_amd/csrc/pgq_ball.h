@@ -129,6 +129,7 @@ __device__ __forceinline__ bool ball_decides(const BallRule &rule, int64_t n, u3
 #ifndef PGQ_BALL_WAVES
 #define PGQ_BALL_WAVES 8 // wavefronts per SIMD k_src_ball is compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs), 4 = one (128)
 #endif
+constexpr int kBallFarRows = 16; // rows per segment whose distance-4 walk all 16 wavefronts take up together (k_src_ball)
 #ifndef PGQ_BALL_UH
 #define PGQ_BALL_UH 4 // row octets (8 rows, 8 lanes each) a wavefront scans per step out of the fixed-stride heads
 #endif
@@ -179,12 +180,13 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 		}
 	};
 	// option meet_trace: time per phase (10-ns ticks of the constant clock, thread 0 of every workgroup), summed over the grid
-	unsigned long long t_last = TRACE ? wall_clock64() : 0ull, t_ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_seg_max = 0, t_seg0 = 0;
+	unsigned long long t_last = TRACE ? wall_clock64() : 0ull, t_ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_pmax[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_seg_max = 0, t_seg0 = 0;
 	auto tick = [&](int k) {
 		if constexpr (TRACE) {
 			if (tid == 0) {
 				const unsigned long long now = wall_clock64();
 				t_ph[k] += now - t_last;
+				t_pmax[k] = max(t_pmax[k], now - t_last);
 				t_last = now;
 			}
 		}
@@ -452,7 +454,10 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 					}
 				}
 				__syncthreads();
-				const u32 n3 = s_n3;
+				// ... at most kBallFarRows of them: a source with a small ball and many far or unreachable destinations (R-MAT-22: one
+				// segment walked its 32 K-entry allowance for several hundred rows, 6.5-8.9 ms of a 9.4-ms kernel) leaves the rest
+				// open — the pair-centric kernels behind take them a row per workgroup, side by side
+				const u32 n3 = min(s_n3, (u32)kBallFarRows);
 				for (u32 r = 0; r < n3; r++) {
 					const u32 t = (u32)s_q1[r];
 					const int degD = (int)s_in[t].y;
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 		if (tid == 0) {
 			for (int k = 0; k < 8; k++) atomicAdd(&trace[k], t_ph[k]);
 			atomicMax(&trace[8], t_seg_max);
+			for (int k = 0; k < 8; k++) atomicMax(&trace[9 + k], t_pmax[k]); // the longest single phase of each kind
 		}
 	}
 	// statistics: one pair of atomics per workgroup, spread over 32 slots

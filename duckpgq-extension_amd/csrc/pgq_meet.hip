@@ -38,6 +38,7 @@ struct MeetPath {
 	int32_t v1, v2, v3, pad;
 };
 
+constexpr int kMeet3ExpMax = 4096;  // longest one-hop list k_meet3 expands from (one wavefront); beyond: k_meet4d
 constexpr int kMeetWPB = 1;         // wavefronts per k_meet3 workgroup: one, so that a finished row frees its slot at once
 #ifndef PGQ_MEET3_WAVES
 #define PGQ_MEET3_WAVES 8 // wavefronts per SIMD k_meet3<false> is compiled for (64 VGPRs; 4.2 KB of LDS per wavefront: 8 fit)
@@ -261,6 +262,9 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 	const int64_t wave0 = (int64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 	const int64_t nwaves = (int64_t)((gridDim.x * blockDim.x) >> 6);
 	for (int64_t i = wave0; i < n; i += nwaves) {
+#ifdef PGQ_MEET3_ROWTRACE
+		const unsigned long long rt0 = wall_clock64();
+#endif
 		const int64_t s = src[i], d = dst[i];
 		{
 			if (s < 0) { // NULL row (iterativelength.cpp:99-101)
@@ -302,7 +306,10 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 		const int set_n = fwd ? degD : degS;
 		const int exp_n = fwd ? degS : degD;
 		{
-			if (set_n > kSetRegMax) { // both lists too long for the registers
+			// both lists too long for the registers — or the expanded side's own list is a hub's: its distance-2 test alone is one
+			// wavefront reading exp_n descriptors 256 per round trip (R-MAT-22: a 100,000-neighbour endpoint among 1024 random pairs
+			// held the kernel for 70 us); the bit-map kernel reads it with 16 wavefronts
+			if (set_n > kSetRegMax || (!PATHS && exp_n > kMeet3ExpMax)) {
 				if (lane == 0) {
 					out[i] = kMeetOpen;
 					queue_push(q, (u32)i, ent);
@@ -355,7 +362,10 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 			{
 				const u32 v = lane < exp_n ? d0.x : kMeetEmpty;
 				const u32 pass = v != kMeetEmpty ? (flt_test<BIGV>(bm[flt_word(v)], v) & 1u) : 0u;
-				verify_candidates(R, pass, make_int4((int)v, 0, 0, 0), [&](u32 x, int) { mid = min(mid, x); });
+				verify_candidates(R, pass, make_int4((int)v, 0, 0, 0), [&](u32 x, int) {
+					mid = min(mid, x);
+					return !PATHS; // a hop count needs any common neighbour, a path the smallest
+				});
 			}
 			// the rest of a long one-hop list, 256 ids per round trip (a hub's 5000 neighbours were 78 dependent trips of 64)
 			for (int pb = 64; pb < exp_n; pb += 256) {
@@ -370,7 +380,11 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 #pragma unroll
 				for (int u = 0; u < 4; u++)
 					if (v[u] != kMeetEmpty) pass |= (flt_test<BIGV>(bm[flt_word(v[u])], v[u]) & 1u) << u;
-				verify_candidates(R, pass, make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]), [&](u32 x, int) { mid = min(mid, x); });
+				verify_candidates(R, pass, make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]), [&](u32 x, int) {
+					mid = min(mid, x);
+					return !PATHS;
+				});
+				if (!PATHS && mid != kMeetEmpty) break;
 			}
 			if (mid != kMeetEmpty) {
 				if (lane == 0) {
@@ -387,6 +401,10 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 		u64 best = ~0ull; // wave-uniform: smallest (outer vertex << 32 | inner vertex) over the witnesses (PATHS), or 0 = found
 		bool capped = false;
 		int resume = 0;
+#ifdef PGQ_MEET3_ROWTRACE
+		const unsigned long long rt1 = wall_clock64();
+		const unsigned long long ent_before = entries;
+#endif
 		entries += seg_walk<DEPTH, PATHS>(
 		    exp_desc, exp_n, 0, 1, xp, win, true, d0, (unsigned long long)cap, capped, resume,
 		    [&](const int4 &v, bool ok, u32 ev) {
@@ -397,13 +415,23 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 				    if constexpr (PATHS) { // backward walk: expanded vertex = second-to-last, entry = the one before it
 					    const u32 y = (u32)__builtin_amdgcn_readlane((int)ev, L);
 					    best = min(best, (u64)y << 32 | x);
+					    return false;
 				    } else {
 					    best = 0;
+					    return true;
 				    }
 			    });
 		    },
 		    [&]() { return best != ~0ull; });
 		const bool found = best != ~0ull;
+#ifdef PGQ_MEET3_ROWTRACE
+		{
+			const unsigned long long rt2 = wall_clock64();
+			if (lane == 0 && rt2 - rt0 > 2000) // > 20 us
+				printf("meet3 row %lld: start +%.1f us, head %.1f us, walk %.1f us, degS %d degD %d workS %u workD %u set %d exp %d walked %llu found %d capped %d\n", (long long)i,
+				       0.0, (rt1 - rt0) * 0.01, (rt2 - rt1) * 0.01, degS, degD, workS, workD, set_n, exp_n, entries - ent_before, (int)found, (int)capped);
+		}
+#endif
 		if (lane == 0) {
 			if constexpr (PATHS) {
 				if (found) {
@@ -1025,7 +1053,12 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 	}
 	const int mw = bm_words + 4;
 	u32 *const gmap = GM ? gmaps + (size_t)blockIdx.x * 2 * mw : nullptr;
-	u32 *const qbase = queues + (size_t)blockIdx.x * 4 * qcap; // [side][parity][qcap]
+	u32 *const qbase = queues + (size_t)blockIdx.x * 5 * qcap; // [side][parity][qcap], then the touched-word list [qcap]
+	// GM: the two maps are 2 x V / 8 bytes per row (R-MAT-22: 1 MB) and a search that ends after a few hundred vertices used to
+	// pay their full clear — 22 GB of stores per 2048 x 1024 cross product, most of the kernel's 7.7 ms.  The thread whose
+	// atomicOr finds a word still zero lists it; the next row clears the listed words (a list over `qcap`: the full clear).
+	u32 *const tlist = qbase + (size_t)4 * qcap;
+	__shared__ u32 s_tn;
 	__shared__ int s_found;
 	__shared__ u32 s_cnt;
 	__shared__ unsigned long long s_work;
@@ -1046,13 +1079,21 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 		if constexpr (GM) return __hip_atomic_load(&gmap[side * mw + (x >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		else return s_map[side * mw + (x >> 5)];
 	};
+	if (tid == 0) s_tn = ~0u; // the maps arrive with whatever the last launch left: the first row clears them all
 	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
 		__syncthreads();
 		const int64_t s = src[i], d = dst[i]; // open rows: ids in range, src != dst, both have edges
 		const u32 row = didx[i] & ~kMeetKnown4Bit;
 		if constexpr (GM) {
-			uint4 *m4 = reinterpret_cast<uint4 *>(gmap); // mw is a multiple of 4, slices are 16-byte aligned
-			for (int k = tid; k < 2 * mw / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
+			const u32 tn = s_tn;
+			if (tn > (u32)qcap) {
+				uint4 *m4 = reinterpret_cast<uint4 *>(gmap); // mw is a multiple of 4, slices are 16-byte aligned
+				for (int k = tid; k < 2 * mw / 4; k += 1024) m4[k] = make_uint4(0, 0, 0, 0);
+			} else {
+				for (u32 k = tid; k < tn; k += 1024) gmap[tlist[k]] = 0;
+			}
+			__syncthreads();
+			if (tid == 0) s_tn = 0;
 		} else {
 			for (int k = tid; k < 2 * mw; k += 1024) s_map[k] = 0;
 		}
@@ -1063,6 +1104,11 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 			(void)or_rtn(1, (u32)d);
 			qbase[0] = (u32)s;
 			qbase[2 * qcap] = (u32)d;
+			if constexpr (GM) {
+				tlist[0] = (u32)s >> 5;
+				tlist[1] = (u32)mw + ((u32)d >> 5);
+				s_tn = 2;
+			}
 		}
 		int nf[2] = { 1, 1 }, lvl[2] = { 0, 0 }, par[2] = { 0, 0 };
 		int64_t work[2] = { off[s + 1] - off[s], roff[d + 1] - roff[d] };
@@ -1093,6 +1139,20 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 				    for (int k = 0; k < 4; k++) old[k] = or_rtn(side, xs[k]);
 #pragma unroll
 				    for (int k = 0; k < 4; k++) oth[k] = word_of(side ^ 1, xs[k]);
+				    if constexpr (GM) { // words this search has just made non-zero (the masked lanes' spare word included)
+#pragma unroll
+					    for (int k = 0; k < 4; k++) {
+						    const bool first = old[k] == 0u;
+						    const u64 m = __ballot(first);
+						    if (m) {
+							    u32 base = 0;
+							    if (lane == 0) base = atomicAdd(&s_tn, (u32)__popcll(m));
+							    base = (u32)__shfl((int)base, 0);
+							    const u32 slot = base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+							    if (first && slot < (u32)qcap) tlist[slot] = (u32)(side * mw) + (xs[k] >> 5);
+						    }
+					    }
+				    }
 #pragma unroll
 				    for (int k = 0; k < 4; k++) {
 					    const bool in = (valid >> k) & 1u;
@@ -1284,6 +1344,19 @@ static void meet_attributes() {
 	attr_set.store(1);
 }
 
+// debugging aid (option meet_trace): where k_src_ball's time goes
+static int print_ball_trace(const unsigned long long *b_trace, u32 nseg, u32 open) {
+	unsigned long long t[17];
+	PGQ_HIP_TRY(hipMemcpy(t, b_trace, sizeof(t), hipMemcpyDeviceToHost));
+	const double seg = (double)std::max<u32>(nseg, 1) * 100.0;
+	fprintf(stderr, "[pgq] k_src_ball trace: longest single phase, us: rows+clear %.1f, S1 %.1f, S2 %.1f, in-ball tests %.1f, in-list scans %.1f, distance 4 %.1f, "
+	        "output %.1f, between segments %.1f\n", t[9] * 0.01, t[10] * 0.01, t[11] * 0.01, t[12] * 0.01, t[13] * 0.01, t[14] * 0.01, t[15] * 0.01, t[16] * 0.01);
+	fprintf(stderr, "[pgq] k_src_ball trace: %u segments, %u rows left open, us per segment: rows+clear %.1f, S1 %.1f, S2 %.1f, in-ball tests %.1f, in-list scans %.1f, "
+	        "distance 4 %.1f, output %.1f, between segments %.1f; longest segment %.1f us\n",
+	        nseg, open, t[0] / seg, t[1] / seg, t[2] / seg, t[3] / seg, t[4] / seg, t[5] / seg, t[6] / seg, t[7] / seg, (double)t[8] * 0.01);
+	return PGQ_OK;
+}
+
 // Runs the pre-pass over n rows (device memory, or pinned host memory the device can address: the chunk entry points
 // hand their staging block over as it is); rows it answers get their hop count (or -1 for NULL) in d_out, the others end
 // up in ws->open_src / open_dst / open_idx and are counted in *n_open.  The whole chain — decision (large inputs),
@@ -1380,7 +1453,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		maps_bytes = (size_t)grid4 * bm_words * 4;
 	}
 	const size_t bi_map_words = (run_bi && !bi_lds) ? (size_t)bi_grid * 2 * mwb : 0;
-	const size_t bi_bytes = run_bi ? (bi_map_words + (size_t)bi_grid * 4 * qcap) * 4 + 64 : 0;
+	const size_t bi_bytes = run_bi ? (bi_map_words + (size_t)bi_grid * 5 * qcap) * 4 + 64 : 0;
 	if (maps_bytes + bi_bytes > 0) PGQ_TRY(ws->meet_maps.reserve(maps_bytes + bi_bytes + 64));
 	u32 *gmaps = ws->meet_maps.as<u32>();
 	u32 *bi_maps = gmaps ? gmaps + (maps_bytes + 15) / 16 * 4 : nullptr;
@@ -1479,6 +1552,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			return PGQ_OK;
 		}
 		if (ball_ran) *ball_ran = true;
+		if (b_trace) PGQ_TRY(print_ball_trace(b_trace, h.ball_nseg, h.ball_open));
 		ws->open_src = q[0].src;
 		ws->open_dst = q[0].dst;
 		ws->open_idx = q[0].idx;
@@ -1617,14 +1691,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		        grid4, rows, h.count[0], most, (double)(t1 - t0) * 0.01, (double)(last_start - t0) * 0.01,
 		        (double)(first_end - t0) * 0.01, (double)longest * 0.01);
 	}
-	if (b_trace && h.ball_go) { // debugging aid: where k_src_ball's time goes
-		unsigned long long t[9];
-		PGQ_HIP_TRY(hipMemcpy(t, b_trace, sizeof(t), hipMemcpyDeviceToHost));
-		const double seg = (double)std::max<u32>(h.ball_nseg, 1) * 100.0;
-		fprintf(stderr, "[pgq] k_src_ball trace: %u segments, us per segment: rows+clear %.1f, S1 %.1f, S2 %.1f, in-ball tests %.1f, in-list scans %.1f, "
-		        "distance 4 %.1f, output %.1f, between segments %.1f; longest segment %.1f us\n",
-		        h.ball_nseg, t[0] / seg, t[1] / seg, t[2] / seg, t[3] / seg, t[4] / seg, t[5] / seg, t[6] / seg, t[7] / seg, (double)t[8] * 0.01);
-	}
+	if (b_trace && h.ball_go) PGQ_TRY(print_ball_trace(b_trace, h.ball_nseg, h.ball_open));
 	if (ball_mode && h.ball_go) { // the source-centric kernel took the call: what is open sits in region 0, counted by itself
 		if (h.bad) return fail(PGQ_ERR_INVALID_ARG, "src/dst rowid out of range [0,V)");
 		if (ball_ran) *ball_ran = true;
@@ -1737,7 +1804,7 @@ int meet_bidirectional(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_sr
 	const int qcap = std::max(1024, opt.bibfs_queue);
 	const u32 grid = (u32)std::min<int64_t>(n, device_cus());
 	const size_t map_words = bi_lds ? 0 : (size_t)grid * 2 * mwb;
-	PGQ_TRY(ws->meet_maps.reserve((map_words + (size_t)grid * 4 * qcap) * 4 + 64));
+	PGQ_TRY(ws->meet_maps.reserve((map_words + (size_t)grid * 5 * qcap) * 4 + 64));
 	u32 *maps = ws->meet_maps.as<u32>();
 	u32 *queues = maps + map_words;
 	meet_attributes();

@@ -452,6 +452,180 @@ __global__ __launch_bounds__(64 * kMeetWPB, PATHS ? 6 : (DEPTH > 4 ? 4 : (DEPTH 
 	meet_finalize(db, fin);
 }
 
+// ---- k_meet3 for chunk-sized calls: several wavefronts per row (k_meet3w, round 6) ------------------------------------
+// A call of <= meet_wide_rows rows (one or two DuckDB chunks) leaves most of the chip's 8192 wavefront slots empty, and its
+// duration is its slowest row's: a two-hop walk of ~9,000 entries that meets its witness late (or not at all: distance >= 4)
+// is ~40 list requests, 10 dependent round trips of one wavefront with four in flight — 18-22 us of k_meet3's 28 (row trace,
+// 2048 rows of the SF100-shaped graph).  Here a row is a workgroup of WPB wavefronts: all of them hold the set in their
+// registers (the same loads, cached), the filter is built once in LDS, distances 1 and 2 are tested by every wavefront alike
+// (so that the branches stay uniform across the workgroup), and the two-hop walk is split request by request (seg_walk's
+// stride); the first witness any of them finds ends the row.  Same tests in the same order as k_meet3: same answers.
+template <bool BIGV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_meet3w(int64_t n, const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                    int64_t V, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                    const int64_t *__restrict__ roff, const int32_t *__restrict__ radj,
+                                                    const uint4 *__restrict__ fdesc, const uint4 *__restrict__ rdesc,
+                                                    const int32_t *__restrict__ padj, const int32_t *__restrict__ rpadj,
+                                                    const u32 *__restrict__ fwork, const u32 *__restrict__ rwork,
+                                                    int64_t *__restrict__ out, int64_t cap, const u32 *__restrict__ go,
+                                                    MeetDevBlock *__restrict__ db, MeetQueue q, MeetHostBlock *__restrict__ fin) {
+	static_assert(kFltWords / 256 <= 4 && (WPB == 2 || WPB == 4), "the filter is cleared in at most four 1-KB parts");
+	__shared__ __attribute__((aligned(16))) u32 bm[kFltWords];
+	__shared__ __attribute__((aligned(16))) unsigned char win_all[WPB][64];
+	__shared__ u32 s_found, s_capped;
+	MeetCounters *const mc = &db->m;
+	if ((go && *go == 0) || db->ball.go) {
+		meet_finalize(db, fin);
+		return;
+	}
+	const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+	unsigned char *const win = win_all[wib];
+	win[lane] = 0;
+	unsigned long long entries = 0; // wave-uniform
+	u32 vertices = 0;
+	// every branch below is taken by all wavefronts of the workgroup alike (it depends on the row alone)
+	for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+		__syncthreads(); // the row before: its filter and flags are no longer read
+		const int64_t s = src[i], d = dst[i];
+		if (s < 0) { // NULL row (iterativelength.cpp:99-101)
+			if (tid == 0) out[i] = -1;
+			continue;
+		}
+		if (s >= V || d < 0 || d >= V) {
+			if (tid == 0) {
+				mc->bad = 1;
+				out[i] = -1;
+			}
+			continue;
+		}
+		if (s == d) { // iterativelength.cpp:102-103
+			if (tid == 0) out[i] = 0;
+			continue;
+		}
+		const int so = (int)off[s], se = (int)off[s + 1], di = (int)roff[d], de = (int)roff[d + 1];
+		const u32 workS = fwork[s], workD = rwork[d];
+		const int degS = se - so, degD = de - di;
+		if (degS == 0 || degD == 0) { // no path can exist: NULL like an exhausted search (iterativelength.cpp:133-139)
+			if (tid == 0) out[i] = -1;
+			continue;
+		}
+		MeetEntry ent = { (u32)i, 0u, (u32)s, (u32)d, (u32)so, (u32)degS, (u32)di, (u32)degD, workS, workD, 0u, 0u };
+		bool fwd = workS <= workD; // the side k_meet3 picks
+		if ((fwd ? degD : degS) > kSetRegMax) fwd = !fwd;
+		const int set_n = fwd ? degD : degS;
+		const int exp_n = fwd ? degS : degD;
+		if (set_n > kSetRegMax || exp_n > kMeet3ExpMax) {
+			if (tid == 0) {
+				out[i] = kMeetOpen;
+				queue_push(q, (u32)i, ent);
+			}
+			continue;
+		}
+		const int32_t *set_adj = fwd ? radj + di : adj + so;
+		const uint4 *exp_desc = fwd ? fdesc + so : rdesc + di;
+		const int32_t *xp = fwd ? padj : rpadj;
+		const u32 other = (u32)(fwd ? s : d);
+		RegSet R;
+		R.rounds = (set_n + 63) >> 6;
+#pragma unroll
+		for (int k = 0; k < kSetRegs; k++) {
+			R.r[k] = kMeetEmpty;
+			if (k < R.rounds) {
+				const int p = k * 64 + lane;
+				const u32 x = (u32)set_adj[min(p, set_n - 1)];
+				R.r[k] = p < set_n ? x : kMeetEmpty;
+			}
+		}
+		uint4 d0 = make_uint4(0, 0, 0, 0);
+		if (lane < exp_n) d0 = exp_desc[lane];
+		for (int k = wib; k < kFltWords / 256; k += WPB) reinterpret_cast<uint4_alias *>(bm)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+		if (tid == 0) {
+			s_found = 0;
+			s_capped = 0;
+		}
+		__syncthreads();
+		bool hit = false;
+#pragma unroll
+		for (int k = 0; k < kSetRegs; k++) {
+			if (k < R.rounds) {
+				const u32 x = R.r[k];
+				if (x != kMeetEmpty) {
+					hit |= x == other;
+					if ((k % WPB) == wib) atomicOr(&bm[flt_word(x)], flt_mask<BIGV>(x)); // the set's registers are shared out for the filter
+				}
+			}
+		}
+		if (wib == 0) {
+			entries += (unsigned long long)set_n;
+			vertices += (u32)exp_n;
+		}
+		__syncthreads();
+		if (__any(hit)) {
+			if (tid == 0) out[i] = 1;
+			continue;
+		}
+		u32 mid = kMeetEmpty; // distance 2: any common neighbour
+		{
+			const u32 v = lane < exp_n ? d0.x : kMeetEmpty;
+			const u32 pass = v != kMeetEmpty ? (flt_test<BIGV>(bm[flt_word(v)], v) & 1u) : 0u;
+			verify_candidates(R, pass, make_int4((int)v, 0, 0, 0), [&](u32 x, int) {
+				mid = x;
+				return true;
+			});
+		}
+		for (int pb = 64; pb < exp_n && mid == kMeetEmpty; pb += 256) {
+			u32 v[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int p = pb + 64 * u + lane;
+				v[u] = exp_desc[min(p, exp_n - 1)].x;
+				if (p >= exp_n) v[u] = kMeetEmpty;
+			}
+			u32 pass = 0;
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (v[u] != kMeetEmpty) pass |= (flt_test<BIGV>(bm[flt_word(v[u])], v[u]) & 1u) << u;
+			verify_candidates(R, pass, make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]), [&](u32 x, int) {
+				mid = x;
+				return true;
+			});
+		}
+		if (mid != kMeetEmpty) {
+			if (tid == 0) out[i] = 2;
+			continue;
+		}
+		// distance 3: the walk's requests dealt out to the WPB wavefronts; every one may request cap / WPB entries
+		bool mine = false, capped = false;
+		int resume = 0;
+		entries += seg_walk<PGQ_MEET3_DEPTH_SMALL, false>(
+		    exp_desc, exp_n, wib, WPB, xp, win, true, d0, (unsigned long long)cap / WPB, capped, resume,
+		    [&](const int4 &v, bool, u32) {
+			    const u32 pass = flt_pass4<BIGV>(bm, v);
+			    verify_candidates(R, pass, v, [&](u32, int) {
+				    mine = true;
+				    return true;
+			    });
+		    },
+		    [&]() {
+			    if (mine) s_found = 1;
+			    return *(volatile u32 *)&s_found != 0u;
+		    });
+		if (mine) s_found = 1;
+		if (capped) s_capped = 1;
+		__syncthreads();
+		if (tid == 0) {
+			const bool found = s_found != 0u, cut = s_capped != 0u;
+			out[i] = found ? 3 : (cut ? kMeetOpen : kMeetOpen4);
+			if (!found) { // (a cut walk is taken up from its start by the bit-map kernel: the wavefronts stopped in different rounds)
+				ent.flags = cut ? (kEntKnown3 | (fwd ? kEntFwd : 0u)) : kEntKnown4;
+				queue_push(q, (u32)i, ent);
+			}
+		}
+	}
+	if (lane == 0) meet_add_stats(mc, 0, entries, (unsigned long long)vertices);
+	meet_finalize(db, fin);
+}
+
 // ---- distance <= 4 with an exact vertex bit map, path variant (k_meet4) ---------------------------------------------
 // For the `shortestpath` rows k_meet3<true> leaves open (distance 4, or lists / walks over its caps): one 1024-thread
 // workgroup per row, the bit map in LDS when it fits (V <= ~1.2 M), else a slice of a global buffer (GM):
@@ -1586,6 +1760,20 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		if (paths) {
 			if (bigv) PGQ_MEET3(true, true, PGQ_MEET3_DEPTH);
 			else PGQ_MEET3(true, false, PGQ_MEET3_DEPTH);
+		} else if (small && n <= (int64_t)opt.meet_wide_rows && (opt.meet_wide_rows_always || (double)c->E * 4.0 > 256e6)) {
+			// chunk-sized calls on a graph whose adjacency does not fit the Infinity Cache (a list request is a DRAM round trip,
+			// ~3.5 us under load): several wavefronts per row (k_meet3w: 97 VGPRs, four wavefronts per SIMD = 4096 on the chip) —
+			// four while all rows are resident at once, else two.  Measured: R-MAT-22 x 1024 pairs 49 -> 41 us; the SF100-shaped
+			// graph (160 MB of padded lists, cache resident) 24.1 -> 25.5 us at 1024 rows, 29.1 -> 29.7 at 2048: not taken there
+#define PGQ_MEET3W(B, W)                                                                                                  \
+	hipLaunchKernelGGL((k_meet3w<B, W>), dim3((unsigned)n), dim3(64 * W), 0, st, n, d_src, d_dst, c->V, c->off, c->adj, c->roff, c->radj, \
+	                   c->fdesc, c->rdesc, c->padj, c->rpadj, c->fwork, c->rwork, d_out, cap, d_go, db, q[0], fin)
+			const bool four = n * 4 <= (int64_t)device_cus() * 16;
+			if (bigv && four) PGQ_MEET3W(true, 4);
+			else if (bigv) PGQ_MEET3W(true, 2);
+			else if (four) PGQ_MEET3W(false, 4);
+			else PGQ_MEET3W(false, 2);
+#undef PGQ_MEET3W
 		} else if (small) {
 			if (bigv) PGQ_MEET3(false, true, PGQ_MEET3_DEPTH_SMALL);
 			else PGQ_MEET3(false, false, PGQ_MEET3_DEPTH_SMALL);

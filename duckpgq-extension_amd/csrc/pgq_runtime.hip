@@ -228,6 +228,8 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "meet", &o.meet, nullptr },
 		{ "meet_cap", &o.meet_cap, nullptr },
 		{ "meet_cap_small", &o.meet_cap_small, nullptr },
+		{ "meet_wide_rows", &o.meet_wide_rows, nullptr },
+		{ "meet_wide_rows_always", &o.meet_wide_rows_always, nullptr },
 		{ "meet4_test_cap", &o.meet4_test_cap, nullptr },
 		{ "chunk_zero_copy", &o.chunk_zero_copy, nullptr },
 		{ "meet_small_rows", &o.meet_small_rows, nullptr },

@@ -17,7 +17,7 @@ def _defaults():
                  ("relax_small_limit", 2048), ("chain", 1), ("chain_cap", 4096), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 14), ("meet_cap_paths", 1 << 14), ("meet_cap_small", 1 << 14), ("meet_small_rows", 16384), ("chunk_zero_copy", 1), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
+                 ("meet", 0), ("meet_cap", 1 << 14), ("meet_cap_paths", 1 << 14), ("meet_cap_small", 1 << 14), ("meet_small_rows", 16384), ("meet_wide_rows", 2048), ("meet_wide_rows_always", 0), ("chunk_zero_copy", 1), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
@@ -211,6 +211,44 @@ def test_random_graph_all_variants(words, mode, base_config):
         ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
         assert lens(ln, ok) == want
         assert st.shortestpath(0, V, ps[:700], pd[:700]) == opaths
+
+
+@pytest.mark.parametrize("cap,lds_kb", [(1 << 14, 150), (2000, 150), (64, 0), (1 << 14, 0)])
+def test_meet_prepass_several_wavefronts_per_row(cap, lds_kb):
+    # k_meet3w: chunk-sized calls (<= meet_wide_rows) on graphs beyond the Infinity Cache get 4 wavefronts per row while all rows
+    # are resident at once (<= 1024), else 2; meet_wide_rows_always takes it on any graph.  Same answers as k_meet3, cut walks
+    # (small caps) handed to the bit-map kernel (LDS / global maps) from their start.
+    rng = np.random.default_rng(91 + cap)
+    V, E = 6000, 60000
+    st, ora = both(V, random_graph(rng, V, E, skew=True))
+    V2 = 4000
+    st2, ora2 = both(V2, random_graph(rng, V2, 5000), csr_id=1)  # sparse: dead ends, unreachable pairs, long distances
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_bias", 1e9)
+    pgq.set_option("meet_cap_small", cap)
+    pgq.set_option("meet4_lds_kb", lds_kb)
+    pgq.set_option("meet_wide_rows_always", 1)
+    for n in (1, 63, 900, 2000, 2048):
+        ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        ps[: n // 40] = pd[: n // 40]
+        valid = rng.random(n) > 0.05
+        oln, ook = ora.lean_iterativelength(V, ps, pd)
+        ln, ok = st.iterativelength(0, V, ps, pd, src_valid=valid)
+        assert lens(ln, ok) == [int(v) if (k and vv) else None for v, k, vv in zip(oln, ook, valid)], n
+        ps, pd = rng.integers(0, V2, n), rng.integers(0, V2, n)
+        oln, ook = ora2.lean_iterativelength(V2, ps, pd)
+        ln, ok = st2.iterativelength(1, V2, ps, pd)
+        assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)], n
+    # ids outside [0, V) are refused like everywhere
+    dev = st.device_csr(0)
+    import torch
+    t_s = torch.from_numpy(rng.integers(0, V, 500)).cuda()
+    t_d = torch.from_numpy(rng.integers(0, V, 500)).cuda()
+    t_o = torch.empty(500, dtype=torch.int64, device="cuda")
+    dev.iterativelength_bulk_ptr(500, t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+    t_d[17] = V
+    with pytest.raises(pgq.PgqError):
+        dev.iterativelength_bulk_ptr(500, t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
 
 
 @pytest.mark.parametrize("cap,lds_kb,align", [(1 << 18, 150, 4), (3000, 150, 16), (1, 150, 4), (1 << 18, 0, 32), (300, 150, 4)])

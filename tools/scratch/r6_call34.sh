@@ -1,0 +1,24 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+O=$R/gpurun_out/r6c34
+mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "meet or prepass or golden or chunk or small or udf" > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
+run() { wl=$1; tag=$2; shift; shift; timeout 600 python bench.py --workload $wl --no-cpu-baseline --no-first-call --no-legs --steps 30 "$@" > $O/$tag.json 2> $O/$tag.err; python - <<PY
+import json
+try:
+    d=json.loads(open("$O/$tag.json").read().strip().splitlines()[-1])
+    print("$tag", "ms", round(d["ms_per_step"],4), {k:round(v["ms_per_step"],4) for k,v in d["roofline_by_kernel"].items()})
+except Exception as e:
+    print("$tag failed", e); print(open("$O/$tag.err").read()[-800:])
+PY
+}
+run snb_sf100 n2048 --pairs-per-gpu 2048
+run snb_sf100 n2048_off --pairs-per-gpu 2048 --set meet_wide_rows=0
+run snb_sf100 n1024 --pairs-per-gpu 1024
+run snb_sf100 n1024_off --pairs-per-gpu 1024 --set meet_wide_rows=0
+run snb_sf100 n4096w --pairs-per-gpu 4096 --set meet_wide_rows=4096
+run snb_sf100 n4096 --pairs-per-gpu 4096
+run rmat22 rmat
+run rmat22 rmat_off --set meet_wide_rows=0

@@ -99,6 +99,7 @@ def parse():
     ap.add_argument("--cross-sources", type=int, default=2048, help="snb_cross / msbfs_cross leg: distinct sources")
     ap.add_argument("--cross-dests", type=int, default=1024, help="snb_cross / msbfs_cross leg: destinations per source")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="pgq_set_option before the run (experiments; recorded in config.options)")
+    ap.add_argument("--trace-steps", action="store_true", help="debugging: print every timed step's end time and counters to stderr")
     ap.add_argument("--cross-shuffle", action="store_true", help="snb_cross / rmat22_cross: rows in random order (a hash join's output) instead of grouped by source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="N = 1 default workload: skip the msbfs_cross and cheapest_general legs")
@@ -314,6 +315,10 @@ class Bench:
         t0 = time.perf_counter()
         for k in range(steps):
             step(k)
+            if self.a.trace_steps:  # debugging: every step on its own (the figure below then includes a sync per step)
+                self.sync_all()
+                print("[bench] %s step %d done at +%.3f ms, stats %s" % (wl, k, (time.perf_counter() - t0) * 1e3, {
+                    kk: vv for kk, vv in pgq.get_stats().items() if kk in ("ball_calls", "meet_pairs", "levels", "batches", "host_waits")}), file=sys.stderr)
         drain()
         self.sync_all()
         elapsed = time.perf_counter() - t0
@@ -428,6 +433,8 @@ def roofline_of(m, workload, copy_gbps, elapsed):
     step_bytes = sum(m["stats"]["algo_bytes"].values())
     prepass = [k for k in PREPASS if kms.get(k, 0.0) > 0]
     chain = prepass if (prepass and dom in PREPASS) else [k for k in kms if kms[k] > 0]
+    if chain is prepass and kms.get("prep", 0.0) > 0:  # rows sorted by source in front of the source-centric kernel (ball_sort): part of the chain
+        chain = prepass = prepass + ["prep"]
     c_ms, c_b = sum(kms[k] for k in chain), sum(kb[k] for k in chain)
     c_gbps = c_b / 1e9 / (c_ms / 1e3) if c_ms > 0 else 0.0
     no_model = [k for k in chain if kb.get(k, 0.0) <= 0]
@@ -545,7 +552,7 @@ def config_leg(bench, a, wl, copy_gbps, snb_graph, snb_csr):
         cp = cross_pairs(V, a.cross_sources * a.cross_dests, a.cross_sources, PAIR_SEED["snb_cross"] + 22)
         cp_t = torch.from_numpy(cp).to(dev)
         fc2 = None if a.no_first_call else bench.first_call(make_csr, cp_t, max(1, a.first_call_handles // 2))
-        mc = bench.run("rmat22_cross", csr, cp_t, len(cp), max(2, min(a.steps, 4)), 1)
+        mc = bench.run("rmat22_cross", csr, cp_t, len(cp), max(2, min(a.steps, 8)), 2)
         xleg, _ = leg_summary(bench, mc, "rmat22_cross", len(cp), copy_gbps)
         xleg["workload"] = "%s iterativelength, %d distinct sources x %d destinations each = %d rows (match.cpp:467-495 shape)" % (
             name, a.cross_sources, len(cp) // a.cross_sources, len(cp))

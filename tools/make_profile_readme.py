@@ -60,6 +60,12 @@ for w, title in (("snb_sf100_8192", "SF100 graph, 8192 random pairs (configs[3]'
                  ("snb_cross_2048x32", "cross product 2048 sources x 32 destinations = 65,536 rows (the device's decision: pre-pass)"),
                  ("snb_cross_2048x128", "cross product 2048 sources x 128 destinations = 262,144 rows (source-centric kernel)"),
                  ("rmat22_cross_lanes", "R-MAT-22 cross product through the lane batches alone (`PGQ_MEET=0`: no source-centric kernel, no pre-pass)"),
+                 ("snb_cross_shuffled", "the 2048 x 1024 cross product with its rows in random order (a hash join's output): sorted by source for `k_src_ball` (`ball_sort`)"),
+                 ("snb_cross_shuffled_nosort", "... the same rows with `ball_sort = 0`: lane batches"),
+                 ("rmat22", "configs[1] as a workload of its own (20 steps)"),
+                 ("rmat22_cross", "R-MAT-22 cross product as a workload of its own (as routed)"),
+                 ("snb_cheapest_512", "weighted knows graph, 512 pairs, one lane per source (shipped)"),
+                 ("snb_cheapest_512_bidir", "... the same pairs searched from both ends (`relax_bidir = 1`, off as shipped)"),
                  ("snb_cross_allv", "32 sources x every vertex = 14.4 M rows"),
                  ("forest_cheapest_double", "configs[4], double weights"),
                  ("forest_cheapest_2_28", "configs[4] at the named scale: reply forest V = 2^28 (268 M vertices, 215 M edges), int64 weights")):
@@ -131,6 +137,15 @@ cl = load("chunk_latency.json")
 if cl:
     L += ["## C-ABI call latencies (`tools/chunk_latency.py`, SF100-shaped graph, ms)", "",
           "| call | ms |", "|---|---|"] + ["| %s | %.3f |" % (k.replace("_ms", ""), v) for k, v in cl.items()] + [""]
+ct = os.path.join(rdir, "chunk_throughput.txt")
+if os.path.exists(ct) and os.path.getsize(ct):
+    try:
+        tj = json.loads(open(ct).read().strip().splitlines()[-1])
+        L += ["## Concurrent chunk calls (`tools/chunk_throughput.py` -> `tools/chunk_mt.cpp`: T native threads, one 2048-row "
+              "`pgq_iterativelength` call per DataChunk each, one shared CSR)", "", "| shape, threads | rows/s | ms per chunk |", "|---|---|---|"]
+        L += ["| %s | %s | %.4f |" % (k, fmt(v["rows_per_s"]), v["ms_per_chunk"]) for k, v in tj.items()] + [""]
+    except ValueError:
+        pass
 mc = os.path.join(rdir, "membench_copy.jsonl")
 if os.path.exists(mc):
     rows = [json.loads(x) for x in open(mc) if x.startswith("{")]

@@ -23,12 +23,18 @@ b bench_snb_cross_allv python bench.py --workload snb_cross_allv --no-cpu-baseli
 b bench_rmat22_cross python bench.py --workload rmat22_cross --no-cpu-baseline --steps 4 --warmup 2
 b bench_rmat22_cross_lanes PGQ_MEET=0 python bench.py --workload rmat22_cross --no-cpu-baseline --steps 4 --warmup 2
 b bench_snb_paths python bench.py --workload snb_paths --no-cpu-baseline
+b bench_snb_cross_shuffled python bench.py --workload snb_cross --cross-shuffle --no-cpu-baseline
+b bench_snb_cross_shuffled_nosort python bench.py --workload snb_cross --cross-shuffle --set ball_sort=0 --no-cpu-baseline
+b bench_rmat22 python bench.py --workload rmat22 --no-cpu-baseline --steps 20
+b bench_snb_cheapest_512 python bench.py --workload snb_cheapest --pairs-per-gpu 512 --no-cpu-baseline --steps 2 --warmup 1
+b bench_snb_cheapest_512_bidir python bench.py --workload snb_cheapest --pairs-per-gpu 512 --set relax_bidir=1 --no-cpu-baseline --steps 2 --warmup 1
 st() { tag=$1; shift; (cd /tmp && export TMPDIR=/tmp && timeout 400 env "$@" > $O/stats_$tag.log 2>&1; rm -f $O/stats_$tag/*kernel_trace.csv); }
 st snb rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb -o s -- python $R/bench.py --no-cpu-baseline --no-legs --no-first-call
 st snb_cross_ball rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb_cross_ball -o s -- python $R/bench.py --workload snb_cross --no-cpu-baseline --no-first-call --steps 5
 st snb_cross PGQ_BALL=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb_cross -o s -- python $R/bench.py --workload snb_cross --no-cpu-baseline --no-first-call --steps 5
 st rmat22_cross rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_rmat22_cross -o s -- python $R/bench.py --workload rmat22_cross --no-cpu-baseline --no-first-call --steps 3 --warmup 1
 timeout 300 python tools/chunk_latency.py > $O/chunk_latency.json 2> $O/chunk_latency.err; cat $O/chunk_latency.json
+timeout 300 python tools/chunk_throughput.py > $O/chunk_throughput.txt 2> $O/chunk_throughput.err; cat $O/chunk_throughput.txt
 fi
 if [ "$PART" = 2 ]; then
 cd /tmp && export TMPDIR=/tmp

@@ -75,7 +75,7 @@ def _summarise(agg, launches):
 if __name__ == "__main__":
     wl = sys.argv[1] if len(sys.argv) > 1 else "snb_sf100"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = summarise(glob.glob(os.path.join(root, "gpurun_out", "prof", wl + "_*", "*counter_collection.csv")))
+    out = summarise(glob.glob(os.path.join(root, "gpurun_out", "prof", wl + "_[A-Z]", "*counter_collection.csv")))
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(root, "profiles", "pmc_%s.json" % wl), "w"), indent=1, sort_keys=True)
     for k in sorted(out, key=lambda k: -out[k].get("hbm_bytes_per_launch", 0)):

@@ -20,6 +20,7 @@ Default workload = BASELINE.json configs[3] (the config the metric "MS-BFS MTEPS
                               it (round 6: the source-centric kernel k_src_ball, one two-hop ball per source run)
             msbfs_cross_lanes the same rows forced through the lane-batched MS-BFS (handle option ball = 0): the frontier
                               expansion kernels' own figures (rounds 1-5's msbfs_cross)
+            msbfs_cross_shuffled  the same rows in random order (a hash join's output): sorted by source for k_src_ball
             msbfs_cross_rmat22  the same call shape on R-MAT-22 (configs[1]'s graph): 2048 x 1024 rows, frontier arrays far past
                               the 256-MiB Infinity Cache — the MS-BFS level kernels against DRAM
             snb_paths         configs[2]: shortestpath + reconstruction, 4096 pairs, same CSR
@@ -645,7 +646,7 @@ def main():
         m2 = bench.run(a.workload, csr, mine2, total2, a.steps, a.warmup, paths=paths, cheapest=cheapest)
         leg2, _ = leg_summary(bench, m2, a.workload, total2, copy_gbps)
         other = (mode2, {k: leg2[k] for k in ("ms_per_step", "pairs_per_s", "mteps_logical", "mteps_physical")}, total2)
-    cross = cross_lanes = None
+    cross = cross_lanes = cross_shuf = None
     cross_multi = None
     if world > 1 and a.workload == "snb_sf100" and not a.no_legs:
         # N > 1: the cross product shards BY SOURCE — rows are grouped by source and cut into contiguous ranges, so every rank keeps
@@ -690,6 +691,17 @@ def main():
         if first_lanes:
             cross_lanes["first_call"] = first_lanes
         assert bool((ml["out_len"] == mc["out_len"]).all()), "the two routes of the cross product disagree"
+        # the same rows in random order (a hash join's output): declined by the source-centric kernel as they lie, sorted by
+        # source for it (option ball_sort), answers scattered back — compared row by row with the grouped leg's output
+        perm = np.random.default_rng(PAIR_SEED["snb_cross"] + 1).permutation(len(cp))
+        perm_t = torch.from_numpy(perm).to(dev)
+        sp_t = cp_t[perm_t].contiguous()
+        csr_s = fresh_csr()  # a handle of its own: no memo of the grouped buffers
+        msx = bench.run("snb_cross_shuffled", csr_s, sp_t, len(cp), max(2, min(a.steps, 5)), min(a.warmup, 2))
+        del csr_s
+        cross_shuf, _ = leg_summary(bench, msx, "snb_cross_shuffled", len(cp), copy_gbps)
+        cross_shuf["workload"] = "the msbfs_cross rows in random order: sorted by source in front of the source-centric kernel (ball_sort), scattered back"
+        assert bool((msx["out_len"] == mc["out_len"][perm_t]).all()), "the shuffled cross product's answers differ from the grouped one's"
 
     wleg = None
     if world == 1 and a.workload == "snb_sf100" and not a.no_legs and a.cheapest_pairs > 0:
@@ -788,6 +800,13 @@ def main():
                     cross_lanes["cpu_baseline"]["rows_compared"] = int(len(cp))
                     cross_lanes["cpu_baseline"]["rows_equal"] = int(len(cp))
                 legs["msbfs_cross_lanes"] = cross_lanes
+            if cross_shuf is not None:
+                if not a.no_cpu_baseline:
+                    cross_shuf["cpu_baseline"] = {k: cross["cpu_baseline"][k] for k in cross.get("cpu_baseline", {}) if k in ("value", "unit", "cores")}
+                    cross_shuf["cpu_baseline"]["sample"] = "output identical to msbfs_cross's under the row permutation (asserted): its comparison holds for these rows"
+                    cross_shuf["cpu_baseline"]["rows_compared"] = int(len(cp))
+                    cross_shuf["cpu_baseline"]["rows_equal"] = int(len(cp))
+                legs["msbfs_cross_shuffled"] = cross_shuf
             legs["prepass"]["workload"] = "%d random pairs (default_rng(4)): every row answered by the pair-centric kernels" % total_pairs
             if "cpu_baseline" in out:
                 legs["prepass"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "pairs_per_s", "rows_compared", "rows_equal")}
@@ -798,6 +817,7 @@ def main():
             out["legs_by_config"] = {"configs[1] R-MAT-22 iterativelength 1024 pairs": "rmat22",
                                      "configs[1]'s graph in the binder's call shape (DRAM-resident frontier arrays)": "msbfs_cross_rmat22",
                                      "configs[3] cross product forced through the lane batches": "msbfs_cross_lanes",
+                                     "configs[3] cross product, rows in random order (sorted by source first)": "msbfs_cross_shuffled",
                                      "configs[2] SF100 shortestpath + reconstruction 4096 pairs": "snb_paths",
                                      "configs[3] SF100 iterativelength 65,536 pairs": "prepass (= the top-level fields)",
                                      "configs[3] in the binder's call shape (cross product)": "msbfs_cross",

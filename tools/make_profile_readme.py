@@ -47,12 +47,13 @@ if default:
     rows.append(("configs[3] on one GPU: SF100-shaped knows, iterativelength, 65,536 random pairs (the line's top level = leg `prepass`)", top))
     titles = {"msbfs_cross": "same graph, the binder's call shape: 2048 sources x 1024 destinations = 2.1 M rows grouped by source (leg `msbfs_cross`, as routed: the source-centric kernel `k_src_ball`)",
               "msbfs_cross_lanes": "the same rows forced through the lane-batched MS-BFS (leg `msbfs_cross_lanes`, `ball = 0`)",
+              "msbfs_cross_shuffled": "the same rows in random order, as routed: sorted by source for `k_src_ball` (leg `msbfs_cross_shuffled`)",
               "msbfs_cross_rmat22": "R-MAT scale 22 in the binder's call shape: 2048 x 1024 rows (leg `msbfs_cross_rmat22`, as routed)",
               "snb_paths": "configs[2]: SF100-shaped knows, shortestpath + reconstruction, 4096 pairs (leg `snb_paths`)",
               "rmat22": "configs[1]: R-MAT scale 22, iterativelength, 1024 pairs (leg `rmat22`)",
               "forest_cheapest": "configs[4]: reply forest V = 2^24, int64 weights, cheapest_path_length, 4096 pairs (leg `forest_cheapest`)",
               "cheapest_general": "configs[4]'s operator on a general graph: weighted knows graph, 4096 pairs (leg `cheapest_general`, one step)"}
-    for k in ("msbfs_cross", "msbfs_cross_lanes", "msbfs_cross_rmat22", "snb_paths", "rmat22", "forest_cheapest", "cheapest_general"):
+    for k in ("msbfs_cross", "msbfs_cross_lanes", "msbfs_cross_shuffled", "msbfs_cross_rmat22", "snb_paths", "rmat22", "forest_cheapest", "cheapest_general"):
         if k in (default.get("legs") or {}):
             rows.append((titles[k], default["legs"][k]))
 for w, title in (("snb_sf100_8192", "SF100 graph, 8192 random pairs (configs[3]'s shard at 8 GPUs)"),

@@ -129,6 +129,7 @@ __device__ __forceinline__ bool ball_decides(const BallRule &rule, int64_t n, u3
 #ifndef PGQ_BALL_WAVES
 #define PGQ_BALL_WAVES 8 // wavefronts per SIMD k_src_ball is compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs), 4 = one (128)
 #endif
+constexpr int kBallMaxS1 = 4096;  // out-degree up to which a source's two-hop ball is walked (64 rounds of 64 neighbours)
 constexpr int kBallFarRows = 16; // rows per segment whose distance-4 walk all 16 wavefronts take up together (k_src_ball)
 #ifndef PGQ_BALL_UH
 #define PGQ_BALL_UH 4 // row octets (8 rows, 8 lanes each) a wavefront scans per step out of the fixed-stride heads
@@ -267,8 +268,13 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 			tick(1);
 			if (s_res[tid] == kBallOpenI && bit(di32)) s_res[tid] = 1;
 			__syncthreads(); // every test against S1 is done before S2's marks land
-			// S2 = S1 + N_out(S1): the 16 wavefronts share every round of the source's descriptors
-			{
+			// S2 = S1 + N_out(S1): the 16 wavefronts share every round of the source's descriptors.  Not for a hub: its walk is a
+			// round of 64 neighbours after the other, each a dependent descriptor read before its few list requests (R-MAT-22:
+			// a source with ~100,000 neighbours of ~16 entries each took 5.4 ms over a thousand rounds to reach the cap, the
+			// whole kernel's duration — for a ball that is cut, i.e. proves nothing beyond its set bits).  Such a ball stays S1.
+			if (degS > kBallMaxS1) {
+				if (tid == 0) s_capped = 1;
+			} else {
 				bool capped = false;
 				int resume = 0;
 				const unsigned long long e1 = seg_walk<2, false>(

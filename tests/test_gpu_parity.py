@@ -409,6 +409,17 @@ def test_source_centric_ball_matches_oracle(lds_kb, ball_cap, test_cap, head_mb)
     oln, ook = ora3.lean_iterativelength(V3, ps, pd)
     ln, ok = st3.iterativelength(2, V3, ps, pd)
     assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
+    # (c2) a hub source: over 4096 out-neighbours — its two-hop ball is not walked (S1 only), its rows go on to the other kernels
+    V4 = 9000
+    hub = np.zeros(6000, dtype=np.int64)
+    s4 = np.concatenate([hub, rng.integers(0, V4, 30000)])
+    d4 = np.concatenate([rng.choice(np.arange(1, V4), 6000, replace=False), rng.integers(0, V4, 30000)])
+    st4, ora4 = both(V4, (s4, d4, np.arange(len(s4), dtype=np.int64)), csr_id=3)
+    ps, pd, valid = grouped_rows(rng, V4, [700, 300, 900])
+    ps[:700] = 0  # the first run's source is the hub
+    oln, ook = ora4.lean_iterativelength(V4, ps, pd)
+    ln, ok = st4.iterativelength(3, V4, ps, pd)
+    assert lens(ln, ok) == [int(v) if k else None for v, k in zip(oln, ook)]
     # (d) through the bulk entry point on device arrays, 40,000 rows (the decision kernel's range), out-of-range ids refused
     import torch
     ps, pd, _ = grouped_rows(rng, V, [9000, 13000, 1024, 1024, 15952])

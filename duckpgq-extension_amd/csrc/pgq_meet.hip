@@ -1611,7 +1611,9 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	const int bibfs_rows = opt.bibfs_rows <= 0 ? 0 : std::max(opt.bibfs_rows, (int)std::min<int64_t>(opt.bibfs_rows_max, c->E / 4096));
 	// (sized by what the last call left AND by this call's rows: a handle's first call knows nothing of the former, and 64
 	// workgroups for the 35,000 far rows of an R-MAT-22 cross product made that call 11 ms longer than the ones after it)
-	const int want_grid = std::max(far_rows / 16, (int)std::min<int64_t>(n / 64, 1 << 20));
+	// (on graphs whose maps are global — V past the LDS: there far rows are the rule; a graph with LDS maps keeps the small
+	// grid until a call has left far rows: every workgroup owns 2.6 MB of queues, 512 of them 1.3 GB allocated on first use)
+	const int want_grid = std::max(far_rows / 16, bi_lds ? 0 : (int)std::min<int64_t>(n / 64, 1 << 20));
 	const u32 bi_grid = (u32)std::min(std::max(std::max(1, opt.bibfs_grid), std::min(want_grid, 2 * device_cus())), std::max(1, bibfs_rows));
 	// k_meet4d hands rows out dynamically: a grid of exactly the workgroups the chip holds (meet4_grid_mult = 2 per CU).
 	// A row alone on its CU is through in ~15 us, beside a second one in ~20 (the phases of a row are short bursts of

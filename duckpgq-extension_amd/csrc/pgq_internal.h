@@ -102,6 +102,7 @@ struct Options {
 	int probe = 1;          // destination probe before each expansion
 	int probe2 = 1;         // two-hop destination probe when few pairs are left
 	int probe2_div = 4;     // ... when open pairs <= lanes / probe2_div
+	int probe_max_in = 4096; // destinations with more in-neighbours are not probed (one wavefront's serial scan); k_detect answers them a level later
 	int probe2_abs = 4096;  // ... or when at most this many pairs are open, whatever the batch width
 	int detect_grid_mult = 8;  // k_detect grid = this many 256-thread workgroups per CU at most (rows are taken grid-stride)
 	int sort_single_batch = 0; // 1: rows sorted by lane even when the distinct sources fit one batch (round-4 behaviour; tests)
@@ -172,6 +173,8 @@ struct Options {
 	                                // of two).  Measured on 1 source x 2048 destinations: 64, 128, 256 and 1024 all give 0.065 ms per chunk — the call is
 	                                // its launches and its wait, not the scan — so the shorter segments stay an option
 	int ball_grid = 0;          // > 0: at most this many workgroups of k_src_ball (debugging / sweeps)
+	int route_timing = 1;     // large calls grouped by source: the route that measured faster on this graph shape is kept (search_device)
+	double route_try_factor = 4.0; // ... the lane batches are tried once when the source-centric route took this many times their modelled time
 	int ball_sort = 1;          // rows with repeated sources that are NOT grouped are sorted by source first (0: such calls take the older routes)
 	double ball_bias = 1.0;     // the ball runs while ball_bias x its estimated bytes <= the cheaper of the pre-pass and the lane batches
 };
@@ -315,6 +318,10 @@ struct pgq_csr {
 	// call): above ~2 % those rows drag the lane batches along anyway (R-MAT: far and unreachable pairs), and the kernel
 	// stays out of the chain until the CSR is uploaded again
 	std::atomic<double> ball_open_frac { 0.0 };
+	// large grouped calls, wall time per row in ns as measured on this graph shape (0: not yet): through the source-centric
+	// kernel (everything it took: its own kernels and the search of the rows it left open) and through the lane batches
+	std::atomic<double> route_ball_ns { 0.0 }, route_lanes_ns { 0.0 };
+	std::atomic<int> route_try_lanes { 0 }; // the former cost far more than the byte model's price of the latter: time the latter once
 	bool is_replica = false;
 };
 

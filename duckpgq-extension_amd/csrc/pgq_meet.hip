@@ -1687,6 +1687,16 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 			rule.seg_floor = 1024.0 * (double)std::max(0, opt.ball_seg_kb);
 			rule.seg_bytes = 4.0 * c->two_hop_mean + 32.0 * mean_deg + 64.0;
 			rule.row_bytes = 4.0 * std::min(mean_deg, 64.0) + (c->rhead ? 0.0 : 128.0) + 32.0; // the first 64 entries of the in-list, the line its position sits in (without rhead), the row
+			// a ball in a global map: every mark is a look in DRAM and an atomic there (R-MAT-22: ~5 ns per entry and workgroup
+			// against ~1 ns in LDS) ...
+			if (!ball_lds) rule.seg_bytes *= 8.0;
+			// ... and what this kernel leaves open is the pre-pass's to answer, at that kernel's measured bytes per row: the share of
+			// rows the last call on this graph shape left open (0 before the first) prices it.  R-MAT-22, 2048 x 1024: 1.7 % open x
+			// 1.7 MB per row = 28 KB per row — the lane batches (12 ms) are then the cheaper route, not this one (16.7 ms).
+			{
+				const double bpr = meet_bytes > 0 && n > 0 ? meet_bytes / (double)n : c->meet_bpr.load(std::memory_order_relaxed);
+				rule.row_bytes += c->ball_open_frac.load(std::memory_order_relaxed) * std::max(0.0, bpr);
+			}
 			rule.meet_bytes = meet_bytes;
 			rule.edge_bytes = edge_bytes > 0 ? edge_bytes : (double)c->E;
 			rule.bias = opt.ball_bias;
@@ -1740,6 +1750,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		S.algo_bytes[K_BALL] += 4.0 * (double)h.ball_entries + 16.0 * (double)h.ball_descs + 32.0 * (double)n + 24.0 * (double)h.ball_nseg;
 		S.ball_segments += h.ball_nseg;
 		S.ball_calls++;
+		if (est_sources) *est_sources = (double)h.ball_nrun; // (exact: the source runs it counted)
 		*n_open = h.ball_open;
 		return PGQ_OK;
 	}
@@ -1898,6 +1909,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		S.algo_bytes[K_BALL] += 4.0 * (double)h.ball_entries + 16.0 * (double)h.ball_descs + 32.0 * (double)n + 24.0 * (double)h.ball_nseg;
 		S.ball_segments += h.ball_nseg;
 		S.ball_calls++;
+		if (est_sources) *est_sources = (double)h.ball_nrun; // (exact: the source runs it counted)
 		*n_open = h.ball_open;
 		return PGQ_OK;
 	}

@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u3
                                                 u32 base_lane, const u64 *__restrict__ front,
                                                 const u32 *__restrict__ nz, const int64_t *__restrict__ roff,
                                                 const int32_t *__restrict__ radj, int level, u64 *__restrict__ rep,
-                                                Counters *__restrict__ cnt) {
+                                                Counters *__restrict__ cnt, int max_in) {
 	// Persistent wavefronts over 64-row chunks: a chunk's result words are read coalesced, and only the rows still open
 	// (a ballot) get the wave-wide in-list scan — late levels of a cross product have millions of answered rows and a
 	// few thousand open ones (a wavefront per ROW cost 2.4 ms of launches for 2 M rows).  Active-lane bits and the
@@ -1236,8 +1236,11 @@ __global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u3
 	__shared__ u32 q_row[kQueue], q_lane[kQueue];
 	__shared__ int q_dst[kQueue];
 	__shared__ u32 q_n, q_next, q_cut;
+	constexpr int kHubQueue = 256;
+	__shared__ u32 h_row[kHubQueue], h_lane[kHubQueue], h_n, h_found;
+	__shared__ int h_dst[kHubQueue];
 	if (cnt->done) return;
-	if (threadIdx.x == 0) s_open = 0, q_n = 0, q_next = 0, q_cut = (u32)kQueue;
+	if (threadIdx.x == 0) s_open = 0, q_n = 0, q_next = 0, q_cut = (u32)kQueue, h_n = 0;
 	if (threadIdx.x < WD) s_act[threadIdx.x] = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
@@ -1257,6 +1260,22 @@ __global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u3
 		if (b == e) { // nothing points at dst: unreachable, no search needed (reported as NULL like :133-139)
 			if (lane == 0) sres[row] = -2;
 			return;
+		}
+		// a hub destination's in-list is not one wavefront's serial scan (64 entries per dependent round trip; R-MAT-22, 2048 x
+		// 1024 rows: a few hundred destinations with 10^4..10^5 in-neighbours made every probe launch 1.4 ms, 12.9 of the call's
+		// 23.8 ms): it is queued, and the workgroup's 16 wavefronts scan it together at the end
+		if (e - b > (int64_t)max_in) {
+			u32 p = kHubQueue;
+			if (lane == 0) p = atomicAdd(&h_n, 1u);
+			p = (u32)__builtin_amdgcn_readfirstlane((int)p);
+			if (p < (u32)kHubQueue) {
+				if (lane == 0) {
+					h_row[p] = (u32)(row - lo);
+					h_lane[p] = l;
+					h_dst[p] = d;
+				}
+				return;
+			} // (a full queue: scanned here after all)
 		}
 		bool found = false;
 		for (int64_t base = b; base < e && !found; base += 64) {
@@ -1328,6 +1347,42 @@ __global__ __launch_bounds__(1024) void k_probe(int64_t lo, int64_t hi, const u3
 			p = (u32)__builtin_amdgcn_readfirstlane((int)p);
 			if (p >= filled) break;
 			probe_row(lo + (int64_t)q_row[p], q_lane[p], q_dst[p]);
+		}
+	}
+	// the hub destinations: one row after the other, 1024 in-neighbours per step
+	__syncthreads();
+	{
+		const u32 hn = min(h_n, (u32)kHubQueue);
+		for (u32 h = 0; h < hn; h++) {
+			if (threadIdx.x == 0) h_found = 0;
+			__syncthreads();
+			const u32 l = h_lane[h];
+			const int d = h_dst[h], w = (int)(l >> 6);
+			const u64 bit = 1ull << (l & 63);
+			const int64_t b = roff[d], e = roff[d + 1];
+			for (int64_t base = b; base < e; base += 4 * 1024) {
+				bool hit = false;
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int64_t j = base + u * 1024 + threadIdx.x;
+					if (j < e) {
+						const int v = radj[j];
+						if ((nz[v] >> w) & 1u) hit |= (front[(size_t)v * WD + w] & bit) != 0;
+					}
+				}
+				if (__any(hit) && lane == 0) h_found = 1;
+				if (*(volatile u32 *)&h_found) break; // (a wavefront that has not seen the flag yet runs one more step: harmless)
+			}
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				if (h_found) {
+					sres[lo + (int64_t)h_row[h]] = level;
+				} else {
+					n_open++;
+					if (!(s_act[w] & bit)) atomicOr(&s_act[w], bit);
+				}
+			}
+			__syncthreads();
 		}
 	}
 	if (lane == 0 && n_open) atomicAdd(&s_open, n_open);
@@ -1869,6 +1924,9 @@ struct SearchOutput {
 	// remembers about "these buffers" says nothing about THESE rows (round-5 advisor finding: unrelated chunks hit the memo,
 	// and every change of shape was routed one call late) — such calls neither read nor write it
 	bool no_memo = false;
+	bool prefer_lanes = false; // (in) large grouped call on a graph where the lane batches measured faster than the source-centric route, or their trial
+	int route = 0;             // (out) 1: the source-centric kernel took the call (as it lay, or sorted by source)
+	double source_runs = -1;   // (out) ... and counted this many source runs
 };
 static constexpr int kMaxTeLevels = 1024;
 
@@ -2022,6 +2080,13 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 		// k_level_reset logs and checks on the device (SpecArgs) and its memsets are kernels that honour `done`.
 		auto enqueue_level = [&](int t, u32 bits, bool spec, int prev_stop) -> int {
 			LevelBuf *cur = hs.cur;
+			// The two-hop probe replaces an expansion for the rows still open — while it is the cheaper of the two: a row walks the
+			// in-lists of its destination's in-neighbours (the graph's mean two-hop walk, at most probe2_cap entries), two
+			// gathered 64-byte sectors per entry, one workgroup per row; a dense level moves E x (8 + 6 WD) bytes.  R-MAT-22
+			// (mean two-hop walk over the cap): 4096 open rows made each probe 2.3 ms where a level takes 1.9, five times per
+			// call, without saving a level — 11 of the cross product's 23.8 ms through the lanes.
+			const int64_t probe2_rows_worth = std::max<int64_t>(
+			    64, (int64_t)((double)E * (8.0 + 6.0 * WD) / (128.0 * std::max(64.0, std::min((double)opt.probe2_cap, c->two_hop_mean)))));
 			const bool push = bits & kLvPush, sparse_level = bits & kLvSparse, probe_now = bits & kLvProbe;
 			LevelBuf *nxt = level_buf(t, push, cur);
 			const bool lanes_level = sparse_level && lanes_ok;
@@ -2058,13 +2123,14 @@ static int run_batches(pgq_csr *c, Workspace *sh, Workspace *ws, int b0, int bst
 				// up to one wavefront per row (few rows: the wavefronts of a 64-row chunk share its open rows), at most 8192
 				hipLaunchKernelGGL(k_probe<WD>, dim3(std::min(blocks_for((hi - lo) * 64, 1024), (unsigned)kOpenGrid)), dim3(1024), 0, st, lo, hi,
 				                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
-				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, ws->dpart.as<u64>(), d_cnt);
+				                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t, ws->dpart.as<u64>(), d_cnt, std::max(64, opt.probe_max_in));
 				if (opt.probe2 && !with_paths)
 					hipLaunchKernelGGL(k_probe2<WD>, dim3((unsigned)std::min<int64_t>(hi - lo, 2 * ncu)), dim3(1024), 0, st, lo, hi,
 					                   sh->skey.as<u32>(), sh->sdst.as<int32_t>(), sh->sres.as<int32_t>(), base_lane,
 					                   cur->buf.as<u64>(), cur->nz.as<u32>(), c->roff, c->radj, t,
-					                   (u32)std::max<int64_t>(std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),
-					                                       std::min<int64_t>(hi - lo, opt.probe2_abs)),
+					                   (u32)std::min<int64_t>(probe2_rows_worth,
+					                                          std::max<int64_t>(std::min<int64_t>(L / std::max(1, opt.probe2_div), (hi - lo) / std::max(1, opt.probe2_div)),
+					                                                            std::min<int64_t>(hi - lo, opt.probe2_abs))),
 					                   (int64_t)opt.probe2_cap, ws->dpart.as<u64>(), act_nxt, d_cnt);
 				else
 					hipLaunchKernelGGL(k_open_merge, dim3(1), dim3(256), 0, st, ws->dpart.as<u64>(), act_nxt, WD, d_cnt);
@@ -2531,9 +2597,49 @@ static bool prepass_takes(const pgq_csr *c, int64_t n, const SearchOutput &outp)
 }
 
 // Lane assignment + sorting of the rows, then the templated batch loop; results scattered back to row order.
+static int search_device_impl(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                              int64_t *d_out_len, bool with_paths, int64_t *d_out_off, int64_t *d_child_ext,
+                              int64_t child_cap_ext, SearchOutput &outp);
+// The byte models that pick a route price kernels at streaming rate; on a graph past the caches the source-centric route is
+// nothing like that (R-MAT-22, 2048 x 1024 rows: global bit maps marked through DRAM atomics, 35,000 far rows searched one
+// by one — 16.7 ms where the model says 0.1) and the lane batches are 4.6 x their model (12 ms).  So large grouped calls are
+// TIMED, per graph shape: the wall time per row of the source-centric route is kept; when it is over `route_try_factor` x the
+// lane batches' modelled time the next such call goes through the lanes once, and from then on through whichever measured
+// faster.  Every route is exact, so this only moves time.  (The figures travel with the calibration cache.)
 static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                          int64_t *d_out_len, bool with_paths, int64_t *d_out_off, int64_t *d_child_ext,
                          int64_t child_cap_ext, SearchOutput &outp) {
+	const Options &o = options();
+	const bool timed = o.route_timing && o.ball == 1 && outp.depth == 0 && !with_paths && !outp.want_te && !outp.bidir && !outp.no_ball &&
+	                   outp.ball_hint != 0 && n >= 65536;
+	if (!timed) return search_device_impl(c, ws, n, d_src, d_dst, d_out_len, with_paths, d_out_off, d_child_ext, child_cap_ext, outp);
+	const double tb = c->route_ball_ns.load(std::memory_order_relaxed), tl = c->route_lanes_ns.load(std::memory_order_relaxed);
+	const bool trial = tb > 0 && tl <= 0 && c->route_try_lanes.load(std::memory_order_relaxed) != 0;
+	outp.prefer_lanes = trial || (tb > 0 && tl > 0 && tl < tb);
+	// (such a call neither follows nor feeds the route memo: what it would leave there — "these buffers go to the lanes" — must
+	// not outlive the preference, and the decision kernel in front of the lanes is 40 us of a call that takes milliseconds)
+	if (outp.prefer_lanes) outp.no_memo = true;
+	const int64_t levels0 = tstats().s.levels;
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = search_device_impl(c, ws, n, d_src, d_dst, d_out_len, with_paths, d_out_off, d_child_ext, child_cap_ext, outp);
+	if (rc != PGQ_OK) return rc;
+	const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (double)n;
+	if (outp.route == 1) {
+		c->route_ball_ns.store(tb > 0 ? 0.5 * tb + 0.5 * ns : ns, std::memory_order_relaxed);
+		if (outp.source_runs > 0) { // the lane batches' modelled time per row, at 8 TB/s
+			const double lanes_ns = lanes_cost_bytes(o.meet_bias * (double)c->E, std::min(outp.source_runs, (double)c->V), (double)n, (double)c->V) / 8000.0 / (double)n;
+			if (ns > o.route_try_factor * lanes_ns) c->route_try_lanes.store(1, std::memory_order_relaxed);
+		}
+	} else if (outp.prefer_lanes && tstats().s.levels > levels0) { // (the lane batches did run)
+		c->route_lanes_ns.store(tl > 0 ? 0.5 * tl + 0.5 * ns : ns, std::memory_order_relaxed);
+		c->route_try_lanes.store(0, std::memory_order_relaxed);
+	}
+	return PGQ_OK;
+}
+
+static int search_device_impl(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
+                              int64_t *d_out_len, bool with_paths, int64_t *d_out_off, int64_t *d_child_ext,
+                              int64_t child_cap_ext, SearchOutput &outp) {
 	hipStream_t st = ws->stream;
 	pgq_stats_t &S = tstats().s;
 	S.pairs += n;
@@ -2563,7 +2669,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	int decide_mode = decide ? 1 : 0, observed_go = -1; // 2: the memo vouches for the pre-pass, the sample only observes (meet_prepass)
 	// round 6: the source-centric kernels open the pre-pass's chain and decide on the device (pgq_ball.h); not for paths,
 	// not for the rows that kernel itself left open
-	int ball_mode = (with_paths || outp.no_ball || outp.bidir || n < 2) ? 0 : std::max(0, std::min(2, mopt.ball));
+	int ball_mode = (with_paths || outp.no_ball || outp.bidir || outp.prefer_lanes || n < 2) ? 0 : std::max(0, std::min(2, mopt.ball));
 	const bool ball_possible = ball_mode != 0 && c->ball_open_frac.load(std::memory_order_relaxed) <= 0.02; // before the memo's say on THESE rows as they lie
 	if (ball_mode == 1) {
 		if (outp.ball_hint == 0 || c->ball_open_frac.load(std::memory_order_relaxed) > 0.02) ball_mode = 0;
@@ -2663,6 +2769,10 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 			const double now = (double)nd / (double)n, old = c->ball_open_frac.load(std::memory_order_relaxed);
 			c->ball_open_frac.store(0.5 * old + 0.5 * now, std::memory_order_relaxed);
 		}
+		if (ball_ran) {
+			outp.route = 1;
+			outp.source_runs = est_sources;
+		}
 		if (!*ran && !ball_ran) return PGQ_OK;
 		*ran = true;
 		if (n >= 1024 && !ball_ran) { // what these rows really moved refines the CSR's bytes per row (half the weight to the newest call)
@@ -2732,9 +2842,12 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		}
 		u32 nd = 0;
 		bool ran = true, took_ball = false;
+		double runs = -1.0;
 		PGQ_TRY(meet_prepass(c, ws, n, ws->sort_src.as<int64_t>(), ws->sort_dst.as<int64_t>(), ws->sort_out.as<int64_t>(), &nd, nullptr, 0, meet_bytes,
-		                     edge_bytes, &ran, nullptr, 3, &took_ball));
+		                     edge_bytes, &ran, nullptr, 3, &took_ball, &runs));
 		if (!took_ball) return PGQ_OK;
+		outp.route = 1;
+		outp.source_runs = runs;
 		if (nd > 0) { // what the kernel left open, in sorted positions: answered like run_meet's open rows, applied to the sorted output
 			PGQ_TRY(ws->def_len.reserve((size_t)nd * 8));
 			WorkspaceLease inner;

@@ -209,6 +209,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "probe2_cap", &o.probe2_cap, nullptr },
 		{ "probe2_div", &o.probe2_div, nullptr },
 		{ "probe2_abs", &o.probe2_abs, nullptr },
+		{ "probe_max_in", &o.probe_max_in, nullptr },
 		{ "probe_always", &o.probe_always, nullptr },
 		{ "detect_grid_mult", &o.detect_grid_mult, nullptr },
 		{ "sort_single_batch", &o.sort_single_batch, nullptr },
@@ -264,6 +265,8 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "ball_cap", &o.ball_cap, nullptr },
 		{ "ball_test_cap", &o.ball_test_cap, nullptr },
 		{ "ball_sort", &o.ball_sort, nullptr },
+		{ "route_timing", &o.route_timing, nullptr },
+		{ "route_try_factor", nullptr, &o.route_try_factor },
 		{ "ball_seg_kb", &o.ball_seg_kb, nullptr },
 		{ "ball_grid", &o.ball_grid, nullptr },
 		{ "ball_seg_rows_small", &o.ball_seg_rows_small, nullptr },
@@ -1373,7 +1376,8 @@ static int finish_upload(pgq_csr *c, const int64_t *d_adj64, hipStream_t st) { /
 struct CalEntry {
 	int64_t V, E, max_out, max_in;
 	double two_hop_mean;
-	double meet_bpr, ball_open_frac;
+	double meet_bpr, ball_open_frac, route_ball_ns, route_lanes_ns;
+	int route_try_lanes;
 	std::vector<uint8_t> level_plan[6];
 };
 static std::mutex g_cal_lock;
@@ -1388,6 +1392,9 @@ void calibration_load(pgq_csr *c) {
 		if (cal_same(e, c)) {
 			c->meet_bpr.store(e.meet_bpr, std::memory_order_relaxed);
 			c->ball_open_frac.store(e.ball_open_frac, std::memory_order_relaxed);
+			c->route_ball_ns.store(e.route_ball_ns, std::memory_order_relaxed);
+			c->route_lanes_ns.store(e.route_lanes_ns, std::memory_order_relaxed);
+			c->route_try_lanes.store(e.route_try_lanes, std::memory_order_relaxed);
 			std::lock_guard<std::mutex> g2(c->plan_lock);
 			for (int k = 0; k < 6; k++) c->level_plan[k] = e.level_plan[k];
 			return;
@@ -1396,8 +1403,9 @@ void calibration_load(pgq_csr *c) {
 void calibration_store(pgq_csr *c) {
 	if (!c || c->is_replica || !options().calibration_cache) return;
 	CalEntry n { c->V, c->E, c->max_out_degree, c->max_in_degree, c->two_hop_mean, c->meet_bpr.load(std::memory_order_relaxed),
-		         c->ball_open_frac.load(std::memory_order_relaxed), {} };
-	bool any = n.meet_bpr > 0 || n.ball_open_frac > 0;
+		         c->ball_open_frac.load(std::memory_order_relaxed), c->route_ball_ns.load(std::memory_order_relaxed),
+		         c->route_lanes_ns.load(std::memory_order_relaxed), c->route_try_lanes.load(std::memory_order_relaxed), {} };
+	bool any = n.meet_bpr > 0 || n.ball_open_frac > 0 || n.route_ball_ns > 0;
 	{
 		std::lock_guard<std::mutex> g2(c->plan_lock);
 		for (int k = 0; k < 6; k++) {

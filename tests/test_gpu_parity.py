@@ -28,7 +28,7 @@ def _defaults():
                  ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1),
                  # the source-centric kernel (round 6) would take every grouped input before the kernels under test see it; its own
                  # tests and the shipped configuration switch it on
-                 ("ball", 0), ("ball_cap", 1 << 20), ("ball_test_cap", 1 << 15), ("ball_bias", 1.0), ("ball_sort", 1), ("ball_seg_kb", 512), ("ball_grid", 0), ("ball_head_mb", 512)):
+                 ("ball", 0), ("ball_cap", 1 << 20), ("ball_test_cap", 1 << 15), ("ball_bias", 1.0), ("ball_sort", 1), ("route_timing", 1), ("route_try_factor", 4.0), ("calibration_cache", 1), ("ball_seg_kb", 512), ("ball_grid", 0), ("ball_head_mb", 512)):
         pgq.set_option(k, v)
     yield
 
@@ -485,6 +485,41 @@ def test_source_centric_ball_is_chosen_by_the_source_runs():
     pgq.reset_stats()
     ln, ok = st.iterativelength(0, V, ps, pd)
     assert (ok == ook).all() and (ln[ok] == oln[ok]).all()
+
+
+def test_large_grouped_calls_keep_the_route_that_measured_faster():
+    # route_timing (shipped on): calls of >= 65,536 rows that the source-centric kernel takes are timed per graph shape; when
+    # they cost over route_try_factor x the lane batches' modelled time, the next one goes through the lanes once, and from
+    # then on through whichever was faster.  Same answers whatever the route; route_try_factor = 0 forces the trial.
+    import torch
+    rng = np.random.default_rng(71)
+    V, E = 20000, 400000
+    st, ora = both(V, random_graph(rng, V, E))
+    pgq.set_option("meet", 1)
+    pgq.set_option("ball", 1)
+    pgq.set_option("ball_seg_kb", 16)
+    pgq.set_option("calibration_cache", 0)  # (the measured times travel with it: this test wants a graph nobody has timed)
+    dev = st.device_csr(0)
+    ps = np.repeat(rng.choice(V, 70, replace=False), 1000)
+    pd = rng.integers(0, V, len(ps))
+    oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
+    want = np.where(ook, oln, -1)
+    t_s, t_d = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+    seen = []
+    for timing, factor, calls in ((1, 0.0, 4), (0, 0.0, 2)):
+        pgq.set_option("route_timing", timing)
+        pgq.set_option("route_try_factor", factor)
+        for k in range(calls):
+            t_o = torch.full((len(ps),), -7, dtype=torch.int64, device="cuda")
+            pgq.reset_stats()
+            dev.iterativelength_bulk_ptr(len(ps), t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+            assert (t_o.cpu().numpy() == want).all(), (timing, k)
+            stt = pgq.get_stats()
+            seen.append((timing, k, stt["ball_calls"] >= 1, stt["levels"] > 0))
+    assert seen[0][2] and not seen[0][3]          # first call: the source-centric kernel
+    assert seen[1][3] and not seen[1][2]          # second: the lane batches, once (the trial)
+    assert seen[2][2] != seen[2][3] and seen[3][2:] == seen[2][2:]  # then one of the two, and it stays
+    assert all(x[2] and not x[3] for x in seen[4:]), seen  # route_timing = 0: the byte models alone
 
 
 def test_ungrouped_rows_of_few_sources_are_sorted_for_the_source_centric_kernel():

@@ -17,7 +17,7 @@ def _defaults():
                  ("relax_small_limit", 2048), ("chain", 1), ("chain_cap", 4096), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 14), ("meet_cap_paths", 1 << 14), ("meet_cap_small", 1 << 14), ("meet_small_rows", 16384), ("meet_wide_rows", 2048), ("meet_wide_rows_always", 0), ("chunk_zero_copy", 1), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
+                 ("meet", 0), ("meet_cap", 1 << 14), ("meet_cap_paths", 1 << 14), ("meet_cap_small", 1 << 14), ("meet_small_rows", 16384), ("meet_wide_rows", 2048), ("meet_wide_rows_always", 0), ("meet_spin_wait", 0), ("chunk_zero_copy", 1), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
@@ -249,6 +249,32 @@ def test_meet_prepass_several_wavefronts_per_row(cap, lds_kb):
     t_d[17] = V
     with pytest.raises(pgq.PgqError):
         dev.iterativelength_bulk_ptr(500, t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+
+
+def test_meet_spin_wait_returns_complete_results():
+    # meet_spin_wait = 1: the chain's wait polls the report its last workgroup writes into pinned memory; chunk calls (results in
+    # the pinned staging block) and bulk calls (results in HBM, read back here through the library's stream) — 200 calls each
+    import torch
+    rng = np.random.default_rng(97)
+    V, E = 6000, 60000
+    st, ora = both(V, random_graph(rng, V, E, skew=True))
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_bias", 1e9)
+    pgq.set_option("meet_spin_wait", 1)
+    dev = st.device_csr(0)
+    for n in (1, 64, 2048, 8192):
+        ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        oln, ook = ora.lean_iterativelength(V, ps, pd)
+        want = [int(v) if k else None for v, k in zip(oln, ook)]
+        for _ in range(50 if n <= 2048 else 10):
+            ln, ok = st.iterativelength(0, V, ps, pd)
+            assert lens(ln, ok) == want, n
+        t_s, t_d = torch.from_numpy(ps).cuda(), torch.from_numpy(pd).cuda()
+        for _ in range(50 if n <= 2048 else 10):
+            t_o = torch.full((n,), -7, dtype=torch.int64, device="cuda")
+            dev.iterativelength_bulk_ptr(n, t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+            torch.cuda.synchronize()
+            assert (t_o.cpu().numpy() == np.where(ook, oln, -1)).all(), n
 
 
 @pytest.mark.parametrize("cap,lds_kb,align", [(1 << 18, 150, 4), (3000, 150, 16), (1, 150, 4), (1 << 18, 0, 32), (300, 150, 4)])

@@ -128,6 +128,7 @@ struct Options {
 	int meet_cap = 1 << 14; // adjacency entries a pair's two-hop walk may scan in k_meet3 (one wavefront); beyond: k_meet4d (16 wavefronts)
 	int chunk_zero_copy = 1;     // chunk entry points: the pre-pass kernels read / write the pinned staging block directly
 	int meet_small_rows = 16384; // calls of at most this many rows are latency-bound: k_meet3 with more requests in flight and meet_cap_small
+	int paths_reserve_mb = 1024; // shortestpath through the pre-pass: its lists' buffer is reserved up to this size up front (9 elements per row fit below ~15 M rows), written again at the exact size beyond
 	int meet_spin_wait = 0;      // the chain's wait polls its pinned report (5-6 us per call) instead of synchronising the stream; see meet_wait
 	int meet_wide_rows = 2048;   // calls of at most this many rows on graphs beyond the Infinity Cache: 2-4 wavefronts per row in the first stage (k_meet3w); 0: off
 	int meet_wide_rows_always = 0; // ... on every graph (tests)

@@ -1956,6 +1956,18 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 	return PGQ_OK;
 }
 
+// shortestpath: the caller reserved less than 9 elements per row (paths_reserve_mb) and the lists did not fit: the list
+// offsets (meet_poff) and inner vertices (meet_rec) of the chain that just ran are still in the workspace — written again
+int meet_reemit_paths(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, const int64_t *d_out, MeetPathsOut *po) {
+	hipStream_t st = ws->stream;
+	PGQ_HIP_TRY(hipMemsetAsync(po->d_out_off, 0, (size_t)n * 8, st));
+	KernelTimer kt(st, K_RECON);
+	hipLaunchKernelGGL(k_emit_paths, dim3((unsigned)n), dim3(256), 0, st, n, d_src, d_dst, d_out, ws->meet_rec.as<MeetPath>(), ws->meet_poff.as<int64_t>(),
+	                   c->off, c->adj, c->edge_ids, po->d_child, po->child_cap, po->d_out_off);
+	kt.stop();
+	return PGQ_OK;
+}
+
 // The sampled decision alone, waited for: shortestpath on a large input asks before it reserves 72 bytes per row for the
 // lists of the rows the pre-pass would answer (a cross product is called off: nothing of it would be used).
 int meet_decide_alone(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, double meet_bytes, double edge_bytes, bool *go) {

@@ -2707,13 +2707,23 @@ static int search_device_impl(pgq_csr *c, Workspace *ws, int64_t n, const int64_
 			po.d_child = d_child_ext;
 			po.child_cap = child_cap_ext;
 		} else {
-			PGQ_TRY(ws->child.reserve((size_t)std::max<int64_t>(n * 9, 1) * 8));
+			// at most 9 elements per row (distance 4) — up to paths_reserve_mb; a call whose lists need more (over ~15 M rows at
+			// the shipped 1 GB) has them written again into a buffer of the exact size (round-5 advisor finding: 72 bytes per row
+			// reserved up front whatever the call)
+			const size_t want = (size_t)std::max<int64_t>(n * 9, 1) * 8, lim = (size_t)std::max(0, mopt.paths_reserve_mb) << 20; // (0: 4 KB — the tests' way to the second emission)
+			PGQ_TRY(ws->child.reserve(std::min(want, std::max<size_t>(lim, 4096))));
 			po.d_child = ws->child.as<int64_t>();
 			po.child_cap = (int64_t)(ws->child.cap / 8);
 		}
 		PGQ_HIP_TRY(hipMemsetAsync(d_out_off, 0, (size_t)n * 8, st));
 		PGQ_TRY(meet_prepass(c, ws, n, d_src, d_dst, d_out_len, &nd, &po, decide_mode, meet_bytes, edge_bytes, ran, &observed_go));
 		if (!*ran) return PGQ_OK;
+		if (!d_child_ext && po.total > po.child_cap) { // (the kernel skipped the lists that did not fit)
+			PGQ_TRY(ws->child.reserve((size_t)po.total * 8));
+			po.d_child = ws->child.as<int64_t>();
+			po.child_cap = (int64_t)(ws->child.cap / 8);
+			PGQ_TRY(meet_reemit_paths(c, ws, n, d_src, d_dst, d_out_len, &po));
+		}
 		const int64_t total = po.total;
 		WorkspaceLease inner;
 		SearchOutput so2;

@@ -231,6 +231,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "meet_cap_small", &o.meet_cap_small, nullptr },
 		{ "meet_wide_rows", &o.meet_wide_rows, nullptr },
 		{ "meet_spin_wait", &o.meet_spin_wait, nullptr },
+		{ "paths_reserve_mb", &o.paths_reserve_mb, nullptr },
 		{ "meet_wide_rows_always", &o.meet_wide_rows_always, nullptr },
 		{ "meet4_test_cap", &o.meet4_test_cap, nullptr },
 		{ "chunk_zero_copy", &o.chunk_zero_copy, nullptr },

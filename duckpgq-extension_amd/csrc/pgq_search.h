@@ -324,6 +324,8 @@ struct MeetPathsOut {
 	int64_t *d_out_off = nullptr;
 	int64_t total = 0;
 };
+// the lists of the rows the last meet_prepass(po) on this workspace answered, written again into po's (now larger) buffer
+int meet_reemit_paths(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, const int64_t *d_out, MeetPathsOut *po);
 int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst, int64_t *d_out,
                  u32 *n_open, MeetPathsOut *po, int decide_mode, double meet_bytes, double edge_bytes, bool *ran, int *observed_go,
                  int ball_mode = 0, bool *ball_ran = nullptr, double *est_sources = nullptr);

@@ -17,7 +17,7 @@ def _defaults():
                  ("relax_small_limit", 2048), ("chain", 1), ("chain_cap", 4096), ("probe2", 1), ("probe2_abs", 512), ("lanes", 1), ("lanes_unroll", 2),
                  # the pair-centric pre-pass would answer most pairs of these small graphs before the level kernels
                  # under test see them; the tests that exercise it switch it on themselves
-                 ("meet", 0), ("meet_cap", 1 << 14), ("meet_cap_paths", 1 << 14), ("meet_cap_small", 1 << 14), ("meet_small_rows", 16384), ("meet_wide_rows", 2048), ("meet_wide_rows_always", 0), ("meet_spin_wait", 0), ("chunk_zero_copy", 1), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
+                 ("meet", 0), ("meet_cap", 1 << 14), ("meet_cap_paths", 1 << 14), ("meet_cap_small", 1 << 14), ("meet_small_rows", 16384), ("meet_wide_rows", 2048), ("meet_wide_rows_always", 0), ("meet_spin_wait", 0), ("paths_reserve_mb", 1024), ("chunk_zero_copy", 1), ("meet_bias", 1.0), ("meet4", 1), ("meet4_cap", 1 << 20), ("meet4_lds_kb", 150),
                  ("bibfs_rows", 256), ("bibfs_cap", 8 << 20), ("bibfs_queue", 1 << 17),
                  # the per-row weighted search would answer every int64 row before the relaxation kernels under test run
                  ("wbibfs", 0), ("wbibfs_cap", 64 << 20), ("wbibfs_queue", 1 << 17), ("wbibfs_far", 1 << 21), ("wbibfs_delta_div", 64), ("wbibfs_mem_mb", 2048),
@@ -249,6 +249,22 @@ def test_meet_prepass_several_wavefronts_per_row(cap, lds_kb):
     t_d[17] = V
     with pytest.raises(pgq.PgqError):
         dev.iterativelength_bulk_ptr(500, t_s.data_ptr(), t_d.data_ptr(), t_o.data_ptr())
+
+
+def test_shortestpath_lists_written_again_when_the_reservation_was_short():
+    # paths_reserve_mb: the pre-pass's list buffer is reserved up to a limit up front (9 elements per row fit below ~15 M rows
+    # at the shipped 1 GB); lists that did not fit are written again into a buffer of the exact size.  0 MB = 4 KB forces it.
+    rng = np.random.default_rng(101)
+    V, E = 6000, 60000
+    st, ora = both(V, random_graph(rng, V, E, skew=True))
+    pgq.set_option("meet", 1)
+    pgq.set_option("meet_bias", 1e9)
+    ps, pd = rng.integers(0, V, 3000), rng.integers(0, V, 3000)
+    want = ora.lean_shortestpath(V, ps, pd)
+    for mb in (0, 1024, 0):
+        pgq.set_option("paths_reserve_mb", mb)
+        assert st.shortestpath(0, V, ps, pd) == want, mb
+    pgq.set_option("paths_reserve_mb", 1024)
 
 
 def test_meet_spin_wait_returns_complete_results():

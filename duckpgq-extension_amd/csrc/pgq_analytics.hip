@@ -369,6 +369,19 @@ __global__ void k_wcc_gather_edges(u32 n, const u32 *__restrict__ slots, const u
 	out[2 * (size_t)i + 1] = adj[slots[i]];
 }
 
+// component id of every forest entry = the root of its tree (the replayed forest is read-only here)
+__global__ void k_wcc_ids(int64_t vs, const int32_t *__restrict__ forest, int64_t *__restrict__ ids) {
+	const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= vs) return;
+	int32_t x = (int32_t)v;
+	for (;;) {
+		const int32_t p = forest[x];
+		if (p == x) break;
+		x = p;
+	}
+	ids[v] = (int64_t)x;
+}
+
 static int wcc_compute(pgq_csr *c, Workspace *ws) {
 	std::lock_guard<std::mutex> g(c->lazy_lock); // per handle, like the reference's bind-data lock: unrelated CSRs and devices do not wait
 	
@@ -376,7 +389,16 @@ static int wcc_compute(pgq_csr *c, Workspace *ws) {
 	hipStream_t st = ws->stream;
 	const int64_t V = c->V, E = c->E, vs = V + 2;
 	DevBuf slot_src, comp, comp2, hook, best, msf, sel, tmp, edges, cnt;
-	std::vector<int64_t> forest((size_t)vs, 0);
+	std::vector<int32_t> forest((size_t)vs, 0); // (4-byte entries: V + 2 < 2^31, and the replay is a walk over this array in cache)
+	static const bool wtrace = getenv("PGQ_WCC_TRACE") != nullptr; // where the once-per-handle computation's time goes (stderr)
+	auto tnow = []() { return std::chrono::steady_clock::now(); };
+	auto t_start = tnow();
+	auto lap = [&](const char *what) {
+		if (!wtrace) return;
+		const auto t = tnow();
+		fprintf(stderr, "[pgq] wcc %s: %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count());
+		t_start = t;
+	};
 	auto body = [&]() -> int {
 		std::vector<int32_t> h_edges;
 		u32 n_msf = 0;
@@ -414,6 +436,7 @@ static int wcc_compute(pgq_csr *c, Workspace *ws) {
 				hipLaunchKernelGGL(k_wcc_flatten, dim3(blocks_for(V)), dim3(256), 0, st, V, hook.as<u32>(), cur, nxt);
 				std::swap(cur, nxt);
 			}
+			lap("Boruvka rounds");
 			// the chosen slots in ascending order (= the order the reference processes them in)
 			PGQ_TRY(sel.reserve((size_t)std::min<int64_t>(E, V) * 4 + 64));
 			size_t sb = 0;
@@ -432,32 +455,38 @@ static int wcc_compute(pgq_csr *c, Workspace *ws) {
 				PGQ_TRY(staged_download(h_edges.data(), edges.p, (size_t)n_msf * 8, st));
 			}
 		}
+		lap("chosen slots to the host");
 		// the reference's schedule on the edges that matter (weakly_connected_component.cpp:14-34,77-90); entry V + 1 is
 		// left at 0 by the reference's resize and never linked
-		for (int64_t i = 0; i < vs - 1; i++) forest[(size_t)i] = i;
-		auto root = [&](int64_t x) {
+		int32_t *const f = forest.data();
+		for (int64_t i = 0; i < vs - 1; i++) f[i] = (int32_t)i;
+		auto root = [&](int32_t x) {
 			for (;;) {
-				const int64_t p = forest[(size_t)x];
+				const int32_t p = f[x];
 				if (p == x) return x;
-				forest[(size_t)x] = forest[(size_t)p];
+				f[x] = f[p];
 				x = p;
 			}
 		};
 		for (u32 i = 0; i < n_msf; i++) {
-			const int64_t ra = root(h_edges[2 * (size_t)i]), rb = root(h_edges[2 * (size_t)i + 1]);
-			if (ra != rb) forest[(size_t)ra] = rb;
+			const int32_t ra = root(h_edges[2 * (size_t)i]), rb = root(h_edges[2 * (size_t)i + 1]);
+			if (ra != rb) f[ra] = rb;
 		}
-		std::vector<int64_t> ids((size_t)vs);
-		for (int64_t v = 0; v < vs; v++) ids[(size_t)v] = root(v); // v = V + 1: forest entry 0 -> the root of vertex 0 (:94-96 accepts it)
+		lap("Link replay");
+		// the ids (FindTreeRoot of every entry, :94-96) are read off on the device: the forest goes up as it is (1.8 MB instead
+		// of 3.6 MB of ids after a host pass over every vertex); v = V + 1: forest entry 0 -> the root of vertex 0
 		int64_t *d_ids = nullptr;
 		PGQ_TRY(dev_alloc_as(&d_ids, (size_t)vs));
-		hipError_t e1 = hipMemcpyAsync(d_ids, ids.data(), (size_t)vs * 8, hipMemcpyHostToDevice, st);
+		hipError_t e0 = hook.reserve((size_t)vs * 4) == PGQ_OK ? hipSuccess : hipErrorOutOfMemory;
+		hipError_t e1 = e0 == hipSuccess ? hipMemcpyAsync(hook.p, f, (size_t)vs * 4, hipMemcpyHostToDevice, st) : e0;
+		if (e1 == hipSuccess) hipLaunchKernelGGL(k_wcc_ids, dim3(blocks_for(vs)), dim3(256), 0, st, vs, hook.as<int32_t>(), d_ids);
 		hipError_t e2 = hipStreamSynchronize(st);
 		if (e1 != hipSuccess || e2 != hipSuccess) {
 			dev_free(d_ids);
 			return fail(PGQ_ERR_HIP, "copying the component ids failed");
 		}
 		c->wcc = d_ids;
+		lap("ids + upload");
 		return PGQ_OK;
 	};
 	const int rc = body();

@@ -1242,6 +1242,8 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 	u32 vertices = 0;
 	auto or_rtn = [&](int side, u32 x) -> u32 {
 		if constexpr (GM) { // look first: a bit that is set needs no read-modify-write (hubs are reached over and over)
+			// (tried: no look for levels of a few thousand entries — one dependent round trip less per level; configs[1]'s k_bibfs
+			// stayed at 107-110 us: a level there is ~10 us of five dependent DRAM trips and four barriers whatever its size)
 			const u32 w = __hip_atomic_load(&gmap[side * mw + (x >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if ((w >> (x & 31)) & 1u) return w;
 			return atomicOr(&gmap[side * mw + (x >> 5)], 1u << (x & 31));
@@ -1287,10 +1289,17 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 		int nf[2] = { 1, 1 }, lvl[2] = { 0, 0 }, par[2] = { 0, 0 };
 		int64_t work[2] = { off[s + 1] - off[s], roff[d + 1] - roff[d] };
 		int64_t result = kMeetOpen;
+#ifdef PGQ_MEET3_ROWTRACE
+		const unsigned long long bt0 = wall_clock64();
+		unsigned long long bt_work = 0;
+#endif
 		__syncthreads();
 		for (;;) {
 			const int side = work[0] <= work[1] ? 0 : 1; // 0: forward from src, 1: backward from dst
 			if (work[side] > cap) break;
+#ifdef PGQ_MEET3_ROWTRACE
+			bt_work += (unsigned long long)work[side];
+#endif
 			const int64_t *xoff = side ? roff : off;
 			const int32_t *xadj = side ? radj : adj;
 			const u32 *cur = qbase + (size_t)(side * 2 + par[side]) * qcap;
@@ -1373,6 +1382,11 @@ __global__ __launch_bounds__(1024) void k_bibfs(MeetQueue qin, u32 max_rows,
 			par[side] ^= 1;
 			__syncthreads(); // s_cnt / s_work are reset by the next round
 		}
+#ifdef PGQ_MEET3_ROWTRACE
+		if (tid == 0 && wall_clock64() - bt0 > 3000)
+			printf("bibfs row %u: %.1f us, levels %d + %d, frontier entries expanded %llu, last frontiers %d / %d, result %lld\n", row, (wall_clock64() - bt0) * 0.01,
+			       lvl[0], lvl[1], bt_work, nf[0], nf[1], (long long)result);
+#endif
 		if (tid == 0) {
 			out_rows[row] = result;
 			if (result == kMeetOpen) {

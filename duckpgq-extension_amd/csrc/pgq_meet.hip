@@ -1515,13 +1515,15 @@ static int meet_buffers(Workspace *ws, int64_t n, MeetQueue q[2], MeetDevBlock *
 	return PGQ_OK;
 }
 // waits for the chain and takes over what its last workgroup wrote into the pinned block
-static int meet_wait(Workspace *ws, MeetHostBlock *hb) {
+static int meet_wait(Workspace *ws, MeetHostBlock *hb, bool report_is_last = true) {
 	// meet_spin_wait (off as shipped): poll the report the chain's last workgroup writes into pinned memory instead of asking
 	// the runtime for the stream — 5-6 us per call (2048 rows 55.6 -> 50.5 us, 8192 rows 78.7 -> 73.0, one row 26 -> 21).  The
 	// call then returns on the kernels' own system-scope fences (every workgroup fences before its ticket, the last one before
 	// the report) without the end-of-kernel release a stream synchronisation adds; results are complete by construction, but a
 	// consumer on ANOTHER stream is no longer covered by the runtime's guarantee — hence an option, not the default.
-	if (options().meet_spin_wait && !options().profile) {
+	// (only where the report IS the chain's last word: shortestpath's scan and list emission run behind the stage kernels —
+	// tests/soak_gpu.py caught a call that returned on the report with its lists still unwritten)
+	if (options().meet_spin_wait && report_is_last && !options().profile) {
 		const auto t0 = std::chrono::steady_clock::now();
 		for (u32 it = 0;; it++) {
 			if (*(volatile u32 *)&hb->done == 1u) {
@@ -1903,7 +1905,7 @@ int meet_prepass(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, con
 		                   c->edge_ids, po->d_child, po->child_cap, po->d_out_off);
 		kt.stop();
 	}
-	PGQ_TRY(meet_wait(ws, hb));
+	PGQ_TRY(meet_wait(ws, hb, !paths));
 	if (decide_mode == 2 && observed_go && *h_go) *observed_go = (int)*h_go - 1;
 	if (paths) po->total = *h_total;
 	const MeetHostBlock &h = *hb;

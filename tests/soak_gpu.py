@@ -3,8 +3,9 @@
 prefix): `python tests/soak_gpu.py [seconds] [seed]` draws graphs (size, degree, skew), option sets (shipped values with the
 source-centric kernel, its sort and the route timing on; caps and map placement varied) and inputs (grouped by source,
 the same rows shuffled, scattered pairs, a few sources x many rows; 1 .. 300,000 rows; NULL rows) and compares
-iterativelength — through the chunk API and the bulk API — with the oracle's lean restatement, row by row.  Exit code 1 on
-the first mismatch (the case is printed with its seed)."""
+iterativelength — through the chunk API and the bulk API — with the oracle's lean restatement, row by row.  A third
+argument `paths` soaks shortestpath lists and cheapest_path_length (int64 with and without zeros, double) instead.  Exit
+code 1 on the first mismatch (the case is printed with its seed)."""
 import os
 import sys
 import time
@@ -22,6 +23,47 @@ import torch  # noqa: E402
 
 t_end = time.time() + budget
 case = 0
+mode = sys.argv[3] if len(sys.argv) > 3 else "lengths"
+while mode == "paths" and time.time() < t_end:  # shortestpath lists and cheapest_path_length (int64 and double weights)
+    seed = seed0 * 100003 + case
+    rng = np.random.default_rng(seed)
+    case += 1
+    V = int(rng.choice([300, 3000, 20000]))
+    E = int(V * float(rng.choice([1.5, 5, 14])))
+    if rng.random() < 0.5:
+        s = (rng.random(E) ** 3 * V).astype(np.int64)
+        d = (rng.random(E) ** 2 * V).astype(np.int64)
+    else:
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    e = np.arange(E, dtype=np.int64)
+    wkind = int(rng.integers(0, 3))
+    w = [rng.integers(1, 1000, E), rng.integers(0, 4, E), rng.random(E) + 0.01][wkind]
+    opts = {"meet": int(rng.integers(0, 2)), "meet_bias": 1e9, "paths_reserve_mb": int(rng.choice([0, 1024])), "meet_cap_paths": int(rng.choice([300, 1 << 14])),
+            "meet4_lds_kb": int(rng.choice([0, 150])), "relax_bidir": int(rng.integers(0, 2)), "relax_light": int(rng.choice([0, 2])),
+            "relax_labels32": int(rng.integers(0, 2)), "chain": int(rng.integers(0, 2)), "streams": int(rng.choice([1, 3])),
+            "relax_bidir_c0_div": int(rng.choice([1, 64, 1 << 20])), "meet_spin_wait": int(rng.integers(0, 2))}
+    for k, v in opts.items():
+        pgq.set_option(k, v)
+    st = pgq.PgqState()
+    st.build_csr(0, V, s, d, e, w)
+    ora = OracleCSR.from_edges(V, s, d, e, w)
+    for rep in range(2):
+        n = int(rng.choice([1, 64, 700, 2500]))
+        ps, pd = rng.integers(0, V, n), rng.integers(0, V, n)
+        if rng.random() < 0.3:
+            ps = ps[rng.integers(0, max(1, n // 50), n)]
+        if st.shortestpath(0, V, ps, pd) != ora.lean_shortestpath(V, ps, pd):
+            print("MISMATCH paths seed", seed, "rep", rep, "n", n, "V", V, "E", E, opts)
+            sys.exit(1)
+        out, ok = st.cheapest_path_length(0, V, ps, pd)
+        lout, lok = ora.lean_cheapest_path_length(V, ps, pd)
+        if not ((ok == lok).all() and out[ok].tobytes() == lout[ok].tobytes()):
+            print("MISMATCH cheapest seed", seed, "rep", rep, "n", n, "V", V, "E", E, "weights", wkind, opts)
+            sys.exit(1)
+    del st
+if mode == "paths":
+    print("soak ok (paths + cheapest): %d graphs x 2 inputs in %.0f s" % (case, budget))
+    sys.exit(0)
 while time.time() < t_end:
     seed = seed0 * 100003 + case
     rng = np.random.default_rng(seed)

@@ -935,3 +935,91 @@ def test_source_centric_ball_rule_matches_bfs():
                             assert want == -1 or want >= 5
                     else:
                         assert g == want, (trial, caps, int(ps[a]), int(pd[a + k]), g, want)
+
+
+# ---- the two-ended batched relaxation (relax_batches_bidir, pgq_cheapest.hip), one lane ---------------------------------
+
+def two_ended_model(V, off, adj, w, roff, radj, rw, s, t, cap0, step, rng):
+    """One (src, dst) pair under relax_batches_bidir's schedule: a round = one launch forward, then one backward; a launch
+    reads the pair's bound mu ONCE (its start), expands what is dirty with a label below min(cap, mu), walks the expanded
+    vertex's weight-sorted list while the candidate stays below min(mu, 2 cap) (a candidate the cap cut, not mu, keeps the
+    side alive), offers label + other side's label for every vertex it expands; the offers land at the launch's end.  A phase
+    ends with a round in which neither side expanded: finished when mu < 2 cap or a side is not alive; else the cap rises
+    and every labelled vertex is dirty again.  The order inside a launch is arbitrary (shuffled here)."""
+    if s == t:
+        return 0
+    lists = []
+    for o, a, ww in ((off, adj, w), (roff, radj, rw)):
+        per = []
+        for v in range(V):
+            es = sorted(zip(ww[o[v]:o[v + 1]].tolist(), a[o[v]:o[v + 1]].tolist()))
+            per.append(es)
+        lists.append(per)
+    lab = [{s: 0}, {t: 0}]
+    dirty = [{s}, {t}]
+    mu, cap = INF, cap0
+    for _phase in range(10000):
+        alive = [False, False]
+        min_def = INF
+        while True:
+            expanded = 0
+            for side in (0, 1):
+                mu0 = mu  # the launch's bound
+                bound = min(mu0, 2 * cap)
+                cur = list(dirty[side])
+                rng.shuffle(cur)
+                nxt = set()
+                offers = INF
+                for v in cur:
+                    dv = lab[side][v]
+                    if dv >= mu0:
+                        continue  # dead: nothing beyond the pair's bound matters
+                    if dv >= cap:
+                        nxt.add(v)  # deferred: over the cap
+                        alive[side] = True
+                        min_def = min(min_def, dv)
+                        continue
+                    expanded += 1
+                    if v in lab[side ^ 1]:
+                        offers = min(offers, dv + lab[side ^ 1][v])
+                    for ww_, u in lists[side][v]:
+                        cand = dv + ww_
+                        if cand >= bound:
+                            if cand < mu0:  # the cap cut it, not the pair's bound
+                                alive[side] = True
+                                min_def = min(min_def, cand >> 1)
+                            break
+                        if cand < lab[side].get(u, INF):
+                            lab[side][u] = cand
+                            nxt.add(u)
+                dirty[side] = nxt
+                mu = min(mu, offers)
+            if expanded == 0:
+                break
+        if mu < 2 * cap or not alive[0] or not alive[1]:
+            return None if mu == INF else mu
+        nc = max(cap + step, cap + cap // 4)
+        if min_def != INF and min_def + 1 > nc:
+            nc = min_def + 1
+        cap = nc
+        dirty = [set(lab[0]), set(lab[1])]
+    raise AssertionError("the schedule does not terminate")
+
+
+def test_two_ended_relaxation_schedule_matches_dijkstra():
+    rng = np.random.default_rng(23)
+    for trial in range(60):
+        V = int(rng.integers(5, 60))
+        E = int(rng.integers(V, V * 6))
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        if trial % 4 == 3:
+            w = np.full(E, 7)  # one weight: nearly every band is empty
+        else:
+            w = rng.integers(0 if trial % 3 == 0 else 1, 40, E)  # every third graph has zero-weight edges
+        off, adj, roff, radj, ww, rw, order = _csr(V, s, d, w)
+        ora = OracleCSR.adopt(V, off, adj, np.arange(E, dtype=np.int64), ww.astype(np.int64))
+        ps, pd = rng.integers(0, V, 30), rng.integers(0, V, 30)
+        out, ok = ora.lean_cheapest_path_length(V, ps, pd)
+        for a, b, want, k in zip(ps.tolist(), pd.tolist(), out.tolist(), ok.tolist()):
+            cap0, step = int(rng.integers(1, 30)), int(rng.integers(1, 10))
+            assert two_ended_model(V, off, adj, ww, roff, radj, rw, a, b, cap0, step, rng) == (want if k else None), (trial, a, b, cap0, step)

@@ -322,8 +322,12 @@ struct pgq_csr {
 	std::atomic<double> ball_open_frac { 0.0 };
 	// large grouped calls, wall time per row in ns as measured on this graph shape (0: not yet): through the source-centric
 	// kernel (everything it took: its own kernels and the search of the rows it left open) and through the lane batches
+	// (the BEST time seen, not a mean: a process's first call of a kind also pays for allocations, kernel attributes, the
+	// calibration — 26 ms where the call takes 0.3; the first version took that sample for the route's cost and left the SF100
+	// cross product on the lane batches, 7 x slower, for good)
 	std::atomic<double> route_ball_ns { 0.0 }, route_lanes_ns { 0.0 };
-	std::atomic<int> route_try_lanes { 0 }; // the former cost far more than the byte model's price of the latter: time the latter once
+	std::atomic<int> route_ball_samples { 0 }, route_lanes_samples { 0 };
+	std::atomic<int> route_try_lanes { 0 }; // the former cost far more than the byte model's price of the latter: time the latter (twice)
 	bool is_replica = false;
 };
 

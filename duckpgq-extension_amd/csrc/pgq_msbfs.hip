@@ -2603,9 +2603,10 @@ static int search_device_impl(pgq_csr *c, Workspace *ws, int64_t n, const int64_
 // The byte models that pick a route price kernels at streaming rate; on a graph past the caches the source-centric route is
 // nothing like that (R-MAT-22, 2048 x 1024 rows: global bit maps marked through DRAM atomics, 35,000 far rows searched one
 // by one — 16.7 ms where the model says 0.1) and the lane batches are 4.6 x their model (12 ms).  So large grouped calls are
-// TIMED, per graph shape: the wall time per row of the source-centric route is kept; when it is over `route_try_factor` x the
-// lane batches' modelled time the next such call goes through the lanes once, and from then on through whichever measured
-// faster.  Every route is exact, so this only moves time.  (The figures travel with the calibration cache.)
+// TIMED, per graph shape: the best wall time per row of the source-centric route is kept (the best of at least two calls: a
+// process's first call of a kind pays for allocations, kernel attributes and the calibration); when it is over
+// `route_try_factor` x the lane batches' modelled time the next two such calls go through the lanes, and from then on through
+// whichever measured faster.  Every route is exact, so this only moves time.  (The figures travel with the calibration cache.)
 static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_src, const int64_t *d_dst,
                          int64_t *d_out_len, bool with_paths, int64_t *d_out_off, int64_t *d_child_ext,
                          int64_t child_cap_ext, SearchOutput &outp) {
@@ -2614,8 +2615,10 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	                   outp.ball_hint != 0 && n >= 65536;
 	if (!timed) return search_device_impl(c, ws, n, d_src, d_dst, d_out_len, with_paths, d_out_off, d_child_ext, child_cap_ext, outp);
 	const double tb = c->route_ball_ns.load(std::memory_order_relaxed), tl = c->route_lanes_ns.load(std::memory_order_relaxed);
-	const bool trial = tb > 0 && tl <= 0 && c->route_try_lanes.load(std::memory_order_relaxed) != 0;
-	outp.prefer_lanes = trial || (tb > 0 && tl > 0 && tl < tb);
+	const int nb_s = c->route_ball_samples.load(std::memory_order_relaxed), nl_s = c->route_lanes_samples.load(std::memory_order_relaxed);
+	// both figures are the best of at least two calls before they decide anything (a first call pays one-time costs)
+	const bool trial = nb_s >= 2 && nl_s < 2 && c->route_try_lanes.load(std::memory_order_relaxed) != 0;
+	outp.prefer_lanes = trial || (nb_s >= 2 && nl_s >= 2 && tl < tb);
 	// (such a call neither follows nor feeds the route memo: what it would leave there — "these buffers go to the lanes" — must
 	// not outlive the preference, and the decision kernel in front of the lanes is 40 us of a call that takes milliseconds)
 	if (outp.prefer_lanes) outp.no_memo = true;
@@ -2625,14 +2628,16 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 	if (rc != PGQ_OK) return rc;
 	const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (double)n;
 	if (outp.route == 1) {
-		c->route_ball_ns.store(tb > 0 ? 0.5 * tb + 0.5 * ns : ns, std::memory_order_relaxed);
-		if (outp.source_runs > 0) { // the lane batches' modelled time per row, at 8 TB/s
+		const double best = nb_s > 0 ? std::min(tb, ns) : ns;
+		c->route_ball_ns.store(best, std::memory_order_relaxed);
+		c->route_ball_samples.store(nb_s + 1, std::memory_order_relaxed);
+		if (nb_s + 1 >= 2 && outp.source_runs > 0) { // the lane batches' modelled time per row, at 8 TB/s
 			const double lanes_ns = lanes_cost_bytes(o.meet_bias * (double)c->E, std::min(outp.source_runs, (double)c->V), (double)n, (double)c->V) / 8000.0 / (double)n;
-			if (ns > o.route_try_factor * lanes_ns) c->route_try_lanes.store(1, std::memory_order_relaxed);
+			if (best > o.route_try_factor * lanes_ns) c->route_try_lanes.store(1, std::memory_order_relaxed);
 		}
 	} else if (outp.prefer_lanes && tstats().s.levels > levels0) { // (the lane batches did run)
-		c->route_lanes_ns.store(tl > 0 ? 0.5 * tl + 0.5 * ns : ns, std::memory_order_relaxed);
-		c->route_try_lanes.store(0, std::memory_order_relaxed);
+		c->route_lanes_ns.store(nl_s > 0 ? std::min(tl, ns) : ns, std::memory_order_relaxed);
+		c->route_lanes_samples.store(nl_s + 1, std::memory_order_relaxed);
 	}
 	return PGQ_OK;
 }

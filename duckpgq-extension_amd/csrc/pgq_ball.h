@@ -199,11 +199,7 @@ __global__ __launch_bounds__(kBallRows, PGQ_BALL_WAVES) void k_src_ball(int64_t 
 		tick(7);
 		if constexpr (TRACE) t_seg0 = t_last;
 		if (tid == 0) {
-#ifdef PGQ_BALL_STATIC_JOBS
-			s_job = job + gridDim.x; // (experiment: static striding, no atomic)
-#else
-			s_job = gridDim.x + atomicAdd(&db->ball.next_job, 1u); // read at the segment's end: the round trip is off its path
-#endif
+			s_job = gridDim.x + atomicAdd(&db->ball.next_job, 1u); // read at the segment's end: the round trip is off its path (static striding instead: 0.292 -> 0.302 ms)
 			s_len = kBallRows;
 			s_n1 = 0;
 			s_n2 = 0;

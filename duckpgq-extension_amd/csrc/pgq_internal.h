@@ -176,6 +176,7 @@ struct Options {
 	                                // its launches and its wait, not the scan — so the shorter segments stay an option
 	int ball_grid = 0;          // > 0: at most this many workgroups of k_src_ball (debugging / sweeps)
 	int route_timing = 1;     // large calls grouped by source: the route that measured faster on this graph shape is kept (search_device)
+	int route_timing_rows = 65536; // ... calls of at least this many rows
 	double route_try_factor = 4.0; // ... the lane batches are tried once when the source-centric route took this many times their modelled time
 	int ball_sort = 1;          // rows with repeated sources that are NOT grouped are sorted by source first (0: such calls take the older routes)
 	double ball_bias = 1.0;     // the ball runs while ball_bias x its estimated bytes <= the cheaper of the pre-pass and the lane batches
@@ -327,6 +328,7 @@ struct pgq_csr {
 	// cross product on the lane batches, 7 x slower, for good)
 	std::atomic<double> route_ball_ns { 0.0 }, route_lanes_ns { 0.0 };
 	std::atomic<int> route_ball_samples { 0 }, route_lanes_samples { 0 };
+	std::atomic<int64_t> route_rows { 0 }; // rows of the calls the figures come from: they speak for calls of at least half that size
 	std::atomic<int> route_try_lanes { 0 }; // the former cost far more than the byte model's price of the latter: time the latter (twice)
 	bool is_replica = false;
 };

@@ -2612,13 +2612,16 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
                          int64_t child_cap_ext, SearchOutput &outp) {
 	const Options &o = options();
 	const bool timed = o.route_timing && o.ball == 1 && outp.depth == 0 && !with_paths && !outp.want_te && !outp.bidir && !outp.no_ball &&
-	                   outp.ball_hint != 0 && n >= 65536;
+	                   outp.ball_hint != 0 && n >= (int64_t)std::max(1, o.route_timing_rows);
 	if (!timed) return search_device_impl(c, ws, n, d_src, d_dst, d_out_len, with_paths, d_out_off, d_child_ext, child_cap_ext, outp);
 	const double tb = c->route_ball_ns.load(std::memory_order_relaxed), tl = c->route_lanes_ns.load(std::memory_order_relaxed);
 	const int nb_s = c->route_ball_samples.load(std::memory_order_relaxed), nl_s = c->route_lanes_samples.load(std::memory_order_relaxed);
 	// both figures are the best of at least two calls before they decide anything (a first call pays one-time costs)
-	const bool trial = nb_s >= 2 && nl_s < 2 && c->route_try_lanes.load(std::memory_order_relaxed) != 0;
-	outp.prefer_lanes = trial || (nb_s >= 2 && nl_s >= 2 && tl < tb);
+	// ... and they speak for calls of their own size: a lane batch costs the same for 32 rows per source as for 1024, the
+	// source-centric route does not — a call with under half the measured rows is left to the byte models
+	const bool same_size = n * 2 >= c->route_rows.load(std::memory_order_relaxed);
+	const bool trial = same_size && nb_s >= 2 && nl_s < 2 && c->route_try_lanes.load(std::memory_order_relaxed) != 0;
+	outp.prefer_lanes = trial || (same_size && nb_s >= 2 && nl_s >= 2 && tl < tb);
 	// (such a call neither follows nor feeds the route memo: what it would leave there — "these buffers go to the lanes" — must
 	// not outlive the preference, and the decision kernel in front of the lanes is 40 us of a call that takes milliseconds)
 	if (outp.prefer_lanes) outp.no_memo = true;
@@ -2631,6 +2634,7 @@ static int search_device(pgq_csr *c, Workspace *ws, int64_t n, const int64_t *d_
 		const double best = nb_s > 0 ? std::min(tb, ns) : ns;
 		c->route_ball_ns.store(best, std::memory_order_relaxed);
 		c->route_ball_samples.store(nb_s + 1, std::memory_order_relaxed);
+		if (nb_s == 0 || n > c->route_rows.load(std::memory_order_relaxed)) c->route_rows.store(n, std::memory_order_relaxed);
 		if (nb_s + 1 >= 2 && outp.source_runs > 0) { // the lane batches' modelled time per row, at 8 TB/s
 			const double lanes_ns = lanes_cost_bytes(o.meet_bias * (double)c->E, std::min(outp.source_runs, (double)c->V), (double)n, (double)c->V) / 8000.0 / (double)n;
 			if (best > o.route_try_factor * lanes_ns) c->route_try_lanes.store(1, std::memory_order_relaxed);

@@ -268,6 +268,7 @@ static std::vector<OptRef> option_table(Options &o) {
 		{ "ball_test_cap", &o.ball_test_cap, nullptr },
 		{ "ball_sort", &o.ball_sort, nullptr },
 		{ "route_timing", &o.route_timing, nullptr },
+		{ "route_timing_rows", &o.route_timing_rows, nullptr },
 		{ "route_try_factor", nullptr, &o.route_try_factor },
 		{ "ball_seg_kb", &o.ball_seg_kb, nullptr },
 		{ "ball_grid", &o.ball_grid, nullptr },
@@ -1380,6 +1381,7 @@ struct CalEntry {
 	double two_hop_mean;
 	double meet_bpr, ball_open_frac, route_ball_ns, route_lanes_ns;
 	int route_try_lanes, route_ball_samples, route_lanes_samples;
+	int64_t route_rows;
 	std::vector<uint8_t> level_plan[6];
 };
 static std::mutex g_cal_lock;
@@ -1399,6 +1401,7 @@ void calibration_load(pgq_csr *c) {
 			c->route_try_lanes.store(e.route_try_lanes, std::memory_order_relaxed);
 			c->route_ball_samples.store(e.route_ball_samples, std::memory_order_relaxed);
 			c->route_lanes_samples.store(e.route_lanes_samples, std::memory_order_relaxed);
+			c->route_rows.store(e.route_rows, std::memory_order_relaxed);
 			std::lock_guard<std::mutex> g2(c->plan_lock);
 			for (int k = 0; k < 6; k++) c->level_plan[k] = e.level_plan[k];
 			return;
@@ -1409,7 +1412,8 @@ void calibration_store(pgq_csr *c) {
 	CalEntry n { c->V, c->E, c->max_out_degree, c->max_in_degree, c->two_hop_mean, c->meet_bpr.load(std::memory_order_relaxed),
 		         c->ball_open_frac.load(std::memory_order_relaxed), c->route_ball_ns.load(std::memory_order_relaxed),
 		         c->route_lanes_ns.load(std::memory_order_relaxed), c->route_try_lanes.load(std::memory_order_relaxed),
-		         c->route_ball_samples.load(std::memory_order_relaxed), c->route_lanes_samples.load(std::memory_order_relaxed), {} };
+		         c->route_ball_samples.load(std::memory_order_relaxed), c->route_lanes_samples.load(std::memory_order_relaxed),
+		         c->route_rows.load(std::memory_order_relaxed), {} };
 	bool any = n.meet_bpr > 0 || n.ball_open_frac > 0 || n.route_ball_ns > 0;
 	{
 		std::lock_guard<std::mutex> g2(c->plan_lock);

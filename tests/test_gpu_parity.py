@@ -28,7 +28,7 @@ def _defaults():
                  ("spec_levels", 1), ("sort_single_batch", 0), ("detect_unroll", 4), ("detect_grid_mult", 8), ("route_memo", 1), ("stage2_ahead", 1), ("meet_calibrate", 1),
                  # the source-centric kernel (round 6) would take every grouped input before the kernels under test see it; its own
                  # tests and the shipped configuration switch it on
-                 ("ball", 0), ("ball_cap", 1 << 20), ("ball_test_cap", 1 << 15), ("ball_bias", 1.0), ("ball_sort", 1), ("route_timing", 1), ("route_try_factor", 4.0), ("calibration_cache", 1), ("ball_seg_kb", 512), ("ball_grid", 0), ("ball_head_mb", 512)):
+                 ("ball", 0), ("ball_cap", 1 << 20), ("ball_test_cap", 1 << 15), ("ball_bias", 1.0), ("ball_sort", 1), ("route_timing", 1), ("route_timing_rows", 65536), ("route_try_factor", 4.0), ("calibration_cache", 1), ("ball_seg_kb", 512), ("ball_grid", 0), ("ball_head_mb", 512)):
         pgq.set_option(k, v)
     yield
 
@@ -542,6 +542,7 @@ def test_large_grouped_calls_keep_the_route_that_measured_faster():
     pgq.set_option("ball_seg_kb", 16)
     pgq.set_option("calibration_cache", 0)  # (the measured times travel with it: this test wants a graph nobody has timed)
     dev = st.device_csr(0)
+    pgq.set_option("route_timing_rows", 16384)
     ps = np.repeat(rng.choice(V, 70, replace=False), 1000)
     pd = rng.integers(0, V, len(ps))
     oln, ook = ora.lean_iterativelength(V, ps, pd, nthreads=4)
@@ -562,6 +563,18 @@ def test_large_grouped_calls_keep_the_route_that_measured_faster():
     assert all(x[3] and not x[2] for x in seen[2:4]), seen  # two through the lane batches (the trial, best of two)
     assert seen[4][2] != seen[4][3] and seen[5][2:] == seen[4][2:], seen  # then one of the two, and it stays
     assert all(x[2] and not x[3] for x in seen[6:]), seen  # route_timing = 0: the byte models alone
+    # what was measured on 70,000 rows says nothing about a call of under half that size (a lane batch costs the same for 32
+    # rows per source as for 1000): 30,000 grouped rows go by the byte models, i.e. to the source-centric kernel here
+    pgq.set_option("route_timing", 1)
+    ps2 = np.repeat(rng.choice(V, 30, replace=False), 1000)
+    pd2 = rng.integers(0, V, len(ps2))
+    oln2, ook2 = ora.lean_iterativelength(V, ps2, pd2, nthreads=4)
+    t_s2, t_d2 = torch.from_numpy(ps2).cuda(), torch.from_numpy(pd2).cuda()
+    t_o2 = torch.full((len(ps2),), -7, dtype=torch.int64, device="cuda")
+    pgq.reset_stats()
+    dev.iterativelength_bulk_ptr(len(ps2), t_s2.data_ptr(), t_d2.data_ptr(), t_o2.data_ptr())
+    assert (t_o2.cpu().numpy() == np.where(ook2, oln2, -1)).all()
+    assert pgq.get_stats()["ball_calls"] >= 1 and pgq.get_stats()["levels"] == 0
 
 
 def test_ungrouped_rows_of_few_sources_are_sorted_for_the_source_centric_kernel():

@@ -32,6 +32,7 @@ st() { tag=$1; shift; (cd /tmp && export TMPDIR=/tmp && timeout 400 env "$@" > $
 st snb rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb -o s -- python $R/bench.py --no-cpu-baseline --no-legs --no-first-call
 st snb_cross_ball rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb_cross_ball -o s -- python $R/bench.py --workload snb_cross --no-cpu-baseline --no-first-call --steps 5
 st snb_cross PGQ_BALL=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb_cross -o s -- python $R/bench.py --workload snb_cross --no-cpu-baseline --no-first-call --steps 5
+st snb_cross_shuffled rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_snb_cross_shuffled -o s -- python $R/bench.py --workload snb_cross --cross-shuffle --no-cpu-baseline --no-first-call --steps 5
 st rmat22_cross rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_rmat22_cross -o s -- python $R/bench.py --workload rmat22_cross --no-cpu-baseline --no-first-call --steps 3 --warmup 1
 timeout 300 python tools/chunk_latency.py > $O/chunk_latency.json 2> $O/chunk_latency.err; cat $O/chunk_latency.json
 timeout 300 python tools/chunk_throughput.py > $O/chunk_throughput.txt 2> $O/chunk_throughput.err; cat $O/chunk_throughput.txt
